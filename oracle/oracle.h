@@ -1,0 +1,53 @@
+/* TEST INFRASTRUCTURE ONLY — CPU restatement ("oracle") of the SSDR-AL hot-path C++ ops.
+ *
+ * Nothing in the product (ssdr-al_amd/, include/) may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+ * checker / reported baseline.  Parity pinning: every function here is checked against
+ * the real reference build (oracle/_ref/libssdr_ref.so, made by oracle/Makefile from
+ * /root/reference) in tests/test_oracle_vs_ref.py and against the golden vectors under
+ * tests/golden/ that were generated from that build (tests/golden/make_golden.py).
+ *
+ * Paths cited below are relative to /root/reference/SSDR_AL_s3dis/utils/.
+ */
+#ifndef SSDR_ORACLE_H
+#define SSDR_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:5-106.
+ * order: 0 = reference order (libstdc++ unordered_map iteration order, emulated),
+ *        1 = ascending voxel key.
+ * out_* must hold n rows.  out_keys (optional) receives the size_t voxel key per row.
+ * Returns the number of occupied voxels M. */
+long oracle_grid_subsampling(const float* pts, size_t n,
+                             const float* feats, size_t fdim,
+                             const int32_t* cls, size_t ldim,
+                             float dl, int order,
+                             float* out_pts, float* out_feats, int32_t* out_cls,
+                             uint64_t* out_keys);
+
+/* nearest_neighbors/knn_.cxx:22-44 (cpp_knn), :72-135 (cpp_knn_batch[_omp]) with the
+ * nanoflann v1.2.3 semantics of nearest_neighbors/nanoflann.hpp (tree build :848-975,
+ * search :1164-1178,:1271-1329, result set :36-102, metric :280-304).
+ * out_dist (optional) receives the squared distances.  Slots >= min(K,npts) hold 0. */
+void oracle_knn(const float* pts, size_t npts, size_t dim,
+                const float* queries, size_t nq, size_t K,
+                int64_t* out_idx, float* out_dist);
+void oracle_knn_batch(const float* pts, size_t batch, size_t npts, size_t dim,
+                      const float* queries, size_t nq, size_t K,
+                      int64_t* out_idx, int threads);
+
+/* Exposes the emulated kd-tree for white-box tests of the GPU builder:
+ * vind (npts), and per node: left,right,divfeat,child1,child2 (int32 x5) + divlow,divhigh (float x2).
+ * Returns the node count (nodes are numbered in pre-order, root = 0). */
+long oracle_kdtree_dump(const float* pts, size_t npts, size_t dim, size_t leaf_max,
+                        int64_t* vind, int32_t* node_i5, float* node_f2, size_t node_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
