@@ -1,0 +1,67 @@
+// Library state of libssdr_al.so: device selection, the library stream, error text, grow-only buffers.
+#include "ssdr_internal.hpp"
+#include <mutex>
+
+namespace ssdr {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+}
+
+Context& ctx() { static Context c; return c; }
+
+static std::mutex g_init_mu;
+
+static int do_init(int device) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    Context& c = ctx();
+    if (c.ready) return SSDR_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libssdr_al has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return SSDR_ERR_NO_DEVICE;
+    }
+    if (device < 0) device = 0;
+    if (device >= n) { set_error("device %d out of range (%d devices)", device, n); return SSDR_ERR_INVALID; }
+    SSDR_HIP(hipSetDevice(device));
+    SSDR_HIP(hipStreamCreate(&c.stream));
+    SSDR_HIP(hipEventCreate(&c.ev0));
+    SSDR_HIP(hipEventCreate(&c.ev1));
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c.num_cu = cu;
+    c.device = device; c.ready = true;
+    return SSDR_OK;
+}
+
+int ensure_init() { return ctx().ready ? SSDR_OK : do_init(0); }
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return SSDR_OK;
+    if (p) { SSDR_HIP(hipStreamSynchronize(ctx().stream)); SSDR_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    SSDR_HIP(hipMalloc(&p, want));
+    cap = want;
+    return SSDR_OK;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+}  // namespace ssdr
+
+extern "C" {
+const char* ssdr_version(void) { return "ssdr_al-gfx950 0.1"; }
+const char* ssdr_last_error(void) { return ssdr::g_err.c_str(); }
+int ssdr_init(int device) { return ssdr::ctx().ready ? SSDR_OK : ssdr::do_init(device); }
+void ssdr_shutdown(void) {}
+int ssdr_stream_sync(void* stream) {
+    SSDR_TRY(ssdr::ensure_init());
+    SSDR_HIP(hipStreamSynchronize(ssdr::pick_stream(stream)));
+    return SSDR_OK;
+}
+float ssdr_last_gpu_ms(void) { return ssdr::ctx().last_ms; }
+}

@@ -1,0 +1,410 @@
+// Exact K-nearest-neighbour search for gfx950 with the reference's tie order.
+//
+// The reference op (S3/utils/nearest_neighbors/knn_.cxx:22-135) answers every query by walking a
+// nanoflann v1.2.3 kd-tree (S3/utils/nearest_neighbors/nanoflann.hpp).  Among equidistant candidates
+// (duplicated points of padded tiles, S3/s3dis_dataset.py:147-150) the order of the returned indices
+// is the order in which that walk meets them, so bit-identical indices need the *same tree* and the
+// *same walk*.  This file therefore has two parts, both written for 64-wide wavefronts:
+//
+//   build   level-synchronous construction of all trees of a batch at once (one workgroup per open
+//           node per level).  The split rule is nanoflann's middleSplit_ (:898-937); its two-pointer
+//           planeSplit sweeps (:948-975) are replaced by an equivalent closed form: the k-th
+//           misplaced element from the left swaps with the k-th misplaced element from the right,
+//           which wavefront ballots + prefix sums compute in parallel and which yields the same
+//           permutation of `vind` (tests/test_kdtree_*.py compare it with the oracle element by
+//           element).
+//   search  one lane per query, explicit stack, the visiting order of searchLevel (:1271-1329) and
+//           the insertion rule of KNNResultSet::addPoint (:63-92).  Queries are taken in tree order
+//           so the 64 lanes of a wavefront walk neighbouring leaves.
+//
+// Distances are ((dx*dx + dy*dy) + dz*dz) in fp32 with contraction disabled (this TU is compiled
+// with -ffp-contract=off), the arithmetic of L2_Adaptor::evalMetric (:280-304) for dim == 3.
+#include "ssdr_internal.hpp"
+#include "block_prims.hpp"
+#include <cfloat>
+#include <cstring>
+#include <algorithm>
+
+namespace ssdr {
+
+namespace {
+
+constexpr int LEAF_MAX = 10;         // knn_.cxx:28 / KDTreeTableAdaptor.h:134
+constexpr int MAX_LEVELS = 40;       // levels launched per build == search stack depth
+constexpr int CTR_NODES = 0, CTR_STATUS = 1, CTR_DEPTH = 2, CTR_QUEUE0 = 8;
+constexpr int ST_QUEUE_OVF = 1, ST_NODE_OVF = 2, ST_DEPTH_OVF = 4;
+
+// The two-pointer sweep of nanoflann.hpp:951-961 (and :966-973) in closed form: positions [start,end)
+// hold `lim - start` elements with left(i) == true; the k-th left-side element with !left swaps with the
+// k-th right-side element (counted from the right end) with left.
+template <class Left>
+__device__ void hoare_sweep(int* ind, float* val, int* tmp, int start, int end, int lim, Left left,
+                            int (*s_w)[U][BS / 64]) {
+    int m = block_compact(start, lim, [&](int i) { return !left(i); },
+                          [&](int k, int i) { tmp[start + k] = i; }, s_w);
+    if (m == 0) return;   // uniform
+    block_compact(lim, end, [&](int i) { return left(i); },
+                  [&](int k, int i) { tmp[start + m + (m - 1 - k)] = i; }, s_w);
+    for (int k = threadIdx.x; k < m; k += BS) {
+        int a = tmp[start + k], b = tmp[start + m + k];
+        int ia = ind[a], ib = ind[b]; ind[a] = ib; ind[b] = ia;
+        float va = val[a], vb = val[b]; val[a] = vb; val[b] = va;
+    }
+    __syncthreads();
+}
+
+struct ForestPtrs {
+    KdTreeDesc* desc; int* vind; float4* sorted; int4* node_a; float4* node_b; float* node_box; int* node_tree;
+    int* queue; int* ctr; int* tmp; float* val; int node_cap; int queue_cap;
+};
+
+__global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
+    __shared__ float s_mm[(BS / 64) * 6];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = tid; i < n; i += BS) {
+        f.vind[voff + i] = i;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { float v = P[3 * (size_t)i + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+    }
+    block_minmax3(mn, mx, s_mm);
+    if (tid == 0) {
+        for (int d = 0; d < 3; ++d) { f.desc[t].lo[d] = mn[d]; f.desc[t].hi[d] = mx[d]; f.node_box[6 * t + d] = mn[d]; f.node_box[6 * t + 3 + d] = mx[d]; }
+        f.desc[t].root = t;
+        f.node_a[t] = make_int4(voff, voff + n, -1, -1);
+        f.node_b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        f.node_tree[t] = t;
+        if (t == 0) atomicAdd(&f.ctr[CTR_NODES], (int)gridDim.x);   // roots are nodes 0..ntrees-1
+        if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_QUEUE0], 1); f.queue[q] = t; }
+    }
+}
+
+// One level of divideTree (nanoflann.hpp:848-896) for every open node.
+__global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
+    __shared__ float s_mm[(BS / 64) * 6];
+    __shared__ int s_sum[(BS / 64) * 2];
+    __shared__ int s_w[2][U][BS / 64];
+    __shared__ int s_child;
+    const int tid = threadIdx.x;
+    const int nq = min(f.ctr[CTR_QUEUE0 + level], f.queue_cap);
+    const int* qin = f.queue + (level & 1) * f.queue_cap;
+    int* qout = f.queue + ((level + 1) & 1) * f.queue_cap;
+    if (blockIdx.x == 0 && tid == 0 && nq > 0) {
+        atomicMax(&f.ctr[CTR_DEPTH], level + 1);
+        if (level + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
+    }
+    for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        const int node = qin[qi];
+        const int4 na = f.node_a[node];
+        const int left = na.x, count = na.y - na.x;
+        const int tree = f.node_tree[node];
+        const float* P = f.desc[tree].pts;
+        int* ind = f.vind + left; float* val = f.val + left; int* tmp = f.tmp + left;
+        float lo[3], hi[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { lo[d] = f.node_box[6 * (size_t)node + d]; hi[d] = f.node_box[6 * (size_t)node + 3 + d]; }
+
+        // computeMinMax (:837-846) for all three dimensions at once
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = tid; i < count; i += BS) {
+            const size_t p = (size_t)ind[i] * 3;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { float v = P[p + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+        }
+        block_minmax3(mn, mx, s_mm);
+
+        // middleSplit_ (:898-937)
+        const float EPS = 0.00001f;
+        float max_span = hi[0] - lo[0];
+#pragma unroll
+        for (int d = 1; d < 3; ++d) { float s = hi[d] - lo[d]; if (s > max_span) max_span = s; }
+        float max_spread = -1.f; int cf = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s = hi[d] - lo[d];
+            if (s > (1 - EPS) * max_span) { float spread = mx[d] - mn[d]; if (spread > max_spread) { cf = d; max_spread = spread; } }
+        }
+        const float lo_c = cf == 0 ? lo[0] : (cf == 1 ? lo[1] : lo[2]);
+        const float hi_c = cf == 0 ? hi[0] : (cf == 1 ? hi[1] : hi[2]);
+        const float mn_c = cf == 0 ? mn[0] : (cf == 1 ? mn[1] : mn[2]);
+        const float mx_c = cf == 0 ? mx[0] : (cf == 1 ? mx[1] : mx[2]);
+        const float split_val = (lo_c + hi_c) / 2;
+        const float cut = split_val < mn_c ? mn_c : (split_val > mx_c ? mx_c : split_val);
+
+        // stage the cut coordinate by position; count "< cut" and "== cut"
+        int cL = 0, cE = 0;
+        for (int i = tid; i < count; i += BS) {
+            float v = P[(size_t)ind[i] * 3 + cf];
+            val[i] = v; cL += v < cut; cE += v == cut;
+        }
+        block_sum2(cL, cE, s_sum);   // barrier inside also publishes val[]
+
+        // planeSplit (:948-975)
+        const int lim1 = cL, lim2 = cL + cE;
+        hoare_sweep(ind, val, tmp, 0, count, lim1, [&](int i) { return val[i] < cut; }, s_w);
+        if (cE > 0) hoare_sweep(ind, val, tmp, lim1, count, lim2, [&](int i) { return val[i] <= cut; }, s_w);
+        int idx;
+        if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
+
+        // tight child boxes along the cut dimension (:878-882): divlow = max over left, divhigh = min over right
+        float m3n[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, m3x[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = tid; i < count; i += BS) {
+            float v = val[i];
+            if (i < idx) m3x[0] = fmaxf(m3x[0], v); else m3n[0] = fminf(m3n[0], v);
+        }
+        block_minmax3(m3n, m3x, s_mm);
+
+        if (tid == 0) {
+            int c = atomicAdd(&f.ctr[CTR_NODES], 2);
+            if (c + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c = -1; }
+            s_child = c;
+        }
+        __syncthreads();
+        const int c1 = s_child;
+        if (c1 >= 0 && tid < 2) {
+            const int c = c1 + tid;
+            const int cl = tid == 0 ? left : left + idx, cr = tid == 0 ? left + idx : left + count;
+            f.node_a[c] = make_int4(cl, cr, -1, -1);
+            f.node_b[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f.node_tree[c] = tree;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                f.node_box[6 * (size_t)c + d] = (tid == 1 && d == cf) ? cut : lo[d];
+                f.node_box[6 * (size_t)c + 3 + d] = (tid == 0 && d == cf) ? cut : hi[d];
+            }
+            if (cr - cl > LEAF_MAX) {
+                int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
+                if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+            }
+        }
+        if (c1 >= 0 && tid == 0) {
+            f.node_a[node] = make_int4(na.x, na.y, c1, c1 + 1);
+            f.node_b[node] = make_float4(m3x[0], m3n[0], __int_as_float(cf), 0.f);
+        }
+        __syncthreads();
+    }
+}
+
+// Points re-ordered by vind, index in .w: leaf scans become contiguous 16-byte loads.
+__global__ void kd_sort_points_kernel(ForestPtrs f, int ntrees) {
+    for (int t = blockIdx.y; t < ntrees; t += gridDim.y) {
+        const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            int id = f.vind[voff + i];
+            f.sorted[voff + i] = make_float4(P[3 * (size_t)id], P[3 * (size_t)id + 1], P[3 * (size_t)id + 2], __int_as_float(id));
+        }
+    }
+}
+
+// ---- search -------------------------------------------------------------------------------------
+struct SearchArgs {
+    const KdTreeDesc* desc; const int* vind; const float4* sorted; const int4* node_a; const float4* node_b;
+    int tree0; const float* queries; size_t q_stride; int nq; int qorder_tree0; void* out; size_t out_stride; int* ctr;
+};
+
+template <int K>
+struct RegSet {   // KNNResultSet (:36-102) in registers
+    float d[K]; int id[K];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { d[j] = FLT_MAX; id[j] = 0; }
+    }
+    __device__ __forceinline__ float worst() const { return d[K - 1]; }
+    __device__ __forceinline__ void add(float dist, int index) {   // requires dist < worst()
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            if (d[j - 1] > dist) { d[j] = d[j - 1]; id[j] = id[j - 1]; }
+            else if (d[j] > dist) { d[j] = dist; id[j] = index; }
+        }
+        if (d[0] > dist) { d[0] = dist; id[0] = index; }
+    }
+    __device__ __forceinline__ int get(int j) const { return id[j]; }
+};
+
+struct LdsSet {   // same rule, slots in LDS ([slot][lane]) for arbitrary K
+    float* d; int* id; int K;
+    __device__ __forceinline__ void init() { for (int j = 0; j < K; ++j) { d[j * 64] = FLT_MAX; id[j * 64] = 0; } }
+    __device__ __forceinline__ float worst() const { return d[(K - 1) * 64]; }
+    __device__ __forceinline__ void add(float dist, int index) {
+        int j = K - 1;
+        for (; j > 0; --j) {
+            if (d[(j - 1) * 64] > dist) { d[j * 64] = d[(j - 1) * 64]; id[j * 64] = id[(j - 1) * 64]; }
+            else break;
+        }
+        d[j * 64] = dist; id[j * 64] = index;
+    }
+    __device__ __forceinline__ int get(int j) const { return id[j * 64]; }
+};
+
+template <class RS>
+__device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& td, float qx, float qy, float qz, RS& rs) {
+    int stk_node[MAX_LEVELS]; float stk_m[MAX_LEVELS], stk_0[MAX_LEVELS], stk_1[MAX_LEVELS], stk_2[MAX_LEVELS];
+    int sp = 0;
+    // computeInitialDistances (:977-993)
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, mind = 0.f;
+    if (qx < td.lo[0]) { d0 = (qx - td.lo[0]) * (qx - td.lo[0]); mind += d0; }
+    if (qx > td.hi[0]) { d0 = (qx - td.hi[0]) * (qx - td.hi[0]); mind += d0; }
+    if (qy < td.lo[1]) { d1 = (qy - td.lo[1]) * (qy - td.lo[1]); mind += d1; }
+    if (qy > td.hi[1]) { d1 = (qy - td.hi[1]) * (qy - td.hi[1]); mind += d1; }
+    if (qz < td.lo[2]) { d2 = (qz - td.lo[2]) * (qz - td.lo[2]); mind += d2; }
+    if (qz > td.hi[2]) { d2 = (qz - td.hi[2]) * (qz - td.hi[2]); mind += d2; }
+    int node = td.root;
+    for (;;) {
+        int4 na = a.node_a[node];
+        while (na.z >= 0) {   // internal: take the near child, defer the far one (:1292-1326)
+            const float4 nb = a.node_b[node];
+            const int cf = __float_as_int(nb.z);
+            const float val = cf == 0 ? qx : (cf == 1 ? qy : qz);
+            const float diff1 = val - nb.x, diff2 = val - nb.y;
+            int best, other; float cut;
+            if ((diff1 + diff2) < 0) { best = na.z; other = na.w; cut = (val - nb.y) * (val - nb.y); }
+            else                     { best = na.w; other = na.z; cut = (val - nb.x) * (val - nb.x); }
+            const float dst = cf == 0 ? d0 : (cf == 1 ? d1 : d2);
+            const float m2 = mind + cut - dst;
+            if (sp < MAX_LEVELS) {
+                stk_node[sp] = other; stk_m[sp] = m2;
+                stk_0[sp] = cf == 0 ? cut : d0; stk_1[sp] = cf == 1 ? cut : d1; stk_2[sp] = cf == 2 ? cut : d2;
+                ++sp;
+            } else atomicOr(&a.ctr[CTR_STATUS], ST_DEPTH_OVF);
+            node = best; na = a.node_a[node];
+        }
+        {   // leaf (:1275-1289)
+            const float worst = rs.worst();
+            for (int i = na.x; i < na.y; ++i) {
+                const float4 p = a.sorted[i];
+                const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+                if (dist < worst && dist < rs.worst()) rs.add(dist, __float_as_int(p.w));   // addPoint keeps nothing >= the current worst
+            }
+        }
+        bool found = false;
+        while (sp > 0) {
+            --sp;
+            if (stk_m[sp] <= rs.worst()) { node = stk_node[sp]; mind = stk_m[sp]; d0 = stk_0[sp]; d1 = stk_1[sp]; d2 = stk_2[sp]; found = true; break; }
+        }
+        if (!found) break;
+    }
+}
+
+template <int K, typename OutT>
+__global__ __launch_bounds__(256) void kd_search_kernel(SearchArgs a) {
+    const int t = blockIdx.y;
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= a.nq) return;
+    const KdTreeDesc td = a.desc[a.tree0 + t];
+    int q = qi;
+    if (a.qorder_tree0 >= 0) q = a.vind[a.desc[a.qorder_tree0 + t].voff + qi];
+    const float* Q = a.queries + (size_t)t * a.q_stride + 3 * (size_t)q;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    RegSet<K> rs; rs.init();
+    if (td.n > 0) kd_walk(a, td, qx, qy, qz, rs);
+    OutT* o = reinterpret_cast<OutT*>(a.out) + (size_t)t * a.out_stride + (size_t)q * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) o[j] = (OutT)rs.get(j);
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) {
+    SSDR_DYN_SHARED(float, s_dyn);
+    const int t = blockIdx.y;
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= a.nq) return;
+    const KdTreeDesc td = a.desc[a.tree0 + t];
+    int q = qi;
+    if (a.qorder_tree0 >= 0) q = a.vind[a.desc[a.qorder_tree0 + t].voff + qi];
+    const float* Q = a.queries + (size_t)t * a.q_stride + 3 * (size_t)q;
+    LdsSet rs; rs.K = K; rs.d = s_dyn + threadIdx.x; rs.id = reinterpret_cast<int*>(s_dyn + 64 * K) + threadIdx.x;
+    rs.init();
+    if (td.n > 0) kd_walk(a, td, Q[0], Q[1], Q[2], rs);
+    OutT* o = reinterpret_cast<OutT*>(a.out) + (size_t)t * a.out_stride + (size_t)q * K;
+    for (int j = 0; j < K; ++j) o[j] = (OutT)rs.get(j);
+}
+
+ForestPtrs ptrs(const KdForest& f) {
+    ForestPtrs p;
+    p.desc = f.desc.as<KdTreeDesc>(); p.vind = f.vind.as<int>(); p.sorted = f.sorted.as<float4>();
+    p.node_a = f.node_a.as<int4>(); p.node_b = f.node_b.as<float4>(); p.node_box = f.node_box.as<float>();
+    p.node_tree = f.node_tree.as<int>(); p.queue = f.queue.as<int>(); p.ctr = f.counters.as<int>();
+    p.tmp = f.tmp.as<int>(); p.val = f.val.as<float>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
+    return p;
+}
+
+}  // namespace
+
+int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s) {
+    std::vector<KdTreeDesc> trees = trees_in;
+    long total = 0;
+    for (auto& t : trees) { t.voff = (int)total; t.root = 0; total += t.n; if (total > 0x3fffffffL) { set_error("kd_build: too many points"); return SSDR_ERR_INVALID; } }
+    f.ntrees = (int)trees.size(); f.total_pts = (int)total;
+    f.node_cap = f.ntrees + 2 * (int)total + 2;
+    f.queue_cap = (int)(total / (LEAF_MAX + 1)) + f.ntrees + 16;
+    const size_t tp = (size_t)(total ? total : 1);
+    SSDR_TRY(f.desc.reserve(sizeof(KdTreeDesc) * (trees.size() + 1)));
+    SSDR_TRY(f.vind.reserve(4 * tp)); SSDR_TRY(f.sorted.reserve(16 * tp));
+    SSDR_TRY(f.tmp.reserve(4 * tp)); SSDR_TRY(f.val.reserve(4 * tp));
+    SSDR_TRY(f.node_a.reserve(16 * (size_t)f.node_cap)); SSDR_TRY(f.node_b.reserve(16 * (size_t)f.node_cap));
+    SSDR_TRY(f.node_box.reserve(24 * (size_t)f.node_cap)); SSDR_TRY(f.node_tree.reserve(4 * (size_t)f.node_cap));
+    SSDR_TRY(f.queue.reserve(8 * (size_t)f.queue_cap));
+    SSDR_TRY(f.counters.reserve(4 * (CTR_QUEUE0 + MAX_LEVELS + 8)));
+    if (f.ntrees == 0) return SSDR_OK;
+    // descriptors travel through a pinned staging buffer; the event guards its reuse by the next build
+    if (f.staging_cap < trees.size()) {
+        if (f.staging) (void)hipHostFree(f.staging);
+        f.staging_cap = trees.size() * 2;
+        SSDR_HIP(hipHostMalloc(&f.staging, sizeof(KdTreeDesc) * f.staging_cap));
+    }
+    if (!f.staging_ev) SSDR_HIP(hipEventCreate(&f.staging_ev)); else SSDR_HIP(hipEventSynchronize(f.staging_ev));
+    memcpy(f.staging, trees.data(), sizeof(KdTreeDesc) * trees.size());
+    SSDR_HIP(hipMemcpyAsync(f.desc.p, f.staging, sizeof(KdTreeDesc) * trees.size(), hipMemcpyHostToDevice, s));
+    SSDR_HIP(hipEventRecord(f.staging_ev, s));
+    SSDR_HIP(hipMemsetAsync(f.counters.p, 0, 4 * (CTR_QUEUE0 + MAX_LEVELS + 8), s));
+    ForestPtrs p = ptrs(f);
+    hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(BS), 0, s, p);
+    const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
+    for (int level = 0; level < MAX_LEVELS; ++level)
+        hipLaunchKernelGGL(kd_split_kernel, dim3(grid), dim3(BS), 0, s, p, level);
+    int maxn = 0; for (auto& t : trees) maxn = std::max(maxn, t.n);
+    dim3 g((unsigned)std::max(1, std::min((maxn + 255) / 256, 64)), (unsigned)std::min(f.ntrees, 65535));
+    hipLaunchKernelGGL(kd_sort_points_kernel, g, dim3(256), 0, s, p, f.ntrees);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, size_t q_stride, int nq, int K,
+              int qorder_tree0, void* d_out, bool out_i64, size_t out_stride, hipStream_t s) {
+    if (ntrees <= 0 || nq <= 0 || K <= 0) return SSDR_OK;
+    if (K > 256) { set_error("K=%d > 256 is not supported", K); return SSDR_ERR_UNSUPPORTED; }
+    ForestPtrs p = ptrs(f);
+    SearchArgs a{p.desc, p.vind, p.sorted, p.node_a, p.node_b, tree0, d_queries, q_stride, nq, qorder_tree0, d_out, out_stride, p.ctr};
+    dim3 grid((unsigned)((nq + 255) / 256), (unsigned)ntrees);
+    if (K == 16) {
+        if (out_i64) hipLaunchKernelGGL((kd_search_kernel<16, int64_t>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((kd_search_kernel<16, int32_t>), grid, dim3(256), 0, s, a);
+    } else if (K == 1) {
+        if (out_i64) hipLaunchKernelGGL((kd_search_kernel<1, int64_t>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((kd_search_kernel<1, int32_t>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 g2((unsigned)((nq + 63) / 64), (unsigned)ntrees);
+        size_t lds = (size_t)64 * K * 8;
+        if (out_i64) hipLaunchKernelGGL((kd_search_any_kernel<int64_t>), g2, dim3(64), lds, s, a, K);
+        else hipLaunchKernelGGL((kd_search_any_kernel<int32_t>), g2, dim3(64), lds, s, a, K);
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int kd_check(const KdForest& f, hipStream_t s) {
+    if (!f.counters.p) return SSDR_OK;
+    int h[3] = {0, 0, 0};
+    SSDR_HIP(hipMemcpyAsync(h, f.counters.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    SSDR_HIP(hipStreamSynchronize(s));
+    if (h[CTR_STATUS]) {
+        set_error("kd-tree device status 0x%x (1=queue overflow 2=node overflow 4=tree deeper than %d levels), depth=%d",
+                  h[CTR_STATUS], MAX_LEVELS, h[CTR_DEPTH]);
+        return SSDR_ERR_INTERNAL;
+    }
+    return SSDR_OK;
+}
+
+}  // namespace ssdr

@@ -1,0 +1,185 @@
+// Stable LSD radix sort of (u64 key, u32 value) pairs for gfx950, 8 bits per pass.
+//
+// Used by the voxel-grid subsampling (sort points by voxel key, ties keep input order) and by the
+// emulation of the reference's output order.  HBM-bound integer work: per executed pass each pair is
+// read twice and written once (histogram, scatter).  Passes whose digit is identical in every key are
+// skipped on the device without a host round-trip: a pre-pass accumulates AND / OR of all keys and
+// every kernel of pass p derives "executed?" and its ping-pong parity from those two words.
+//
+// Stability inside a 2048-pair tile comes from wave-level digit matching: 8 ballots give every lane
+// the mask of lanes holding the same digit; its rank is the popcount of the lower lanes, and per-wave
+// digit counts are combined through LDS in wave order.
+#include "ssdr_internal.hpp"
+
+namespace ssdr {
+namespace {
+
+constexpr int RS_BS = 256, RS_ITEMS = 8, RS_TILE = RS_BS * RS_ITEMS;
+
+struct SortPtrs {
+    uint64_t* k[2]; uint32_t* v[2];
+    unsigned long long* andor;   // [0] = AND of keys, [1] = OR of keys
+    unsigned* hist;              // [256][nblocks_max]
+    const int* d_n; int n_host; int nblocks_max;
+};
+
+__device__ __forceinline__ int sort_n(const SortPtrs& s) { return s.d_n ? min(*s.d_n, s.n_host) : s.n_host; }
+__device__ __forceinline__ bool pass_runs(const SortPtrs& s, int p, int& parity) {
+    const unsigned long long diff = s.andor[0] ^ s.andor[1];
+    int par = 0;
+    for (int q = 0; q < p; ++q) par ^= ((diff >> (8 * q)) & 0xffull) != 0;
+    parity = par;
+    return ((diff >> (8 * p)) & 0xffull) != 0;
+}
+
+__global__ __launch_bounds__(RS_BS) void rs_andor_init(SortPtrs s) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { s.andor[0] = ~0ull; s.andor[1] = 0ull; }
+}
+
+__global__ __launch_bounds__(RS_BS) void rs_andor(SortPtrs s) {
+    const int n = sort_n(s);
+    unsigned long long a = ~0ull, o = 0ull;
+    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { unsigned long long k = s.k[0][i]; a &= k; o |= k; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)a, off), hi = __shfl_xor((unsigned)(a >> 32), off);
+        a &= ((unsigned long long)hi << 32) | lo;
+        lo = __shfl_xor((unsigned)o, off); hi = __shfl_xor((unsigned)(o >> 32), off);
+        o |= ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAnd(&s.andor[0], a); atomicOr(&s.andor[1], o); }
+}
+
+__global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
+    __shared__ unsigned h[256];
+    int par; if (!pass_runs(s, p, par)) return;
+    const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
+    const uint64_t* K = s.k[par];
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            int i = b * RS_TILE + j * RS_BS + threadIdx.x;
+            if (i < n) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
+        }
+        __syncthreads();
+        s.hist[(size_t)threadIdx.x * s.nblocks_max + b] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// exclusive scan of hist[d][b] in (d, b) order, one workgroup
+__global__ __launch_bounds__(1024) void rs_scan(SortPtrs s, int p) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    int par; if (!pass_runs(s, p, par)) return;
+    const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
+    const int total = 256 * nb, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        const int e = base + tid;
+        size_t addr = 0; unsigned x = 0;
+        if (e < total) { addr = (size_t)(e / nb) * s.nblocks_max + (e % nb); x = s.hist[addr]; }
+        unsigned incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        unsigned wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { unsigned c = wsum[w]; if (w < wid) wbase += c; tot += c; }
+        const unsigned carry = carry_s;
+        if (e < total) s.hist[addr] = carry + wbase + incl - x;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
+    __shared__ unsigned s_cnt[RS_BS / 64][256];
+    __shared__ unsigned s_run[256];
+    int par; if (!pass_runs(s, p, par)) return;
+    const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
+    const uint64_t* K = s.k[par]; const uint32_t* V = s.v[par];
+    uint64_t* KO = s.k[par ^ 1]; uint32_t* VO = s.v[par ^ 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        s_run[tid] = s.hist[(size_t)tid * s.nblocks_max + b];
+#pragma unroll
+        for (int w = 0; w < RS_BS / 64; ++w) s_cnt[w][tid] = 0;
+        __syncthreads();
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const int i = b * RS_TILE + j * RS_BS + tid;
+            const bool valid = i < n;
+            uint64_t key = 0; uint32_t val = 0; unsigned d = 0;
+            if (valid) { key = K[i]; val = V[i]; d = (unsigned)((key >> (8 * p)) & 0xff); }
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (d >> bit) & 1;
+                const unsigned long long bal = __ballot(valid && one);
+                m &= one ? bal : ~bal;
+            }
+            const int rank = __popcll(m & lt);
+            if (valid && rank == 0) s_cnt[wid][d] = (unsigned)__popcll(m);
+            __syncthreads();
+            if (valid) {
+                unsigned pos = s_run[d] + rank;
+                for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
+                KO[pos] = key; VO[pos] = val;
+            }
+            __syncthreads();
+            {
+                unsigned t = 0;
+#pragma unroll
+                for (int w = 0; w < RS_BS / 64; ++w) { t += s_cnt[w][tid]; s_cnt[w][tid] = 0; }
+                s_run[tid] += t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// after the last pass the result may sit in buffer 1: bring it home to buffer 0
+__global__ __launch_bounds__(RS_BS) void rs_finish(SortPtrs s) {
+    const unsigned long long diff = s.andor[0] ^ s.andor[1];
+    int par = 0;
+    for (int q = 0; q < 8; ++q) par ^= ((diff >> (8 * q)) & 0xffull) != 0;
+    if (!par) return;
+    const int n = sort_n(s);
+    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { s.k[0][i] = s.k[1][i]; s.v[0][i] = s.v[1][i]; }
+}
+
+}  // namespace
+
+int RadixSorter::reserve(size_t n_max) {
+    nblocks_max = (int)((n_max + RS_TILE - 1) / RS_TILE) + 1;
+    SSDR_TRY(k1.reserve(8 * n_max + 16)); SSDR_TRY(v1.reserve(4 * n_max + 16));
+    SSDR_TRY(hist.reserve(4 * 256 * (size_t)nblocks_max)); SSDR_TRY(andor.reserve(16));
+    return SSDR_OK;
+}
+
+int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t st) {
+    if (n_host <= 0) return SSDR_OK;
+    SSDR_TRY(reserve((size_t)n_host));
+    SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>();
+    s.andor = andor.as<unsigned long long>(); s.hist = hist.as<unsigned>(); s.d_n = d_n; s.n_host = n_host; s.nblocks_max = nblocks_max;
+    const int nb = (n_host + RS_TILE - 1) / RS_TILE;
+    const int g = std::max(1, std::min(nb, ctx().num_cu * 8));
+    hipLaunchKernelGGL(rs_andor_init, dim3(1), dim3(RS_BS), 0, st, s);
+    hipLaunchKernelGGL(rs_andor, dim3(g), dim3(RS_BS), 0, st, s);
+    for (int p = 0; p < 8; ++p) {
+        hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
+        hipLaunchKernelGGL(rs_scan, dim3(1), dim3(1024), 0, st, s, p);
+        hipLaunchKernelGGL(rs_scatter, dim3(g), dim3(RS_BS), 0, st, s, p);
+    }
+    hipLaunchKernelGGL(rs_finish, dim3(g), dim3(RS_BS), 0, st, s);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+}  // namespace ssdr

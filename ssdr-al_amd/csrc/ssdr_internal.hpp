@@ -1,0 +1,95 @@
+// Internal helpers shared by the HIP translation units of libssdr_al.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/ssdr_al.h"
+
+#ifndef HIPEMU
+#define SSDR_DYN_SHARED(type, name) extern __shared__ type name[]
+#endif
+
+namespace ssdr {
+
+void set_error(const char* fmt, ...);
+
+#define SSDR_HIP(call)                                                                        \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            ssdr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return SSDR_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define SSDR_TRY(call)                  \
+    do {                                \
+        int s__ = (call);               \
+        if (s__ != SSDR_OK) return s__; \
+    } while (0)
+
+// A named, grow-only device buffer.  Workspaces are kept across calls so steady-state calls do not
+// touch hipMalloc (Guideline 9: no allocation in the launch path once warm).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    int num_cu = 256;
+};
+Context& ctx();
+int ensure_init();
+inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
+
+// ---- radix sort (radix_sort.hip) ----------------------------------------------------------------
+// Stable sort of (u64 key, u32 value) pairs, in place (result in keys/vals).  d_n (optional) is a device
+// int holding the live count (<= n_host); n_host sizes the launches.
+struct RadixSorter {
+    DevBuf k1, v1, hist, andor;
+    int nblocks_max = 0;
+    int reserve(size_t n_max);
+    int sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t s);
+};
+
+// ---- kd-tree forest (kdtree.hip) ----------------------------------------------------------------
+struct KdTreeDesc {      // one independent support set
+    const float* pts;    // device pointer, n x 3 row-major
+    int n;
+    int voff;            // offset of this tree's slice in vind / sorted
+    int root;            // node id of the root
+    float lo[3], hi[3];  // tight root box
+};
+
+struct KdForest {
+    DevBuf desc, vind, sorted, node_a, node_b, node_box, node_tree, queue, counters, tmp, val;
+    KdTreeDesc* staging = nullptr; size_t staging_cap = 0; hipEvent_t staging_ev = nullptr;
+    int ntrees = 0;
+    int total_pts = 0;
+    int node_cap = 0;
+    int queue_cap = 0;
+};
+
+// Builds `ntrees` trees described by host descriptors (pts/n filled in; voff/root/lo/hi are computed).
+int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees, hipStream_t s);
+// For every tree t in [tree0, tree0+ntrees): queries q = d_queries + (t-tree0)*q_stride floats, nq each.
+// qorder_tree >= 0: visit queries in the vind order of forest tree (qorder_tree0 + (t-tree0)) (must have n == nq).
+// out: int32 or int64 [ntrees][nq][K].
+int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, size_t q_stride, int nq, int K,
+              int qorder_tree0, void* d_out, bool out_i64, size_t out_stride, hipStream_t s);
+// Reads back the device status flags of the forest (synchronises the stream).
+int kd_check(const KdForest& f, hipStream_t s);
+
+}  // namespace ssdr

@@ -1,0 +1,295 @@
+// Voxel-grid barycentre subsampling for gfx950.
+//
+// Reference: S3/utils/cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:5-106 — one
+// thread walks the cloud and accumulates into an std::unordered_map keyed by the voxel index.  What makes
+// the result reproducible bit for bit is (a) the fp32 key arithmetic (:27-31, :53-56), (b) that every
+// voxel's sums are taken in *input order* (:59-70) and (c) the finalisation `sum * (float)(1.0/count)` for
+// positions but `sum / (float)count` for features (:87-95).  The map itself is irrelevant, so here:
+//
+//   keys     one pass computes the size_t voxel key of every point (same fp32 ops, contraction off)
+//   sort     stable radix sort of (key, point index): members of a voxel become contiguous and stay in
+//            input order (radix_sort.hip)
+//   heads    ballot + prefix-sum compaction of segment heads -> M voxels, seg_start[M+1]
+//   reduce   one lane per voxel adds its members sequentially (the order the reference adds them in),
+//            and replays the label histogram's first-maximum rule (:97-101), including the iteration
+//            order of the reference's per-voxel unordered_map<int,int> (13 -> 29 buckets, most recently
+//            first-seen label first)
+//   order    SSDR_ORDER_KEY: rows by ascending key.  SSDR_ORDER_REFERENCE: rows permuted into the
+//            iteration order of the reference's unordered_map<size_t,...> (subsample_order.hip).
+#include "ssdr_internal.hpp"
+#include "block_prims.hpp"
+
+namespace ssdr {
+namespace {
+
+constexpr int LAB_CAP = 29;
+
+struct GsParams {
+    float org[3]; float dl;
+    unsigned long long nx, ny;
+    int m;            // number of voxels
+    int status;       // 1 = more than LAB_CAP distinct labels in one voxel
+};
+
+__global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict__ P, int n, float* partial) {
+    __shared__ float s_mm[(BS / 64) * 6];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { float v = P[3 * (size_t)i + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+    }
+    block_minmax3(mn, mx, s_mm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { partial[6 * blockIdx.x + d] = mn[d]; partial[6 * blockIdx.x + 3 + d] = mx[d]; }
+    }
+}
+
+__global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts, float dl, GsParams* prm) {
+    __shared__ float s_mm[(BS / 64) * 6];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = threadIdx.x; i < nparts; i += BS) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], partial[6 * i + d]); mx[d] = fmaxf(mx[d], partial[6 * i + 3 + d]); }
+    }
+    block_minmax3(mn, mx, s_mm);
+    if (threadIdx.x == 0) {
+        // grid_subsampling.cpp:27-31
+        const float inv = 1 / dl;
+        float org[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { org[d] = floorf(mn[d] * inv) * dl; prm->org[d] = org[d]; }
+        prm->dl = dl;
+        prm->nx = (unsigned long long)(long long)floorf((mx[0] - org[0]) / dl) + 1ull;
+        prm->ny = (unsigned long long)(long long)floorf((mx[1] - org[1]) / dl) + 1ull;
+        prm->m = 0; prm->status = 0;
+    }
+}
+
+__global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals) {
+    const float ox = prm->org[0], oy = prm->org[1], oz = prm->org[2], dl = prm->dl;
+    const unsigned long long nx = prm->nx, ny = prm->ny;
+    for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
+        // grid_subsampling.cpp:53-56 (size_t arithmetic wraps)
+        const unsigned long long ix = (unsigned long long)(long long)floorf((P[3 * (size_t)i] - ox) / dl);
+        const unsigned long long iy = (unsigned long long)(long long)floorf((P[3 * (size_t)i + 1] - oy) / dl);
+        const unsigned long long iz = (unsigned long long)(long long)floorf((P[3 * (size_t)i + 2] - oz) / dl);
+        keys[i] = ix + nx * iy + nx * ny * iz;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// ---- segment heads: 3-step compaction -------------------------------------------------------------
+__global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict__ ks, int n, int* bsum) {
+    __shared__ int s_sum[(BS / 64) * 2];
+    const int base = blockIdx.x * CHUNK;
+    int c = 0, z = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { int i = base + u * BS + threadIdx.x; if (i < n) c += (i == 0) || (ks[i] != ks[i - 1]); }
+    block_sum2(c, z, s_sum);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParams* prm, int* seg_start, int n) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int e = base + tid;
+        const int x = e < nb ? bsum[e] : 0;
+        int incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { int c = wsum[w]; if (w < wid) wbase += c; tot += c; }
+        const int carry = carry_s;
+        if (e < nb) bsum[e] = carry + wbase + incl - x;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) { prm->m = carry_s; seg_start[carry_s] = n; }
+}
+
+__global__ __launch_bounds__(BS) void gs_heads_write(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) {
+    __shared__ int s_w[2][U][BS / 64];
+    const int base = blockIdx.x * CHUNK, off = bsum[blockIdx.x];
+    const int hi = min(n, base + CHUNK);
+    block_compact(base, hi, [&](int i) { return (i == 0) || (ks[i] != ks[i - 1]); },
+                  [&](int k, int i) { seg_start[off + k] = i; }, s_w);
+}
+
+// ---- per-voxel reduction ----------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lab_bucket(int l, unsigned nb) { return (unsigned)((unsigned long long)(long long)l % nb); }
+
+// Majority label of one voxel column with the reference's tie rule (grid_subsampling.cpp:97-101 over
+// grid_subsampling.h:19,46-49): the histogram is an unordered_map<int,int>; std::max_element returns the
+// first maximum in *iteration order*.  The list below is kept in that order.
+__device__ int voxel_label(const int* __restrict__ cls, int ldim, int col, const uint32_t* __restrict__ vs, int s, int e, int* status) {
+    int lab[LAB_CAP], cnt[LAB_CAP];
+    int nl = 0; unsigned nbk = 13;
+    for (int j = s; j < e; ++j) {
+        const int L = cls[(size_t)vs[j] * ldim + col];
+        int t = 0;
+        for (; t < nl; ++t) if (lab[t] == L) { cnt[t]++; break; }
+        if (t < nl) continue;
+        if (nl == 13 && nbk == 13) {
+            // rehash 13 -> 29 before the 14th insert: runs by first occurrence, members in list order, all reversed
+            int tl[13], tc[13]; unsigned used = 0; int w = 0;
+            for (int i = 0; i < 13; ++i) if (!((used >> i) & 1)) {
+                const unsigned b = lab_bucket(lab[i], 29);
+                for (int k = i; k < 13; ++k) if (!((used >> k) & 1) && lab_bucket(lab[k], 29) == b) { used |= 1u << k; tl[w] = lab[k]; tc[w] = cnt[k]; ++w; }
+            }
+            for (int i = 0; i < 13; ++i) { lab[i] = tl[12 - i]; cnt[i] = tc[12 - i]; }
+            nbk = 29;
+        }
+        if (nl == LAB_CAP) { atomicOr(status, 1); break; }
+        const unsigned b = lab_bucket(L, nbk);
+        int pos = 0;
+        for (int i = 0; i < nl; ++i) if (lab_bucket(lab[i], nbk) == b) { pos = i; break; }
+        for (int i = nl; i > pos; --i) { lab[i] = lab[i - 1]; cnt[i] = cnt[i - 1]; }
+        lab[pos] = L; cnt[pos] = 1; ++nl;
+    }
+    int best = 0;
+    for (int t = 1; t < nl; ++t) if (cnt[best] < cnt[t]) best = t;
+    return nl ? lab[best] : 0;
+}
+
+__global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, const float* __restrict__ F, int fdim,
+                                                const int* __restrict__ cls, int ldim,
+                                                const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
+                                                const int* __restrict__ row_of_voxel,
+                                                float* out_p, float* out_f, int* out_c, long long* out_m, uint64_t* out_first, const uint64_t* ks) {
+    const int m = prm->m;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out_m) *out_m = m;
+    for (int v = blockIdx.x * BS + threadIdx.x; v < m; v += gridDim.x * BS) {
+        const int s = seg_start[v], e = seg_start[v + 1];
+        const int count = e - s;
+        const int row = row_of_voxel ? row_of_voxel[v] : v;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = s; j < e; ++j) { const size_t id = vs[j]; sx += P[3 * id]; sy += P[3 * id + 1]; sz += P[3 * id + 2]; }
+        const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
+        out_p[3 * (size_t)row] = sx * a; out_p[3 * (size_t)row + 1] = sy * a; out_p[3 * (size_t)row + 2] = sz * a;
+        if (F) {
+            const float c = (float)count;
+            for (int f0 = 0; f0 < fdim; f0 += 4) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int j = s; j < e; ++j) {
+                    const size_t id = vs[j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (f0 + k < fdim) acc[k] += F[id * fdim + f0 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (f0 + k < fdim) out_f[(size_t)row * fdim + f0 + k] = acc[k] / c;   // :90-94
+            }
+        }
+        if (cls) for (int col = 0; col < ldim; ++col) out_c[(size_t)row * ldim + col] = voxel_label(cls, ldim, col, vs, s, e, &prm->status);
+        if (out_first) out_first[v] = ks[s];
+    }
+}
+
+struct GsState {
+    RadixSorter sorter;
+    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row;
+    size_t last_m = 0, last_fdim = 0, last_ldim = 0;
+};
+GsState& gs() { static GsState s; return s; }
+
+}  // namespace
+
+int subsample_order_reference(const uint64_t* d_ks, const uint32_t* d_vs, const int* d_seg_start, const int* d_m, int n_host,
+                              int* d_row_of_voxel, hipStream_t s);
+
+int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t fdim, const int32_t* d_c, size_t ldim, float dl,
+                          int order, float* d_op, float* d_of, int32_t* d_oc, int64_t* d_om, hipStream_t s) {
+    GsState& S = gs();
+    const int ni = (int)n;
+    const int gmm = std::max(1, std::min((ni + BS - 1) / BS, 1024));
+    const int nb = (ni + CHUNK - 1) / CHUNK;
+    SSDR_TRY(S.keys.reserve(8 * n + 16)); SSDR_TRY(S.vals.reserve(4 * n + 16));
+    SSDR_TRY(S.partial.reserve(24 * 1024)); SSDR_TRY(S.params.reserve(sizeof(GsParams)));
+    SSDR_TRY(S.bsum.reserve(4 * (size_t)nb + 16)); SSDR_TRY(S.seg.reserve(4 * (n + 2)));
+    GsParams* prm = S.params.as<GsParams>();
+    hipLaunchKernelGGL(gs_minmax_partial, dim3(gmm), dim3(BS), 0, s, d_p, ni, S.partial.as<float>());
+    hipLaunchKernelGGL(gs_params, dim3(1), dim3(BS), 0, s, S.partial.as<float>(), gmm, dl, prm);
+    const int g = std::max(1, std::min((ni + BS - 1) / BS, ctx().num_cu * 16));
+    hipLaunchKernelGGL(gs_keys, dim3(g), dim3(BS), 0, s, d_p, ni, prm, S.keys.as<uint64_t>(), S.vals.as<uint32_t>());
+    SSDR_TRY(S.sorter.sort(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), ni, nullptr, s));
+    hipLaunchKernelGGL(gs_heads_count, dim3(nb), dim3(BS), 0, s, S.keys.as<uint64_t>(), ni, S.bsum.as<int>());
+    hipLaunchKernelGGL(gs_heads_scan, dim3(1), dim3(1024), 0, s, S.bsum.as<int>(), nb, prm, S.seg.as<int>(), ni);
+    hipLaunchKernelGGL(gs_heads_write, dim3(nb), dim3(BS), 0, s, S.keys.as<uint64_t>(), ni, S.bsum.as<int>(), S.seg.as<int>());
+    const int* row = nullptr;
+    if (order == SSDR_ORDER_REFERENCE) {
+        SSDR_TRY(S.row.reserve(4 * n + 16));
+        SSDR_TRY(subsample_order_reference(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), S.seg.as<int>(), &prm->m, ni, S.row.as<int>(), s));
+        row = S.row.as<int>();
+    }
+    hipLaunchKernelGGL(gs_reduce, dim3(g), dim3(BS), 0, s, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
+                       row, d_op, d_of, d_oc, (long long*)d_om, (uint64_t*)nullptr, S.keys.as<uint64_t>());
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+}  // namespace ssdr
+
+using namespace ssdr;
+
+extern "C" {
+
+int ssdr_grid_subsample_dev(const float* d_points, size_t n, const float* d_features, size_t fdim, const int32_t* d_classes,
+                            size_t ldim, float sampleDl, int order, float* d_out_points, float* d_out_features,
+                            int32_t* d_out_classes, int64_t* d_out_m, void* stream) {
+    if (!d_points || !d_out_points || n == 0 || n > 0x3fffffff) { set_error("grid_subsample: bad points / n"); return n == 0 ? SSDR_ERR_EMPTY : SSDR_ERR_INVALID; }
+    if (!(sampleDl > 0.f)) { set_error("grid_subsample: sampleDl must be > 0"); return SSDR_ERR_INVALID; }
+    if (d_features && (!fdim || !d_out_features)) { set_error("grid_subsample: features given without fdim / output"); return SSDR_ERR_INVALID; }
+    if (d_classes && (!ldim || !d_out_classes)) { set_error("grid_subsample: classes given without ldim / output"); return SSDR_ERR_INVALID; }
+    if (order != SSDR_ORDER_REFERENCE && order != SSDR_ORDER_KEY) { set_error("grid_subsample: unknown order %d", order); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    return grid_subsample_device(d_points, n, d_features, d_features ? fdim : 0, d_classes, d_classes ? ldim : 0, sampleDl, order,
+                                 d_out_points, d_out_features, d_out_classes, d_out_m, pick_stream(stream));
+}
+
+int ssdr_grid_subsample(const float* points, size_t n, const float* features, size_t fdim, const int32_t* classes, size_t ldim,
+                        float sampleDl, int order, size_t* out_m) {
+    if (!points || !out_m) { set_error("grid_subsample: NULL argument"); return SSDR_ERR_INVALID; }
+    if (n == 0) { set_error("Error"); return SSDR_ERR_EMPTY; }
+    SSDR_TRY(ensure_init());
+    GsState& S = gs(); Context& c = ctx(); hipStream_t s = c.stream;
+    if (!features) fdim = 0;
+    if (!classes) ldim = 0;
+    SSDR_TRY(S.in_p.reserve(12 * n)); SSDR_TRY(S.out_p.reserve(12 * n)); SSDR_TRY(S.out_m.reserve(16));
+    SSDR_HIP(hipMemcpyAsync(S.in_p.p, points, 12 * n, hipMemcpyHostToDevice, s));
+    if (fdim) { SSDR_TRY(S.in_f.reserve(4 * n * fdim)); SSDR_TRY(S.out_f.reserve(4 * n * fdim)); SSDR_HIP(hipMemcpyAsync(S.in_f.p, features, 4 * n * fdim, hipMemcpyHostToDevice, s)); }
+    if (ldim) { SSDR_TRY(S.in_c.reserve(4 * n * ldim)); SSDR_TRY(S.out_c.reserve(4 * n * ldim)); SSDR_HIP(hipMemcpyAsync(S.in_c.p, classes, 4 * n * ldim, hipMemcpyHostToDevice, s)); }
+    SSDR_HIP(hipEventRecord(c.ev0, s));
+    SSDR_TRY(ssdr_grid_subsample_dev(S.in_p.as<float>(), n, fdim ? S.in_f.as<float>() : nullptr, fdim, ldim ? S.in_c.as<int32_t>() : nullptr, ldim,
+                                     sampleDl, order, S.out_p.as<float>(), fdim ? S.out_f.as<float>() : nullptr,
+                                     ldim ? S.out_c.as<int32_t>() : nullptr, S.out_m.as<int64_t>(), s));
+    SSDR_HIP(hipEventRecord(c.ev1, s));
+    GsParams h;
+    SSDR_HIP(hipMemcpyAsync(&h, S.params.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    SSDR_HIP(hipStreamSynchronize(s));
+    SSDR_HIP(hipEventElapsedTime(&c.last_ms, c.ev0, c.ev1));
+    if (h.status) { set_error("grid_subsample: a voxel holds more than %d distinct labels in one column (unsupported)", LAB_CAP); return SSDR_ERR_UNSUPPORTED; }
+    S.last_m = (size_t)h.m; S.last_fdim = fdim; S.last_ldim = ldim;
+    *out_m = S.last_m;
+    if (S.last_m == 0) { set_error("Error"); return SSDR_ERR_EMPTY; }
+    return SSDR_OK;
+}
+
+int ssdr_grid_subsample_fetch(float* out_points, float* out_features, int32_t* out_classes) {
+    SSDR_TRY(ensure_init());
+    GsState& S = gs(); hipStream_t s = ctx().stream;
+    if (out_points) SSDR_HIP(hipMemcpyAsync(out_points, S.out_p.p, 12 * S.last_m, hipMemcpyDeviceToHost, s));
+    if (out_features && S.last_fdim) SSDR_HIP(hipMemcpyAsync(out_features, S.out_f.p, 4 * S.last_m * S.last_fdim, hipMemcpyDeviceToHost, s));
+    if (out_classes && S.last_ldim) SSDR_HIP(hipMemcpyAsync(out_classes, S.out_c.p, 4 * S.last_m * S.last_ldim, hipMemcpyDeviceToHost, s));
+    SSDR_HIP(hipStreamSynchronize(s));
+    return SSDR_OK;
+}
+
+}

@@ -1,0 +1,79 @@
+"""ctypes binding of libssdr_al.so (C ABI: include/ssdr_al.h).
+
+The library is the gfx950 HIP build made by ``ssdr-al_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no CPU fallback: if the shared object is missing, or no HIP device is present, every op raises.
+``SSDR_AL_LIBRARY`` may point at another build of the same ABI (the CPU logic-test build used by the
+``-m "not gpu"`` tests sets it explicitly); nothing selects such a build implicitly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_PATH = os.path.join(_PKG, "libssdr_al.so")
+
+SSDR_OK = 0
+ORDER_REFERENCE, ORDER_KEY = 0, 1
+
+_lib = None
+_forced_path = None
+
+
+class SsdrError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("libssdr_al status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib_path():
+    return _forced_path or os.environ.get("SSDR_AL_LIBRARY", DEFAULT_PATH)
+
+
+def use(path):
+    """Bind to another build of the same C ABI (tests switch between the CPU logic build and the gfx950
+    build); ``None`` returns to the default resolution."""
+    global _lib, _forced_path
+    _forced_path = path
+    _lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise SsdrError(-1, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        L = C.CDLL(path)
+        vp, sz, f32, i32 = C.c_void_p, C.c_size_t, C.c_float, C.c_int
+        L.ssdr_version.restype = C.c_char_p
+        L.ssdr_last_error.restype = C.c_char_p
+        L.ssdr_last_gpu_ms.restype = C.c_float
+        L.ssdr_init.argtypes = [i32]
+        L.ssdr_stream_sync.argtypes = [vp]
+        L.ssdr_knn.argtypes = [vp, sz, sz, vp, sz, sz, vp]
+        L.ssdr_knn_batch.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
+        L.ssdr_knn_batch_i32.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
+        L.ssdr_knn_batch_dev.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp, vp]
+        L.ssdr_knn_pyramid.argtypes = [vp, sz, sz, sz, vp, sz, vp, vp, vp]
+        L.ssdr_knn_pyramid_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, vp, vp, vp]
+        L.ssdr_grid_subsample.argtypes = [vp, sz, vp, sz, vp, sz, f32, i32, C.POINTER(sz)]
+        L.ssdr_grid_subsample_fetch.argtypes = [vp, vp, vp]
+        L.ssdr_grid_subsample_dev.argtypes = [vp, sz, vp, sz, vp, sz, f32, i32, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != SSDR_OK:
+        raise SsdrError(status, lib().ssdr_last_error().decode())
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def last_gpu_ms():
+    return float(lib().ssdr_last_gpu_ms())

@@ -1,0 +1,224 @@
+// TEST INFRASTRUCTURE ONLY — a minimal CPU stand-in for <hip/hip_runtime.h>.
+//
+// The container the kernels are written in has no GPU, so the HIP sources under ssdr-al_amd/csrc are
+// additionally compiled with g++ against this header into tests/hipemu/libssdr_al_emu.so and the
+// kernel *logic* (indices, barriers, wave ballots / shuffles, atomics) is exercised by the
+// `-m "not gpu"` tests.  It is never shipped, never loaded by the product loader, and proves nothing
+// about performance or about the memory model; the `-m gpu` tests run the real gfx950 build.
+//
+// Execution model: each workgroup runs as `blockDim` ucontext fibers on one OS thread (workgroups are
+// spread over OpenMP threads).  A fiber runs until it reaches __syncthreads() or a wave-level
+// operation (__ballot, __shfl*); a wave operation completes once every unfinished lane of that
+// 64-lane wave is blocked, with the lanes blocked at the operation as its active set; a barrier
+// completes once every unfinished fiber of the workgroup waits at it.
+#pragma once
+#include <ucontext.h>
+#include <time.h>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define HIPEMU 1
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint3e { unsigned x, y, z; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+static inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }
+static inline int2 make_int2(int a, int b) { return int2{a, b}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
+
+namespace hipemu {
+enum { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct Fiber { ucontext_t ctx; char* stack = nullptr; int state = READY; uint3e tid; int lane, wave, op; };
+struct WaveX { uint64_t val[64], snap[64]; uint64_t snap_mask; };
+struct BlockState {
+    std::vector<Fiber> fibers; std::vector<WaveX> waves; ucontext_t sched; Fiber* cur = nullptr;
+    const std::function<void()>* body = nullptr;
+};
+inline thread_local BlockState* g_bs = nullptr;
+inline thread_local char* g_dynshared = nullptr;
+constexpr size_t STACK = 256 * 1024;
+
+inline void yield_to_sched() { BlockState* b = g_bs; swapcontext(&b->cur->ctx, &b->sched); }
+inline void fiber_entry() { BlockState* b = g_bs; (*b->body)(); b->cur->state = DONE; swapcontext(&b->cur->ctx, &b->sched); }
+}  // namespace hipemu
+
+inline thread_local uint3e threadIdx, blockIdx;
+inline thread_local dim3 blockDim, gridDim;
+
+namespace hipemu {
+inline void run_block(BlockState& bs, unsigned nthreads, const std::function<void()>& body) {
+    g_bs = &bs; bs.body = &body;
+    if (bs.fibers.size() < nthreads) bs.fibers.resize(nthreads);
+    bs.waves.resize((nthreads + 63) / 64);
+    for (unsigned t = 0; t < nthreads; ++t) {
+        Fiber& f = bs.fibers[t];
+        if (!f.stack) f.stack = (char*)malloc(STACK);
+        f.state = READY; f.lane = t & 63; f.wave = t >> 6;
+        f.tid.x = t % blockDim.x; f.tid.y = (t / blockDim.x) % blockDim.y; f.tid.z = t / (blockDim.x * blockDim.y);
+        getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &bs.sched;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    for (;;) {
+        bool any = false; unsigned done = 0;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            Fiber& f = bs.fibers[t];
+            if (f.state == READY) { bs.cur = &f; threadIdx = f.tid; swapcontext(&bs.sched, &f.ctx); any = true; }
+            if (f.state == DONE) ++done;
+        }
+        if (done == nthreads) break;
+        bool released = false;
+        for (size_t w = 0; w < bs.waves.size(); ++w) {
+            uint64_t mask = 0; int op = -1;
+            unsigned lo = (unsigned)w * 64, hi = std::min(nthreads, lo + 64);
+            for (unsigned t = lo; t < hi; ++t)
+                if (bs.fibers[t].state == WAIT_WAVE) {
+                    mask |= 1ull << (t - lo);
+                    if (op >= 0 && op != bs.fibers[t].op) { fprintf(stderr, "hipemu: lanes of one wave wait at different wave ops\n"); abort(); }
+                    op = bs.fibers[t].op;
+                }
+            if (!mask) continue;
+            memcpy(bs.waves[w].snap, bs.waves[w].val, sizeof(bs.waves[w].val)); bs.waves[w].snap_mask = mask;
+            for (unsigned t = lo; t < hi; ++t) if (bs.fibers[t].state == WAIT_WAVE) bs.fibers[t].state = READY;
+            released = true;
+        }
+        if (released) continue;
+        unsigned waiting = 0;
+        for (unsigned t = 0; t < nthreads; ++t) if (bs.fibers[t].state == WAIT_BLOCK) ++waiting;
+        if (waiting + done == nthreads && waiting) { for (unsigned t = 0; t < nthreads; ++t) if (bs.fibers[t].state == WAIT_BLOCK) bs.fibers[t].state = READY; continue; }
+        if (!any) { fprintf(stderr, "hipemu: deadlock\n"); abort(); }
+    }
+}
+
+inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    const long nblocks = (long)grid.x * grid.y * grid.z; const unsigned nthreads = block.x * block.y * block.z;
+#pragma omp parallel
+    {
+        BlockState bs; std::vector<char> dyn(shmem + 64);
+        g_dynshared = dyn.data(); blockDim = block; gridDim = grid;
+#pragma omp for schedule(dynamic, 1)
+        for (long b = 0; b < nblocks; ++b) {
+            blockIdx.x = (unsigned)(b % grid.x); blockIdx.y = (unsigned)((b / grid.x) % grid.y); blockIdx.z = (unsigned)(b / ((long)grid.x * grid.y));
+            run_block(bs, nthreads, body);
+        }
+        for (auto& f : bs.fibers) free(f.stack);
+    }
+}
+
+inline uint64_t wave_op(uint64_t v, int op) {
+    BlockState* b = g_bs; Fiber* f = b->cur;
+    b->waves[f->wave].val[f->lane] = v; f->op = op; f->state = WAIT_WAVE; yield_to_sched();
+    return 0;
+}
+template <class T> inline uint64_t to_bits(T v) { uint64_t u = 0; memcpy(&u, &v, sizeof(T)); return u; }
+template <class T> inline T from_bits(uint64_t u) { T v; memcpy(&v, &u, sizeof(T)); return v; }
+}  // namespace hipemu
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
+#define SSDR_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(hipemu::g_dynshared)
+
+static inline void __syncthreads() { hipemu::g_bs->cur->state = hipemu::WAIT_BLOCK; hipemu::yield_to_sched(); }
+static inline unsigned long long __ballot(int p) {
+    hipemu::wave_op(p ? 1 : 0, 1);
+    auto& w = hipemu::g_bs->waves[hipemu::g_bs->cur->wave]; unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (((w.snap_mask >> l) & 1) && w.snap[l]) m |= 1ull << l;
+    return m;
+}
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+    hipemu::wave_op(hipemu::to_bits(v), 2);
+    auto* f = hipemu::g_bs->cur; auto& w = hipemu::g_bs->waves[f->wave];
+    int l = (f->lane & ~(width - 1)) + (src & (width - 1));
+    return ((w.snap_mask >> l) & 1) ? hipemu::from_bits<T>(w.snap[l]) : v;
+}
+template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { return __shfl(v, (hipemu::g_bs->cur->lane ^ m) & (width - 1), width); }
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = (hipemu::g_bs->cur->lane & (width - 1)) + (int)d; int self = hipemu::g_bs->cur->lane & (width - 1);
+    return __shfl(v, l < width ? l : self, width);
+}
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int self = hipemu::g_bs->cur->lane & (width - 1); int l = self - (int)d;
+    return __shfl(v, l >= 0 ? l : self, width);
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+static inline double __longlong_as_double(long long i) { double f; memcpy(&f, &i, 8); return f; }
+static inline long long __double_as_longlong(double f) { long long i; memcpy(&i, &f, 8); return i; }
+#define __expf(x) expf(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+using std::max; using std::min;
+
+// workgroups run on several OS threads, so these must be real atomics
+template <class T, class F> static inline T hipemu_rmw(T* p, F f) {
+    T o; __atomic_load(p, &o, __ATOMIC_RELAXED);
+    for (;;) { T n = f(o); if (__atomic_compare_exchange(p, &o, &n, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) return o; }
+}
+template <class T> static inline T atomicAdd(T* p, T v) { return hipemu_rmw(p, [v](T o) { return (T)(o + v); }); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+template <class T> static inline T atomicMax(T* p, T v) { return hipemu_rmw(p, [v](T o) { return v > o ? v : o; }); }
+template <class T> static inline T atomicMin(T* p, T v) { return hipemu_rmw(p, [v](T o) { return v < o ? v : o; }); }
+template <class T> static inline T atomicOr(T* p, T v) { return hipemu_rmw(p, [v](T o) { return (T)(o | v); }); }
+template <class T> static inline T atomicAnd(T* p, T v) { return hipemu_rmw(p, [v](T o) { return (T)(o & v); }); }
+template <class T> static inline T atomicExch(T* p, T v) { return hipemu_rmw(p, [v](T) { return v; }); }
+template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = c; __atomic_compare_exchange(p, &o, &v, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED); return o; }
+static inline void __threadfence() {}
+
+// ---- runtime API (host memory stands in for device memory) --------------------------------------
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = malloc(sizeof(double)); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline double hipemu_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { *(double*)e = hipemu_now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*(double*)b - *(double*)a); return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) memmove((char*)d + r * dp, (const char*)s + r * sp, w);
+    return hipSuccess;
+}

@@ -1,0 +1,111 @@
+"""KNN parity: the HIP kd-tree path through the C ABI against the golden vectors of the reference build and
+against the oracle on fresh inputs.  Bit-exact index equality, ties included."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+KNN_CASES = ["uniform", "room", "lattice", "duplicate_padded", "tiny7", "all_same"]
+
+
+@pytest.mark.parametrize("case", KNN_CASES)
+def test_knn_matches_reference_golden(backend, golden, case):
+    from ssdr_al import knn
+    g = golden("knn_golden.npz")
+    p = g[case + "/pts"]
+    sub = p[: max(1, len(p) // 4)]
+    assert_bits_equal(knn.knn(p, p, 16).astype(np.int32), g[case + "/self16"], "self16")
+    assert_bits_equal(knn.knn(p, p, 1).astype(np.int32), g[case + "/self1"], "self1")
+    assert_bits_equal(knn.knn(p, p, 5).astype(np.int32), g[case + "/self5"], "self5 (generic-K kernel)")
+    assert_bits_equal(knn.knn(sub, p, 1).astype(np.int32), g[case + "/up1"], "up1")
+
+
+def test_knn_batch_matches_reference_golden(backend, golden):
+    from ssdr_al import knn
+    g = golden("knn_golden.npz")
+    out = knn.knn_batch(g["batch/pts"], g["batch/q"], 16, omp=True)
+    assert out.dtype == np.int64 and out.shape == (3, 150, 16)
+    assert_bits_equal(out.astype(np.int32), g["batch/idx16"])
+    assert_bits_equal(knn.knn_batch_i32(g["batch/pts"], g["batch/q"], 16), g["batch/idx16"])
+
+
+def test_pyramid_matches_reference_golden(backend, golden):
+    from ssdr_al import knn
+    g = golden("pyramid_golden.npz")
+    neigh, sub, interp = knn.knn_pyramid(g["xyz"], g["ratios"], 16)
+    for i in range(5):
+        assert_bits_equal(neigh[i], g["neigh%d" % i], "neigh%d" % i)
+        assert_bits_equal(sub[i], g["sub%d" % i], "sub%d" % i)
+        assert_bits_equal(interp[i], g["interp%d" % i], "interp%d" % i)
+
+
+def test_knn_k_larger_than_support(backend, orc):
+    from ssdr_al import knn
+    rng = np.random.default_rng(3)
+    p = rng.random((7, 3), dtype=np.float32)
+    q = rng.random((20, 3), dtype=np.float32)
+    out = knn.knn(p, q, 16)
+    assert_bits_equal(out, orc.knn(p, q, 16))
+    assert (out[:, 7:] == 0).all()          # knn_.cxx:30-31: zero-initialised, never written
+
+
+def test_knn_rejects_unsupported_dim(backend):
+    from ssdr_al import _lib, knn
+    with pytest.raises(_lib.SsdrError) as e:
+        knn.knn(np.zeros((8, 4), np.float32), np.zeros((8, 4), np.float32), 2)
+    assert e.value.status == 5
+
+
+def test_knn_fresh_inputs_against_oracle(backend, orc):
+    from ssdr_al import knn
+    rng = np.random.default_rng(11)
+    n = 3000 if backend == "emu" else 40960
+    p = (rng.random((n, 3), dtype=np.float32) * np.array([8, 6, 3], np.float32)).astype(np.float32)
+    p[: n // 3, 2] = 0
+    p[-n // 5:] = p[: n // 5]                 # padded-by-duplication tile (s3dis_dataset.py:147-150)
+    p = p[rng.permutation(n)][None]
+    assert_bits_equal(knn.knn_batch(p, p, 16), orc.knn_batch(p, p, 16, threads=4))
+    assert_bits_equal(knn.knn_batch(p[:, : n // 4], p, 1), orc.knn_batch(p[:, : n // 4], p, 1, threads=4))
+
+
+@pytest.mark.gpu
+def test_pyramid_full_size_properties():
+    """BASELINE config 2 shape: B=16 tiles of 40960 points.  Size-independent properties + oracle on 2 tiles."""
+    from conftest import GPU_LIB, _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    import oracle
+    from ssdr_al import _lib, knn
+    _lib.use(GPU_LIB)
+    try:
+        rng = np.random.default_rng(5)
+        B, N = 16, 40960
+        xyz = (rng.random((B, N, 3), dtype=np.float32) * np.array([10, 8, 3], np.float32)).astype(np.float32)
+        xyz[:, : N // 2, 2] = 0
+        xyz[3, -5000:] = xyz[3, :5000]
+        neigh, sub, interp = knn.knn_pyramid(xyz, [4, 4, 4, 4, 2], 16)
+        sizes = [40960, 10240, 2560, 640, 160, 80]
+        for i in range(5):
+            assert neigh[i].shape == (B, sizes[i], 16) and interp[i].shape == (B, sizes[i], 1)
+            assert neigh[i].min() >= 0 and neigh[i].max() < sizes[i]
+            assert interp[i].min() >= 0 and interp[i].max() < sizes[i + 1]
+            assert np.array_equal(sub[i], neigh[i][:, : sizes[i + 1]])
+            # ascending distances; the query itself is at distance 0
+            pts = xyz[:, : sizes[i]]
+            d = ((pts[:, :, None, :] - np.take_along_axis(pts[:, None], neigh[i][..., None].astype(np.int64), 2)
+                  if False else 0))
+            b = 3
+            nb = pts[b][neigh[i][b]]
+            dist = ((pts[b][:, None, :] - nb) ** 2).sum(-1)
+            assert (np.diff(dist, axis=1) >= -1e-6).all()
+            assert (dist[:, 0] == 0).all()
+        o = oracle.c()
+        for b in (0, 3):
+            cur = xyz[b:b + 1]
+            for i, r in enumerate([4, 4, 4, 4, 2]):
+                assert_bits_equal(neigh[i][b:b + 1], o.knn_batch(cur, cur, 16).astype(np.int32), "tile %d level %d" % (b, i))
+                s = cur[:, : cur.shape[1] // r]
+                assert_bits_equal(interp[i][b:b + 1], o.knn_batch(s, cur, 1).astype(np.int32))
+                cur = s
+    finally:
+        _lib.use(None)

@@ -1,0 +1,77 @@
+"""Grid-subsampling parity: HIP path through the C ABI / the reference-named module surface against the
+golden vectors of the reference build and the oracle.  Bit-exact rows, reference row order included."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+
+def test_subsample_matches_reference_golden(backend, golden):
+    import cpp_wrappers.cpp_subsampling.grid_subsampling as cpp_subsampling   # helper_tool.py:14
+    g = golden("subsample_golden.npz")
+    assert_bits_equal(cpp_subsampling.compute(g["hand/pts"], sampleDl=1.0), g["hand/out"], "hand order")
+    for nm in ("tieA", "tieB"):
+        out = cpp_subsampling.compute(g[nm + "/pts"], classes=g[nm + "/cls"], sampleDl=1.0)
+        assert_bits_equal(out[1], g[nm + "/out_cls"], nm)
+    p, f, c = cpp_subsampling.compute(g["room/pts"], features=g["room/col"], classes=g["room/lab"], sampleDl=0.04)
+    assert p.dtype == np.float32 and f.dtype == np.float32 and c.dtype == np.int32 and c.ndim == 2
+    assert_bits_equal(p, g["room/out_pts"]); assert_bits_equal(f, g["room/out_col"]); assert_bits_equal(c, g["room/out_lab"])
+    assert_bits_equal(cpp_subsampling.compute(g["one/pts"], sampleDl=0.1), g["one/out"])
+    assert_bits_equal(cpp_subsampling.compute(g["neg/pts"], sampleDl=0.3), g["neg/out"])
+    p, c = cpp_subsampling.compute(g["manylab/pts"], classes=g["manylab/cls"], sampleDl=0.5)
+    assert_bits_equal(p, g["manylab/out_pts"]); assert_bits_equal(c, g["manylab/out_cls"])
+
+
+def test_subsample_interface_errors(backend):
+    """Argument handling of wrapper.cpp:70-190."""
+    import cpp_wrappers.cpp_subsampling.grid_subsampling as cpp_subsampling
+    p = np.zeros((10, 3), np.float32)
+    with pytest.raises(TypeError):
+        cpp_subsampling.compute(p, p)                                   # features are keyword-only ("O|$OOfsi")
+    with pytest.raises(RuntimeError, match="Error parsing method"):
+        cpp_subsampling.compute(p, method="median")
+    with pytest.raises(RuntimeError, match=r"points.shape is not \(N, 3\)"):
+        cpp_subsampling.compute(np.zeros((10, 2), np.float32))
+    with pytest.raises(RuntimeError, match=r"features.shape is not \(N, d\)"):
+        cpp_subsampling.compute(p, features=np.zeros(10, np.float32))
+    with pytest.raises(RuntimeError, match=r"features.shape is not \(N, d\)"):
+        cpp_subsampling.compute(p, features=np.zeros((9, 2), np.float32))
+    with pytest.raises(RuntimeError, match=r"classes.shape is not \(N,\) or \(N, d\)"):
+        cpp_subsampling.compute(p, classes=np.zeros(9, np.int32))
+    with pytest.raises(RuntimeError, match="^Error$"):
+        cpp_subsampling.compute(np.zeros((0, 3), np.float32))
+    out = cpp_subsampling.compute(p + 0.5, sampleDl=1.0, method="voxelcenters")   # accepted, still barycentres
+    assert out.shape == (1, 3)
+
+
+def test_data_processing_facade(backend, orc):
+    """DataProcessing.grid_sub_sampling / knn_search keep their reference signatures (helper_tool.py:173-235)."""
+    from ssdr_al.helper_tool import DataProcessing as DP
+    rng = np.random.default_rng(2)
+    n = 4000
+    xyz = rng.random((n, 3), dtype=np.float32) * 2
+    col = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    lab = rng.integers(0, 13, n).astype(np.uint8)
+    sp, sc, sl = DP.grid_sub_sampling(xyz, col, lab, 0.04)                         # data_prepare_s3dis.py:58
+    ep, ec, el = orc.grid_subsampling(xyz, col.astype(np.float32), lab.astype(np.int32), 0.04)
+    assert_bits_equal(sp, ep); assert_bits_equal(sc, ec); assert_bits_equal(sl, el)
+    assert DP.grid_sub_sampling(xyz, grid_size=0.1).shape[1] == 3
+    idx = DP.knn_search(sp[None, :500], sp[None, :800], 16)
+    assert idx.dtype == np.int32 and idx.shape == (1, 800, 16)
+    assert_bits_equal(idx, orc.knn_batch(sp[None, :500], sp[None, :800], 16).astype(np.int32))
+
+
+def test_subsample_fresh_inputs_against_oracle(backend, orc):
+    from ssdr_al import subsampling
+    rng = np.random.default_rng(13)
+    n = 25000 if backend == "emu" else 1000000
+    pts = (rng.random((n, 3), dtype=np.float32) * np.array([10, 8, 3], np.float32) - np.array([4, 3, 1], np.float32)).astype(np.float32)
+    pts[: n // 2, 2] = np.float32(-1) + rng.normal(0, 0.002, n // 2).astype(np.float32)
+    col = rng.integers(0, 256, (n, 3)).astype(np.float32)
+    lab = rng.integers(0, 13, n).astype(np.int32)
+    dl = 0.06 if backend == "emu" else 0.04
+    for order in ("reference", "key"):
+        got = subsampling.compute(pts, features=col, classes=lab, sampleDl=dl, order=order)
+        exp = orc.grid_subsampling(pts, col, lab, dl, order=order)
+        for x, y in zip(got, exp):
+            assert_bits_equal(x, y, order)
