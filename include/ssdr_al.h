@@ -105,6 +105,30 @@ int ssdr_grid_subsample_dev(const float* d_points, size_t n,
                             float* d_out_points, float* d_out_features, int32_t* d_out_classes,
                             int64_t* d_out_m, void* stream);
 
+/* ---- RandLA-Net inference (replaces the TF1 graph of S3/RandLANet.py:140-180, 505-585 run by
+ *      model.sess.run([prob_logits, last_second_features, ...]) in S3/sampler2.py:598 / :327) ----------
+ * fp32 throughout (exact-f32 MFMA).  Weights are handed over per layer with batch-norm already folded
+ * (W [in,out] row-major, b [out]); the layer table is documented in csrc/randla_model.hip and built from the
+ * reference's variable scopes by ssdr_al/randlanet.py.  Inputs are device pointers:
+ *   d_features [B,N0,in_dim]   d_xyz [B,N0,3] (level i uses the first N_i points, tf_map's prefix sub-sampling)
+ *   d_neigh_idx[i] int32 [B,N_i,16]  (sub_idx[i] is its prefix)   d_interp_idx[i] int32 [B,N_i,1]
+ * Outputs: d_probs [B*N0,C] = softmax(logits) (RandLANet.py:84), d_feat32 [B*N0,32] = last_second_features
+ * (RandLANet.py:45,175). */
+int  ssdr_randla_create(int num_layers, const int32_t* d_out, int k_n, int num_classes, int in_dim, void** handle);
+int  ssdr_randla_num_layers(void* handle);
+int  ssdr_randla_layer_shape(void* handle, int layer, int* in, int* out, int* has_bias);
+int  ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* b);   /* host pointers */
+void ssdr_randla_destroy(void* handle);
+int  ssdr_randla_infer_dev(void* handle, size_t batch_size, size_t npts, const float* d_features, const float* d_xyz,
+                           const int32_t* ratios, int32_t* const* d_neigh_idx, int32_t* const* d_interp_idx,
+                           float* d_probs, float* d_feat32, void* stream);
+
+/* ---- plain device memory for callers without their own allocator (tests, the ctypes mirror) ---------- */
+int ssdr_dev_alloc(size_t bytes, void** d_ptr);
+int ssdr_dev_free(void* d_ptr);
+int ssdr_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
+int ssdr_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

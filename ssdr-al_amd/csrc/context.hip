@@ -64,4 +64,23 @@ int ssdr_stream_sync(void* stream) {
     return SSDR_OK;
 }
 float ssdr_last_gpu_ms(void) { return ssdr::ctx().last_ms; }
+int ssdr_dev_alloc(size_t bytes, void** d_ptr) {
+    if (!d_ptr) { ssdr::set_error("dev_alloc: NULL"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ssdr::ensure_init());
+    SSDR_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return SSDR_OK;
+}
+int ssdr_dev_free(void* d_ptr) { if (d_ptr) SSDR_HIP(hipFree(d_ptr)); return SSDR_OK; }
+int ssdr_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
+    SSDR_TRY(ssdr::ensure_init());
+    SSDR_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ssdr::ctx().stream));
+    SSDR_HIP(hipStreamSynchronize(ssdr::ctx().stream));
+    return SSDR_OK;
+}
+int ssdr_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
+    SSDR_TRY(ssdr::ensure_init());
+    SSDR_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ssdr::ctx().stream));
+    SSDR_HIP(hipStreamSynchronize(ssdr::ctx().stream));
+    return SSDR_OK;
+}
 }

@@ -1,0 +1,333 @@
+// RandLA-Net inference kernels for gfx950 (fp32 data, exact-f32 MFMA v_mfma_f32_16x16x4_f32).
+//
+// Reference network: S3/RandLANet.py:140-180 (inference), :505-585 (dilated_res_block, building_block,
+// relative_pos_encoding, att_pooling, random_sample, nearest_interpolation) over S3/helper_tf_util.py:111-246
+// (1x1 conv + bias + BN + leaky-relu 0.2).  BN is folded into W/b on the host, so every conv is
+// y = act(x W + b).
+//
+//   lfa_att_kernel   the K-expanded part of one building_block half, fused so that no [N,K,d] tensor ever
+//                    reaches HBM: neighbour gather + relative position encoding (:529-535) + LocSE 1x1 conv
+//                    (+ for the second half the LFAmlp2 conv of the *encoded* positions, :523) + concat +
+//                    attention scores (dense d x d, :578) + softmax over the K neighbours (:579) + weighted
+//                    sum (:580-581).  One 16x16 MFMA tile = the 16 neighbours of one point x 16 channels, so
+//                    the softmax over K is a reduction over the 4 accumulator registers and 4 lane groups.
+//   dense_kernel     per-point 1x1 convs as a tiled GEMM with up to two concatenated inputs, the second one
+//                    optionally row-gathered (decoder: concat[skip, nearest_interpolation(feature)], :165-170;
+//                    residual: mlp2(agg) + shortcut(feature) as one GEMM over the stacked weights, :508-512).
+//   gather_max       random_sample (:537-548): gather K rows, max over K.
+//   head_kernel      fc (32 -> C, no BN / no act, :176) + softmax (:84).
+#include "ssdr_internal.hpp"
+#include "randla.hpp"
+
+namespace ssdr {
+
+#ifndef HIPEMU
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#else
+typedef hipemu_f32x4 f32x4;
+static inline f32x4 mfma16(float a, float b, f32x4 c) { return hipemu_mfma_f32_16x16x4f32(a, b, c); }
+#endif
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * 0.2f; }
+
+// ---- dense --------------------------------------------------------------------------------------------
+constexpr int DT = 64, DKC = 32, DAS = DKC + 2, DBS = DT + 16;
+
+__global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
+    __shared__ float As[DT * DAS];
+    __shared__ float Bs[DKC * DBS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = blockIdx.x * DT, col0 = blockIdx.y * DT;
+    const int K = a.k1 + a.k2;
+    // this thread's A row (fixed over the k loop)
+    const int ar = tid >> 2, ak = (tid & 3) * 8;
+    const int grow = row0 + ar;
+    const float* x1r = nullptr; const float* x2r = nullptr;
+    if (grow < a.M) {
+        x1r = a.x1 + (size_t)grow * a.k1;
+        if (a.k2) {
+            size_t r2 = (size_t)grow;
+            if (a.idx2) r2 = (size_t)(grow / a.m_per_batch) * a.x2_rows_per_batch + (size_t)a.idx2[grow];
+            x2r = a.x2 + r2 * a.k2;
+        }
+    }
+    const int bk = tid >> 3, bc = (tid & 7) * 8;
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < K; kc += DKC) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gk = kc + ak + j;
+            float v = 0.f;
+            if (x1r) { if (gk < a.k1) v = x1r[gk]; else if (gk < K) v = x2r[gk - a.k1]; }
+            As[ar * DAS + ak + j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gk = kc + bk, gc = col0 + bc + j;
+            Bs[bk * DBS + bc + j] = (gk < K && gc < a.N) ? a.W[(size_t)gk * a.N + gc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < DKC / 4; ++ks) {
+            const float av = As[(w * 16 + (lane & 15)) * DAS + ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(av, Bs[(ks * 4 + (lane >> 4)) * DBS + c * 16 + (lane & 15)], acc[c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = col0 + c * 16 + (lane & 15);
+        if (col >= a.N) continue;
+        const float bv = a.b ? a.b[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + w * 16 + (lane >> 4) * 4 + r;
+            if (row < a.M) { float v = acc[c][r] + bv; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
+        }
+    }
+}
+
+// ---- fused local-feature-aggregation attention half -----------------------------------------------------
+template <int D> struct LfaCfg {
+    static constexpr int H = D / 2;
+    static constexpr int PTS = (1024 / D) < 32 ? (1024 / D) : 32;     // points per workgroup
+    static constexpr int ROWS = PTS * 16;
+    static constexpr int LD = D + 2;                                   // LDS row stride == 2 (mod 32): conflict-free A reads
+    static constexpr int NCT = D / 16;                                 // column tiles of the attention GEMM
+    static constexpr int NC_W = (D / 64) > 1 ? (D / 64) : 1;           // column tiles per wave
+    static constexpr int NP_W = (PTS * NCT / 4) / NC_W;                // point tiles per wave
+    static constexpr int NCT2 = (H / 16) > 1 ? (H / 16) : 1;           // column tiles of the LFAmlp2 GEMM
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)ROWS * LD + (size_t)ROWS * 10) + sizeof(int) * ROWS;
+};
+
+template <int D, bool SECOND>
+__global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
+    using C = LfaCfg<D>;
+    constexpr int H = C::H, PTS = C::PTS, ROWS = C::ROWS, LD = C::LD;
+    SSDR_DYN_SHARED(float, smem);
+    float* F = smem;                              // [ROWS][LD]   concat(f_neighbours, f_xyz)
+    float* REL = smem + (size_t)ROWS * LD;        // [ROWS][10]
+    int* NBR = reinterpret_cast<int*>(REL + (size_t)ROWS * 10);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, pt0 = blockIdx.x * PTS;
+    const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
+    const int* neigh = a.neigh + (size_t)b * a.n * 16;
+
+    // relative_pos_encoding (:529-535): [ |d|, d(3), p(3), p_nbr(3) ]
+    for (int row = tid; row < ROWS; row += 256) {
+        const int n = pt0 + (row >> 4);
+        float r[10]; int j = 0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) r[q] = 0.f;
+        if (n < a.n) {
+            j = neigh[(size_t)n * 16 + (row & 15)];
+            const float px = xyz[3 * (size_t)n], py = xyz[3 * (size_t)n + 1], pz = xyz[3 * (size_t)n + 2];
+            const float qx = xyz[3 * (size_t)j], qy = xyz[3 * (size_t)j + 1], qz = xyz[3 * (size_t)j + 2];
+            const float dx = px - qx, dy = py - qy, dz = pz - qz;
+            r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+            r[1] = dx; r[2] = dy; r[3] = dz; r[4] = px; r[5] = py; r[6] = pz; r[7] = qx; r[8] = qy; r[9] = qz;
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) REL[row * 10 + q] = r[q];
+        NBR[row] = j;
+    }
+    __syncthreads();
+
+    // LocSE conv 10 -> H (LFAmlp1, :518).  First half: straight into the f_xyz columns [H,2H).
+    // Second half: into columns [0,H) as the A operand of the LFAmlp2 GEMM below.
+    {
+        constexpr int XOFF = SECOND ? 0 : H;
+        for (int e = tid; e < ROWS * H; e += 256) {
+            const int row = e / H, c = e % H;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) s += REL[row * 10 + q] * a.w_l1[q * H + c];
+            F[row * LD + XOFF + c] = lrelu(s + a.b_l1[c]);
+        }
+    }
+    __syncthreads();
+
+    if (SECOND) {
+        // f_xyz <- conv H -> H of the encoded positions (LFAmlp2, :523) on the matrix cores
+        constexpr int NCT2 = C::NCT2, T2W = PTS * NCT2 / 4;
+        f32x4 acc2[T2W];
+#pragma unroll
+        for (int t = 0; t < T2W; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < T2W; ++t) {
+            const int tile = w * T2W + t, p = tile / NCT2, ct = tile % NCT2;
+            const int col = ct * 16 + (lane & 15);
+            for (int kb = 0; kb < H; kb += 4) {
+                const int k = kb + (lane >> 4);
+                const float av = (k < H) ? F[(p * 16 + (lane & 15)) * LD + k] : 0.f;
+                const float bv = (k < H && col < H) ? a.w_l2[k * H + col] : 0.f;
+                acc2[t] = mfma16(av, bv, acc2[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T2W; ++t) {
+            const int tile = w * T2W + t, p = tile / NCT2, ct = tile % NCT2;
+            const int col = ct * 16 + (lane & 15);
+            if (col < H) {
+                const float bv = a.b_l2[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) F[(p * 16 + (lane >> 4) * 4 + r) * LD + H + col] = lrelu(acc2[t][r] + bv);
+            }
+        }
+        __syncthreads();
+    }
+
+    // gather_neighbour (:519 / :524): neighbour features into columns [0,H)
+    {
+        const float* fin = a.fin + (size_t)b * a.n * H;
+        for (int e = tid; e < ROWS * H; e += 256) {
+            const int row = e / H, c = e % H;
+            F[row * LD + c] = (pt0 + (row >> 4) < a.n) ? fin[(size_t)NBR[row] * H + c] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // attention scores S = F * Wfc (:578), one 16x16 tile = 16 neighbours x 16 channels
+    constexpr int NC_W = C::NC_W, NP_W = C::NP_W;
+    const int ct0 = (D >= 64) ? w * NC_W : 0;
+    const int p0 = (D >= 64) ? 0 : w * NP_W;
+    f32x4 acc[NP_W][NC_W];
+#pragma unroll
+    for (int p = 0; p < NP_W; ++p)
+#pragma unroll
+        for (int c = 0; c < NC_W; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < D; kb += 4) {
+        const int k = kb + (lane >> 4);
+        float av[NP_W], bv[NC_W];
+#pragma unroll
+        for (int p = 0; p < NP_W; ++p) av[p] = F[((p0 + p) * 16 + (lane & 15)) * LD + k];
+#pragma unroll
+        for (int c = 0; c < NC_W; ++c) bv[c] = a.w_fc[(size_t)k * D + (ct0 + c) * 16 + (lane & 15)];
+#pragma unroll
+        for (int p = 0; p < NP_W; ++p)
+#pragma unroll
+            for (int c = 0; c < NC_W; ++c) acc[p][c] = mfma16(av[p], bv[c], acc[p][c]);
+    }
+
+    // softmax over the 16 neighbours (:579) and weighted sum (:580-581)
+    float* out = a.out + (size_t)b * a.n * D;
+#pragma unroll
+    for (int p = 0; p < NP_W; ++p) {
+        const int n = pt0 + p0 + p;
+#pragma unroll
+        for (int c = 0; c < NC_W; ++c) {
+            const int col = (ct0 + c) * 16 + (lane & 15);
+            float m = fmaxf(fmaxf(acc[p][c][0], acc[p][c][1]), fmaxf(acc[p][c][2], acc[p][c][3]));
+            m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+            float e[4], s = 0.f, v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e[r] = expf(acc[p][c][r] - m); s += e[r]; }
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v += F[((p0 + p) * 16 + (lane >> 4) * 4 + r) * LD + col] * (e[r] / s);
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if ((lane >> 4) == 0 && n < a.n) out[(size_t)n * D + col] = v;
+        }
+    }
+}
+
+// ---- random_sample (:537-548) --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict__ f, const int* __restrict__ idx, int n_in, int n_out,
+                                                         int idx_rows, int C, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const float* fb = f + (size_t)b * n_in * C;
+    const int* ib = idx + (size_t)b * idx_rows * 16;
+    float* ob = out + (size_t)b * n_out * C;
+    const size_t total = (size_t)n_out * C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int m = (int)(e / C), c = (int)(e % C);
+        float v = -3.402823466e+38f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v = fmaxf(v, fb[(size_t)ib[(size_t)m * 16 + k] * C + c]);
+        ob[e] = v;
+    }
+}
+
+// ---- fc (32 -> C) + softmax (:176, :84) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                   int M, int C, float* __restrict__ probs) {
+    __shared__ float Ws[32 * 32 + 32];
+    for (int i = threadIdx.x; i < 32 * C; i += 256) Ws[i] = W[i];
+    for (int i = threadIdx.x; i < C; i += 256) Ws[32 * 32 + i] = bias[i];
+    __syncthreads();
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < M; r += gridDim.x * 256) {
+        float xin[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) xin[i] = x[(size_t)r * 32 + i];
+        float logit[32]; float m = -3.402823466e+38f;
+        for (int c = 0; c < C; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) s += xin[i] * Ws[i * C + c];
+            s += Ws[32 * 32 + c]; logit[c] = s; m = fmaxf(m, s);
+        }
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) { logit[c] = expf(logit[c] - m); sum += logit[c]; }
+        for (int c = 0; c < C; ++c) probs[(size_t)r * C + c] = logit[c] / sum;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+int launch_dense(const DenseArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return SSDR_OK;
+    dim3 grid((unsigned)((a.M + DT - 1) / DT), (unsigned)((a.N + DT - 1) / DT));
+    hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, s, a);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+template <int D> static int launch_lfa_d(const LfaArgs& a, bool second, int B, hipStream_t s) {
+    using C = LfaCfg<D>;
+    dim3 grid((unsigned)((a.n + C::PTS - 1) / C::PTS), (unsigned)B);
+    static bool attr_done = false;   // more than 64 KiB of dynamic LDS needs the opt-in
+    if (!attr_done) {
+        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_att_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_att_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_done = true;
+    }
+    if (second) hipLaunchKernelGGL((lfa_att_kernel<D, true>), grid, dim3(256), C::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((lfa_att_kernel<D, false>), grid, dim3(256), C::LDS_BYTES, s, a);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int launch_lfa(int D, const LfaArgs& a, bool second, int B, hipStream_t s) {
+    if (a.n <= 0 || B <= 0) return SSDR_OK;
+    switch (D) {
+        case 16: return launch_lfa_d<16>(a, second, B, s);
+        case 64: return launch_lfa_d<64>(a, second, B, s);
+        case 128: return launch_lfa_d<128>(a, second, B, s);
+        case 256: return launch_lfa_d<256>(a, second, B, s);
+        case 512: return launch_lfa_d<512>(a, second, B, s);
+        default: set_error("d_out=%d is not supported (16, 64, 128, 256, 512)", D); return SSDR_ERR_UNSUPPORTED;
+    }
+}
+
+int launch_gather_max(const float* f, const int* idx, int n_in, int n_out, int idx_rows, int C, float* out, int B, hipStream_t s) {
+    if (n_out <= 0 || B <= 0) return SSDR_OK;
+    const size_t total = (size_t)n_out * C;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 4096)), (unsigned)B);
+    hipLaunchKernelGGL(gather_max_kernel, grid, dim3(256), 0, s, f, idx, n_in, n_out, idx_rows, C, out);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int launch_head(const float* x, const float* W, const float* b, int M, int C, float* probs, hipStream_t s) {
+    if (M <= 0) return SSDR_OK;
+    if (C > 32) { set_error("num_classes=%d > 32 is not supported", C); return SSDR_ERR_UNSUPPORTED; }
+    dim3 grid((unsigned)std::max(1, std::min((M + 255) / 256, 4096)));
+    hipLaunchKernelGGL(head_kernel, grid, dim3(256), 0, s, x, W, b, M, C, probs);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+}  // namespace ssdr

@@ -1,0 +1,175 @@
+// RandLA-Net inference driver + C ABI (include/ssdr_al.h, "RandLA-Net" section).
+//
+// Layer table (BN already folded by the caller; W row-major [in,out], b [out]):
+//   0                fc0        in_dim -> 8                                   (RandLANet.py:144-146)
+//   1 + 8*i + 0..7   encoder i: mlp1 (d_in->h), LFAmlp1 (10->h), att1 fc (d->d, no bias), att1 mlp (d->h),
+//                               LFAmlp2 (h->h), att2 fc (d->d, no bias), att2 mlp (d->d),
+//                               residual = vstack(mlp2, shortcut) (d + d_in -> 2d)      (:505-527, :572-585)
+//   1 + 8*L          decoder_0  (2*d_L -> 2*d_L)                                       (:159-161)
+//   2 + 8*L + j      Decoder_layer_j: [skip | interp] -> skip                          (:165-172)
+//   then fc1 (->64), fc2 (64->32 = last_second_features), fc (32->C)                   (:174-178)
+#include "ssdr_internal.hpp"
+#include "randla.hpp"
+
+namespace ssdr {
+namespace {
+
+struct Layer { int in = 0, out = 0; bool has_b = true; DevBuf W, b; bool set = false; };
+
+struct Model {
+    int L = 5, K = 16, C = 13, in_dim = 6;
+    int d_out[8] = {16, 64, 128, 256, 512, 0, 0, 0};
+    std::vector<Layer> layers;
+    std::vector<DevBuf> ws;      // activation workspaces
+};
+
+int n_layers(const Model& m) { return 1 + 8 * m.L + 1 + m.L + 3; }
+
+void shapes(Model& m) {
+    m.layers.assign(n_layers(m), Layer());
+    auto set = [&](int i, int in, int out, bool b) { m.layers[i].in = in; m.layers[i].out = out; m.layers[i].has_b = b; };
+    set(0, m.in_dim, 8, true);
+    int d_in = 8;
+    std::vector<int> enc_ch; enc_ch.push_back(2 * m.d_out[0]);
+    for (int i = 0; i < m.L; ++i) {
+        const int d = m.d_out[i], h = d / 2, base = 1 + 8 * i;
+        set(base + 0, d_in, h, true); set(base + 1, 10, h, true); set(base + 2, d, d, false); set(base + 3, d, h, true);
+        set(base + 4, h, h, true); set(base + 5, d, d, false); set(base + 6, d, d, true); set(base + 7, d + d_in, 2 * d, true);
+        d_in = 2 * d; enc_ch.push_back(2 * d);
+    }
+    int idx = 1 + 8 * m.L;
+    set(idx++, d_in, d_in, true);
+    int feat = d_in;
+    for (int j = 0; j < m.L; ++j) { const int skip = enc_ch[enc_ch.size() - j - 2]; set(idx++, skip + feat, skip, true); feat = skip; }
+    set(idx++, feat, 64, true); set(idx++, 64, 32, true); set(idx++, 32, m.C, true);
+}
+
+DenseArgs dense(const float* x1, int k1, const Layer& ly, float* y, int M, int act) {
+    DenseArgs a{}; a.x1 = x1; a.k1 = k1; a.x2 = nullptr; a.k2 = 0; a.idx2 = nullptr; a.m_per_batch = 1; a.x2_rows_per_batch = 0;
+    a.W = ly.W.as<float>(); a.b = ly.has_b ? ly.b.as<float>() : nullptr; a.y = y; a.M = M; a.N = ly.out; a.act = act;
+    return a;
+}
+
+}  // namespace
+}  // namespace ssdr
+
+using namespace ssdr;
+
+extern "C" {
+
+int ssdr_randla_create(int num_layers, const int32_t* d_out, int k_n, int num_classes, int in_dim, void** handle) {
+    if (!handle || !d_out || num_layers < 1 || num_layers > 8) { set_error("randla_create: bad arguments"); return SSDR_ERR_INVALID; }
+    if (k_n != 16) { set_error("randla: k_n=%d is not supported (16)", k_n); return SSDR_ERR_UNSUPPORTED; }
+    if (num_classes < 1 || num_classes > 32) { set_error("randla: num_classes must be in [1,32]"); return SSDR_ERR_UNSUPPORTED; }
+    for (int i = 0; i < num_layers; ++i)
+        if (d_out[i] != 16 && d_out[i] != 64 && d_out[i] != 128 && d_out[i] != 256 && d_out[i] != 512) { set_error("randla: d_out[%d]=%d is not supported", i, d_out[i]); return SSDR_ERR_UNSUPPORTED; }
+    Model* m = new Model();
+    m->L = num_layers; m->K = k_n; m->C = num_classes; m->in_dim = in_dim;
+    for (int i = 0; i < num_layers; ++i) m->d_out[i] = d_out[i];
+    shapes(*m);
+    *handle = m;
+    return SSDR_OK;
+}
+
+int ssdr_randla_num_layers(void* handle) { return handle ? n_layers(*static_cast<Model*>(handle)) : 0; }
+
+int ssdr_randla_layer_shape(void* handle, int layer, int* in, int* out, int* has_bias) {
+    Model* m = static_cast<Model*>(handle);
+    if (!m || layer < 0 || layer >= n_layers(*m)) { set_error("randla_layer_shape: bad layer"); return SSDR_ERR_INVALID; }
+    if (in) *in = m->layers[layer].in;
+    if (out) *out = m->layers[layer].out;
+    if (has_bias) *has_bias = m->layers[layer].has_b;
+    return SSDR_OK;
+}
+
+int ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* b) {
+    Model* m = static_cast<Model*>(handle);
+    if (!m || layer < 0 || layer >= n_layers(*m) || !W) { set_error("randla_set_layer: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    Layer& ly = m->layers[layer];
+    if (ly.has_b && !b) { set_error("randla_set_layer: layer %d needs a bias", layer); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ly.W.reserve(sizeof(float) * (size_t)ly.in * ly.out));
+    SSDR_HIP(hipMemcpy(ly.W.p, W, sizeof(float) * (size_t)ly.in * ly.out, hipMemcpyHostToDevice));
+    if (ly.has_b) { SSDR_TRY(ly.b.reserve(sizeof(float) * ly.out)); SSDR_HIP(hipMemcpy(ly.b.p, b, sizeof(float) * ly.out, hipMemcpyHostToDevice)); }
+    ly.set = true;
+    return SSDR_OK;
+}
+
+void ssdr_randla_destroy(void* handle) {
+    Model* m = static_cast<Model*>(handle);
+    if (!m) return;
+    for (auto& l : m->layers) { l.W.release(); l.b.release(); }
+    for (auto& w : m->ws) w.release();
+    delete m;
+}
+
+int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_features, const float* d_xyz,
+                          const int32_t* ratios, int32_t* const* d_neigh_idx, int32_t* const* d_interp_idx,
+                          float* d_probs, float* d_feat32, void* stream) {
+    Model* m = static_cast<Model*>(handle);
+    if (!m || !d_features || !d_xyz || !ratios || !d_neigh_idx || !d_interp_idx || !d_probs || !d_feat32 || B == 0 || n0 == 0) { set_error("randla_infer: bad arguments"); return SSDR_ERR_INVALID; }
+    for (auto& l : m->layers) if (!l.set) { set_error("randla_infer: not every layer has weights"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream);
+    const int L = m->L, Bi = (int)B;
+    std::vector<int> N(L + 1); N[0] = (int)n0;
+    for (int i = 0; i < L; ++i) { if (ratios[i] <= 0) { set_error("ratio must be positive"); return SSDR_ERR_INVALID; } N[i + 1] = N[i] / ratios[i]; }
+    if (N[L] <= 0) { set_error("randla_infer: tile too small for the pyramid"); return SSDR_ERR_INVALID; }
+
+    // workspaces: per level f_pc, agg(d), agg-mlp, out(2d), sampled(2d); decoder ping-pong; fc1/fc2
+    size_t need = 0;
+    auto idxs = [&](int level, int which) { return level * 6 + which; };
+    if (m->ws.size() < (size_t)(6 * L + 6)) m->ws.resize(6 * L + 6);
+    auto buf = [&](int slot, size_t floats) -> float* { if (m->ws[slot].reserve(floats * 4) != SSDR_OK) return nullptr; (void)need; return m->ws[slot].as<float>(); };
+
+    // fc0
+    float* f0 = buf(6 * L + 0, B * N[0] * 8); if (!f0) return SSDR_ERR_HIP;
+    SSDR_TRY(launch_dense(dense(d_features, m->in_dim, m->layers[0], f0, Bi * N[0], 1), s));
+    const float* f = f0; int d_in = 8;
+    std::vector<const float*> enc; std::vector<int> enc_ch, enc_n;
+    for (int i = 0; i < L; ++i) {
+        const int d = m->d_out[i], h = d / 2, base = 1 + 8 * i, n = N[i];
+        const size_t rows = B * (size_t)n;
+        float* f_pc = buf(idxs(i, 0), rows * h); float* agg = buf(idxs(i, 1), rows * d); float* aggm = buf(idxs(i, 2), rows * d);
+        float* out = buf(idxs(i, 3), rows * 2 * d); float* samp = buf(idxs(i, 4), B * (size_t)N[i + 1] * 2 * d);
+        if (!f_pc || !agg || !aggm || !out || !samp) return SSDR_ERR_HIP;
+        SSDR_TRY(launch_dense(dense(f, d_in, m->layers[base + 0], f_pc, (int)rows, 1), s));                 // mlp1
+        LfaArgs la{}; la.xyz = d_xyz; la.xyz_batch_stride = n0 * 3; la.neigh = d_neigh_idx[i]; la.n = n;
+        la.w_l1 = m->layers[base + 1].W.as<float>(); la.b_l1 = m->layers[base + 1].b.as<float>();
+        la.w_l2 = m->layers[base + 4].W.as<float>(); la.b_l2 = m->layers[base + 4].b.as<float>();
+        la.fin = f_pc; la.w_fc = m->layers[base + 2].W.as<float>(); la.out = agg;
+        SSDR_TRY(launch_lfa(d, la, false, Bi, s));                                                          // LocSE + att pool 1
+        SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 3], aggm, (int)rows, 1), s));                   // att1 mlp d->h
+        la.fin = aggm; la.w_fc = m->layers[base + 5].W.as<float>(); la.out = agg;
+        SSDR_TRY(launch_lfa(d, la, true, Bi, s));                                                           // LocSE2 + att pool 2
+        SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
+        DenseArgs r = dense(aggm, d, m->layers[base + 7], out, (int)rows, 1);                               // lrelu(mlp2 + shortcut)
+        r.x2 = f; r.k2 = d_in;
+        SSDR_TRY(launch_dense(r, s));
+        SSDR_TRY(launch_gather_max(out, d_neigh_idx[i], n, N[i + 1], n, 2 * d, samp, Bi, s));               // random_sample
+        if (i == 0) { enc.push_back(out); enc_ch.push_back(2 * d); enc_n.push_back(n); }
+        enc.push_back(samp); enc_ch.push_back(2 * d); enc_n.push_back(N[i + 1]);
+        f = samp; d_in = 2 * d;
+    }
+    int li = 1 + 8 * L;
+    float* dec = buf(6 * L + 1, B * (size_t)N[L] * d_in); if (!dec) return SSDR_ERR_HIP;
+    SSDR_TRY(launch_dense(dense(enc.back(), d_in, m->layers[li++], dec, Bi * N[L], 1), s));                  // decoder_0
+    const float* feat = dec; int feat_c = d_in, feat_n = N[L];
+    for (int j = 0; j < L; ++j) {
+        const int e = (int)enc.size() - j - 2;
+        const int skip_c = enc_ch[e], n = enc_n[e];
+        float* y = buf(6 * L + 2 + (j & 1), B * (size_t)n * skip_c); if (!y) return SSDR_ERR_HIP;
+        DenseArgs a = dense(enc[e], skip_c, m->layers[li++], y, Bi * n, 1);
+        a.x2 = feat; a.k2 = feat_c; a.idx2 = d_interp_idx[L - 1 - j]; a.m_per_batch = n; a.x2_rows_per_batch = feat_n;
+        SSDR_TRY(launch_dense(a, s));
+        feat = y; feat_c = skip_c; feat_n = n;
+    }
+    float* f1 = buf(6 * L + 4, B * (size_t)N[0] * 64); if (!f1) return SSDR_ERR_HIP;
+    SSDR_TRY(launch_dense(dense(feat, feat_c, m->layers[li++], f1, Bi * N[0], 1), s));                       // fc1
+    SSDR_TRY(launch_dense(dense(f1, 64, m->layers[li++], d_feat32, Bi * N[0], 1), s));                       // fc2 = last_second_features
+    const Layer& fc = m->layers[li++];
+    SSDR_TRY(launch_head(d_feat32, fc.W.as<float>(), fc.b.as<float>(), Bi * N[0], m->C, d_probs, s));        // fc + softmax
+    return SSDR_OK;
+}
+
+}

@@ -61,6 +61,17 @@ def lib():
         L.ssdr_grid_subsample.argtypes = [vp, sz, vp, sz, vp, sz, f32, i32, C.POINTER(sz)]
         L.ssdr_grid_subsample_fetch.argtypes = [vp, vp, vp]
         L.ssdr_grid_subsample_dev.argtypes = [vp, sz, vp, sz, vp, sz, f32, i32, vp, vp, vp, vp, vp]
+        L.ssdr_randla_create.argtypes = [i32, vp, i32, i32, i32, C.POINTER(vp)]
+        L.ssdr_randla_num_layers.argtypes = [vp]
+        L.ssdr_randla_layer_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.ssdr_randla_set_layer.argtypes = [vp, i32, vp, vp]
+        L.ssdr_randla_destroy.argtypes = [vp]
+        L.ssdr_randla_destroy.restype = None
+        L.ssdr_randla_infer_dev.argtypes = [vp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.ssdr_dev_alloc.argtypes = [sz, C.POINTER(vp)]
+        L.ssdr_dev_free.argtypes = [vp]
+        L.ssdr_memcpy_h2d.argtypes = [vp, vp, sz]
+        L.ssdr_memcpy_d2h.argtypes = [vp, vp, sz]
         _lib = L
     return _lib
 
@@ -77,3 +88,41 @@ def ptr(a):
 
 def last_gpu_ms():
     return float(lib().ssdr_last_gpu_ms())
+
+
+class DevArray:
+    """A device buffer owned through the C ABI (ssdr_dev_alloc / ssdr_memcpy_*): lets the mirror keep tiles
+    resident between stages without any framework dependency."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().ssdr_dev_alloc(max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+        self._owner_lib = lib()
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        check(lib().ssdr_memcpy_h2d(d.ptr, ptr(a), d.nbytes))
+        return d
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        check(lib().ssdr_memcpy_d2h(ptr(out), self.ptr, self.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._owner_lib.ssdr_dev_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def sync(stream=None):
+    check(lib().ssdr_stream_sync(stream))

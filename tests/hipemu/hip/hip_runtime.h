@@ -49,6 +49,8 @@ typedef void* hipEvent_t;
 enum { hipSuccess = 0, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipDeviceAttributeMultiprocessorCount = 1 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 
 namespace hipemu {
 enum { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
@@ -191,6 +193,27 @@ template <class T> static inline T atomicAnd(T* p, T v) { return hipemu_rmw(p, [
 template <class T> static inline T atomicExch(T* p, T v) { return hipemu_rmw(p, [v](T) { return v; }); }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = c; __atomic_compare_exchange(p, &o, &v, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED); return o; }
 static inline void __threadfence() {}
+
+// f32-in MFMA 16x16x4 (v_mfma_f32_16x16x4_f32): lane l holds A[l&15][l>>4], B[l>>4][l&15]; C/D col = l&15,
+// rows (l>>4)*4 + r.  Result is a k-ordered fmaf chain (cdna_hip_programming.md section 3).
+typedef float hipemu_f32x4 __attribute__((vector_size(16)));
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c) {
+    uint64_t packed = (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32);
+    hipemu::wave_op(packed, 3);
+    auto* f = hipemu::g_bs->cur; auto& w = hipemu::g_bs->waves[f->wave];
+    const int col = f->lane & 15, rg = f->lane >> 4;
+    hipemu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = rg * 4 + r; float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            const float av = __uint_as_float((unsigned)(w.snap[row + 16 * k] & 0xffffffffu));
+            const float bv = __uint_as_float((unsigned)(w.snap[col + 16 * k] >> 32));
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
 
 // ---- runtime API (host memory stands in for device memory) --------------------------------------
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }

@@ -1,0 +1,140 @@
+"""RandLA-Net inference parity.  PARITY UNPINNED by the reference (TensorFlow 1.x cannot run here): the oracle is
+oracle/randla_np.py, cross-checked below against an independent torch-CPU formulation; the HIP path must agree
+with it within 1e-3 absolute on last_second_features and probabilities (north_star tolerance, fp32)."""
+import numpy as np
+import pytest
+
+TOL = 1e-3
+
+
+def _inputs(B, N, seed=0):
+    import oracle
+    from oracle import randla_np as R
+    o = oracle.c()
+    rng = np.random.default_rng(seed)
+    xyz0 = (rng.random((B, N, 3), dtype=np.float32) * np.array([4, 3, 2.5], np.float32)).astype(np.float32)
+    xyz0[:, : N // 3, 2] = 0
+    xyz0[0, -N // 8:] = xyz0[0, : N // 8]                      # duplicated points (padded tile)
+    feat = np.concatenate([xyz0 - xyz0.mean(1, keepdims=True), rng.random((B, N, 3), dtype=np.float32)], -1)
+    pyr = R.build_pyramid(xyz0, [4, 4, 4, 4, 2], lambda s, q, k: o.knn_batch(s, q, k, threads=4))
+    return xyz0, feat, pyr
+
+
+def test_numpy_oracle_against_independent_torch_formulation():
+    """Same network written a second time with torch.nn.functional ops in float64 (conv as F.conv2d 1x1 on NCHW,
+    BN as F.batch_norm, gathers as torch.gather) — guards the oracle against a restatement slip."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import randla_np as R
+    W = R.init_weights(3)
+    xyz0, feat, (xyz, neigh, sub, interp) = _inputs(2, 512, seed=1)
+    p_np, f_np = R.forward(W, feat, xyz, neigh, sub, interp, dtype=np.float64)
+
+    T = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+
+    def conv(x, name):            # x [B,C,N,K]
+        e = W[name]
+        w = T(e["W"])
+        w = w if e["transposed"] else w.t()                   # -> [out,in]
+        y = F.conv2d(x, w[:, :, None, None], None if e["b"] is None else T(e["b"]))
+        if e["bn"] is not None:
+            g, beta, mu, var = [T(a) for a in e["bn"]]
+            y = F.batch_norm(y, mu, var, g, beta, False, 0.0, R.BN_EPS)
+        return F.leaky_relu(y, 0.2) if e["act"] else y
+
+    def gather(f, idx):           # f [B,C,N,1], idx [B,M,K] -> [B,C,M,K]
+        B, C = f.shape[0], f.shape[1]
+        i = torch.from_numpy(idx.astype(np.int64)).reshape(B, 1, -1).expand(B, C, -1)
+        return torch.gather(f[..., 0], 2, i).reshape(B, C, idx.shape[1], idx.shape[2])
+
+    def att(fset, name):
+        a = F.conv2d(fset, T(W[name + "fc"]["W"]).t()[:, :, None, None])
+        s = torch.softmax(a, dim=3)
+        return conv((fset * s).sum(3, keepdim=True), name + "mlp")
+
+    f = conv(T(feat).permute(0, 2, 1)[..., None], "fc0")
+    enc = []
+    for i in range(5):
+        p = "Encoder_layer_%d" % i
+        x = T(xyz[i]).permute(0, 2, 1)[..., None]
+        f_pc = conv(f, p + "mlp1")
+        nx = gather(x, neigh[i]); tile = x.expand_as(nx); rel = tile - nx
+        dis = torch.sqrt((rel * rel).sum(1, keepdim=True))
+        f_xyz = conv(torch.cat([dis, rel, tile, nx], 1), p + "LFAmlp1")
+        agg = att(torch.cat([gather(f_pc, neigh[i]), f_xyz], 1), p + "LFAatt_pooling_1")
+        f_xyz = conv(f_xyz, p + "LFAmlp2")
+        agg = att(torch.cat([gather(agg, neigh[i]), f_xyz], 1), p + "LFAatt_pooling_2")
+        out = F.leaky_relu(conv(agg, p + "mlp2") + conv(f, p + "shortcut"), 0.2)
+        samp = gather(out, sub[i]).max(3, keepdim=True)[0]
+        if i == 0:
+            enc.append(out)
+        enc.append(samp)
+        f = samp
+    f = conv(enc[-1], "decoder_0")
+    for j in range(5):
+        f = conv(torch.cat([enc[-j - 2], gather(f, interp[-j - 1])], 1), "Decoder_layer_%d" % j)
+    f2 = conv(conv(f, "fc1"), "fc2")
+    logits = conv(f2, "fc")[..., 0].permute(0, 2, 1).reshape(-1, 13)
+    probs = torch.softmax(logits, 1).numpy()
+    feat32 = f2[..., 0].permute(0, 2, 1).reshape(-1, 32).numpy()
+    assert np.abs(probs - p_np).max() < 1e-9 and np.abs(feat32 - f_np).max() < 1e-8
+
+
+def test_oracle_fp32_close_to_fp64():
+    from oracle import randla_np as R
+    W = R.init_weights(0)
+    xyz0, feat, (xyz, neigh, sub, interp) = _inputs(1, 1024)
+    p32, f32 = R.forward(W, feat, xyz, neigh, sub, interp, dtype=np.float32)
+    p64, f64 = R.forward(W, feat, xyz, neigh, sub, interp, dtype=np.float64)
+    assert np.abs(p32 - p64).max() < 1e-4 and np.abs(f32 - f64).max() < 2e-4
+
+
+def test_layer_table_shapes_and_bn_fold():
+    from oracle import randla_np as R
+    specs = R.layer_specs()
+    assert len(specs) == 55 and specs[0][:3] == ("fc0", 6, 8) and specs[-1][:3] == ("fc", 32, 13)
+    assert [s[1:3] for s in specs if s[0].startswith("Decoder_layer")] == [(1536, 512), (768, 256), (384, 128), (160, 32), (64, 32)]
+    e = R.init_weights(1)["Encoder_layer_1mlp1"]
+    w, b = R.fold_bn(e, np.float64)
+    x = np.random.default_rng(0).normal(size=(5, 32))
+    assert np.allclose(R._lrelu(x @ w + b), R._conv(x, e), atol=1e-6)
+
+
+def test_randla_matches_oracle(backend):
+    from oracle import randla_np as R
+    from ssdr_al import randlanet
+    B, N = (1, 1024) if backend == "emu" else (2, 8192)
+    W = R.init_weights(0)
+    xyz0, feat, (xyz, neigh, sub, interp) = _inputs(B, N)
+    p, f = R.forward(W, feat, xyz, neigh, sub, interp, dtype=np.float32)
+    gp, gf = randlanet.Network().load(W).infer(feat, xyz0)
+    assert gp.shape == (B * N, 13) and gf.shape == (B * N, 32)
+    assert np.abs(gp - p).max() < TOL, np.abs(gp - p).max()
+    assert np.abs(gf - f).max() < TOL, np.abs(gf - f).max()
+
+
+@pytest.mark.gpu
+def test_randla_full_size_batch16_properties():
+    """BASELINE config 3 shape (B=16 x 40960): probabilities are a distribution, outputs finite, and the result of
+    a tile does not depend on which batch slot it sits in (tiles are independent units)."""
+    from conftest import GPU_LIB, _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    from oracle import randla_np as R
+    from ssdr_al import _lib, randlanet
+    _lib.use(GPU_LIB)
+    try:
+        rng = np.random.default_rng(9)
+        B, N = 16, 40960
+        xyz = (rng.random((B, N, 3), dtype=np.float32) * np.array([10, 8, 3], np.float32)).astype(np.float32)
+        xyz[5] = xyz[2]
+        feat = np.concatenate([xyz - xyz.mean(1, keepdims=True), rng.random((B, N, 3), dtype=np.float32)], -1)
+        feat[5] = feat[2]
+        net = randlanet.Network().load(R.init_weights(0))
+        p, f = net.infer(feat, xyz)
+        assert np.isfinite(p).all() and np.isfinite(f).all()
+        assert np.abs(p.sum(1) - 1).max() < 1e-5 and p.min() >= 0
+        p = p.reshape(B, N, 13); f = f.reshape(B, N, 32)
+        assert np.array_equal(p[5], p[2]) and np.array_equal(f[5], f[2])
+    finally:
+        _lib.use(None)
