@@ -1,0 +1,69 @@
+"""oracle/select_np.py against the golden vectors produced by the reference's own Python (CPU only)."""
+import numpy as np
+
+from oracle import select_np as S
+
+
+def _g(golden):
+    return golden("select_golden.npz")
+
+
+def test_point_uncertainty(golden):
+    g = _g(golden)
+    for mode in ("lc", "entropy", "sb"):
+        assert np.array_equal(S.point_uncertainty(g["u/prob"], mode), g["u/pu_" + mode]), mode
+
+
+def test_region_stats_and_clsbal(golden):
+    g = _g(golden)
+    prob = g["u/prob"]; cls = np.argmax(prob, -1); pu = g["u/pu_sb"]
+    for mode in ("mean", "sum_weight", "WetSU"):
+        ru, dom, cnt = S.region_stats(pu, cls, g["u/offsets"], g["u/points"], 13, mode)
+        assert np.allclose(ru, g["u/ru_" + mode], rtol=1e-12, atol=0), mode
+        assert np.array_equal(dom, g["u/dom"])
+    lab, pur = S.dominant_labels(cls.astype(np.int32), g["u/offsets"], g["u/points"])
+    assert np.array_equal(lab, g["u/dom"]) and np.allclose(pur, g["u/purity"])
+    cb = S.add_clsbal(13, g["u/dom"], g["u/ru_WetSU"], g["u/selected_class_list"])
+    assert np.allclose(cb, g["u/clsbal"], rtol=1e-14)
+
+
+def _blocks(g):
+    out = []
+    for name in ("cloudA", "cloudB"):
+        xyz, off, pts = g["f/%s/xyz" % name], g["f/%s/offsets" % name], g["f/%s/points" % name]
+        cen = S.bbox_centres(xyz, off, pts)
+        out.append((xyz, off, pts, cen))
+    return out
+
+
+def test_chamfer_and_adjacency(golden):
+    g = _g(golden)
+    blocks = _blocks(g)
+    for (xyz, off, pts, cen), name in zip(blocks, ("cloudA", "cloudB")):
+        cd = S.create_cd(xyz, off, pts, cen)
+        assert np.allclose(cd, g["f/%s/cd" % name], rtol=1e-13, atol=1e-15)
+    # assemble the global matrix the reference builds: rows = unlabeled refs then labelled refs
+    refs = list(zip(g["f/unl_cloud"], g["f/unl_sp"])) + list(zip(g["f/lab_cloud"], g["f/lab_sp"]))
+    N = len(refs); adj = np.zeros((N, N))
+    for c, (xyz, off, pts, cen) in enumerate(blocks):
+        rows = [i for i, (cc, _) in enumerate(refs) if cc == c]
+        sp = [refs[i][1] for i in rows]
+        sub_off = np.concatenate([[0], np.cumsum([off[s + 1] - off[s] for s in sp])]).astype(np.int32)
+        sub_pts = np.concatenate([pts[off[s]:off[s + 1]] for s in sp])
+        cen_s = S.bbox_centres(xyz, sub_off, sub_pts)
+        A = S.block_adjacency(cen_s, S.create_cd(xyz, sub_off, sub_pts, cen_s))
+        adj[np.ix_(rows, rows)] = A
+    assert np.allclose(adj, g["f/adj"], rtol=1e-12, atol=1e-15)
+    V = np.concatenate([g["f/unl_feat"], g["f/lab_feat"]]).astype(np.float64)
+    for gn in (1, 2, 3):
+        comb = S.propagate([adj], [np.arange(N)], V, gn)
+        seq = S.farthest_features_sample(comb[:9], 5, int(g["f/gcnfps_start_%d" % gn]))
+        a = [int(g["f/unl_sp"][i]) for i in seq if g["f/unl_cloud"][i] == 0]
+        b = [int(g["f/unl_sp"][i]) for i in seq if g["f/unl_cloud"][i] == 1]
+        assert a == list(g["f/gcnfps_A_%d" % gn]) and b == list(g["f/gcnfps_B_%d" % gn])
+
+
+def test_fps_and_kcenter_sequences(golden):
+    g = _g(golden)
+    assert np.array_equal(S.farthest_features_sample(g["fps/feat"], 50, int(g["fps/start"])), g["fps/seq"])
+    assert np.array_equal(S.kcenter_greedy(g["kc/feat"], g["kc/already"], 30), g["kc/seq"])
