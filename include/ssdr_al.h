@@ -123,6 +123,49 @@ int  ssdr_randla_infer_dev(void* handle, size_t batch_size, size_t npts, const f
                            const int32_t* ratios, int32_t* const* d_neigh_idx, int32_t* const* d_interp_idx,
                            float* d_probs, float* d_feat32, void* stream);
 
+/* ---- selection stage (replaces the NumPy / sklearn host code of S3/sampler2.py:12-47,102-115,262-266,313-342,
+ *      612-640, S3/fps_gcn_cpu.py:12-178 and S3/kcenterGreedy.py:60-128) ---------------------------------------
+ * Superpoints are CSR: sp_off int32 [S+1] into sp_pts int32 [T] (point ids) == the reference's `components`.
+ * All pointers are device pointers; float64 where the reference computes in float64. */
+#define SSDR_UNC_LC 0       /* 1 - max p                          (sampler2.py:29-34) */
+#define SSDR_UNC_ENTROPY 1  /* -sum p log2 p                      (:35-40, :247-255)  */
+#define SSDR_UNC_SB 2       /* second best / best                 (:41-44)            */
+#define SSDR_REGION_MEAN 0        /* sampler2.py:13-14 */
+#define SSDR_REGION_SUM_WEIGHT 1  /* :15-18 */
+#define SSDR_REGION_WETSU 2       /* :19-26 */
+/* compute_point_uncertainty + argmax class (sampler2.py:28-47, :602) */
+int ssdr_point_uncertainty_dev(const float* d_probs, size_t n, int num_classes, int mode, float* d_unc, int32_t* d_cls, void* stream);
+/* per-superpoint region uncertainty (float64), dominant predicted class and its member count (sampler2.py:612-626) */
+int ssdr_region_stats_dev(const float* d_unc, const int32_t* d_cls, const int32_t* d_sp_off, const int32_t* d_sp_pts, size_t S,
+                          int num_classes, int mode, double* d_region_unc, int32_t* d_dom, int32_t* d_dom_cnt, void* stream);
+/* ssdr_max_dominant: per-superpoint dominant ground-truth label + purity (sampler2.py:102-106, :127-144) */
+int ssdr_dominant_label_dev(const int32_t* d_labels, const int32_t* d_sp_off, const int32_t* d_sp_pts, size_t S, int num_labels,
+                            int32_t* d_label, double* d_purity, void* stream);
+/* add_clsbal (sampler2.py:262-266), in place on d_region_unc */
+int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected,
+                    double* d_region_unc, void* stream);
+/* sorted_inds = argsort(-u) (sampler2.py:640); equal values keep ascending index */
+int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorted_inds, void* stream);
+/* compute_features (sampler2.py:333,339): float32 mean of feat rows over the dominant-class members of the
+ * superpoints d_sel[0..nsel) (d_sel == NULL: superpoints 0..nsel-1) */
+int ssdr_segment_mean_features_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom,
+                                   const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel, size_t nsel,
+                                   float* d_out, void* stream);
+/* One cloud's block of fps_adj_all (fps_gcn_cpu.py:40-117) for its superpoints d_sel[0..nsel): bbox centres
+ * [nsel,3], directed chamfer means [nsel,nsel] (cd = dir + dir^T, create_cd :12-38) and the normalised adjacency
+ * (S-I)D^-1 + I [nsel,nsel]; gcn_top > 0 keeps the top entries per row (:153-160).  max_sp_size >= largest
+ * superpoint in d_sel. */
+int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel, size_t nsel,
+                         size_t max_sp_size, int gcn_top, double* d_centres, double* d_cd_dir, double* d_adj, void* stream);
+/* One hop of sum_i A^i V on a block (fps_gcn_cpu.py:162-167): vout[rows] = adj * vin[rows]; comb[rows] += vout[rows] */
+int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, const double* d_vin, int feat_dim, double* d_vout,
+                       double* d_comb, void* stream);
+/* farthest_features_sample (fps_gcn_cpu.py:119-147); `start` is the reference's np.random.randint draw */
+int ssdr_fps_dev(const double* d_feat, size_t n, int feat_dim, int start, size_t count, int32_t* d_out, void* stream);
+/* kCenterGreedy.select_batch_ (kcenterGreedy.py:84-128) with direct float64 Euclidean distances */
+int ssdr_kcenter_dev(const double* d_feat, size_t n, int feat_dim, const int32_t* d_already_selected, size_t n_already, size_t count,
+                     int32_t* d_out, void* stream);
+
 /* ---- plain device memory for callers without their own allocator (tests, the ctypes mirror) ---------- */
 int ssdr_dev_alloc(size_t bytes, void** d_ptr);
 int ssdr_dev_free(void* d_ptr);

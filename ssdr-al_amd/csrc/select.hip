@@ -1,0 +1,475 @@
+// Selection stage of one active-learning round for gfx950: per-point uncertainty, per-superpoint statistics,
+// candidate features, chamfer / adjacency / feature propagation per cloud, farthest-point and k-center sampling.
+//
+// Reference (S3 = /root/reference/SSDR_AL_s3dis/): S3/sampler2.py:12-47,102-115,262-266,313-342,612-640;
+// S3/fps_gcn_cpu.py:12-178; S3/kcenterGreedy.py:60-128.  The reference does all of this in NumPy / sklearn on
+// the host, in float64 for everything after the network.  The kernels keep float64 there and, where a NumPy
+// reduction decides a discrete outcome (the arg-max chain of FPS), reproduce NumPy's pairwise summation order
+// (np_pairwise below) so that identical inputs give the identical index sequence.
+//
+// Superpoints are CSR: sp_off[S+1] into sp_pts[T] (point ids), the same information as the reference's
+// pickled `components` object array (S3/partition/compute_superpoint.py:63-68).
+#include "ssdr_internal.hpp"
+#include "block_prims.hpp"
+
+namespace ssdr {
+namespace {
+
+// NumPy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum) over get(i), i in [0,n)
+template <class T, class Get>
+__device__ T np_pairwise(Get get, int n) {
+    // iterative version of the recursion: blocks are produced left to right; partial sums are combined exactly
+    // like the call tree sum(a[:n2]) + sum(a[n2:]) with n2 = n/2 - (n/2)%8.
+    struct Fr { int lo, n; int state; T left; };
+    Fr st[24]; int sp = 0; T ret = T(0);
+    st[0] = Fr{0, n, 0, T(0)};
+    while (sp >= 0) {
+        Fr& f = st[sp];
+        if (f.n <= 128) {
+            T res;
+            if (f.n < 8) { res = T(0); for (int i = 0; i < f.n; ++i) res += get(f.lo + i); }
+            else {
+                T r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = get(f.lo + j);
+                int i = 8;
+                for (; i < f.n - (f.n % 8); i += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] += get(f.lo + i + j);
+                }
+                res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < f.n; ++i) res += get(f.lo + i);
+            }
+            ret = res; --sp;
+        } else if (f.state == 0) {
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            f.state = 1; st[sp + 1] = Fr{f.lo, n2, 0, T(0)}; ++sp;
+        } else if (f.state == 1) {
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            f.left = ret; f.state = 2; st[sp + 1] = Fr{f.lo + n2, f.n - n2, 0, T(0)}; ++sp;
+        } else { ret = f.left + ret; --sp; }
+    }
+    return ret;
+}
+
+// ---- U1: compute_point_uncertainty (sampler2.py:28-47) + argmax class (:602) ------------------------------
+__global__ __launch_bounds__(256) void sel_point_unc(const float* __restrict__ prob, int n, int C, int mode, float* unc, int* cls) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float* p = prob + (size_t)i * C;
+        float best = p[0], second = -1.f; int bi = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = p[c];
+            if (v > best) { second = best; best = v; bi = c; }
+            else if (v > second) second = v;
+        }
+        float u;
+        if (mode == 0) u = 1.0f - best;                              // lc
+        else if (mode == 2) u = second / best;                       // sb: sorted[-2] / sorted[-1]
+        else {                                                       // entropy, float32 like np.sum over 13 classes
+            u = -1.f * np_pairwise<float>([&](int c) { const float v = p[c]; const float k = log2f(v); return v * (__builtin_isinf(k) ? 0.f : k); }, C);
+        }
+        unc[i] = u; cls[i] = bi;
+    }
+}
+
+// ---- U2: per-superpoint loop of TSampler.prediction (sampler2.py:612-626) ---------------------------------
+// mode 0 mean, 1 sum_weight, 2 WetSU.  One lane per superpoint (sums must follow NumPy's order).
+__global__ __launch_bounds__(256) void sel_region_stats(const float* __restrict__ unc, const int* __restrict__ cls,
+                                                        const int* __restrict__ sp_off, const int* __restrict__ sp_pts, int S, int C, int mode,
+                                                        double* region_unc, int* dom, int* dom_cnt) {
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) {
+        const int lo = sp_off[s], n = sp_off[s + 1] - lo;
+        if (n <= 0) { region_unc[s] = 0.0; dom[s] = 0; dom_cnt[s] = 0; continue; }
+        int h[32];
+        for (int c = 0; c < 32; ++c) h[c] = 0;
+        for (int j = 0; j < n; ++j) { const int c = cls[sp_pts[lo + j]]; if (c >= 0 && c < 32) h[c]++; }
+        int d = 0;
+        for (int c = 1; c < C; ++c) if (h[c] > h[d]) d = c;           // np.argmax: first maximum
+        dom[s] = d; dom_cnt[s] = h[d];
+        double r;
+        if (mode == 0) {
+            const float sum = np_pairwise<float>([&](int j) { return unc[sp_pts[lo + j]]; }, n);
+            r = (double)(float)((double)sum / (double)n);
+        } else if (mode == 1) {                                      // weights_percentage (:92-100) * uncertainty
+            r = np_pairwise<double>([&](int j) { const int p = sp_pts[lo + j]; return ((double)h[cls[p]] / (double)n) * (double)unc[p]; }, n);
+        } else {                                                     // WetSU (:19-26)
+            const double a = np_pairwise<double>([&](int j) { const int p = sp_pts[lo + j]; return (double)unc[p] * (cls[p] == d ? 1.0 : 0.0); }, n);
+            const double b = np_pairwise<double>([&](int j) { const int p = sp_pts[lo + j]; return (double)unc[p] * (1.0 - (cls[p] == d ? 1.0 : 0.0)); }, n);
+            r = a - b;
+        }
+        region_unc[s] = r;
+    }
+}
+
+// ---- D1: dominant ground-truth label + purity (sampler2.py:102-106 via oracle_labeling :127-144) ------------
+__global__ __launch_bounds__(256) void sel_dominant_label(const int* __restrict__ labels, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                          int S, int num_labels, int* out_label, double* out_purity, int* status) {
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) {
+        const int lo = sp_off[s], n = sp_off[s + 1] - lo;
+        int h[64];
+        for (int c = 0; c < 64; ++c) h[c] = 0;
+        for (int j = 0; j < n; ++j) { const int c = labels[sp_pts[lo + j]]; if (c >= 0 && c < 64 && c < num_labels) h[c]++; else atomicOr(status, 1); }
+        int d = 0;
+        for (int c = 1; c < num_labels && c < 64; ++c) if (h[c] > h[d]) d = c;
+        out_label[s] = d; out_purity[s] = n > 0 ? (double)h[d] / (double)n : 0.0;
+    }
+}
+
+// ---- clsbal (sampler2.py:262-266): u *= exp(-freq(dominant class among candidates + already selected)) -------
+__global__ __launch_bounds__(256) void sel_class_hist(const int* __restrict__ region_class, int S, const int* __restrict__ extra, int n_extra, int* hist) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S + n_extra; i += gridDim.x * 256) {
+        const int c = i < S ? region_class[i] : extra[i - S];
+        if (c >= 0 && c < 64) atomicAdd(&hist[c], 1);
+    }
+}
+__global__ __launch_bounds__(256) void sel_clsbal(const int* __restrict__ region_class, int S, int total, const int* __restrict__ hist, double* region_unc) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
+        const double w = (double)hist[region_class[i]] / (double)total;
+        region_unc[i] = region_unc[i] * exp(-w);
+    }
+}
+
+// ---- ranking: argsort(-u) (sampler2.py:640), ties by ascending index --------------------------------------------
+__global__ __launch_bounds__(256) void sel_rank_keys(const double* __restrict__ u, int S, uint64_t* keys, uint32_t* vals) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
+        unsigned long long b = (unsigned long long)__double_as_longlong(-u[i]);
+        b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);            // order-preserving map of IEEE doubles to u64
+        keys[i] = b; vals[i] = (uint32_t)i;
+    }
+}
+
+// ---- U3: compute_features (sampler2.py:333,339): float32 row-sequential mean over the dominant-class members ----
+__global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict__ feat, int D, const int* __restrict__ cls, const int* __restrict__ dom,
+                                                        const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                        const int* __restrict__ sel, int nsel, float* out) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nsel * D; e += gridDim.x * 256) {
+        const int q = e / D, c = e % D, s = sel ? sel[q] : q;
+        const int lo = sp_off[s], hi = sp_off[s + 1], d = dom[s];
+        float sum = 0.f; int cnt = 0;
+        for (int j = lo; j < hi; ++j) { const int p = sp_pts[j]; if (cls[p] == d) { sum = sum + feat[(size_t)p * D + c]; ++cnt; } }
+        out[(size_t)q * D + c] = cnt ? sum / (float)cnt : 0.f;
+    }
+}
+
+// ---- F1/F2: bbox centres, chamfer, adjacency, propagation for the superpoints `sel` of ONE cloud ----------------
+__global__ __launch_bounds__(256) void sel_centres(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                   const int* __restrict__ sel, int nsel, double* centres) {
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < nsel; q += gridDim.x * 256) {
+        const int s = sel[q], lo = sp_off[s], hi = sp_off[s + 1];
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int j = lo; j < hi; ++j) {
+            const size_t p = sp_pts[j];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { const float v = xyz[3 * p + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) centres[3 * (size_t)q + d] = (double)(mn[d] + mx[d]) / 2.0;   // float32 add, exact halving (fps_gcn_cpu.py:86-88)
+    }
+}
+
+constexpr int CH_TILE = 1024;   // points of the target superpoint staged in LDS per step
+
+// dir[i*nsel + j] = mean over points a of sp_i of min over points b of sp_j of |(a-c_i) - (b-c_j)|   (float64)
+__global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres,
+                                                       double* mins, int max_sp, double* dir) {
+    __shared__ double tb[CH_TILE * 3];
+    double* my_min = mins + (size_t)blockIdx.x * max_sp;
+    for (int pair = blockIdx.x; pair < nsel * nsel; pair += gridDim.x) {
+        const int i = pair / nsel, j = pair % nsel;
+        if (i == j) { if (threadIdx.x == 0) dir[pair] = 0.0; continue; }
+        const int si = sel[i], sj = sel[j];
+        const int loi = sp_off[si], ni = sp_off[si + 1] - loi, loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
+        const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
+        const double cjx = centres[3 * j], cjy = centres[3 * j + 1], cjz = centres[3 * j + 2];
+        for (int a = threadIdx.x; a < ni; a += 256) my_min[a] = 1.0e300;
+        for (int b0 = 0; b0 < nj; b0 += CH_TILE) {
+            const int nb = min(CH_TILE, nj - b0);
+            __syncthreads();
+            for (int b = threadIdx.x; b < nb; b += 256) {
+                const size_t p = sp_pts[loj + b0 + b];
+                tb[3 * b] = (double)xyz[3 * p] - cjx; tb[3 * b + 1] = (double)xyz[3 * p + 1] - cjy; tb[3 * b + 2] = (double)xyz[3 * p + 2] - cjz;
+            }
+            __syncthreads();
+            for (int a = threadIdx.x; a < ni; a += 256) {
+                const size_t p = sp_pts[loi + a];
+                const double ax = (double)xyz[3 * p] - cix, ay = (double)xyz[3 * p + 1] - ciy, az = (double)xyz[3 * p + 2] - ciz;
+                double m = my_min[a];
+                for (int b = 0; b < nb; ++b) {
+                    const double dx = ax - tb[3 * b], dy = ay - tb[3 * b + 1], dz = az - tb[3 * b + 2];
+                    double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+                    m = fmin(m, d);
+                }
+                my_min[a] = m;
+            }
+        }
+        __syncthreads();
+        for (int a = threadIdx.x; a < ni; a += 256) my_min[a] = sqrt(my_min[a]);   // sqrt is monotone: min of roots == root of min
+        __syncthreads();
+        if (threadIdx.x == 0) dir[pair] = np_pairwise<double>([&](int a) { return my_min[a]; }, ni) / (double)ni;   // np.mean
+        __syncthreads();
+    }
+}
+
+// adj = exp(-(ED + CD)) - I (fps_gcn_cpu.py:102-104); rowsum (:106)
+__global__ __launch_bounds__(256) void sel_adj_build(const double* __restrict__ centres, const double* __restrict__ dir, int n, double* adj, double* rowsum) {
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        __shared__ double part[256];
+        double acc = 0.0;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const double dx = centres[3 * i] - centres[3 * j], dy = centres[3 * i + 1] - centres[3 * j + 1], dz = centres[3 * i + 2] - centres[3 * j + 2];
+            const double ed = sqrt((dx * dx + dy * dy) + dz * dz);
+            const double cd = dir[(size_t)i * n + j] + dir[(size_t)j * n + i];
+            double v = exp(-(ed + cd));
+            if (i == j) v = v - 1.0;
+            adj[(size_t)i * n + j] = v; acc += v;
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) rowsum[i] = part[0];
+        __syncthreads();
+    }
+}
+// adj = adj * diag(1/rowsum) + I (:108-115): column j scaled by 1/rowsum[j], inf -> 0
+__global__ __launch_bounds__(256) void sel_adj_norm(const double* __restrict__ rowsum, int n, double* adj) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n * n; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        double dinv = 1.0 / rowsum[j];
+        if (__builtin_isinf(dinv)) dinv = 0.0;
+        adj[e] = adj[e] * dinv + (i == j ? 1.0 : 0.0);
+    }
+}
+// keep the gcn_top largest entries of every row (fps_gcn_cpu.py:153-160); ties keep the higher column index
+__global__ __launch_bounds__(256) void sel_adj_topk(double* adj, int n, int top) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double* row = adj + (size_t)i * n;
+        for (int j = 0; j < n; ++j) {
+            int larger = 0;
+            for (int k = 0; k < n; ++k) larger += (row[k] > row[j]) || (row[k] == row[j] && k > j);
+            if (larger >= top) row[j] = -row[j] - 4.0;      // mark (entries are in [0,2])
+        }
+        for (int j = 0; j < n; ++j) if (row[j] < -1.0) row[j] = 0.0;
+    }
+}
+// Vout[rows[i]] = sum_j adj[i][j] * Vin[rows[j]]  (one hop of fps_gcn_cpu.py:164-165), comb[rows[i]] += Vout
+__global__ __launch_bounds__(256) void sel_propagate(const double* __restrict__ adj, int n, const int* __restrict__ rows, const double* __restrict__ vin, int D,
+                                                     double* vout, double* comb) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * D; e += gridDim.x * 256) {
+        const int i = e / D, c = e % D;
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += adj[(size_t)i * n + j] * vin[(size_t)rows[j] * D + c];
+        vout[(size_t)rows[i] * D + c] = acc;
+        comb[(size_t)rows[i] * D + c] += acc;
+    }
+}
+
+// ---- F4: farthest_features_sample (fps_gcn_cpu.py:119-147) / F5: kCenterGreedy (kcenterGreedy.py:84-128) --------
+struct Part { double v; int i; int pad; };
+
+__device__ __forceinline__ bool better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }   // np.argmax: first maximum
+
+// One step: (1) every block reduces the previous step's partial maxima to learn the current centre,
+// (2) updates the running min-distance of its points, (3) publishes its own partial maximum.
+__global__ __launch_bounds__(256) void fps_step(const double* __restrict__ f, int n, int D, int from_partials, int start, int use_sqrt,
+                                                const Part* __restrict__ pin, int npart, Part* pout, double* mind, int* out) {
+    __shared__ Part s_p[256];
+    __shared__ int s_c;
+    const int tid = threadIdx.x;
+    if (!from_partials) { if (tid == 0) s_c = start; }
+    else {
+        Part b; b.v = -1.0; b.i = 0x7fffffff;
+        for (int k = tid; k < npart; k += 256) if (better(pin[k].v, pin[k].i, b.v, b.i)) b = pin[k];
+        s_p[tid] = b;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o && better(s_p[tid + o].v, s_p[tid + o].i, s_p[tid].v, s_p[tid].i)) s_p[tid] = s_p[tid + o]; __syncthreads(); }
+        if (tid == 0) s_c = s_p[0].i;
+    }
+    __syncthreads();
+    const int c = s_c;
+    if (blockIdx.x == 0 && tid == 0 && out) *out = c;
+    __syncthreads();
+    if (!pout) return;
+    const double* fc = f + (size_t)c * D;
+    Part b; b.v = -1.0; b.i = 0x7fffffff;
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const double* fi = f + (size_t)i * D;
+        double dist = np_pairwise<double>([&](int k) { const double d = fi[k] - fc[k]; return d * d; }, D);
+        if (use_sqrt) dist = sqrt(dist);
+        double m = mind[i];
+        if (dist < m) { m = dist; mind[i] = m; }
+        if (better(m, i, b.v, b.i)) { b.v = m; b.i = i; }
+    }
+    s_p[tid] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o && better(s_p[tid + o].v, s_p[tid + o].i, s_p[tid].v, s_p[tid].i)) s_p[tid] = s_p[tid + o]; __syncthreads(); }
+    if (tid == 0) pout[blockIdx.x] = s_p[0];
+}
+
+__global__ __launch_bounds__(256) void fill_double(double* p, int n, double v) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = v;
+}
+
+// min_distances against the already-selected centres (kcenterGreedy.py:72-82); also the first partial maxima
+__global__ __launch_bounds__(256) void kc_init(const double* __restrict__ f, int n, int D, const int* __restrict__ already, int na, double* mind, Part* pout) {
+    __shared__ Part s_p[256];
+    const int tid = threadIdx.x;
+    Part b; b.v = -1.0; b.i = 0x7fffffff;
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const double* fi = f + (size_t)i * D;
+        double m = 1.0e300;
+        for (int a = 0; a < na; ++a) {
+            const double* fc = f + (size_t)already[a] * D;
+            double dist = np_pairwise<double>([&](int k) { const double d = fi[k] - fc[k]; return d * d; }, D);
+            m = fmin(m, sqrt(dist));
+        }
+        mind[i] = m;
+        if (better(m, i, b.v, b.i)) { b.v = m; b.i = i; }
+    }
+    s_p[tid] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o && better(s_p[tid + o].v, s_p[tid + o].i, s_p[tid].v, s_p[tid].i)) s_p[tid] = s_p[tid + o]; __syncthreads(); }
+    if (tid == 0) pout[blockIdx.x] = s_p[0];
+}
+
+struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp; };
+SelState& sst() { static SelState s; return s; }
+
+inline int grid_for(long n, int cap = 2048) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, cap)); }
+
+}  // namespace
+}  // namespace ssdr
+
+using namespace ssdr;
+
+extern "C" {
+
+int ssdr_point_uncertainty_dev(const float* d_probs, size_t n, int num_classes, int mode, float* d_unc, int32_t* d_cls, void* stream) {
+    if (!d_probs || !d_unc || !d_cls || num_classes < 2 || num_classes > 128 || mode < 0 || mode > 2) { set_error("point_uncertainty: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (n == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_point_unc, dim3(grid_for((long)n)), dim3(256), 0, pick_stream(stream), d_probs, (int)n, num_classes, mode, d_unc, d_cls);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_region_stats_dev(const float* d_unc, const int32_t* d_cls, const int32_t* d_sp_off, const int32_t* d_sp_pts, size_t S, int num_classes,
+                          int mode, double* d_region_unc, int32_t* d_dom, int32_t* d_dom_cnt, void* stream) {
+    if (!d_unc || !d_cls || !d_sp_off || !d_sp_pts || !d_region_unc || !d_dom || !d_dom_cnt || num_classes > 32 || mode < 0 || mode > 2) { set_error("region_stats: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (S == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_region_stats, dim3(grid_for((long)S)), dim3(256), 0, pick_stream(stream), d_unc, d_cls, d_sp_off, d_sp_pts, (int)S, num_classes, mode,
+                       d_region_unc, d_dom, d_dom_cnt);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_dominant_label_dev(const int32_t* d_labels, const int32_t* d_sp_off, const int32_t* d_sp_pts, size_t S, int num_labels,
+                            int32_t* d_label, double* d_purity, void* stream) {
+    if (!d_labels || !d_sp_off || !d_sp_pts || !d_label || !d_purity || num_labels < 1 || num_labels > 64) { set_error("dominant_label: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (S == 0) return SSDR_OK;
+    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    SSDR_TRY(Q.hist.reserve(4 * 64)); SSDR_HIP(hipMemsetAsync(Q.hist.p, 0, 4, s));
+    hipLaunchKernelGGL(sel_dominant_label, dim3(grid_for((long)S)), dim3(256), 0, s, d_labels, d_sp_off, d_sp_pts, (int)S, num_labels, d_label, d_purity, Q.hist.as<int>());
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected, double* d_region_unc, void* stream) {
+    if (!d_region_class || !d_region_unc || (n_selected && !d_selected_class_list)) { set_error("clsbal: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (S == 0) return SSDR_OK;
+    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    SSDR_TRY(Q.hist.reserve(4 * 64)); SSDR_HIP(hipMemsetAsync(Q.hist.p, 0, 4 * 64, s));
+    hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_selected_class_list, (int)n_selected, Q.hist.as<int>());
+    hipLaunchKernelGGL(sel_clsbal, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_class, (int)S, (int)(S + n_selected), Q.hist.as<int>(), d_region_unc);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorted_inds, void* stream) {
+    if (!d_region_unc || !d_sorted_inds) { set_error("rank_regions: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (S == 0) return SSDR_OK;
+    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    SSDR_TRY(Q.keys.reserve(8 * S)); SSDR_TRY(Q.vals.reserve(4 * S));
+    hipLaunchKernelGGL(sel_rank_keys, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_unc, (int)S, Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>());
+    SSDR_TRY(Q.sorter.sort(Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>(), (int)S, nullptr, s));
+    SSDR_HIP(hipMemcpyAsync(d_sorted_inds, Q.vals.p, 4 * S, hipMemcpyDeviceToDevice, s));
+    return SSDR_OK;
+}
+
+int ssdr_segment_mean_features_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const int32_t* d_sp_off,
+                                   const int32_t* d_sp_pts, const int32_t* d_sel, size_t nsel, float* d_out, void* stream) {
+    if (!d_feat || !d_cls || !d_dom || !d_sp_off || !d_sp_pts || !d_out || feat_dim < 1) { set_error("segment_mean_features: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (nsel == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nsel * feat_dim)), dim3(256), 0, pick_stream(stream), d_feat, feat_dim, d_cls, d_dom, d_sp_off, d_sp_pts, d_sel,
+                       (int)nsel, d_out);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel, size_t nsel, size_t max_sp_size,
+                         int gcn_top, double* d_centres, double* d_cd_dir, double* d_adj, void* stream) {
+    if (!d_xyz || !d_sp_off || !d_sp_pts || !d_sel || !d_centres || !d_cd_dir || !d_adj || max_sp_size == 0) { set_error("cloud_graph: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (nsel == 0) return SSDR_OK;
+    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    const int n = (int)nsel;
+    const int gpairs = (int)std::max<long>(1, std::min<long>((long)n * n, (long)ctx().num_cu * 8));
+    SSDR_TRY(Q.mins.reserve(8 * (size_t)gpairs * max_sp_size)); SSDR_TRY(Q.rowsum.reserve(8 * nsel));
+    hipLaunchKernelGGL(sel_centres, dim3(grid_for(n)), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
+    hipLaunchKernelGGL(sel_chamfer_dir, dim3(gpairs), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, Q.mins.as<double>(), (int)max_sp_size, d_cd_dir);
+    hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
+    hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
+    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(grid_for(n)), dim3(256), 0, s, d_adj, n, gcn_top);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, const double* d_vin, int feat_dim, double* d_vout, double* d_comb, void* stream) {
+    if (!d_adj || !d_rows || !d_vin || !d_vout || !d_comb || feat_dim < 1) { set_error("propagate: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (n == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_propagate, dim3(grid_for((long)n * feat_dim)), dim3(256), 0, pick_stream(stream), d_adj, (int)n, d_rows, d_vin, feat_dim, d_vout, d_comb);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_already, size_t na, int start, size_t count, int use_sqrt, int32_t* d_out, hipStream_t s) {
+    SelState& Q = sst();
+    const int nb = grid_for((long)n, ctx().num_cu * 2);
+    SSDR_TRY(Q.part.reserve(sizeof(Part) * 2 * (size_t)nb)); SSDR_TRY(Q.mind.reserve(8 * n));
+    Part* p0 = Q.part.as<Part>(); Part* p1 = p0 + nb;
+    if (d_already && na) hipLaunchKernelGGL(kc_init, dim3(nb), dim3(256), 0, s, d_feat, (int)n, D, d_already, (int)na, Q.mind.as<double>(), p1);
+    else hipLaunchKernelGGL(fill_double, dim3(grid_for((long)n)), dim3(256), 0, s, Q.mind.as<double>(), (int)n, 1.0e10);   // fps_gcn_cpu.py:135
+    const bool seeded = d_already && na;
+    for (size_t it = 0; it < count; ++it) {
+        Part* pin = (it & 1) ? p0 : p1; Part* pout = (it & 1) ? p1 : p0;
+        const bool last = it + 1 == count;
+        // k-center starts from the arg-max of the seeded distances; FPS from `start`
+        hipLaunchKernelGGL(fps_step, dim3(last ? 1 : nb), dim3(256), 0, s, d_feat, (int)n, D, (seeded || it > 0) ? 1 : 0, start, use_sqrt, pin, nb,
+                           last ? (Part*)nullptr : pout, Q.mind.as<double>(), d_out + it);
+        (void)pin;
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_fps_dev(const double* d_feat, size_t n, int feat_dim, int start, size_t count, int32_t* d_out, void* stream) {
+    if (!d_feat || !d_out || feat_dim < 1 || start < 0 || (size_t)start >= n || count > n) { set_error("fps: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (count == 0) return SSDR_OK;
+    return fps_like(d_feat, n, feat_dim, nullptr, 0, start, count, 0, d_out, pick_stream(stream));
+}
+
+int ssdr_kcenter_dev(const double* d_feat, size_t n, int feat_dim, const int32_t* d_already_selected, size_t n_already, size_t count, int32_t* d_out, void* stream) {
+    if (!d_feat || !d_out || feat_dim < 1 || !d_already_selected || n_already == 0) { set_error("kcenter: bad arguments (needs a non-empty already_selected)"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (count == 0) return SSDR_OK;
+    return fps_like(d_feat, n, feat_dim, d_already_selected, n_already, 0, count, 1, d_out, pick_stream(stream));
+}
+
+}

@@ -68,6 +68,17 @@ def lib():
         L.ssdr_randla_destroy.argtypes = [vp]
         L.ssdr_randla_destroy.restype = None
         L.ssdr_randla_infer_dev.argtypes = [vp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
+        f64 = C.c_double
+        L.ssdr_point_uncertainty_dev.argtypes = [vp, sz, i32, i32, vp, vp, vp]
+        L.ssdr_region_stats_dev.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp, vp, vp]
+        L.ssdr_dominant_label_dev.argtypes = [vp, vp, vp, sz, i32, vp, vp, vp]
+        L.ssdr_clsbal_dev.argtypes = [vp, sz, vp, sz, vp, vp]
+        L.ssdr_rank_regions_dev.argtypes = [vp, sz, vp, vp]
+        L.ssdr_segment_mean_features_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, sz, vp, vp]
+        L.ssdr_cloud_graph_dev.argtypes = [vp, vp, vp, vp, sz, sz, i32, vp, vp, vp, vp]
+        L.ssdr_propagate_dev.argtypes = [vp, sz, vp, vp, i32, vp, vp, vp]
+        L.ssdr_fps_dev.argtypes = [vp, sz, i32, i32, sz, vp, vp]
+        L.ssdr_kcenter_dev.argtypes = [vp, sz, i32, vp, sz, sz, vp, vp]
         L.ssdr_dev_alloc.argtypes = [sz, C.POINTER(vp)]
         L.ssdr_dev_free.argtypes = [vp]
         L.ssdr_memcpy_h2d.argtypes = [vp, vp, sz]

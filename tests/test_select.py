@@ -1,0 +1,96 @@
+"""Selection-stage parity: HIP kernels through the C ABI / the reference-named mirror against the golden vectors
+made by the reference's own Python, and against oracle/select_np.py on fresh inputs.  Index sequences and integer
+outputs must be identical; float64 quantities within 1e-12 relative (summation order of BLAS / exp differ)."""
+import numpy as np
+import pytest
+
+from oracle import select_np as O
+
+
+def test_point_uncertainty_golden(backend, golden):
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    for mode in ("lc", "sb"):
+        u, c = sampler.compute_point_uncertainty(g["u/prob"], [mode], return_class=True)
+        assert np.array_equal(u, g["u/pu_" + mode]), mode            # bit-exact float32
+        assert np.array_equal(c, np.argmax(g["u/prob"], -1))
+    u = sampler.compute_point_uncertainty(g["u/prob"], ["entropy"])
+    assert np.allclose(u, g["u/pu_entropy"], rtol=2e-6, atol=1e-7)   # log2f differs in the last ulp
+
+
+def test_region_stats_golden(backend, golden):
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    cls = np.argmax(g["u/prob"], -1).astype(np.int32)
+    for mode in ("mean", "sum_weight", "WetSU"):
+        ru, dom, cnt = sampler.compute_region_stats(g["u/pu_sb"], cls, g["u/offsets"], g["u/points"], 13, [mode])
+        assert np.allclose(ru, g["u/ru_" + mode], rtol=1e-12, atol=0), mode
+        assert np.array_equal(dom, g["u/dom"])
+    ru, dom, cnt = sampler.compute_region_stats(g["u/pu_sb"], cls, g["u/offsets"], g["u/points"], 13, ["WetSU"])
+    assert np.array_equal(ru, g["u/ru_WetSU"])                        # NumPy's pairwise order reproduced exactly
+    lab, pur = sampler.dominant_labels(cls, g["u/offsets"], g["u/points"], 13)
+    assert np.array_equal(lab, g["u/dom"]) and np.allclose(pur, g["u/purity"], rtol=1e-15)
+    cb = sampler.add_clsbal(13, g["u/dom"], g["u/ru_WetSU"], {"selected_class_list": list(g["u/selected_class_list"])})
+    assert np.allclose(cb, g["u/clsbal"], rtol=1e-13)
+    order = sampler.rank_regions(cb)
+    assert np.array_equal(order, O.rank_regions(cb))
+
+
+def test_chamfer_adjacency_gcnfps_golden(backend, golden):
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    clouds = {}
+    for name in ("cloudA", "cloudB"):
+        xyz, off, pts = g["f/%s/xyz" % name], g["f/%s/offsets" % name], g["f/%s/points" % name]
+        clouds[name] = (xyz, off, pts)
+        cd = sampler.create_cd(xyz, off, pts, np.arange(len(off) - 1))
+        assert np.allclose(cd, g["f/%s/cd" % name], rtol=1e-13, atol=1e-15)
+    names = ["cloudA", "cloudB"]
+    unl = [{"cloud_name": names[c], "sp_idx": int(s)} for c, s in zip(g["f/unl_cloud"], g["f/unl_sp"])]
+    lab = [{"cloud_name": names[c], "sp_idx": int(s)} for c, s in zip(g["f/lab_cloud"], g["f/lab_sp"])]
+    # the reference's global adjacency, block by block
+    refs = unl + lab
+    for c, name in enumerate(names):
+        rows = [i for i, r in enumerate(refs) if r["cloud_name"] == name]
+        sel = [refs[i]["sp_idx"] for i in rows]
+        _, _, adj = sampler.cloud_graph(*clouds[name], sel)
+        assert np.allclose(adj, g["f/adj"][np.ix_(rows, rows)], rtol=1e-12, atol=1e-15)
+    for gn in (1, 2, 3):
+        fl = sampler.GCN_FPS_sampling(list(g["f/lab_feat"]), lab, list(g["f/unl_feat"]), unl, clouds, 5, gn, 0, int(g["f/gcnfps_start_%d" % gn]))
+        assert fl.get("cloudA", []) == list(g["f/gcnfps_A_%d" % gn]) and fl.get("cloudB", []) == list(g["f/gcnfps_B_%d" % gn])
+
+
+def test_fps_and_kcenter_golden(backend, golden):
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    assert np.array_equal(sampler.farthest_features_sample(g["fps/feat"], 50, int(g["fps/start"])), g["fps/seq"])
+    kc = sampler.kCenterGreedy(g["kc/feat"])
+    assert kc.select_batch_(g["kc/already"], 30) == list(g["kc/seq"])
+
+
+def test_selection_fresh_inputs_against_oracle(backend):
+    from ssdr_al import sampler
+    rng = np.random.default_rng(21)
+    n, C = (4000, 13) if backend == "emu" else (200000, 13)
+    prob = rng.dirichlet(np.ones(C) * 0.5, n).astype(np.float32)
+    feat = rng.normal(0, 1, (n, 32)).astype(np.float32)
+    sizes = []
+    while sum(sizes) < n:
+        sizes.append(int(rng.integers(5, 400)))
+    sizes[-1] -= sum(sizes) - n
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pts = rng.permutation(n).astype(np.int32)
+    u, cls = sampler.compute_point_uncertainty(prob, ["sb"], return_class=True)
+    assert np.array_equal(u, O.point_uncertainty(prob, "sb"))
+    ru, dom, cnt = sampler.compute_region_stats(u, cls, off, pts, C, ["WetSU"])
+    eru, edom, ecnt = O.region_stats(u, cls, off, pts, C, "WetSU")
+    assert np.array_equal(ru, eru) and np.array_equal(dom, edom) and np.array_equal(cnt, ecnt)
+    sel = O.rank_regions(ru)[:40].astype(np.int32)
+    mf = sampler.segment_mean_features(feat, cls, dom, off, pts, sel)
+    sub_off = np.concatenate([[0], np.cumsum(off[sel + 1] - off[sel])]).astype(np.int32)
+    sub_pts = np.concatenate([pts[off[s]:off[s + 1]] for s in sel])
+    assert np.array_equal(mf, O.segment_mean_features(feat, sub_off, sub_pts, cls, dom[sel]))   # bit-exact float32
+    m = 2000 if backend == "emu" else 20000
+    f = rng.normal(0, 1, (m, 32))
+    k = 60 if backend == "emu" else 600
+    assert np.array_equal(sampler.farthest_features_sample(f, k, 17), O.farthest_features_sample(f, k, 17))
