@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of the SSDR-AL hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the full hot path over one batch of 16 synthetic S3DIS-like rooms per GPU, inputs already
+resident in HBM:  grid-subsample (dl 0.04) of each raw room -> 40960-point tile around a picked centre -> 5-level
+KNN pyramid (k 16) -> RandLA-Net inference (fp32) -> point / superpoint uncertainty, class balance, ranking ->
+candidate features -> per-cloud chamfer graph + one propagation hop -> FPS selection.
+Metric = input tile points through that whole pipe per second (BASELINE.json).  Tiles shard across GPUs with no
+data-path collective until the candidates' propagated features are all-gathered before the (replicated) global
+FPS: weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ssdr-al_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+TILES_PER_GPU = 16
+RAW_DENSITY = 5000.0              # points / m^2 -> 0.4-1.2 M raw points per room
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oracle import randla_np as R          # only the weight initialiser here; the oracle proper runs in cpu_baseline
+    from ssdr_al import _lib, pipeline, synthetic
+    from ssdr_al.helper_tool import ConfigS3DIS
+    _lib.check(_lib.lib().ssdr_init(local_rank))
+
+    weights = R.init_weights(0)
+    rooms = [synthetic.make_room(5000 + rank * TILES_PER_GPU + i, density=RAW_DENSITY) for i in range(TILES_PER_GPU)]
+    hp = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms)
+
+    gather = None
+    if world > 1:
+        import torch
+
+        def gather(comb_local, batch_local):
+            # the one exchange step of the path: per-candidate propagated features (<= a few MB in total)
+            n = torch.tensor([len(comb_local), batch_local], device="cuda", dtype=torch.int64)
+            ns = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(ns, n)
+            nmax = int(max(int(x[0]) for x in ns))
+            pad = torch.zeros((nmax, comb_local.shape[1]), device="cuda", dtype=torch.float64)
+            pad[: len(comb_local)] = torch.from_numpy(comb_local).cuda()
+            bufs = [torch.zeros_like(pad) for _ in range(world)]
+            dist.all_gather(bufs, pad)
+            comb = torch.cat([b[: int(x[0])] for b, x in zip(bufs, ns)]).cpu().numpy()
+            return np.ascontiguousarray(comb), int(sum(int(x[1]) for x in ns))
+
+    def barrier():
+        _lib.sync()
+        if world > 1:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        hp.step(gather)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.step(gather)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    npts = world * TILES_PER_GPU * ConfigS3DIS.num_points * args.steps
+    value = npts / dt / 1e6
+
+    # ---- roofline leg (untimed): per-launch HIP-event timing of the instrumented kernels ------------------
+    roofline = None
+    stage_ms = None
+    if rank == 0:
+        L = _lib.lib()
+        L.ssdr_prof_enable(1)
+        for _ in range(3):
+            hp.step(gather if world == 1 else None)
+        rep = L.ssdr_prof_report().decode().strip().splitlines()
+        L.ssdr_prof_enable(0)
+        rows = []
+        for ln in rep:
+            name, calls, ms, work = ln.rsplit(" ", 3)
+            rows.append((name, int(calls), float(ms), float(work)))
+        rows.sort(key=lambda r: -r[2])
+        name, calls, ms, work = rows[0]
+        mfma = name in ("dense_kernel", "lfa_att_kernel")
+        achieved = work / (ms * 1e-3) / (1e12 if mfma else 1e9)
+        peak = PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBS
+        roofline = {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
+                    "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2),
+                    "others": {r[0]: {"ms_per_step": round(r[2] / 3, 3), "launches_per_step": r[1] // 3} for r in rows}}
+        hp.step(gather if world == 1 else None, timed_stages=True)
+        stage_ms = {k: round(float(v), 3) for k, v in hp.timing.items()}
+        if args.stages:
+            print("stages(ms):", stage_ms, file=sys.stderr)
+
+    # ---- CPU baseline leg (rank 0, N = 1 only): the oracle pipeline on ONE room/tile of the same workload ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pipeline_np
+        cores = os.cpu_count() or 1
+        one = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms[:1])
+        tc = time.perf_counter()
+        ref = pipeline_np.run(one, rooms[:1], weights, threads=cores)
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(ConfigS3DIS.num_points / tcpu / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "port",
+               "sample": "1 room / 1 tile of the same workload (%.1f s): C oracle for subsample + KNN (OpenMP over batch), NumPy (BLAS threads) "
+                         "for RandLA-Net and selection" % tcpu,
+               "stage_ms": {k: round(float(v), 1) for k, v in ref["stage_ms"].items()}}
+
+    if rank == 0:
+        out = {"metric": METRIC, "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "S3DIS-like rooms (synthetic, Area_5 seeds), %d rooms/tiles of 40960 points per GPU per step: grid-subsample "
+                                      "dl=0.04 -> tile -> KNN pyramid k=16 [4,4,4,4,2] -> RandLA-Net infer (random-init, fp32) -> WetSU/sb/clsbal "
+                                      "ranking -> FPS-GCN select (gcn_number=1)" % TILES_PER_GPU,
+                          "tiles_per_gpu": TILES_PER_GPU, "tile_points": ConfigS3DIS.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
+                          "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * TILES_PER_GPU * world), "sharding": "tiles"},
+               "stage_ms": stage_ms, "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,11 @@ const char* ssdr_last_error(void);
 int  ssdr_init(int device);              /* idempotent; selects the HIP device, creates stream + workspace */
 void ssdr_shutdown(void);
 int  ssdr_stream_sync(void* stream);     /* NULL = library stream */
+/* Optional per-launch timing (HIP events on the launch stream) of the instrumented kernels; used by bench.py for
+ * the roofline line.  ssdr_prof_report() synchronises and returns "name calls total_ms total_work\n" lines, where
+ * total_work is the summed algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels) of those launches. */
+int ssdr_prof_enable(int on);
+const char* ssdr_prof_report(void);
 /* Milliseconds spent in the GPU part of the last host-flavour call (HIP events on the library stream). */
 float ssdr_last_gpu_ms(void);
 
@@ -104,6 +109,17 @@ int ssdr_grid_subsample_dev(const float* d_points, size_t n,
                             float sampleDl, int order,
                             float* d_out_points, float* d_out_features, int32_t* d_out_classes,
                             int64_t* d_out_m, void* stream);
+
+/* ---- tile generator (spatially_regular_gen, S3/s3dis_dataset.py:115-154; data_aug, S3/helper_tool.py:185-199) --
+ * From a (sub-sampled) cloud resident on the device — d_points [*,3], d_colors [*,color_dim], live row count
+ * *d_m (device int64, as written by ssdr_grid_subsample_dev; n_max bounds it) — take the num_points points nearest
+ * to center[3] (host), order them by the caller's shuffle d_perm (a permutation of [0,num_points)), subtract the
+ * centre, and emit d_out_xyz [num_points,3], d_out_feat [num_points,3+color_dim] = [xyz_centred, colors*scale]
+ * (may be NULL) and d_out_idx [num_points] = source row (may be NULL).  A cloud with fewer than num_points rows
+ * is padded by duplicating row floor(d_dup_u[r] * m) of the shuffled list (d_dup_u: uniform [0,1) floats). */
+int ssdr_tile_select_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, size_t n_max,
+                         const float* center, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
+                         float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream);
 
 /* ---- RandLA-Net inference (replaces the TF1 graph of S3/RandLANet.py:140-180, 505-585 run by
  *      model.sess.run([prob_logits, last_second_features, ...]) in S3/sampler2.py:598 / :327) ----------

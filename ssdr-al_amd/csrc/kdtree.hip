@@ -378,6 +378,11 @@ int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, 
     ForestPtrs p = ptrs(f);
     SearchArgs a{p.desc, p.vind, p.sorted, p.node_a, p.node_b, tree0, d_queries, q_stride, nq, qorder_tree0, d_out, out_stride, p.ctr};
     dim3 grid((unsigned)((nq + 255) / 256), (unsigned)ntrees);
+    // algorithmic bytes: support + query coordinates read once, indices written once
+    long support = 0;   // not known on the host per tree without the descriptors; callers pass uniform trees
+    (void)support;
+    ProfScope prof(K == 16 ? "kd_search_kernel<16>" : (K == 1 ? "kd_search_kernel<1>" : "kd_search_any_kernel"), s,
+                   (double)ntrees * ((double)nq * 12.0 + (double)nq * K * (out_i64 ? 8.0 : 4.0)));
     if (K == 16) {
         if (out_i64) hipLaunchKernelGGL((kd_search_kernel<16, int64_t>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((kd_search_kernel<16, int32_t>), grid, dim3(256), 0, s, a);

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
 int launch_dense(const DenseArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
     dim3 grid((unsigned)((a.M + DT - 1) / DT), (unsigned)((a.N + DT - 1) / DT));
+    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
     hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, s, a);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
@@ -294,6 +295,9 @@ template <int D> static int launch_lfa_d(const LfaArgs& a, bool second, int B, h
         SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_att_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_done = true;
     }
+    // algorithmic FLOPs: LocSE 10->h, (second half) h->h, attention d->d on n*16 neighbour rows, + the weighted sum
+    const double rows = (double)B * (double)a.n * 16.0;
+    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D));
     if (second) hipLaunchKernelGGL((lfa_att_kernel<D, true>), grid, dim3(256), C::LDS_BYTES, s, a);
     else hipLaunchKernelGGL((lfa_att_kernel<D, false>), grid, dim3(256), C::LDS_BYTES, s, a);
     SSDR_HIP(hipGetLastError());

@@ -54,6 +54,15 @@ Context& ctx();
 int ensure_init();
 inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
 
+// ---- in-library kernel timing (context.hip): HIP events on the launch stream around instrumented launches.
+// Off by default; bench.py switches it on for the roofline leg.  `work` is the launch's algorithmic FLOPs or bytes.
+struct ProfScope {
+    int slot = -1;
+    ProfScope(const char* name, hipStream_t s, double work);
+    ~ProfScope();
+    hipStream_t stream = nullptr;
+};
+
 // ---- radix sort (radix_sort.hip) ----------------------------------------------------------------
 // Stable sort of (u64 key, u32 value) pairs, in place (result in keys/vals).  d_n (optional) is a device
 // int holding the live count (<= n_host); n_host sizes the launches.

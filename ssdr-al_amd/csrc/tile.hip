@@ -1,0 +1,88 @@
+// Tile generator for gfx950: the step between the sub-sampled cloud and the KNN pyramid.
+//
+// Reference: spatially_regular_gen (S3/s3dis_dataset.py:115-154): query the num_points nearest points of a picked
+// centre (sklearn KDTree.query(pick_point, k=num_points)), shuffle them, subtract the centre, and pad a cloud that
+// is smaller than num_points by duplicating randomly chosen points (DP.data_aug, S3/helper_tool.py:185-199).
+// Here: squared distance keys -> stable radix sort (ascending distance, ties by index) -> gather through a
+// caller-supplied shuffle permutation.  Randomness (shuffle, duplicate choice) comes from the caller as arrays,
+// as the reference draws it from np.random on the host.
+#include "ssdr_internal.hpp"
+#include "block_prims.hpp"
+
+namespace ssdr {
+namespace {
+
+__global__ __launch_bounds__(256) void tile_keys(const float* __restrict__ pts, const long long* __restrict__ d_m, int n_host, float cx, float cy, float cz,
+                                                 uint64_t* keys, uint32_t* vals, int* d_count) {
+    const int m = (int)min((long long)n_host, *d_m);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_count = m;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        const float dx = pts[3 * (size_t)i] - cx, dy = pts[3 * (size_t)i + 1] - cy, dz = pts[3 * (size_t)i + 2] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        keys[i] = (uint64_t)__float_as_uint(d);        // non-negative floats order like their bit patterns
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// out row r takes sorted position perm[r] when that position exists (< min(m, num_points)); a cloud smaller than
+// num_points is padded: rows >= m duplicate point floor(dup_u[r] * m) of the *shuffled* list (data_aug).
+__global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts, const float* __restrict__ colors, int cdim,
+                                                   const uint32_t* __restrict__ sorted, const int* __restrict__ d_count,
+                                                   const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
+                                                   float cx, float cy, float cz, float color_scale,
+                                                   float* out_xyz, float* out_feat, int* out_idx) {
+    const int m = *d_count;
+    const int avail = min(m, num_points);
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < num_points; r += gridDim.x * 256) {
+        int pos;
+        if (avail == num_points) pos = perm[r];
+        else {
+            // perm is a permutation of [0,num_points); its entries < avail, in order, shuffle the avail points
+            // (computed by the caller into the first `avail` slots is not possible without m, so: rank on the fly)
+            pos = -1;
+        }
+        if (pos < 0) {
+            // small cloud: row r < avail takes the r-th entry of perm that is < avail; row r >= avail duplicates
+            int want = r < avail ? r : (int)(dup_u[r] * (float)avail);
+            if (want >= avail) want = avail - 1;
+            int seen = 0; pos = 0;
+            for (int q = 0; q < num_points; ++q) { const int v = perm[q]; if (v < avail) { if (seen == want) { pos = v; break; } ++seen; } }
+        }
+        const uint32_t id = sorted[pos];
+        const float x = pts[3 * (size_t)id] - cx, y = pts[3 * (size_t)id + 1] - cy, z = pts[3 * (size_t)id + 2] - cz;
+        out_xyz[3 * (size_t)r] = x; out_xyz[3 * (size_t)r + 1] = y; out_xyz[3 * (size_t)r + 2] = z;
+        if (out_feat) {
+            float* f = out_feat + (size_t)r * (3 + cdim);
+            f[0] = x; f[1] = y; f[2] = z;
+            for (int c = 0; c < cdim; ++c) f[3 + c] = colors[(size_t)id * cdim + c] * color_scale;
+        }
+        if (out_idx) out_idx[r] = (int)id;
+    }
+}
+
+struct TileState { RadixSorter sorter; DevBuf keys, vals, count; };
+TileState& tst() { static TileState s; return s; }
+
+}  // namespace
+}  // namespace ssdr
+
+using namespace ssdr;
+
+extern "C" int ssdr_tile_select_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, size_t n_max,
+                                    const float* center, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
+                                    float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream) {
+    if (!d_points || !d_m || !center || !d_perm || !d_dup_u || !d_out_xyz || n_max == 0 || num_points == 0 || n_max > 0x3fffffff) { set_error("tile_select: bad arguments"); return SSDR_ERR_INVALID; }
+    if (d_out_feat && color_dim > 0 && !d_colors) { set_error("tile_select: colors missing"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    TileState& T = tst(); hipStream_t s = pick_stream(stream);
+    SSDR_TRY(T.keys.reserve(8 * n_max)); SSDR_TRY(T.vals.reserve(4 * n_max)); SSDR_TRY(T.count.reserve(16));
+    const int g = (int)std::max<size_t>(1, std::min<size_t>((n_max + 255) / 256, (size_t)ctx().num_cu * 8));
+    hipLaunchKernelGGL(tile_keys, dim3(g), dim3(256), 0, s, d_points, (const long long*)d_m, (int)n_max, center[0], center[1], center[2],
+                       T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), T.count.as<int>());
+    SSDR_TRY(T.sorter.sort(T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), (int)n_max, T.count.as<int>(), s));
+    const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 1024));
+    hipLaunchKernelGGL(tile_gather, dim3(g2), dim3(256), 0, s, d_points, d_colors, d_colors ? color_dim : 0, T.vals.as<uint32_t>(), T.count.as<int>(),
+                       d_perm, d_dup_u, (int)num_points, center[0], center[1], center[2], color_scale, d_out_xyz, d_out_feat, d_out_idx);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}

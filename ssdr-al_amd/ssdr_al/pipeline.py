@@ -1,0 +1,186 @@
+"""The hot path end to end, device-resident: grid-subsample -> tile -> KNN pyramid -> RandLA-Net inference ->
+uncertainty / region statistics -> candidate features -> per-cloud chamfer graph + propagation -> FPS selection.
+
+This is the sequencing the reference spreads over data_prepare_s3dis.py:58, s3dis_dataset.py:115-183,
+sampler2.py:580-642 (prediction) and :736-781 (the gcn_fps branch of sampling); files, pickles and the label
+simulation are out of scope.  All arithmetic happens in libssdr_al.so; the host only moves small index lists."""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib, randlanet
+from ._lib import DevArray
+from .helper_tool import ConfigS3DIS
+
+
+class HotPath:
+    def __init__(self, weights, config=ConfigS3DIS, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=1, gcn_top=0,
+                 select_per_tile=37, labeled_per_tile=15, seed=0):
+        self.cfg = config
+        self.net = randlanet.Network(config).load(weights)
+        self.sampler_args = list(sampler_args)
+        self.gcn_number, self.gcn_top = gcn_number, gcn_top
+        self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
+        self.rng = np.random.default_rng(seed)
+        self.rooms = []
+        self.timing = None
+
+    # ---- setup (untimed): upload raw rooms, fix the per-room randomness, derive superpoints -------------------
+    def load_rooms(self, rooms):
+        cfg = self.cfg
+        N = cfg.num_points
+        self.B = len(rooms)
+        self.rooms = []
+        for xyz, rgb, lab in rooms:
+            n = len(xyz)
+            r = dict(n=n, pts=DevArray.from_host(xyz.astype(np.float32)), col=DevArray.from_host(rgb.astype(np.float32)),
+                     lab=DevArray.from_host(lab.astype(np.int32).reshape(-1, 1)),
+                     sp=DevArray((n, 3), np.float32), sc=DevArray((n, 3), np.float32), sl=DevArray((n, 1), np.int32), m=DevArray((2,), np.int64))
+            pick = xyz[self.rng.integers(0, n)] + self.rng.normal(0, cfg.noise_init / 10, 3)      # s3dis_dataset.py:119-126
+            r["center"] = np.ascontiguousarray(pick, np.float32)
+            r["perm"] = DevArray.from_host(self.rng.permutation(N).astype(np.int32))              # DP.shuffle_idx :137
+            r["dup"] = DevArray.from_host(self.rng.random(N).astype(np.float32))                  # DP.data_aug's np.random.choice
+            self.rooms.append(r)
+        B = self.B
+        self.xyz = DevArray((B, N, 3), np.float32); self.feat = DevArray((B, N, 6), np.float32)
+        L, K = cfg.num_layers, cfg.k_n
+        self.sizes = [N]
+        for ratio in cfg.sub_sampling_ratio:
+            self.sizes.append(self.sizes[-1] // ratio)
+        self.neigh = [DevArray((B, self.sizes[i], K), np.int32) for i in range(L)]
+        self.interp = [DevArray((B, self.sizes[i], 1), np.int32) for i in range(L)]
+        self.probs = DevArray((B * N, cfg.num_classes), np.float32); self.f32 = DevArray((B * N, 32), np.float32)
+        self.unc = DevArray((B * N,), np.float32); self.cls = DevArray((B * N,), np.int32)
+        # superpoints of the (fixed) tiles: computed once from a dry run of the geometric front end
+        self._front_end()
+        _lib.sync()
+        from .synthetic import superpoints_from_tile
+        tiles = self.xyz.to_host()
+        offs, pts, cloud = [np.zeros(1, np.int32)], [], []
+        for b in range(B):
+            o, p = superpoints_from_tile(tiles[b])
+            pts.append(p + b * N); offs.append(o[1:] + offs[-1][-1]); cloud.append(np.full(len(o) - 1, b, np.int32))
+        self.sp_off_h = np.concatenate(offs).astype(np.int32); self.sp_pts_h = np.concatenate(pts).astype(np.int32)
+        self.sp_cloud_h = np.concatenate(cloud)
+        self.S = len(self.sp_off_h) - 1
+        self.sp_off = DevArray.from_host(self.sp_off_h); self.sp_pts = DevArray.from_host(self.sp_pts_h)
+        self.region_unc = DevArray((self.S,), np.float64); self.dom = DevArray((self.S,), np.int32); self.dom_cnt = DevArray((self.S,), np.int32)
+        self.sorted_inds = DevArray((self.S,), np.int32)
+        # "already labelled" superpoints (stand-in for total_obj / labeled_region_reference_dict) and class list
+        self.labeled = {}
+        for b in range(B):
+            ids = np.flatnonzero(self.sp_cloud_h == b)
+            self.labeled[b] = set(self.rng.choice(ids, min(self.labeled_per_tile, len(ids)), replace=False).tolist())
+        self.selected_class_list = DevArray.from_host(self.rng.integers(0, cfg.num_classes, 4000).astype(np.int32))
+        self.sp_size_h = np.diff(self.sp_off_h)
+        return self
+
+    # ---- stages ------------------------------------------------------------------------------------------------
+    def _front_end(self):
+        cfg, L = self.cfg, _lib.lib()
+        N = cfg.num_points
+        for b, r in enumerate(self.rooms):
+            _lib.check(L.ssdr_grid_subsample_dev(r["pts"].ptr, r["n"], r["col"].ptr, 3, r["lab"].ptr, 1, cfg.sub_grid_size, _lib.ORDER_KEY,
+                                                 r["sp"].ptr, r["sc"].ptr, r["sl"].ptr, r["m"].ptr, None))
+            _lib.check(L.ssdr_tile_select_dev(r["sp"].ptr, r["sc"].ptr, 3, r["m"].ptr, r["n"], _lib.ptr(r["center"]), N, r["perm"].ptr, r["dup"].ptr,
+                                              1.0 / 255.0, self.xyz.ptr + b * N * 12, self.feat.ptr + b * N * 24, None, None))
+
+    def _pyramid(self):
+        cfg = self.cfg
+        arr = C.c_void_p * cfg.num_layers
+        r = np.asarray(cfg.sub_sampling_ratio, np.int32)
+        _lib.check(_lib.lib().ssdr_knn_pyramid_dev(self.xyz.ptr, self.B, cfg.num_points, cfg.num_layers, _lib.ptr(r), cfg.k_n,
+                                                   arr(*[a.ptr for a in self.neigh]), None, arr(*[a.ptr for a in self.interp]), None))
+
+    def _infer(self):
+        self.net.infer_dev(self.B, self.cfg.num_points, self.feat.ptr, self.xyz.ptr, [a.ptr for a in self.neigh], [a.ptr for a in self.interp],
+                           self.probs.ptr, self.f32.ptr)
+
+    def _score(self):
+        cfg, L = self.cfg, _lib.lib()
+        n = self.B * cfg.num_points
+        um = {"lc": 0, "entropy": 1, "sb": 2}[[a for a in self.sampler_args if a in ("lc", "entropy", "sb")][0]]
+        rm = {"mean": 0, "sum_weight": 1, "WetSU": 2}[[a for a in self.sampler_args if a in ("mean", "sum_weight", "WetSU")][0]]
+        _lib.check(L.ssdr_point_uncertainty_dev(self.probs.ptr, n, cfg.num_classes, um, self.unc.ptr, self.cls.ptr, None))
+        _lib.check(L.ssdr_region_stats_dev(self.unc.ptr, self.cls.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, cfg.num_classes, rm,
+                                           self.region_unc.ptr, self.dom.ptr, self.dom_cnt.ptr, None))
+        if "clsbal" in self.sampler_args:
+            _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, self.selected_class_list.shape[0], self.region_unc.ptr, None))
+        _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, None))
+
+    def _candidates(self, sorted_inds):
+        """create_file_top_and_all + the candidate rule of sampling() (sampler2.py:533-552, :745-753) on index lists."""
+        batch_size = min(self.select_per_tile * self.B, len(sorted_inds))
+        top, allc = {}, {}
+        rank = 0
+        for s in sorted_inds:
+            b = int(self.sp_cloud_h[s])
+            if s in self.labeled[b]:
+                continue
+            if rank < batch_size:
+                top.setdefault(b, []).append(int(s))
+            allc.setdefault(b, []).append(int(s))
+            rank += 1
+        unl, sampling_batch = [], 0
+        for b in top:
+            k = len(top[b]); sampling_batch += k
+            unl += [(b, s) for s in allc[b][:2 * k]]
+        lab = [(b, s) for b in sorted(self.labeled) for s in sorted(self.labeled[b])]
+        return unl, lab, sampling_batch
+
+    def _select(self, gather=None):
+        L = _lib.lib()
+        sorted_inds = self.sorted_inds.to_host()            # one small D2H: the host decides the candidate lists
+        unl, lab, sampling_batch = self._candidates(sorted_inds)
+        refs = unl + lab
+        sel = np.array([s for _, s in refs], np.int32)
+        d_sel = DevArray.from_host(sel); d_mf = DevArray((len(sel), 32), np.float32)
+        _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel.ptr, len(sel), d_mf.ptr, None))
+        _lib.sync()
+        V = d_mf.to_host().astype(np.float64)                # float32 -> float64 as np.concatenate/np.matmul promote it
+        d_v = DevArray.from_host(V); d_comb = DevArray.from_host(V)
+        d_tmp = [DevArray(V.shape, np.float64), DevArray(V.shape, np.float64)]
+        blocks = []
+        for b in sorted(set(c for c, _ in refs)):
+            rows = np.array([i for i, (c, _) in enumerate(refs) if c == b], np.int32)
+            ssel = sel[rows]
+            n = len(rows)
+            d = dict(s=DevArray.from_host(ssel), r=DevArray.from_host(rows), c=DevArray((n, 3), np.float64), d=DevArray((n, n), np.float64),
+                     a=DevArray((n, n), np.float64), n=n)
+            _lib.check(L.ssdr_cloud_graph_dev(self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr, d["s"].ptr, n, int(self.sp_size_h[ssel].max()), int(self.gcn_top),
+                                              d["c"].ptr, d["d"].ptr, d["a"].ptr, None))
+            blocks.append(d)
+        src = d_v
+        for hop in range(int(self.gcn_number)):
+            dst = d_tmp[hop & 1]
+            for d in blocks:
+                _lib.check(L.ssdr_propagate_dev(d["a"].ptr, d["n"], d["r"].ptr, src.ptr, 32, dst.ptr, d_comb.ptr, None))
+            src = dst
+        n_unl = len(unl)
+        if gather is not None:                               # multi-GPU: exchange the candidates' propagated features
+            _lib.sync()
+            comb_all, sampling_batch = gather(d_comb.to_host()[:n_unl], sampling_batch)
+            d_comb = DevArray.from_host(comb_all); n_unl = len(comb_all)
+        d_out = DevArray((sampling_batch,), np.int32)
+        start = 0                                            # np.random.randint(0, n) in the reference (:133); fixed here
+        _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
+        _lib.sync()
+        self._keep = (blocks, d_v, d_tmp, d_sel, d_mf)
+        return d_out.to_host(), unl
+
+    def step(self, gather=None, timed_stages=False):
+        """One pass of the hot path over the loaded batch of rooms.  Returns the selected candidate indices."""
+        t = [time.perf_counter()]
+
+        def mark():
+            if timed_stages:
+                _lib.sync(); t.append(time.perf_counter())
+        self._front_end(); mark()
+        self._pyramid(); mark()
+        self._infer(); mark()
+        self._score(); mark()
+        out = self._select(gather); mark()
+        if timed_stages:
+            self.timing = dict(zip(("subsample+tile", "knn_pyramid", "randla_infer", "score", "select"), np.diff(t) * 1e3))
+        return out

@@ -1,0 +1,57 @@
+"""End-to-end hot path (ssdr_al/pipeline.py over the C ABI) against the oracle pipeline, stage by stage."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+
+def _setup(num_points, nrooms, density, select_per_tile, labeled_per_tile):
+    from oracle import randla_np as R
+    from ssdr_al import pipeline, synthetic
+    from ssdr_al.helper_tool import ConfigS3DIS
+
+    class Cfg(ConfigS3DIS):
+        pass
+    Cfg.num_points = num_points
+    W = R.init_weights(0)
+    rooms = [synthetic.make_room(5000 + i, density=density) for i in range(nrooms)]
+    hp = pipeline.HotPath(W, Cfg, select_per_tile=select_per_tile, labeled_per_tile=labeled_per_tile).load_rooms(rooms)
+    return hp, rooms, W
+
+
+def test_hot_path_matches_oracle_stage_by_stage(backend):
+    from oracle import pipeline_np
+    if backend == "emu":
+        hp, rooms, W = _setup(2048, 2, 150.0, 6, 3)
+    else:
+        hp, rooms, W = _setup(40960, 3, 2500.0, 37, 15)
+    sel, unl = hp.step()
+    ref = pipeline_np.run(hp, rooms, W, threads=4)
+    # geometry + indices: bit-exact
+    assert_bits_equal(hp.xyz.to_host(), ref["xyz"], "tile xyz")
+    assert_bits_equal(hp.feat.to_host(), ref["feat"], "tile features")
+    for i in range(5):
+        assert_bits_equal(hp.neigh[i].to_host(), ref["neigh"][i], "neigh%d" % i)
+        assert_bits_equal(hp.interp[i].to_host(), ref["interp"][i], "interp%d" % i)
+    # network: 1e-3 absolute (north_star tolerance, fp32)
+    gp, gf = hp.probs.to_host(), hp.f32.to_host()
+    assert np.abs(gp - ref["probs"]).max() < 1e-3 and np.abs(gf - ref["f32"]).max() < 1e-3
+    # selection: exact given the same network outputs
+    ref2 = pipeline_np.run(hp, rooms, W, threads=4, net_outputs=(gp, gf))
+    assert_bits_equal(hp.unc.to_host(), ref2["unc"], "point uncertainty")
+    assert np.array_equal(hp.cls.to_host(), ref2["cls"])
+    assert np.allclose(hp.region_unc.to_host(), ref2["region_unc"], rtol=1e-12)
+    assert np.array_equal(hp.sorted_inds.to_host(), ref2["sorted_inds"])
+    assert unl == ref2["unl"]
+    assert np.array_equal(sel, ref2["selected"])
+
+
+def test_small_room_is_padded_by_duplication(backend):
+    """A room with fewer than num_points sub-sampled points takes the data_aug path (helper_tool.py:185-199)."""
+    from oracle import pipeline_np
+    hp, rooms, W = _setup(8192 if backend == "emu" else 40960, 1, 60.0 if backend == "emu" else 200.0, 4, 2)
+    hp._front_end()
+    ref = pipeline_np.run(hp, rooms, W, stop_after="front_end")
+    assert ref["m"][0] < hp.cfg.num_points
+    assert_bits_equal(hp.xyz.to_host(), ref["xyz"], "padded tile")
+    assert_bits_equal(hp.feat.to_host(), ref["feat"], "padded tile features")
