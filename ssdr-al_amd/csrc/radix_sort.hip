@@ -20,6 +20,7 @@ struct SortPtrs {
     uint64_t* k[2]; uint32_t* v[2];
     unsigned long long* andor;   // [0] = AND of keys, [1] = OR of keys
     unsigned* hist;              // [256][nblocks_max]
+    unsigned* tot;               // [256] digit totals of the current pass
     const int* d_n; int n_host; int nblocks_max;
 };
 
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(RS_BS) void rs_andor_init(SortPtrs s) {
 }
 
 __global__ __launch_bounds__(RS_BS) void rs_andor(SortPtrs s) {
+    __shared__ unsigned long long sa[RS_BS / 64], so[RS_BS / 64];
     const int n = sort_n(s);
     unsigned long long a = ~0ull, o = 0ull;
     for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { unsigned long long k = s.k[0][i]; a &= k; o |= k; }
@@ -47,7 +49,13 @@ __global__ __launch_bounds__(RS_BS) void rs_andor(SortPtrs s) {
         lo = __shfl_xor((unsigned)o, off); hi = __shfl_xor((unsigned)(o >> 32), off);
         o |= ((unsigned long long)hi << 32) | lo;
     }
-    if ((threadIdx.x & 63) == 0) { atomicAnd(&s.andor[0], a); atomicOr(&s.andor[1], o); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; so[threadIdx.x >> 6] = o; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < RS_BS / 64; ++w) { a &= sa[w]; o |= so[w]; }
+        atomicAnd(&s.andor[0], a); atomicOr(&s.andor[1], o);
+    }
 }
 
 __global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
@@ -69,19 +77,19 @@ __global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
     }
 }
 
-// exclusive scan of hist[d][b] in (d, b) order, one workgroup
-__global__ __launch_bounds__(1024) void rs_scan(SortPtrs s, int p) {
-    __shared__ unsigned wsum[16];
+// per digit d (one workgroup each): exclusive scan of hist[d][0..nb) over the tile axis, digit total to tot[d]
+__global__ __launch_bounds__(RS_BS) void rs_scan(SortPtrs s, int p) {
+    __shared__ unsigned wsum[RS_BS / 64];
     __shared__ unsigned carry_s;
     int par; if (!pass_runs(s, p, par)) return;
     const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
-    const int total = 256 * nb, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    unsigned* row = s.hist + (size_t)blockIdx.x * s.nblocks_max;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < total; base += 1024) {
+    for (int base = 0; base < nb; base += RS_BS) {
         const int e = base + tid;
-        size_t addr = 0; unsigned x = 0;
-        if (e < total) { addr = (size_t)(e / nb) * s.nblocks_max + (e % nb); x = s.hist[addr]; }
+        const unsigned x = e < nb ? row[e] : 0u;
         unsigned incl = x;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off); if (lane >= off) incl += y; }
@@ -89,13 +97,14 @@ __global__ __launch_bounds__(1024) void rs_scan(SortPtrs s, int p) {
         __syncthreads();
         unsigned wbase = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) { unsigned c = wsum[w]; if (w < wid) wbase += c; tot += c; }
+        for (int w = 0; w < RS_BS / 64; ++w) { unsigned c = wsum[w]; if (w < wid) wbase += c; tot += c; }
         const unsigned carry = carry_s;
-        if (e < total) s.hist[addr] = carry + wbase + incl - x;
+        if (e < nb) row[e] = carry + wbase + incl - x;
         __syncthreads();
         if (tid == 0) carry_s = carry + tot;
         __syncthreads();
     }
+    if (tid == 0) s.tot[blockIdx.x] = carry_s;
 }
 
 __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
@@ -107,8 +116,23 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
     uint64_t* KO = s.k[par ^ 1]; uint32_t* VO = s.v[par ^ 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // exclusive scan of the 256 digit totals (thread tid owns digit tid)
+    __shared__ unsigned s_wt[RS_BS / 64];
+    unsigned dbase;
+    {
+        const unsigned x = s.tot[tid];
+        unsigned incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+        if (lane == 63) s_wt[wid] = incl;
+        __syncthreads();
+        unsigned wbase = 0;
+#pragma unroll
+        for (int w = 0; w < RS_BS / 64; ++w) if (w < wid) wbase += s_wt[w];
+        dbase = wbase + incl - x;
+    }
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
-        s_run[tid] = s.hist[(size_t)tid * s.nblocks_max + b];
+        s_run[tid] = dbase + s.hist[(size_t)tid * s.nblocks_max + b];
 #pragma unroll
         for (int w = 0; w < RS_BS / 64; ++w) s_cnt[w][tid] = 0;
         __syncthreads();
@@ -159,7 +183,7 @@ __global__ __launch_bounds__(RS_BS) void rs_finish(SortPtrs s) {
 int RadixSorter::reserve(size_t n_max) {
     nblocks_max = (int)((n_max + RS_TILE - 1) / RS_TILE) + 1;
     SSDR_TRY(k1.reserve(8 * n_max + 16)); SSDR_TRY(v1.reserve(4 * n_max + 16));
-    SSDR_TRY(hist.reserve(4 * 256 * (size_t)nblocks_max)); SSDR_TRY(andor.reserve(16));
+    SSDR_TRY(hist.reserve(4 * 256 * (size_t)nblocks_max + 4 * 256)); SSDR_TRY(andor.reserve(16));
     return SSDR_OK;
 }
 
@@ -167,14 +191,14 @@ int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n
     if (n_host <= 0) return SSDR_OK;
     SSDR_TRY(reserve((size_t)n_host));
     SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>();
-    s.andor = andor.as<unsigned long long>(); s.hist = hist.as<unsigned>(); s.d_n = d_n; s.n_host = n_host; s.nblocks_max = nblocks_max;
+    s.andor = andor.as<unsigned long long>(); s.hist = hist.as<unsigned>(); s.tot = hist.as<unsigned>() + 256 * (size_t)nblocks_max; s.d_n = d_n; s.n_host = n_host; s.nblocks_max = nblocks_max;
     const int nb = (n_host + RS_TILE - 1) / RS_TILE;
     const int g = std::max(1, std::min(nb, ctx().num_cu * 8));
     hipLaunchKernelGGL(rs_andor_init, dim3(1), dim3(RS_BS), 0, st, s);
     hipLaunchKernelGGL(rs_andor, dim3(g), dim3(RS_BS), 0, st, s);
     for (int p = 0; p < 8; ++p) {
         hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
-        hipLaunchKernelGGL(rs_scan, dim3(1), dim3(1024), 0, st, s, p);
+        hipLaunchKernelGGL(rs_scan, dim3(256), dim3(RS_BS), 0, st, s, p);
         hipLaunchKernelGGL(rs_scatter, dim3(g), dim3(RS_BS), 0, st, s, p);
     }
     hipLaunchKernelGGL(rs_finish, dim3(g), dim3(RS_BS), 0, st, s);

@@ -154,60 +154,62 @@ __global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict_
 // ---- F1/F2: bbox centres, chamfer, adjacency, propagation for the superpoints `sel` of ONE cloud ----------------
 __global__ __launch_bounds__(256) void sel_centres(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                    const int* __restrict__ sel, int nsel, double* centres) {
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < nsel; q += gridDim.x * 256) {
+    const int lane = threadIdx.x & 63;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nsel; q += gridDim.x * 4) {      // one wave per superpoint
         const int s = sel[q], lo = sp_off[s], hi = sp_off[s + 1];
         float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int j = lo; j < hi; ++j) {
+        for (int j = lo + lane; j < hi; j += 64) {
             const size_t p = sp_pts[j];
 #pragma unroll
             for (int d = 0; d < 3; ++d) { const float v = xyz[3 * p + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
         }
 #pragma unroll
-        for (int d = 0; d < 3; ++d) centres[3 * (size_t)q + d] = (double)(mn[d] + mx[d]) / 2.0;   // float32 add, exact halving (fps_gcn_cpu.py:86-88)
+        for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) centres[3 * (size_t)q + d] = (double)(mn[d] + mx[d]) / 2.0;   // float32 add, exact halving (fps_gcn_cpu.py:86-88)
+        }
     }
 }
 
-constexpr int CH_TILE = 1024;   // points of the target superpoint staged in LDS per step
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return v;
+}
 
-// dir[i*nsel + j] = mean over points a of sp_i of min over points b of sp_j of |(a-c_i) - (b-c_j)|   (float64)
+// dir[i*nsel + j] = mean over points a of sp_i of min over points b of sp_j of |(a-c_i) - (b-c_j)|   (float64).
+// One wave per ordered pair; every lane owns a strided subset of sp_i's points.  The mean is a wave tree sum, so
+// it can differ from NumPy's pairwise np.mean in the last ulp (the min distances themselves are exact).
 __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres,
-                                                       double* mins, int max_sp, double* dir) {
-    __shared__ double tb[CH_TILE * 3];
-    double* my_min = mins + (size_t)blockIdx.x * max_sp;
-    for (int pair = blockIdx.x; pair < nsel * nsel; pair += gridDim.x) {
+                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir) {
+    const int lane = threadIdx.x & 63;
+    for (int pair = blockIdx.x * 4 + (threadIdx.x >> 6); pair < nsel * nsel; pair += gridDim.x * 4) {
         const int i = pair / nsel, j = pair % nsel;
-        if (i == j) { if (threadIdx.x == 0) dir[pair] = 0.0; continue; }
+        if (i == j) { if (lane == 0) dir[pair] = 0.0; continue; }
         const int si = sel[i], sj = sel[j];
         const int loi = sp_off[si], ni = sp_off[si + 1] - loi, loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
         const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
         const double cjx = centres[3 * j], cjy = centres[3 * j + 1], cjz = centres[3 * j + 2];
-        for (int a = threadIdx.x; a < ni; a += 256) my_min[a] = 1.0e300;
-        for (int b0 = 0; b0 < nj; b0 += CH_TILE) {
-            const int nb = min(CH_TILE, nj - b0);
-            __syncthreads();
-            for (int b = threadIdx.x; b < nb; b += 256) {
-                const size_t p = sp_pts[loj + b0 + b];
-                tb[3 * b] = (double)xyz[3 * p] - cjx; tb[3 * b + 1] = (double)xyz[3 * p + 1] - cjy; tb[3 * b + 2] = (double)xyz[3 * p + 2] - cjz;
+        double acc = 0.0;
+        for (int a = lane; a < ni; a += 64) {
+            const size_t p = sp_pts[loi + a];
+            const double ax = (double)xyz[3 * p] - cix, ay = (double)xyz[3 * p + 1] - ciy, az = (double)xyz[3 * p + 2] - ciz;
+            double m = 1.0e300;
+            for (int b = 0; b < nj; ++b) {
+                const size_t q = sp_pts[loj + b];
+                const double dx = ax - ((double)xyz[3 * q] - cjx), dy = ay - ((double)xyz[3 * q + 1] - cjy), dz = az - ((double)xyz[3 * q + 2] - cjz);
+                double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+                m = fmin(m, d);
             }
-            __syncthreads();
-            for (int a = threadIdx.x; a < ni; a += 256) {
-                const size_t p = sp_pts[loi + a];
-                const double ax = (double)xyz[3 * p] - cix, ay = (double)xyz[3 * p + 1] - ciy, az = (double)xyz[3 * p + 2] - ciz;
-                double m = my_min[a];
-                for (int b = 0; b < nb; ++b) {
-                    const double dx = ax - tb[3 * b], dy = ay - tb[3 * b + 1], dz = az - tb[3 * b + 2];
-                    double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
-                    m = fmin(m, d);
-                }
-                my_min[a] = m;
-            }
+            acc += sqrt(m);        // sqrt is monotone: min of roots == root of min
         }
-        __syncthreads();
-        for (int a = threadIdx.x; a < ni; a += 256) my_min[a] = sqrt(my_min[a]);   // sqrt is monotone: min of roots == root of min
-        __syncthreads();
-        if (threadIdx.x == 0) dir[pair] = np_pairwise<double>([&](int a) { return my_min[a]; }, ni) / (double)ni;   // np.mean
-        __syncthreads();
+        acc = wave_sum_f64(acc);
+        if (lane == 0) dir[pair] = ni > 0 ? acc / (double)ni : 0.0;
     }
 }
 
@@ -304,6 +306,57 @@ __global__ __launch_bounds__(256) void fps_step(const double* __restrict__ f, in
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o && better(s_p[tid + o].v, s_p[tid + o].i, s_p[tid].v, s_p[tid].i)) s_p[tid] = s_p[tid + o]; __syncthreads(); }
     if (tid == 0) pout[blockIdx.x] = s_p[0];
+}
+
+// Whole FPS / k-center chain in ONE workgroup (no launch per iteration) for candidate sets that one CU can sweep
+// per step: mind[] lives in global memory (L2), the arg-max is a wave shuffle + LDS reduction.
+__global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, int n, int D, int from_partials, int start, int use_sqrt,
+                                                  const Part* __restrict__ pin, int npart, double* mind, int count, int* out) {
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    __shared__ int s_c;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    auto block_argmax = [&](double v, int i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long b = __double_as_longlong(v);
+            const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
+            const double ov = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            const int oi = __shfl_xor(i, o);
+            if (better(ov, oi, v, i)) { v = ov; i = oi; }
+        }
+        if (lane == 0) { s_v[wid] = v; s_i[wid] = i; }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = s_v[0]; int bi = s_i[0];
+            for (int w = 1; w < 16; ++w) if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+            s_c = bi;
+        }
+        __syncthreads();
+    };
+    if (!from_partials) { if (tid == 0) s_c = start; __syncthreads(); }
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < npart; k += 1024) if (better(pin[k].v, pin[k].i, v, i)) { v = pin[k].v; i = pin[k].i; }
+        block_argmax(v, i);
+    }
+    for (int it = 0; it < count; ++it) {
+        const int c = s_c;
+        if (tid == 0) out[it] = c;
+        if (it + 1 == count) break;
+        const double* fc = f + (size_t)c * D;
+        double bv = -1.0; int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) {
+            const double* fi = f + (size_t)i * D;
+            double dist = np_pairwise<double>([&](int k) { const double d = fi[k] - fc[k]; return d * d; }, D);
+            if (use_sqrt) dist = sqrt(dist);
+            double m = mind[i];
+            if (dist < m) { m = dist; mind[i] = m; }
+            if (better(m, i, bv, bi)) { bv = m; bi = i; }
+        }
+        __syncthreads();          // everyone has read s_c
+        block_argmax(bv, bi);
+    }
 }
 
 __global__ __launch_bounds__(256) void fill_double(double* p, int n, double v) {
@@ -418,10 +471,10 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     if (nsel == 0) return SSDR_OK;
     SelState& Q = sst(); hipStream_t s = pick_stream(stream);
     const int n = (int)nsel;
-    const int gpairs = (int)std::max<long>(1, std::min<long>((long)n * n, (long)ctx().num_cu * 8));
-    SSDR_TRY(Q.mins.reserve(8 * (size_t)gpairs * max_sp_size)); SSDR_TRY(Q.rowsum.reserve(8 * nsel));
-    hipLaunchKernelGGL(sel_centres, dim3(grid_for(n)), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
-    hipLaunchKernelGGL(sel_chamfer_dir, dim3(gpairs), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, Q.mins.as<double>(), (int)max_sp_size, d_cd_dir);
+    const int gpairs = (int)std::max<long>(1, std::min<long>((long)n * n, (long)ctx().num_cu * 32 * 4));
+    SSDR_TRY(Q.rowsum.reserve(8 * nsel));
+    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
+    hipLaunchKernelGGL(sel_chamfer_dir, dim3((gpairs + 3) / 4 * 1), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir);
     hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(grid_for(n)), dim3(256), 0, s, d_adj, n, gcn_top);
@@ -446,6 +499,11 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     if (d_already && na) hipLaunchKernelGGL(kc_init, dim3(nb), dim3(256), 0, s, d_feat, (int)n, D, d_already, (int)na, Q.mind.as<double>(), p1);
     else hipLaunchKernelGGL(fill_double, dim3(grid_for((long)n)), dim3(256), 0, s, Q.mind.as<double>(), (int)n, 1.0e10);   // fps_gcn_cpu.py:135
     const bool seeded = d_already && na;
+    if (n <= 16384) {     // one CU sweeps the candidates faster than a launch per iteration costs
+        hipLaunchKernelGGL(fps_block, dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     for (size_t it = 0; it < count; ++it) {
         Part* pin = (it & 1) ? p0 : p1; Part* pout = (it & 1) ? p1 : p0;
         const bool last = it + 1 == count;

@@ -104,18 +104,33 @@ def last_gpu_ms():
     return float(lib().ssdr_last_gpu_ms())
 
 
+_pool = {}          # size class -> [device pointers]; avoids hipMalloc/hipFree (both synchronise) in steady state
+
+
+def _size_class(nbytes):
+    c = 256
+    while c < nbytes:
+        c *= 2
+    return c
+
+
 class DevArray:
     """A device buffer owned through the C ABI (ssdr_dev_alloc / ssdr_memcpy_*): lets the mirror keep tiles
-    resident between stages without any framework dependency."""
+    resident between stages without any framework dependency.  Freed buffers are recycled by size class."""
 
     def __init__(self, shape, dtype):
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
-        p = C.c_void_p()
-        check(lib().ssdr_dev_alloc(max(self.nbytes, 1), C.byref(p)))
-        self.ptr = p.value
+        self._cls = _size_class(max(self.nbytes, 1))
         self._owner_lib = lib()
+        free = _pool.get((id(self._owner_lib), self._cls))
+        if free:
+            self.ptr = free.pop()
+        else:
+            p = C.c_void_p()
+            check(lib().ssdr_dev_alloc(self._cls, C.byref(p)))
+            self.ptr = p.value
 
     @classmethod
     def from_host(cls, a):
@@ -132,7 +147,11 @@ class DevArray:
     def __del__(self):
         try:
             if self.ptr:
-                self._owner_lib.ssdr_dev_free(self.ptr)
+                free = _pool.setdefault((id(self._owner_lib), self._cls), [])
+                if len(free) < 64 and self._cls <= (1 << 26):
+                    free.append(self.ptr)
+                else:
+                    self._owner_lib.ssdr_dev_free(self.ptr)
                 self.ptr = None
         except Exception:
             pass
