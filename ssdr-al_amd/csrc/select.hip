@@ -52,6 +52,22 @@ __device__ T np_pairwise(Get get, int n) {
     return ret;
 }
 
+// Same summation order for a compile-time length 8 <= D <= 128 that is a multiple of 8 (fully unrolled: the 32-d
+// feature distance of farthest_features_sample).
+template <int D, class Get>
+__device__ __forceinline__ double np_pairwise_fixed(Get get) {
+    static_assert(D >= 8 && D <= 128 && D % 8 == 0, "np_pairwise_fixed");
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = get(j);
+#pragma unroll
+    for (int i = 8; i < D; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += get(i + j);
+    }
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
 // ---- U1: compute_point_uncertainty (sampler2.py:28-47) + argmax class (:602) ------------------------------
 __global__ __launch_bounds__(256) void sel_point_unc(const float* __restrict__ prob, int n, int C, int mode, float* unc, int* cls) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -182,34 +198,55 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+constexpr int CH_TILE = 1536;   // target points staged per step (36 KiB of float64 coordinates)
+
 // dir[i*nsel + j] = mean over points a of sp_i of min over points b of sp_j of |(a-c_i) - (b-c_j)|   (float64).
-// One wave per ordered pair; every lane owns a strided subset of sp_i's points.  The mean is a wave tree sum, so
-// it can differ from NumPy's pairwise np.mean in the last ulp (the min distances themselves are exact).
+// One workgroup per target superpoint j: its centred points are staged in LDS once and re-used against every
+// source superpoint i (one wave per i, one lane per source point).  The mean is a wave tree sum, so it can differ
+// from NumPy's pairwise np.mean in the last ulp (the min distances themselves are exact).
 __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                        const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir) {
-    const int lane = threadIdx.x & 63;
-    for (int pair = blockIdx.x * 4 + (threadIdx.x >> 6); pair < nsel * nsel; pair += gridDim.x * 4) {
-        const int i = pair / nsel, j = pair % nsel;
-        if (i == j) { if (lane == 0) dir[pair] = 0.0; continue; }
-        const int si = sel[i], sj = sel[j];
-        const int loi = sp_off[si], ni = sp_off[si + 1] - loi, loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
-        const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
+    __shared__ double tb[CH_TILE * 3];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int j = blockIdx.x; j < nsel; j += gridDim.x) {
+        const int sj = sel[j], loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
         const double cjx = centres[3 * j], cjy = centres[3 * j + 1], cjz = centres[3 * j + 2];
-        double acc = 0.0;
-        for (int a = lane; a < ni; a += 64) {
-            const size_t p = sp_pts[loi + a];
-            const double ax = (double)xyz[3 * p] - cix, ay = (double)xyz[3 * p + 1] - ciy, az = (double)xyz[3 * p + 2] - ciz;
-            double m = 1.0e300;
-            for (int b = 0; b < nj; ++b) {
+        if (nj <= CH_TILE) {
+            __syncthreads();
+            for (int b = threadIdx.x; b < nj; b += 256) {
                 const size_t q = sp_pts[loj + b];
-                const double dx = ax - ((double)xyz[3 * q] - cjx), dy = ay - ((double)xyz[3 * q + 1] - cjy), dz = az - ((double)xyz[3 * q + 2] - cjz);
-                double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
-                m = fmin(m, d);
+                tb[3 * b] = (double)xyz[3 * q] - cjx; tb[3 * b + 1] = (double)xyz[3 * q + 1] - cjy; tb[3 * b + 2] = (double)xyz[3 * q + 2] - cjz;
             }
-            acc += sqrt(m);        // sqrt is monotone: min of roots == root of min
+            __syncthreads();
         }
-        acc = wave_sum_f64(acc);
-        if (lane == 0) dir[pair] = ni > 0 ? acc / (double)ni : 0.0;
+        for (int i = wid; i < nsel; i += 4) {
+            if (i == j) { if (lane == 0) dir[(size_t)i * nsel + j] = 0.0; continue; }
+            const int si = sel[i], loi = sp_off[si], ni = sp_off[si + 1] - loi;
+            const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
+            double acc = 0.0;
+            for (int a = lane; a < ni; a += 64) {
+                const size_t p = sp_pts[loi + a];
+                const double ax = (double)xyz[3 * p] - cix, ay = (double)xyz[3 * p + 1] - ciy, az = (double)xyz[3 * p + 2] - ciz;
+                double m = 1.0e300;
+                if (nj <= CH_TILE) {
+                    for (int b = 0; b < nj; ++b) {
+                        const double dx = ax - tb[3 * b], dy = ay - tb[3 * b + 1], dz = az - tb[3 * b + 2];
+                        double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+                        m = fmin(m, d);
+                    }
+                } else {                       // very large target: stream it from global memory
+                    for (int b = 0; b < nj; ++b) {
+                        const size_t q = sp_pts[loj + b];
+                        const double dx = ax - ((double)xyz[3 * q] - cjx), dy = ay - ((double)xyz[3 * q + 1] - cjy), dz = az - ((double)xyz[3 * q + 2] - cjz);
+                        double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+                        m = fmin(m, d);
+                    }
+                }
+                acc += sqrt(m);        // sqrt is monotone: min of roots == root of min
+            }
+            acc = wave_sum_f64(acc);
+            if (lane == 0) dir[(size_t)i * nsel + j] = ni > 0 ? acc / (double)ni : 0.0;
+        }
     }
 }
 
@@ -309,12 +346,16 @@ __global__ __launch_bounds__(256) void fps_step(const double* __restrict__ f, in
 }
 
 // Whole FPS / k-center chain in ONE workgroup (no launch per iteration) for candidate sets that one CU can sweep
-// per step: mind[] lives in global memory (L2), the arg-max is a wave shuffle + LDS reduction.
+// per step.  DF > 0: feature length known at compile time; the first two points of every thread stay in registers
+// (n <= 2048 -> no global feature traffic inside the loop).  mind[] lives in global memory; the arg-max is a wave
+// shuffle + LDS reduction.
+template <int DF>
 __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, int n, int D, int from_partials, int start, int use_sqrt,
                                                   const Part* __restrict__ pin, int npart, double* mind, int count, int* out) {
     __shared__ double s_v[16];
     __shared__ int s_i[16];
     __shared__ int s_c;
+    __shared__ double s_fc[DF > 0 ? DF : 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     auto block_argmax = [&](double v, int i) {
 #pragma unroll
@@ -334,6 +375,18 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
         }
         __syncthreads();
     };
+    constexpr int NR = DF > 0 ? 2 : 0;
+    double reg[NR > 0 ? NR : 1][DF > 0 ? DF : 1];
+    double rmin[NR > 0 ? NR : 1];
+    if (DF > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int i = tid + q * 1024;
+            rmin[q] = i < n ? mind[i] : -1.0;
+#pragma unroll
+            for (int k = 0; k < (DF > 0 ? DF : 1); ++k) reg[q][k] = i < n ? f[(size_t)i * D + k] : 0.0;
+        }
+    }
     if (!from_partials) { if (tid == 0) s_c = start; __syncthreads(); }
     else {
         double v = -1.0; int i = 0x7fffffff;
@@ -345,16 +398,31 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
         if (tid == 0) out[it] = c;
         if (it + 1 == count) break;
         const double* fc = f + (size_t)c * D;
+        if (DF > 0) { if (tid < DF) s_fc[tid] = fc[tid]; __syncthreads(); }
         double bv = -1.0; int bi = 0x7fffffff;
-        for (int i = tid; i < n; i += 1024) {
+        if (DF > 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int i = tid + q * 1024;
+                if (i < n) {
+                    double dist = np_pairwise_fixed<(DF > 0 ? DF : 8)>([&](int k) { const double d = reg[q][k] - s_fc[k]; return d * d; });
+                    if (use_sqrt) dist = sqrt(dist);
+                    if (dist < rmin[q]) rmin[q] = dist;
+                    if (better(rmin[q], i, bv, bi)) { bv = rmin[q]; bi = i; }
+                }
+            }
+        }
+        for (int i = tid + NR * 1024; i < n; i += 1024) {
             const double* fi = f + (size_t)i * D;
-            double dist = np_pairwise<double>([&](int k) { const double d = fi[k] - fc[k]; return d * d; }, D);
+            double dist;
+            if (DF > 0) dist = np_pairwise_fixed<(DF > 0 ? DF : 8)>([&](int k) { const double d = fi[k] - s_fc[k]; return d * d; });
+            else dist = np_pairwise<double>([&](int k) { const double d = fi[k] - fc[k]; return d * d; }, D);
             if (use_sqrt) dist = sqrt(dist);
             double m = mind[i];
             if (dist < m) { m = dist; mind[i] = m; }
             if (better(m, i, bv, bi)) { bv = m; bi = i; }
         }
-        __syncthreads();          // everyone has read s_c
+        __syncthreads();          // everyone has read s_c / s_fc
         block_argmax(bv, bi);
     }
 }
@@ -471,10 +539,9 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     if (nsel == 0) return SSDR_OK;
     SelState& Q = sst(); hipStream_t s = pick_stream(stream);
     const int n = (int)nsel;
-    const int gpairs = (int)std::max<long>(1, std::min<long>((long)n * n, (long)ctx().num_cu * 32 * 4));
     SSDR_TRY(Q.rowsum.reserve(8 * nsel));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
-    hipLaunchKernelGGL(sel_chamfer_dir, dim3((gpairs + 3) / 4 * 1), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir);
+    hipLaunchKernelGGL(sel_chamfer_dir, dim3(std::min(n, 4096)), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir);
     hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(grid_for(n)), dim3(256), 0, s, d_adj, n, gcn_top);
@@ -500,7 +567,8 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     else hipLaunchKernelGGL(fill_double, dim3(grid_for((long)n)), dim3(256), 0, s, Q.mind.as<double>(), (int)n, 1.0e10);   // fps_gcn_cpu.py:135
     const bool seeded = d_already && na;
     if (n <= 16384) {     // one CU sweeps the candidates faster than a launch per iteration costs
-        hipLaunchKernelGGL(fps_block, dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        if (D == 32) hipLaunchKernelGGL((fps_block<32>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        else hipLaunchKernelGGL((fps_block<0>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
     }
