@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__
             }
             __syncthreads();
         }
-        for (int i = wid; i < nsel; i += 4) {
+        for (int i = blockIdx.y * 4 + wid; i < nsel; i += 4 * gridDim.y) {
             if (i == j) { if (lane == 0) dir[(size_t)i * nsel + j] = 0.0; continue; }
             const int si = sel[i], loi = sp_off[si], ni = sp_off[si + 1] - loi;
             const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
@@ -229,11 +229,22 @@ __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__
                 const double ax = (double)xyz[3 * p] - cix, ay = (double)xyz[3 * p + 1] - ciy, az = (double)xyz[3 * p + 2] - ciz;
                 double m = 1.0e300;
                 if (nj <= CH_TILE) {
-                    for (int b = 0; b < nj; ++b) {
+                    double m4[4] = {1.0e300, 1.0e300, 1.0e300, 1.0e300};   // independent chains: min is order-free
+                    int b = 0;
+                    for (; b + 4 <= nj; b += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double dx = ax - tb[3 * (b + u)], dy = ay - tb[3 * (b + u) + 1], dz = az - tb[3 * (b + u) + 2];
+                            double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+                            m4[u] = d < m4[u] ? d : m4[u];
+                        }
+                    }
+                    for (; b < nj; ++b) {
                         const double dx = ax - tb[3 * b], dy = ay - tb[3 * b + 1], dz = az - tb[3 * b + 2];
                         double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
-                        m = fmin(m, d);
+                        m4[0] = d < m4[0] ? d : m4[0];
                     }
+                    m = fmin(fmin(m4[0], m4[1]), fmin(m4[2], m4[3]));
                 } else {                       // very large target: stream it from global memory
                     for (int b = 0; b < nj; ++b) {
                         const size_t q = sp_pts[loj + b];
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
         }
         __syncthreads();
     };
-    constexpr int NR = DF > 0 ? 2 : 0;
+    constexpr int NR = 0;   // points per thread kept in registers: none (64 doubles per point spill at 1024 threads); L2 serves them
     double reg[NR > 0 ? NR : 1][DF > 0 ? DF : 1];
     double rmin[NR > 0 ? NR : 1];
     if (DF > 0) {
@@ -424,6 +435,75 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
         }
         __syncthreads();          // everyone has read s_c / s_fc
         block_argmax(bv, bi);
+    }
+}
+
+// Register-resident variant for small candidate sets (n <= 512 * PPT): every thread owns PPT points whose features
+// and running min-distance never leave its registers; the current centre's features are published through LDS by
+// the owning thread, so the loop touches global memory only to store the selected index.
+template <int DF, int PPT>
+__global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ f, int n, int from_partials, int start, int use_sqrt,
+                                                     const Part* __restrict__ pin, int npart, const double* __restrict__ mind, int count, int* out) {
+    __shared__ double s_v[8];
+    __shared__ int s_i[8];
+    __shared__ int s_c;
+    __shared__ double s_fc[DF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double reg[PPT][DF], rmin[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int i = tid + q * 512;
+        rmin[q] = i < n ? mind[i] : -1.0;
+#pragma unroll
+        for (int k = 0; k < DF; ++k) reg[q][k] = i < n ? f[(size_t)i * DF + k] : 0.0;
+    }
+    auto block_argmax = [&](double v, int i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long b = __double_as_longlong(v);
+            const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
+            const double ov = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            const int oi = __shfl_xor(i, o);
+            if (better(ov, oi, v, i)) { v = ov; i = oi; }
+        }
+        if (lane == 0) { s_v[wid] = v; s_i[wid] = i; }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = s_v[0]; int bi = s_i[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+            s_c = bi;
+        }
+        __syncthreads();
+    };
+    if (!from_partials) { if (tid == 0) s_c = start; __syncthreads(); }
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < npart; k += 512) if (better(pin[k].v, pin[k].i, v, i)) { v = pin[k].v; i = pin[k].i; }
+        block_argmax(v, i);
+    }
+    for (int it = 0; it < count; ++it) {
+        const int c = s_c;
+        if (tid == 0) out[it] = c;
+        if (it + 1 == count) break;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) if (c == tid + q * 512) {
+#pragma unroll
+            for (int k = 0; k < DF; ++k) s_fc[k] = reg[q][k];
+        }
+        __syncthreads();
+        double bv = -1.0; int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int i = tid + q * 512;
+            if (i < n) {
+                double dist = np_pairwise_fixed<DF>([&](int k) { const double d = reg[q][k] - s_fc[k]; return d * d; });
+                if (use_sqrt) dist = sqrt(dist);
+                if (dist < rmin[q]) rmin[q] = dist;
+                if (better(rmin[q], i, bv, bi)) { bv = rmin[q]; bi = i; }
+            }
+        }
+        block_argmax(bv, bi);     // its first barrier also orders the s_fc reads before the next overwrite
     }
 }
 
@@ -541,7 +621,7 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     const int n = (int)nsel;
     SSDR_TRY(Q.rowsum.reserve(8 * nsel));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
-    hipLaunchKernelGGL(sel_chamfer_dir, dim3(std::min(n, 4096)), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir);
+    hipLaunchKernelGGL(sel_chamfer_dir, dim3(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir);
     hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(grid_for(n)), dim3(256), 0, s, d_adj, n, gcn_top);
@@ -566,6 +646,14 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     if (d_already && na) hipLaunchKernelGGL(kc_init, dim3(nb), dim3(256), 0, s, d_feat, (int)n, D, d_already, (int)na, Q.mind.as<double>(), p1);
     else hipLaunchKernelGGL(fill_double, dim3(grid_for((long)n)), dim3(256), 0, s, Q.mind.as<double>(), (int)n, 1.0e10);   // fps_gcn_cpu.py:135
     const bool seeded = d_already && na;
+    if (D == 32 && n <= 1536) {   // register-resident single workgroup
+        const int fp = seeded ? 1 : 0;
+        if (n <= 512) hipLaunchKernelGGL((fps_block_reg<32, 1>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        else if (n <= 1024) hipLaunchKernelGGL((fps_block_reg<32, 2>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        else hipLaunchKernelGGL((fps_block_reg<32, 3>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     if (n <= 16384) {     // one CU sweeps the candidates faster than a launch per iteration costs
         if (D == 32) hipLaunchKernelGGL((fps_block<32>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
         else hipLaunchKernelGGL((fps_block<0>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
