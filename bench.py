@@ -62,20 +62,8 @@ def main():
 
     gather = None
     if world > 1:
-        import torch
-
-        def gather(comb_local, batch_local):
-            # the one exchange step of the path: per-candidate propagated features (<= a few MB in total)
-            n = torch.tensor([len(comb_local), batch_local], device="cuda", dtype=torch.int64)
-            ns = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(ns, n)
-            nmax = int(max(int(x[0]) for x in ns))
-            pad = torch.zeros((nmax, comb_local.shape[1]), device="cuda", dtype=torch.float64)
-            pad[: len(comb_local)] = torch.from_numpy(comb_local).cuda()
-            bufs = [torch.zeros_like(pad) for _ in range(world)]
-            dist.all_gather(bufs, pad)
-            comb = torch.cat([b[: int(x[0])] for b, x in zip(bufs, ns)]).cpu().numpy()
-            return np.ascontiguousarray(comb), int(sum(int(x[1]) for x in ns))
+        from ssdr_al.distributed import make_gather
+        gather = make_gather(dist, "cuda")     # the one exchange step: per-candidate propagated features (a few MB)
 
     def barrier():
         _lib.sync()
