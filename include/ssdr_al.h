@@ -182,6 +182,12 @@ int ssdr_fps_dev(const double* d_feat, size_t n, int feat_dim, int start, size_t
 int ssdr_kcenter_dev(const double* d_feat, size_t n, int feat_dim, const int32_t* d_already_selected, size_t n_already, size_t count,
                      int32_t* d_out, void* stream);
 
+/* ---- chamfer_3D.forward (Semantic3D variant: SSRD_AL_semantic3d/chamfer3D/chamfer3D.cu:12-152, chamfer_cuda.cpp:30-33,
+ *      dist_chamfer_3D.py:29-81).  xyz1 [b,n,3], xyz2 [b,m,3] -> squared distances dist1 [b,n], dist2 [b,m] and
+ *      nearest indices idx1 [b,n] (into xyz2), idx2 [b,m] (into xyz1); fp32; lowest index on exact ties. */
+int ssdr_chamfer3d_forward_dev(const float* d_xyz1, const float* d_xyz2, size_t batch, size_t n, size_t m,
+                               float* d_dist1, float* d_dist2, int32_t* d_idx1, int32_t* d_idx2, void* stream);
+
 /* ---- plain device memory for callers without their own allocator (tests, the ctypes mirror) ---------- */
 int ssdr_dev_alloc(size_t bytes, void** d_ptr);
 int ssdr_dev_free(void* d_ptr);
