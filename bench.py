@@ -58,12 +58,12 @@ def main():
 
     weights = R.init_weights(0)
     rooms = [synthetic.make_room(5000 + rank * TILES_PER_GPU + i, density=RAW_DENSITY) for i in range(TILES_PER_GPU)]
-    hp = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms)
+    hp = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
 
     gather = None
     if world > 1:
-        from ssdr_al.distributed import make_gather
-        gather = make_gather(dist, "cuda")     # the one exchange step: per-candidate propagated features (a few MB)
+        from ssdr_al.distributed import Comm
+        gather = Comm(dist, "cuda")             # the three small exchanges of the selection stage (RCCL)
 
     def barrier():
         _lib.sync()

@@ -160,6 +160,11 @@ int ssdr_dominant_label_dev(const int32_t* d_labels, const int32_t* d_sp_off, co
 /* add_clsbal (sampler2.py:262-266), in place on d_region_unc */
 int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected,
                     double* d_region_unc, void* stream);
+/* the same in two steps for sharded runs: local class histogram (int32[64]), then — after the caller has summed the
+ * histograms of all ranks — the scaling with the global histogram / global count */
+int ssdr_class_hist_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected,
+                        int32_t* d_hist64, void* stream);
+int ssdr_clsbal_hist_dev(const int32_t* d_region_class, size_t S, const int32_t* d_hist64, size_t total, double* d_region_unc, void* stream);
 /* sorted_inds = argsort(-u) (sampler2.py:640); equal values keep ascending index */
 int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorted_inds, void* stream);
 /* compute_features (sampler2.py:333,339): float32 mean of feat rows over the dominant-class members of the

@@ -589,6 +589,26 @@ int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const int32_t* d_se
     return SSDR_OK;
 }
 
+/* multi-GPU flavour of add_clsbal: the class histogram is supplied (all-reduced by the caller) */
+int ssdr_class_hist_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected, int32_t* d_hist64, void* stream) {
+    if (!d_region_class || !d_hist64 || (n_selected && !d_selected_class_list)) { set_error("class_hist: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream);
+    SSDR_HIP(hipMemsetAsync(d_hist64, 0, 4 * 64, s));
+    if (S + n_selected == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_selected_class_list, (int)n_selected, d_hist64);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+int ssdr_clsbal_hist_dev(const int32_t* d_region_class, size_t S, const int32_t* d_hist64, size_t total, double* d_region_unc, void* stream) {
+    if (!d_region_class || !d_hist64 || !d_region_unc || total == 0) { set_error("clsbal_hist: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (S == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_clsbal, dim3(grid_for((long)S)), dim3(256), 0, pick_stream(stream), d_region_class, (int)S, (int)total, d_hist64, d_region_unc);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
 int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorted_inds, void* stream) {
     if (!d_region_unc || !d_sorted_inds) { set_error("rank_regions: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());

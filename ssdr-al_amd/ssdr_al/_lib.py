@@ -73,6 +73,8 @@ def lib():
         L.ssdr_region_stats_dev.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp, vp, vp]
         L.ssdr_dominant_label_dev.argtypes = [vp, vp, vp, sz, i32, vp, vp, vp]
         L.ssdr_clsbal_dev.argtypes = [vp, sz, vp, sz, vp, vp]
+        L.ssdr_class_hist_dev.argtypes = [vp, sz, vp, sz, vp, vp]
+        L.ssdr_clsbal_hist_dev.argtypes = [vp, sz, vp, sz, vp, vp]
         L.ssdr_rank_regions_dev.argtypes = [vp, sz, vp, vp]
         L.ssdr_segment_mean_features_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, sz, vp, vp]
         L.ssdr_cloud_graph_dev.argtypes = [vp, vp, vp, vp, sz, sz, i32, vp, vp, vp, vp]

@@ -1,23 +1,36 @@
-"""The one exchange step of the sharded path: tiles/rooms are sharded across ranks with no
-data-path collective; before the global FPS each rank's propagated candidate features are all-gathered
-(RCCL over xGMI on GPUs = torch.distributed backend "nccl"; "gloo" in the CPU tests) and FPS runs replicated."""
+"""Exchange steps of the sharded path.  Rooms/tiles are sharded across ranks (one process per
+GPU); the data path has no collective until selection, where three small exchanges make the result identical to a
+single-process run over the union of the rooms:
+  1. all-reduce of the 64-bin dominant-class histogram (class balance, sampler2.py:262-266),
+  2. all-gather of the per-superpoint region uncertainties (global top-`batch` cut, sampler2.py:640, :533-552),
+  3. all-gather of the candidates' propagated features before the replicated global FPS (fps_gcn_cpu.py:169-170).
+torch.distributed backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
 import numpy as np
 
 
-def make_gather(dist, device):
-    """Returns gather(comb_local f64[n,32], batch_local) -> (comb_all f64[sum n,32] in rank order, sum batch)."""
-    import torch
-    world = dist.get_world_size()
+class Comm:
+    def __init__(self, dist, device):
+        import torch
+        self.dist, self.device, self.torch = dist, device, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def gather(comb_local, batch_local):
-        n = torch.tensor([len(comb_local), batch_local], device=device, dtype=torch.int64)
-        ns = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(ns, n)
-        nmax = int(max(int(x[0]) for x in ns))
-        pad = torch.zeros((nmax, comb_local.shape[1]), device=device, dtype=torch.float64)
-        pad[: len(comb_local)] = torch.from_numpy(np.ascontiguousarray(comb_local)).to(device)
-        bufs = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)                      # padded all-gather (variable counts)
-        comb = torch.cat([b[: int(x[0])] for b, x in zip(bufs, ns)]).cpu().numpy()
-        return np.ascontiguousarray(comb), int(sum(int(x[1]) for x in ns))
-    return gather
+    def allreduce_sum(self, a):
+        t = self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def allgather_var(self, a):
+        """a [n, ...] -> (concatenation over ranks in rank order, per-rank counts)."""
+        torch = self.torch
+        a = np.ascontiguousarray(a)
+        n = torch.tensor([a.shape[0]], device=self.device, dtype=torch.int64)
+        ns = [torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(ns, n)
+        counts = [int(x[0]) for x in ns]
+        pad = torch.zeros((max(max(counts), 1),) + a.shape[1:], device=self.device, dtype=torch.from_numpy(a).dtype)
+        if a.shape[0]:
+            pad[: a.shape[0]] = torch.from_numpy(a).to(self.device)
+        bufs = [torch.zeros_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad)                      # padded all-gather (variable counts)
+        out = torch.cat([b[:c] for b, c in zip(bufs, counts)]).cpu().numpy()
+        return np.ascontiguousarray(out), counts

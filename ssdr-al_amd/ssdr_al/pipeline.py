@@ -22,17 +22,22 @@ class HotPath:
         self.sampler_args = list(sampler_args)
         self.gcn_number, self.gcn_top = gcn_number, gcn_top
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
-        self.rng = np.random.default_rng(seed)
+        self.seed = seed
+        self.global_order = None
         self.rooms = []
         self.timing = None
 
     # ---- setup (untimed): upload raw rooms, fix the per-room randomness, derive superpoints -------------------
-    def load_rooms(self, rooms):
+    def load_rooms(self, rooms, room_ids=None):
+        """room_ids: global ids of the rooms (sharded runs); all host-drawn randomness is a function of (seed, id), so a
+        sharded run and a single-process run over the union see the same tiles."""
         cfg = self.cfg
         N = cfg.num_points
         self.B = len(rooms)
+        self.room_ids = list(range(len(rooms))) if room_ids is None else list(room_ids)
         self.rooms = []
-        for xyz, rgb, lab in rooms:
+        for (xyz, rgb, lab), rid in zip(rooms, self.room_ids):
+            self.rng = np.random.default_rng([self.seed, rid])
             n = len(xyz)
             r = dict(n=n, pts=DevArray.from_host(xyz.astype(np.float32)), col=DevArray.from_host(rgb.astype(np.float32)),
                      lab=DevArray.from_host(lab.astype(np.int32).reshape(-1, 1)),
@@ -64,6 +69,7 @@ class HotPath:
         self.sp_off_h = np.concatenate(offs).astype(np.int32); self.sp_pts_h = np.concatenate(pts).astype(np.int32)
         self.sp_cloud_h = np.concatenate(cloud)
         self.S = len(self.sp_off_h) - 1
+        self.sp_base = [int(np.flatnonzero(self.sp_cloud_h == b)[0]) for b in range(B)]
         self.sp_off = DevArray.from_host(self.sp_off_h); self.sp_pts = DevArray.from_host(self.sp_pts_h)
         self.region_unc = DevArray((self.S,), np.float64); self.dom = DevArray((self.S,), np.int32); self.dom_cnt = DevArray((self.S,), np.int32)
         self.sorted_inds = DevArray((self.S,), np.int32)
@@ -71,8 +77,10 @@ class HotPath:
         self.labeled = {}
         for b in range(B):
             ids = np.flatnonzero(self.sp_cloud_h == b)
-            self.labeled[b] = set(self.rng.choice(ids, min(self.labeled_per_tile, len(ids)), replace=False).tolist())
-        self.selected_class_list = DevArray.from_host(self.rng.integers(0, cfg.num_classes, 4000).astype(np.int32))
+            rng = np.random.default_rng([self.seed, self.room_ids[b], 1])
+            self.labeled[b] = set(rng.choice(ids, min(self.labeled_per_tile, len(ids)), replace=False).tolist())
+        self.selected_class_list = DevArray.from_host(np.random.default_rng([self.seed, 999983]).integers(0, cfg.num_classes, 4000).astype(np.int32))
+        self.hist = DevArray((64,), np.int32)
         self.sp_size_h = np.diff(self.sp_off_h)
         return self
 
@@ -97,7 +105,7 @@ class HotPath:
         self.net.infer_dev(self.B, self.cfg.num_points, self.feat.ptr, self.xyz.ptr, [a.ptr for a in self.neigh], [a.ptr for a in self.interp],
                            self.probs.ptr, self.f32.ptr)
 
-    def _score(self):
+    def _score(self, comm=None):
         cfg, L = self.cfg, _lib.lib()
         n = self.B * cfg.num_points
         um = {"lc": 0, "entropy": 1, "sb": 2}[[a for a in self.sampler_args if a in ("lc", "entropy", "sb")][0]]
@@ -105,33 +113,71 @@ class HotPath:
         _lib.check(L.ssdr_point_uncertainty_dev(self.probs.ptr, n, cfg.num_classes, um, self.unc.ptr, self.cls.ptr, None))
         _lib.check(L.ssdr_region_stats_dev(self.unc.ptr, self.cls.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, cfg.num_classes, rm,
                                            self.region_unc.ptr, self.dom.ptr, self.dom_cnt.ptr, None))
+        nsel = self.selected_class_list.shape[0]
         if "clsbal" in self.sampler_args:
-            _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, self.selected_class_list.shape[0], self.region_unc.ptr, None))
-        _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, None))
+            if comm is None:
+                _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, None))
+            else:       # exchange 1: the class histogram is global (the already-selected list is counted once, on rank 0)
+                _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, None))
+                _lib.sync()
+                h = comm.allreduce_sum(np.concatenate([self.hist.to_host().astype(np.int64), [self.S]]))
+                self.hist = DevArray.from_host(h[:64].astype(np.int32))
+                _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, int(h[64]) + nsel, self.region_unc.ptr, None))
+        if comm is None:
+            _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, None))
+            self.global_order = None
+        else:           # exchange 2: rank the regions of ALL ranks; labelled regions are taken out before the cut
+            _lib.sync()
+            u = self.region_unc.to_host()
+            lab = np.zeros(self.S, bool)
+            for b in self.labeled:
+                lab[list(self.labeled[b])] = True
+            allu, counts = comm.allgather_var(np.where(lab, -np.inf, u))
+            d_all = DevArray.from_host(allu); d_ord = DevArray((len(allu),), np.int32)
+            _lib.check(L.ssdr_rank_regions_dev(d_all.ptr, len(allu), d_ord.ptr, None))
+            _lib.sync()
+            base = int(sum(counts[: comm.rank]))
+            self.global_order = (d_ord.to_host(), allu, base, self.select_per_tile * self.B * comm.world)
 
     def _candidates(self, sorted_inds):
-        """create_file_top_and_all + the candidate rule of sampling() (sampler2.py:533-552, :745-753) on index lists."""
-        batch_size = min(self.select_per_tile * self.B, len(sorted_inds))
+        """create_file_top_and_all + the candidate rule of sampling() (sampler2.py:533-552, :745-753) on index lists.
+        Candidate order is canonical (cloud ascending, then descending uncertainty): the reference's own order depends
+        on a shuffled DataLoader (sampler2.py:323) and carries no meaning."""
         top, allc = {}, {}
-        rank = 0
-        for s in sorted_inds:
-            b = int(self.sp_cloud_h[s])
-            if s in self.labeled[b]:
-                continue
-            if rank < batch_size:
-                top.setdefault(b, []).append(int(s))
-            allc.setdefault(b, []).append(int(s))
-            rank += 1
+        if self.global_order is None:
+            batch_size = min(self.select_per_tile * self.B, len(sorted_inds))
+            rank = 0
+            for s in sorted_inds:
+                b = int(self.sp_cloud_h[s])
+                if s in self.labeled[b]:
+                    continue
+                if rank < batch_size:
+                    top.setdefault(b, []).append(int(s))
+                allc.setdefault(b, []).append(int(s))
+                rank += 1
+        else:
+            order, allu, base, batch_size = self.global_order
+            rank = 0
+            for g in order:
+                if allu[g] == -np.inf:
+                    break                                   # labelled regions sort last
+                s = int(g) - base
+                if 0 <= s < self.S:
+                    b = int(self.sp_cloud_h[s])
+                    if rank < batch_size:
+                        top.setdefault(b, []).append(s)
+                    allc.setdefault(b, []).append(s)
+                rank += 1
         unl, sampling_batch = [], 0
-        for b in top:
+        for b in sorted(top):
             k = len(top[b]); sampling_batch += k
             unl += [(b, s) for s in allc[b][:2 * k]]
         lab = [(b, s) for b in sorted(self.labeled) for s in sorted(self.labeled[b])]
         return unl, lab, sampling_batch
 
-    def _select(self, gather=None):
+    def _select(self, comm=None):
         L = _lib.lib()
-        sorted_inds = self.sorted_inds.to_host()            # one small D2H: the host decides the candidate lists
+        sorted_inds = self.sorted_inds.to_host() if self.global_order is None else None   # small D2H: the host decides the candidate lists
         unl, lab, sampling_batch = self._candidates(sorted_inds)
         refs = unl + lab
         sel = np.array([s for _, s in refs], np.int32)
@@ -158,18 +204,26 @@ class HotPath:
                 _lib.check(L.ssdr_propagate_dev(d["a"].ptr, d["n"], d["r"].ptr, src.ptr, 32, dst.ptr, d_comb.ptr, None))
             src = dst
         n_unl = len(unl)
-        if gather is not None:                               # multi-GPU: exchange the candidates' propagated features
+        self.unl_cloud_ids = np.array([self.room_ids[b] for b, _ in unl], np.int64)
+        self.unl_sp = np.array([s - self.sp_base[b] for b, s in unl], np.int64)       # superpoint index inside its room
+        if comm is not None:                                 # exchange 3: the candidates' propagated features (+ their ids)
             _lib.sync()
-            comb_all, sampling_batch = gather(d_comb.to_host()[:n_unl], sampling_batch)
+            comb_all, _ = comm.allgather_var(d_comb.to_host()[:n_unl])
+            ids_all, _ = comm.allgather_var(np.stack([self.unl_cloud_ids, self.unl_sp], 1))
+            sampling_batch = int(comm.allreduce_sum(np.array([sampling_batch], np.int64))[0])
             d_comb = DevArray.from_host(comb_all); n_unl = len(comb_all)
+            self.unl_cloud_ids, self.unl_sp = ids_all[:, 0], ids_all[:, 1]
+            self.comb_all = comb_all
         d_out = DevArray((sampling_batch,), np.int32)
         start = 0                                            # np.random.randint(0, n) in the reference (:133); fixed here
         _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
         _lib.sync()
         self._keep = (blocks, d_v, d_tmp, d_sel, d_mf)
-        return d_out.to_host(), unl
+        sel = d_out.to_host()
+        self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
+        return sel, unl
 
-    def step(self, gather=None, timed_stages=False):
+    def step(self, comm=None, timed_stages=False):
         """One pass of the hot path over the loaded batch of rooms.  Returns the selected candidate indices."""
         t = [time.perf_counter()]
 
@@ -179,8 +233,8 @@ class HotPath:
         self._front_end(); mark()
         self._pyramid(); mark()
         self._infer(); mark()
-        self._score(); mark()
-        out = self._select(gather); mark()
+        self._score(comm); mark()
+        out = self._select(comm); mark()
         if timed_stages:
             self.timing = dict(zip(("subsample+tile", "knn_pyramid", "randla_infer", "score", "select"), np.diff(t) * 1e3))
         return out

@@ -16,25 +16,24 @@ def main():
     from oracle import randla_np as R
     from oracle import select_np as S
     from ssdr_al import _lib, pipeline, synthetic
-    from ssdr_al.distributed import make_gather
+    from ssdr_al.distributed import Comm
     from ssdr_al.helper_tool import ConfigS3DIS
     _lib.use(os.path.join(ROOT, "tests", "hipemu", "libssdr_al_emu.so"))
 
     class Cfg(ConfigS3DIS):
-        num_points = 2048
-    rooms = [synthetic.make_room(7000 + rank * 2 + i, density=150.0) for i in range(2)]
-    hp = pipeline.HotPath(R.init_weights(0), Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms(rooms)
-    seen = {}
-    inner = make_gather(dist, "cpu")
-
-    def gather(comb, batch):
-        out = inner(comb, batch)
-        seen["local"], seen["all"], seen["batch"] = comb.copy(), out[0].copy(), out[1]
-        return out
-    sel, unl = hp.step(gather)
-    expect = S.farthest_features_sample(seen["all"], seen["batch"], 0)
-    res = {"rank": rank, "sel": [int(x) for x in sel], "expect": [int(x) for x in expect], "n_local": len(seen["local"]),
-           "n_all": len(seen["all"]), "batch": seen["batch"], "local_sum": float(seen["local"].sum()), "all_sum": float(seen["all"].sum())}
+        num_points = 1024
+    per = 2
+    W = R.init_weights(0)
+    all_rooms = [synthetic.make_room(7000 + i, density=80.0) for i in range(per * world)]
+    mine = list(range(rank * per, (rank + 1) * per))
+    hp = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine)
+    sel, unl = hp.step(Comm(dist, "cpu"))
+    res = {"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
+           "expect": [int(x) for x in S.farthest_features_sample(hp.comb_all, len(sel), 0)]}
+    if rank == 0:      # the same job in ONE process over the union of the rooms
+        one = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms(all_rooms, list(range(per * world)))
+        one.step()
+        res["single"] = one.selected
     with open(os.path.join(os.environ["SSDR_TEST_OUT"], "rank%d.json" % rank), "w") as f:
         json.dump(res, f)
     dist.destroy_process_group()
