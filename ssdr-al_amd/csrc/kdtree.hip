@@ -31,7 +31,9 @@ namespace {
 
 constexpr int LEAF_MAX = 10;         // knn_.cxx:28 / KDTreeTableAdaptor.h:134
 constexpr int MAX_LEVELS = 40;       // levels launched per build == search stack depth
-constexpr int CTR_NODES = 0, CTR_STATUS = 1, CTR_DEPTH = 2, CTR_QUEUE0 = 8;
+constexpr int BIG_LEVELS = 28;       // levels at which nodes above 64 points are still split
+constexpr int CTR_NODES = 0, CTR_STATUS = 1, CTR_DEPTH = 2, CTR_QUEUE0 = 8, CTR_SQUEUE0 = 8 + MAX_LEVELS + 8, CTR_TOTAL = CTR_SQUEUE0 + MAX_LEVELS + 8;
+constexpr int SMALL_MAX = 64;        // nodes up to one wavefront of points are split by a single wave (kd_split_small_kernel)
 constexpr int ST_QUEUE_OVF = 1, ST_NODE_OVF = 2, ST_DEPTH_OVF = 4;
 
 // The two-pointer sweep of nanoflann.hpp:951-961 (and :966-973) in closed form: positions [start,end)
@@ -56,6 +58,7 @@ __device__ void hoare_sweep(int* ind, float* val, int* tmp, int start, int end, 
 struct ForestPtrs {
     KdTreeDesc* desc; int* vind; float4* sorted; int4* node_a; float4* node_b; float* node_box; int* node_tree;
     int* queue; int* ctr; int* tmp; float* val; int node_cap; int queue_cap;
+    int* squeue;     // open nodes with <= SMALL_MAX points, [2][queue_cap]
 };
 
 __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
         f.node_b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         f.node_tree[t] = t;
         if (t == 0) atomicAdd(&f.ctr[CTR_NODES], (int)gridDim.x);   // roots are nodes 0..ntrees-1
-        if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_QUEUE0], 1); f.queue[q] = t; }
+        if (n > SMALL_MAX) { int q = atomicAdd(&f.ctr[CTR_QUEUE0], 1); f.queue[q] = t; }
+        else if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_SQUEUE0], 1); f.squeue[q] = t; }
     }
 }
 
@@ -173,9 +177,13 @@ __global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
                 f.node_box[6 * (size_t)c + d] = (tid == 1 && d == cf) ? cut : lo[d];
                 f.node_box[6 * (size_t)c + 3 + d] = (tid == 0 && d == cf) ? cut : hi[d];
             }
-            if (cr - cl > LEAF_MAX) {
+            if (cr - cl > SMALL_MAX) {
+                if (level + 1 >= BIG_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
                 int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
                 if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+            } else if (cr - cl > LEAF_MAX) {
+                int q = atomicAdd(&f.ctr[CTR_SQUEUE0 + level + 1], 1);
+                if (q < f.queue_cap) f.squeue[((level + 1) & 1) * f.queue_cap + q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
             }
         }
         if (c1 >= 0 && tid == 0) {
@@ -183,6 +191,126 @@ __global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
             f.node_b[node] = make_float4(m3x[0], m3n[0], __int_as_float(cf), 0.f);
         }
         __syncthreads();
+    }
+}
+
+// The same split for nodes of at most 64 points: one wavefront per node, one lane per point.  min/max are wave
+// reductions, the counts are ballots, and the two-pointer sweeps of planeSplit become two LDS permutations whose
+// destinations come from ballot prefix counts (left-side misplaced k <-> right-side misplaced k from the right).
+__global__ __launch_bounds__(BS) void kd_split_small_kernel(ForestPtrs f, int level) {
+    __shared__ int s_pos[BS / 64][2][64];     // [wave][side][rank] -> position
+    __shared__ int s_ind[BS / 64][64];
+    __shared__ float s_xyz[BS / 64][3][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int nq = min(f.ctr[CTR_SQUEUE0 + level], f.queue_cap);
+    const int* qin = f.squeue + (level & 1) * f.queue_cap;
+    if (blockIdx.x == 0 && tid == 0 && nq > 0) {
+        atomicMax(&f.ctr[CTR_DEPTH], level + 1);
+        if (level + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
+    }
+    const int nwg = (nq + BS / 64 - 1) / (BS / 64);
+    for (int g = blockIdx.x; g < nwg; g += gridDim.x) {          // uniform trip count inside a workgroup
+        const int qi = g * (BS / 64) + wid;
+        const bool have = qi < nq;
+        int node = 0, left = 0, count = 0, tree = 0;
+        float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+        if (have) {
+            node = qin[qi];
+            const int4 na = f.node_a[node];
+            left = na.x; count = na.y - na.x; tree = f.node_tree[node];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { lo[d] = f.node_box[6 * (size_t)node + d]; hi[d] = f.node_box[6 * (size_t)node + 3 + d]; }
+        }
+        const bool act = have && lane < count;
+        int id = 0; float c[3] = {0.f, 0.f, 0.f};
+        if (act) {
+            id = f.vind[left + lane];
+            const float* P = f.desc[tree].pts;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) c[d] = P[(size_t)id * 3 + d];
+        }
+        float mn[3], mx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = wave_min(act ? c[d] : FLT_MAX); mx[d] = wave_max(act ? c[d] : -FLT_MAX); }
+        // middleSplit_ (:898-937)
+        const float EPS = 0.00001f;
+        float max_span = hi[0] - lo[0];
+#pragma unroll
+        for (int d = 1; d < 3; ++d) { float sp = hi[d] - lo[d]; if (sp > max_span) max_span = sp; }
+        float max_spread = -1.f; int cf = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float sp = hi[d] - lo[d];
+            if (sp > (1 - EPS) * max_span) { float spread = mx[d] - mn[d]; if (spread > max_spread) { cf = d; max_spread = spread; } }
+        }
+        const float lo_c = cf == 0 ? lo[0] : (cf == 1 ? lo[1] : lo[2]);
+        const float hi_c = cf == 0 ? hi[0] : (cf == 1 ? hi[1] : hi[2]);
+        const float mn_c = cf == 0 ? mn[0] : (cf == 1 ? mn[1] : mn[2]);
+        const float mx_c = cf == 0 ? mx[0] : (cf == 1 ? mx[1] : mx[2]);
+        const float split_val = (lo_c + hi_c) / 2;
+        const float cut = split_val < mn_c ? mn_c : (split_val > mx_c ? mx_c : split_val);
+
+        int lim1 = 0, lim2 = 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {                   // planeSplit (:948-975): "< cut", then "<= cut" on the rest
+            const float v = cf == 0 ? c[0] : (cf == 1 ? c[1] : c[2]);
+            const int start = pass == 0 ? 0 : lim1;
+            const bool in = act && lane >= start;
+            const bool isleft = pass == 0 ? (v < cut) : (v <= cut);
+            const unsigned long long ml = __ballot(in && isleft);
+            const int lim = start + __popcll(ml);
+            if (pass == 0) lim1 = lim; else lim2 = lim;
+            const bool badl = in && lane < lim && !isleft;       // misplaced on the left, k-th from the left
+            const bool badr = in && lane >= lim && isleft;       // misplaced on the right, k-th from the right
+            const unsigned long long mbl = __ballot(badl), mbr = __ballot(badr);
+            if (badl) s_pos[wid][0][__popcll(mbl & lt)] = lane;
+            if (badr) s_pos[wid][1][__popcll(mbr & ~lt & ~(1ull << lane))] = lane;
+            __syncthreads();
+            int dest = lane;
+            if (badl) dest = s_pos[wid][1][__popcll(mbl & lt)];
+            if (badr) dest = s_pos[wid][0][__popcll(mbr & ~lt & ~(1ull << lane))];
+            s_ind[wid][dest] = id;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) s_xyz[wid][d][dest] = c[d];
+            __syncthreads();
+            id = s_ind[wid][lane];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) c[d] = s_xyz[wid][d][lane];
+            __syncthreads();
+        }
+        int idx;
+        if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
+        const float v = cf == 0 ? c[0] : (cf == 1 ? c[1] : c[2]);
+        const float divlow = wave_max((act && lane < idx) ? v : -FLT_MAX);
+        const float divhigh = wave_min((act && lane >= idx) ? v : FLT_MAX);
+        if (act) f.vind[left + lane] = id;
+        int c1 = -1;
+        if (have && lane == 0) {
+            c1 = atomicAdd(&f.ctr[CTR_NODES], 2);
+            if (c1 + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c1 = -1; }
+        }
+        c1 = __shfl(c1, 0);
+        if (have && c1 >= 0 && lane < 2) {
+            const int cn = c1 + lane;
+            const int cl = lane == 0 ? left : left + idx, cr = lane == 0 ? left + idx : left + count;
+            f.node_a[cn] = make_int4(cl, cr, -1, -1);
+            f.node_b[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f.node_tree[cn] = tree;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                f.node_box[6 * (size_t)cn + d] = (lane == 1 && d == cf) ? cut : lo[d];
+                f.node_box[6 * (size_t)cn + 3 + d] = (lane == 0 && d == cf) ? cut : hi[d];
+            }
+            if (cr - cl > LEAF_MAX) {
+                int q = atomicAdd(&f.ctr[CTR_SQUEUE0 + level + 1], 1);
+                if (q < f.queue_cap) f.squeue[((level + 1) & 1) * f.queue_cap + q] = cn; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+            }
+        }
+        if (have && c1 >= 0 && lane == 0) {
+            f.node_a[node] = make_int4(left, left + count, c1, c1 + 1);
+            f.node_b[node] = make_float4(divlow, divhigh, __int_as_float(cf), 0.f);
+        }
     }
 }
 
@@ -327,6 +455,7 @@ ForestPtrs ptrs(const KdForest& f) {
     p.node_a = f.node_a.as<int4>(); p.node_b = f.node_b.as<float4>(); p.node_box = f.node_box.as<float>();
     p.node_tree = f.node_tree.as<int>(); p.queue = f.queue.as<int>(); p.ctr = f.counters.as<int>();
     p.tmp = f.tmp.as<int>(); p.val = f.val.as<float>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
+    p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap;
     return p;
 }
 
@@ -345,8 +474,8 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     SSDR_TRY(f.tmp.reserve(4 * tp)); SSDR_TRY(f.val.reserve(4 * tp));
     SSDR_TRY(f.node_a.reserve(16 * (size_t)f.node_cap)); SSDR_TRY(f.node_b.reserve(16 * (size_t)f.node_cap));
     SSDR_TRY(f.node_box.reserve(24 * (size_t)f.node_cap)); SSDR_TRY(f.node_tree.reserve(4 * (size_t)f.node_cap));
-    SSDR_TRY(f.queue.reserve(8 * (size_t)f.queue_cap));
-    SSDR_TRY(f.counters.reserve(4 * (CTR_QUEUE0 + MAX_LEVELS + 8)));
+    SSDR_TRY(f.queue.reserve(16 * (size_t)f.queue_cap));
+    SSDR_TRY(f.counters.reserve(4 * CTR_TOTAL));
     if (f.ntrees == 0) return SSDR_OK;
     // descriptors travel through a pinned staging buffer; the event guards its reuse by the next build
     if (f.staging_cap < trees.size()) {
@@ -358,12 +487,18 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     memcpy(f.staging, trees.data(), sizeof(KdTreeDesc) * trees.size());
     SSDR_HIP(hipMemcpyAsync(f.desc.p, f.staging, sizeof(KdTreeDesc) * trees.size(), hipMemcpyHostToDevice, s));
     SSDR_HIP(hipEventRecord(f.staging_ev, s));
-    SSDR_HIP(hipMemsetAsync(f.counters.p, 0, 4 * (CTR_QUEUE0 + MAX_LEVELS + 8), s));
+    SSDR_HIP(hipMemsetAsync(f.counters.p, 0, 4 * CTR_TOTAL, s));
     ForestPtrs p = ptrs(f);
     hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(BS), 0, s, p);
     const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
-    for (int level = 0; level < MAX_LEVELS; ++level)
-        hipLaunchKernelGGL(kd_split_kernel, dim3(grid), dim3(BS), 0, s, p, level);
+    // nodes above 64 points: one workgroup each; deeper than BIG_LEVELS a node that large means a degenerate cloud
+    // (flagged, not mis-built).  Nodes of at most 64 points: one wavefront each.
+    int maxn0 = 0; for (auto& t : trees) maxn0 = std::max(maxn0, t.n);
+    const int gsmall = std::max(1, std::min(f.queue_cap / 4 + 1, ctx().num_cu * 8));
+    for (int level = 0; level < MAX_LEVELS; ++level) {
+        if (level < BIG_LEVELS && maxn0 > SMALL_MAX) hipLaunchKernelGGL(kd_split_kernel, dim3(grid), dim3(BS), 0, s, p, level);
+        hipLaunchKernelGGL(kd_split_small_kernel, dim3(gsmall), dim3(BS), 0, s, p, level);
+    }
     int maxn = 0; for (auto& t : trees) maxn = std::max(maxn, t.n);
     dim3 g((unsigned)std::max(1, std::min((maxn + 255) / 256, 64)), (unsigned)std::min(f.ntrees, 65535));
     hipLaunchKernelGGL(kd_sort_points_kernel, g, dim3(256), 0, s, p, f.ntrees);

@@ -168,6 +168,55 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
     }
 }
 
+// Passes 4..7 (key bits 32..63) in ONE single-workgroup kernel.  Voxel keys, distance keys and composite ranks of
+// realistic inputs never have varying bits up there, so this costs one (empty) launch instead of twelve; if a key
+// set does need them the sort stays correct, only slower for those passes.
+__global__ __launch_bounds__(1024) void rs_high_passes(SortPtrs s) {
+    __shared__ unsigned h[256];
+    __shared__ unsigned s_cnt[16][256];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int n = sort_n(s);
+    for (int p = 4; p < 8; ++p) {
+        int par; if (!pass_runs(s, p, par)) continue;      // uniform
+        const uint64_t* K = s.k[par]; const uint32_t* V = s.v[par];
+        uint64_t* KO = s.k[par ^ 1]; uint32_t* VO = s.v[par ^ 1];
+        if (tid < 256) h[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
+        __syncthreads();
+        if (tid == 0) { unsigned run = 0; for (int d = 0; d < 256; ++d) { unsigned c = h[d]; h[d] = run; run += c; } }
+        __syncthreads();
+        for (int base = 0; base < n; base += 1024) {        // stable: tiles in order, waves in order, lanes in order
+            const int i = base + tid;
+            const bool valid = i < n;
+            uint64_t key = 0; uint32_t val = 0; unsigned d = 0;
+            if (valid) { key = K[i]; val = V[i]; d = (unsigned)((key >> (8 * p)) & 0xff); }
+            for (int w = 0; w < 16; ++w) if (tid < 256) s_cnt[w][tid] = 0;
+            __syncthreads();
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (d >> bit) & 1;
+                const unsigned long long bal = __ballot(valid && one);
+                m &= one ? bal : ~bal;
+            }
+            const int rank = __popcll(m & lt);
+            if (valid && rank == 0) s_cnt[wid][d] = (unsigned)__popcll(m);
+            __syncthreads();
+            if (valid) {
+                unsigned pos = h[d] + rank;
+                for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
+                KO[pos] = key; VO[pos] = val;
+            }
+            __syncthreads();
+            if (tid < 256) { unsigned t = 0; for (int w = 0; w < 16; ++w) t += s_cnt[w][tid]; h[tid] += t; }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 // after the last pass the result may sit in buffer 1: bring it home to buffer 0
 __global__ __launch_bounds__(RS_BS) void rs_finish(SortPtrs s) {
     const unsigned long long diff = s.andor[0] ^ s.andor[1];
@@ -187,7 +236,7 @@ int RadixSorter::reserve(size_t n_max) {
     return SSDR_OK;
 }
 
-int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t st) {
+int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t st, int key_bits) {
     if (n_host <= 0) return SSDR_OK;
     SSDR_TRY(reserve((size_t)n_host));
     SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>();
@@ -196,11 +245,13 @@ int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n
     const int g = std::max(1, std::min(nb, ctx().num_cu * 8));
     hipLaunchKernelGGL(rs_andor_init, dim3(1), dim3(RS_BS), 0, st, s);
     hipLaunchKernelGGL(rs_andor, dim3(g), dim3(RS_BS), 0, st, s);
-    for (int p = 0; p < 8; ++p) {
+    const int npass = std::min(4, (std::max(key_bits, 1) + 7) / 8);      // wide passes for the low 32 bits ...
+    for (int p = 0; p < npass; ++p) {
         hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
         hipLaunchKernelGGL(rs_scan, dim3(256), dim3(RS_BS), 0, st, s, p);
         hipLaunchKernelGGL(rs_scatter, dim3(g), dim3(RS_BS), 0, st, s, p);
     }
+    if (key_bits > 32) hipLaunchKernelGGL(rs_high_passes, dim3(1), dim3(1024), 0, st, s);   // ... one kernel for the rest
     hipLaunchKernelGGL(rs_finish, dim3(g), dim3(RS_BS), 0, st, s);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;

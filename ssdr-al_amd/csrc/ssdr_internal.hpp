@@ -70,7 +70,8 @@ struct RadixSorter {
     DevBuf k1, v1, hist, andor;
     int nblocks_max = 0;
     int reserve(size_t n_max);
-    int sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t s);
+    // key_bits: upper bound on the significant key bits when the caller knows one (skips launching higher passes)
+    int sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t s, int key_bits = 64);
 };
 
 // ---- kd-tree forest (kdtree.hip) ----------------------------------------------------------------

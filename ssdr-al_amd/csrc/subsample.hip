@@ -167,29 +167,30 @@ __global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, con
                                                 float* out_p, float* out_f, int* out_c, long long* out_m, uint64_t* out_first, const uint64_t* ks) {
     const int m = prm->m;
     if (blockIdx.x == 0 && threadIdx.x == 0 && out_m) *out_m = m;
-    for (int v = blockIdx.x * BS + threadIdx.x; v < m; v += gridDim.x * BS) {
-        const int s = seg_start[v], e = seg_start[v + 1];
-        const int count = e - s;
+    // one lane per (voxel, output channel): the per-voxel sums stay sequential in input order (what makes them
+    // bit-identical to the reference), the channels of a voxel run side by side and share the index loads
+    const int CH = 3 + (F ? fdim : 0) + (cls ? ldim : 0);
+    const long long total = (long long)m * CH;
+    for (long long e = (long long)blockIdx.x * BS + threadIdx.x; e < total; e += (long long)gridDim.x * BS) {
+        const int v = (int)(e / CH), c = (int)(e % CH);
+        const int s = seg_start[v], en = seg_start[v + 1];
+        const int count = en - s;
         const int row = row_of_voxel ? row_of_voxel[v] : v;
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int j = s; j < e; ++j) { const size_t id = vs[j]; sx += P[3 * id]; sy += P[3 * id + 1]; sz += P[3 * id + 2]; }
-        const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
-        out_p[3 * (size_t)row] = sx * a; out_p[3 * (size_t)row + 1] = sy * a; out_p[3 * (size_t)row + 2] = sz * a;
-        if (F) {
-            const float c = (float)count;
-            for (int f0 = 0; f0 < fdim; f0 += 4) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int j = s; j < e; ++j) {
-                    const size_t id = vs[j];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (f0 + k < fdim) acc[k] += F[id * fdim + f0 + k];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (f0 + k < fdim) out_f[(size_t)row * fdim + f0 + k] = acc[k] / c;   // :90-94
-            }
+        if (c < 3) {
+            float sum = 0.f;
+            for (int j = s; j < en; ++j) sum += P[3 * (size_t)vs[j] + c];
+            const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
+            out_p[3 * (size_t)row + c] = sum * a;
+            if (c == 0 && out_first) out_first[v] = ks[s];
+        } else if (F && c < 3 + fdim) {
+            const int f = c - 3;
+            float acc = 0.f;
+            for (int j = s; j < en; ++j) acc += F[(size_t)vs[j] * fdim + f];
+            out_f[(size_t)row * fdim + f] = acc / (float)count;      // :90-94
+        } else {
+            const int col = c - 3 - (F ? fdim : 0);
+            out_c[(size_t)row * ldim + col] = voxel_label(cls, ldim, col, vs, s, en, &prm->status);
         }
-        if (cls) for (int col = 0; col < ldim; ++col) out_c[(size_t)row * ldim + col] = voxel_label(cls, ldim, col, vs, s, e, &prm->status);
-        if (out_first) out_first[v] = ks[s];
     }
 }
 

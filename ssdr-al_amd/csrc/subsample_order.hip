@@ -43,6 +43,7 @@ struct OrdPtrs {
     int* pfirst; int* tfirst;           // per bucket
     int* cnt;                           // [NSCHED] live element count of each phase's sort (0 = phase not needed)
     int* row_of_voxel;
+    uint32_t* major;                    // per insertion rank: run-order key of the current phase
 };
 
 __device__ __forceinline__ void phase_bounds(int r, int m, int& a, int& k, unsigned long long& B) {
@@ -91,8 +92,15 @@ __global__ __launch_bounds__(BS) void ord_keys(OrdPtrs o, int r) {
         const unsigned long long major = pf != 0x7fffffff ? (unsigned long long)k + (unsigned long long)(a - 1 - pf)
                                                           : (unsigned long long)(k - 1 - (o.tfirst[b] - a));
         const unsigned long long minor = i < a ? (unsigned long long)k + (unsigned long long)(a - 1 - i) : (unsigned long long)(k - 1 - (i - a));
-        o.skey[i] = (major << 32) | minor; o.sval[i] = (uint32_t)t;
+        // two stable 32-bit sorts (minor first, then major) instead of one 64-bit sort: all passes stay wide
+        o.skey[i] = minor; o.sval[i] = (uint32_t)t; o.major[t] = (uint32_t)major;
     }
+}
+
+__global__ __launch_bounds__(BS) void ord_major_keys(OrdPtrs o, int r) {
+    const int m = *o.d_m; int a, k; unsigned long long B; phase_bounds(r, m, a, k, B);
+    if (k <= 0) return;
+    for (int i = blockIdx.x * BS + threadIdx.x; i < a + k; i += gridDim.x * BS) o.skey[i] = o.major[o.sval[i]];
 }
 
 __global__ __launch_bounds__(BS) void ord_store_list(OrdPtrs o, int r) {
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(BS) void ord_store_list(OrdPtrs o, int r) {
     }
 }
 
-struct OrdState { RadixSorter sorter; DevBuf skey, sval, kt, seq, L, pfirst, tfirst, cnt; };
+struct OrdState { RadixSorter sorter; DevBuf skey, sval, kt, seq, L, pfirst, tfirst, cnt, major; };
 OrdState& ost() { static OrdState s; return s; }
 
 }  // namespace
@@ -120,14 +128,14 @@ int subsample_order_reference(const uint64_t* d_ks, const uint32_t* d_vs, const 
     if (nph == NSCHED && BKT_SCHED_H[NSCHED - 1] < (unsigned long long)n_host) { set_error("too many voxels for the order emulation"); return SSDR_ERR_UNSUPPORTED; }
     const size_t bmax = (size_t)BKT_SCHED_H[nph - 1];
     SSDR_TRY(S.skey.reserve(8 * n + 16)); SSDR_TRY(S.sval.reserve(4 * n + 16)); SSDR_TRY(S.kt.reserve(8 * n + 16));
-    SSDR_TRY(S.seq.reserve(4 * n + 16)); SSDR_TRY(S.L.reserve(4 * n + 16));
+    SSDR_TRY(S.seq.reserve(4 * n + 16)); SSDR_TRY(S.L.reserve(4 * n + 16)); SSDR_TRY(S.major.reserve(4 * n + 16));
     SSDR_TRY(S.pfirst.reserve(4 * bmax + 16)); SSDR_TRY(S.tfirst.reserve(4 * bmax + 16)); SSDR_TRY(S.cnt.reserve(4 * NSCHED));
     OrdPtrs o{d_ks, d_vs, d_seg_start, d_m, S.skey.as<uint64_t>(), S.sval.as<uint32_t>(), S.kt.as<uint64_t>(), S.seq.as<uint32_t>(),
-              S.L.as<int>(), S.pfirst.as<int>(), S.tfirst.as<int>(), S.cnt.as<int>(), d_row_of_voxel};
+              S.L.as<int>(), S.pfirst.as<int>(), S.tfirst.as<int>(), S.cnt.as<int>(), d_row_of_voxel, S.major.as<uint32_t>()};
     SSDR_TRY(S.sorter.reserve(n));
     const int g = std::max(1, std::min((n_host + BS - 1) / BS, ctx().num_cu * 8));
     hipLaunchKernelGGL(ord_first_seen_keys, dim3(g), dim3(BS), 0, s, o);
-    SSDR_TRY(S.sorter.sort(o.skey, o.sval, n_host, d_m, s));
+    SSDR_TRY(S.sorter.sort(o.skey, o.sval, n_host, d_m, s, 32));          // first-seen point indices
     hipLaunchKernelGGL(ord_gather_keys, dim3(g), dim3(BS), 0, s, o);
     for (int r = 0; r < nph; ++r) {
         const long long cap = (long long)std::min<unsigned long long>(BKT_SCHED_H[r], (unsigned long long)n_host);
@@ -136,7 +144,10 @@ int subsample_order_reference(const uint64_t* d_ks, const uint32_t* d_vs, const 
         hipLaunchKernelGGL(ord_clear, dim3(gb), dim3(BS), 0, s, o, r);
         hipLaunchKernelGGL(ord_firsts, dim3(gr), dim3(BS), 0, s, o, r);
         hipLaunchKernelGGL(ord_keys, dim3(gr), dim3(BS), 0, s, o, r);
-        SSDR_TRY(S.sorter.sort(o.skey, o.sval, (int)cap, o.cnt + r, s));
+        int bits = 1; while ((1ll << bits) <= 2 * cap) ++bits;           // major, minor < a + k <= cap
+        SSDR_TRY(S.sorter.sort(o.skey, o.sval, (int)cap, o.cnt + r, s, bits));
+        hipLaunchKernelGGL(ord_major_keys, dim3(gr), dim3(BS), 0, s, o, r);
+        SSDR_TRY(S.sorter.sort(o.skey, o.sval, (int)cap, o.cnt + r, s, bits));
         hipLaunchKernelGGL(ord_store_list, dim3(gr), dim3(BS), 0, s, o, r);
     }
     SSDR_HIP(hipGetLastError());

@@ -79,7 +79,7 @@ extern "C" int ssdr_tile_select_dev(const float* d_points, const float* d_colors
     const int g = (int)std::max<size_t>(1, std::min<size_t>((n_max + 255) / 256, (size_t)ctx().num_cu * 8));
     hipLaunchKernelGGL(tile_keys, dim3(g), dim3(256), 0, s, d_points, (const long long*)d_m, (int)n_max, center[0], center[1], center[2],
                        T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), T.count.as<int>());
-    SSDR_TRY(T.sorter.sort(T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), (int)n_max, T.count.as<int>(), s));
+    SSDR_TRY(T.sorter.sort(T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), (int)n_max, T.count.as<int>(), s, 32));   // float bit patterns
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 1024));
     hipLaunchKernelGGL(tile_gather, dim3(g2), dim3(256), 0, s, d_points, d_colors, d_colors ? color_dim : 0, T.vals.as<uint32_t>(), T.count.as<int>(),
                        d_perm, d_dup_u, (int)num_points, center[0], center[1], center[2], color_scale, d_out_xyz, d_out_feat, d_out_idx);
