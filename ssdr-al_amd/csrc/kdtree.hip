@@ -59,6 +59,7 @@ struct ForestPtrs {
     KdTreeDesc* desc; int* vind; float4* sorted; int4* node_a; float4* node_b; float* node_box; int* node_tree;
     int* queue; int* ctr; int* tmp; float* val; int node_cap; int queue_cap;
     int* squeue;     // open nodes with <= SMALL_MAX points, [2][queue_cap]
+    int ntrees;
 };
 
 __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
@@ -78,10 +79,18 @@ __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
         f.node_a[t] = make_int4(voff, voff + n, -1, -1);
         f.node_b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         f.node_tree[t] = t;
-        if (t == 0) atomicAdd(&f.ctr[CTR_NODES], (int)gridDim.x);   // roots are nodes 0..ntrees-1
         if (n > SMALL_MAX) { int q = atomicAdd(&f.ctr[CTR_QUEUE0], 1); f.queue[q] = t; }
         else if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_SQUEUE0], 1); f.squeue[q] = t; }
     }
+}
+
+// Children get node ids without atomics: level l hands out ids base(l) + 2*slot, where base(l) = ntrees + 2 * (number of
+// nodes split at the levels above), big nodes first, then small ones (tens of thousands of waves adding to one counter
+// serialise at ~10 ns each).
+__device__ __forceinline__ int level_node_base(const ForestPtrs& f, int level, int ntrees) {
+    int b = ntrees;
+    for (int j = 0; j < level; ++j) b += 2 * (min(f.ctr[CTR_QUEUE0 + j], f.queue_cap) + min(f.ctr[CTR_SQUEUE0 + j], f.queue_cap));
+    return b;
 }
 
 // One level of divideTree (nanoflann.hpp:848-896) for every open node.
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
         block_minmax3(m3n, m3x, s_mm);
 
         if (tid == 0) {
-            int c = atomicAdd(&f.ctr[CTR_NODES], 2);
+            int c = level_node_base(f, level, f.ntrees) + 2 * qi;
             if (c + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c = -1; }
             s_child = c;
         }
@@ -197,10 +206,13 @@ __global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
 // The same split for nodes of at most 64 points: one wavefront per node, one lane per point.  min/max are wave
 // reductions, the counts are ballots, and the two-pointer sweeps of planeSplit become two LDS permutations whose
 // destinations come from ballot prefix counts (left-side misplaced k <-> right-side misplaced k from the right).
-__global__ __launch_bounds__(BS) void kd_split_small_kernel(ForestPtrs f, int level) {
-    __shared__ int s_pos[BS / 64][2][64];     // [wave][side][rank] -> position
-    __shared__ int s_ind[BS / 64][64];
-    __shared__ float s_xyz[BS / 64][3][64];
+constexpr int SBS = 1024;            // 16 nodes per workgroup step
+__global__ __launch_bounds__(SBS) void kd_split_small_kernel(ForestPtrs f, int level) {
+    __shared__ int s_pos[SBS / 64][2][64];     // [wave][side][rank] -> position
+    __shared__ int s_ind[SBS / 64][64];
+    __shared__ float s_xyz[SBS / 64][3][64];
+    __shared__ int s_npush[SBS / 64];
+    __shared__ int s_qbase;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int nq = min(f.ctr[CTR_SQUEUE0 + level], f.queue_cap);
@@ -209,9 +221,10 @@ __global__ __launch_bounds__(BS) void kd_split_small_kernel(ForestPtrs f, int le
         atomicMax(&f.ctr[CTR_DEPTH], level + 1);
         if (level + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
     }
-    const int nwg = (nq + BS / 64 - 1) / (BS / 64);
+    const int nwg = (nq + SBS / 64 - 1) / (SBS / 64);
+    const int idbase = level_node_base(f, level, f.ntrees) + 2 * min(f.ctr[CTR_QUEUE0 + level], f.queue_cap);
     for (int g = blockIdx.x; g < nwg; g += gridDim.x) {          // uniform trip count inside a workgroup
-        const int qi = g * (BS / 64) + wid;
+        const int qi = g * (SBS / 64) + wid;
         const bool have = qi < nq;
         int node = 0, left = 0, count = 0, tree = 0;
         float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
@@ -286,11 +299,22 @@ __global__ __launch_bounds__(BS) void kd_split_small_kernel(ForestPtrs f, int le
         const float divhigh = wave_min((act && lane >= idx) ? v : FLT_MAX);
         if (act) f.vind[left + lane] = id;
         int c1 = -1;
-        if (have && lane == 0) {
-            c1 = atomicAdd(&f.ctr[CTR_NODES], 2);
-            if (c1 + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c1 = -1; }
+        if (have) {
+            c1 = idbase + 2 * qi;
+            if (c1 + 2 > f.node_cap) { if (lane == 0) atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c1 = -1; }
         }
-        c1 = __shfl(c1, 0);
+        // queue slots for the children that stay open: one atomic per workgroup step instead of one per child
+        const int open0 = (have && c1 >= 0 && idx > LEAF_MAX) ? 1 : 0, open1 = (have && c1 >= 0 && count - idx > LEAF_MAX) ? 1 : 0;
+        if (lane == 0) s_npush[wid] = open0 + open1;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < SBS / 64; ++w) tot += s_npush[w];
+            s_qbase = tot ? atomicAdd(&f.ctr[CTR_SQUEUE0 + level + 1], tot) : 0;
+        }
+        __syncthreads();
+        int qslot = s_qbase;
+        for (int w = 0; w < wid; ++w) qslot += s_npush[w];
         if (have && c1 >= 0 && lane < 2) {
             const int cn = c1 + lane;
             const int cl = lane == 0 ? left : left + idx, cr = lane == 0 ? left + idx : left + count;
@@ -303,10 +327,11 @@ __global__ __launch_bounds__(BS) void kd_split_small_kernel(ForestPtrs f, int le
                 f.node_box[6 * (size_t)cn + 3 + d] = (lane == 0 && d == cf) ? cut : hi[d];
             }
             if (cr - cl > LEAF_MAX) {
-                int q = atomicAdd(&f.ctr[CTR_SQUEUE0 + level + 1], 1);
+                const int q = qslot + (lane == 1 ? open0 : 0);
                 if (q < f.queue_cap) f.squeue[((level + 1) & 1) * f.queue_cap + q] = cn; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
             }
         }
+        __syncthreads();       // s_npush / s_qbase are reused by the next step
         if (have && c1 >= 0 && lane == 0) {
             f.node_a[node] = make_int4(left, left + count, c1, c1 + 1);
             f.node_b[node] = make_float4(divlow, divhigh, __int_as_float(cf), 0.f);
@@ -455,7 +480,7 @@ ForestPtrs ptrs(const KdForest& f) {
     p.node_a = f.node_a.as<int4>(); p.node_b = f.node_b.as<float4>(); p.node_box = f.node_box.as<float>();
     p.node_tree = f.node_tree.as<int>(); p.queue = f.queue.as<int>(); p.ctr = f.counters.as<int>();
     p.tmp = f.tmp.as<int>(); p.val = f.val.as<float>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
-    p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap;
+    p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap; p.ntrees = f.ntrees;
     return p;
 }
 
@@ -494,10 +519,10 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     // nodes above 64 points: one workgroup each; deeper than BIG_LEVELS a node that large means a degenerate cloud
     // (flagged, not mis-built).  Nodes of at most 64 points: one wavefront each.
     int maxn0 = 0; for (auto& t : trees) maxn0 = std::max(maxn0, t.n);
-    const int gsmall = std::max(1, std::min(f.queue_cap / 4 + 1, ctx().num_cu * 8));
+    const int gsmall = std::max(1, std::min(f.queue_cap / 16 + 1, ctx().num_cu * 2));
     for (int level = 0; level < MAX_LEVELS; ++level) {
         if (level < BIG_LEVELS && maxn0 > SMALL_MAX) hipLaunchKernelGGL(kd_split_kernel, dim3(grid), dim3(BS), 0, s, p, level);
-        hipLaunchKernelGGL(kd_split_small_kernel, dim3(gsmall), dim3(BS), 0, s, p, level);
+        hipLaunchKernelGGL(kd_split_small_kernel, dim3(gsmall), dim3(SBS), 0, s, p, level);
     }
     int maxn = 0; for (auto& t : trees) maxn = std::max(maxn, t.n);
     dim3 g((unsigned)std::max(1, std::min((maxn + 255) / 256, 64)), (unsigned)std::min(f.ntrees, 65535));

@@ -160,6 +160,38 @@ __device__ int voxel_label(const int* __restrict__ cls, int ldim, int col, const
     return nl ? lab[best] : 0;
 }
 
+// Fast path of voxel_label for labels in [0,13): they hash to distinct buckets of the 13-bucket table and can never
+// trigger the rehash, so the reference's iteration order is simply "most recently first-seen first" and the first
+// maximum is the largest count, ties to the label first seen LAST.  Returns -1 when a label falls outside [0,13).
+__device__ __forceinline__ int voxel_label_fast(const int* __restrict__ cls, int ldim, int col, const uint32_t* __restrict__ vs, int s, int e) {
+    int cnt[13], seen[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) { cnt[k] = 0; seen[k] = -1; }
+    for (int j = s; j < e; ++j) {
+        const int L = cls[(size_t)vs[j] * ldim + col];
+        if (L < 0 || L >= 13) return -1;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) if (L == k) { if (cnt[k] == 0) seen[k] = j; cnt[k]++; }
+    }
+    int best = 0;
+#pragma unroll
+    for (int k = 1; k < 13; ++k) if (cnt[k] > cnt[best] || (cnt[k] == cnt[best] && seen[k] > seen[best])) best = k;
+    return best;
+}
+
+__global__ __launch_bounds__(BS) void gs_reduce_labels(const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start,
+                                                       GsParams* prm, const int* __restrict__ row_of_voxel, int* out_c) {
+    const long long total = (long long)prm->m * ldim;
+    for (long long e = (long long)blockIdx.x * BS + threadIdx.x; e < total; e += (long long)gridDim.x * BS) {
+        const int v = (int)(e / ldim), col = (int)(e % ldim);
+        const int s = seg_start[v], en = seg_start[v + 1];
+        const int row = row_of_voxel ? row_of_voxel[v] : v;
+        int lab = voxel_label_fast(cls, ldim, col, vs, s, en);
+        if (lab < 0) lab = voxel_label(cls, ldim, col, vs, s, en, &prm->status);
+        out_c[(size_t)row * ldim + col] = lab;
+    }
+}
+
 __global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, const float* __restrict__ F, int fdim,
                                                 const int* __restrict__ cls, int ldim,
                                                 const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
@@ -169,7 +201,7 @@ __global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, con
     if (blockIdx.x == 0 && threadIdx.x == 0 && out_m) *out_m = m;
     // one lane per (voxel, output channel): the per-voxel sums stay sequential in input order (what makes them
     // bit-identical to the reference), the channels of a voxel run side by side and share the index loads
-    const int CH = 3 + (F ? fdim : 0) + (cls ? ldim : 0);
+    const int CH = 3 + (F ? fdim : 0);       // labels have their own kernel (gs_reduce_labels): different work per lane
     const long long total = (long long)m * CH;
     for (long long e = (long long)blockIdx.x * BS + threadIdx.x; e < total; e += (long long)gridDim.x * BS) {
         const int v = (int)(e / CH), c = (int)(e % CH);
@@ -182,14 +214,11 @@ __global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, con
             const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
             out_p[3 * (size_t)row + c] = sum * a;
             if (c == 0 && out_first) out_first[v] = ks[s];
-        } else if (F && c < 3 + fdim) {
+        } else {
             const int f = c - 3;
             float acc = 0.f;
             for (int j = s; j < en; ++j) acc += F[(size_t)vs[j] * fdim + f];
             out_f[(size_t)row * fdim + f] = acc / (float)count;      // :90-94
-        } else {
-            const int col = c - 3 - (F ? fdim : 0);
-            out_c[(size_t)row * ldim + col] = voxel_label(cls, ldim, col, vs, s, en, &prm->status);
         }
     }
 }
@@ -232,6 +261,7 @@ int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t f
     }
     hipLaunchKernelGGL(gs_reduce, dim3(g), dim3(BS), 0, s, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
                        row, d_op, d_of, d_oc, (long long*)d_om, (uint64_t*)nullptr, S.keys.as<uint64_t>());
+    if (d_c) hipLaunchKernelGGL(gs_reduce_labels, dim3(g), dim3(BS), 0, s, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_oc);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
