@@ -178,6 +178,14 @@ int ssdr_segment_mean_features_dev(const float* d_feat, int feat_dim, const int3
  * superpoint in d_sel. */
 int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel, size_t nsel,
                          size_t max_sp_size, int gcn_top, double* d_centres, double* d_cd_dir, double* d_adj, void* stream);
+/* All clouds of a batch in one call: d_sel [n_total] lists the superpoints cloud by cloud, d_coff int32 [num_clouds+1]
+ * gives each cloud's row range in d_sel / d_centres, d_boff int64 [num_clouds+1] the start of its n_c x n_c block in
+ * d_cd_dir / d_adj (both of sum n_c^2 elements); n_max = largest n_c.  Same results as the per-cloud call. */
+int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel,
+                               const int32_t* d_coff, const int64_t* d_boff, size_t num_clouds, size_t n_total, size_t n_max,
+                               int gcn_top, double* d_centres, double* d_cd_dir, double* d_adj, void* stream);
+int ssdr_propagate_batch_dev(const double* d_adj, const int32_t* d_coff, const int64_t* d_boff, size_t num_clouds, size_t n_max,
+                             const int32_t* d_rows, const double* d_vin, int feat_dim, double* d_vout, double* d_comb, void* stream);
 /* One hop of sum_i A^i V on a block (fps_gcn_cpu.py:162-167): vout[rows] = adj * vin[rows]; comb[rows] += vout[rows] */
 int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, const double* d_vin, int feat_dim, double* d_vout,
                        double* d_comb, void* stream);

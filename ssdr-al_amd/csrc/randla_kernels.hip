@@ -32,49 +32,100 @@ static inline f32x4 mfma16(float a, float b, f32x4 c) { return hipemu_mfma_f32_1
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * 0.2f; }
 
 // ---- dense --------------------------------------------------------------------------------------------
-constexpr int DT = 64, DKC = 32, DAS = DKC + 2, DBS = DT + 16;
+// 128 x 64 output tile per workgroup, K in chunks of 32; wave w owns rows [32w, 32w+32) x all 64 columns as 2 x 4
+// MFMA tiles.  The next K chunk is fetched into registers (float4 when every row segment is 16-byte aligned) while
+// the current one is multiplied out of LDS, so global latency hides behind 64 MFMAs per wave and chunk.
+constexpr int DTM = 128, DTN = 64, DKC = 32, DAS = DKC + 2, DBS = DTN + 16;
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
-    __shared__ float As[DT * DAS];
+    __shared__ float As[DTM * DAS];
     __shared__ float Bs[DKC * DBS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int row0 = blockIdx.x * DT, col0 = blockIdx.y * DT;
+    const int row0 = blockIdx.x * DTM, col0 = blockIdx.y * DTN;
     const int K = a.k1 + a.k2;
-    // this thread's A row (fixed over the k loop)
+    // A staging: thread -> rows ar, ar+64 ; 8 consecutive k at ak.   B staging: k row bk, 8 consecutive columns at bc
     const int ar = tid >> 2, ak = (tid & 3) * 8;
-    const int grow = row0 + ar;
-    const float* x1r = nullptr; const float* x2r = nullptr;
-    if (grow < a.M) {
-        x1r = a.x1 + (size_t)grow * a.k1;
-        if (a.k2) {
-            size_t r2 = (size_t)grow;
-            if (a.idx2) r2 = (size_t)(grow / a.m_per_batch) * a.x2_rows_per_batch + (size_t)a.idx2[grow];
-            x2r = a.x2 + r2 * a.k2;
+    const float* x1r[2]; const float* x2r[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int grow = row0 + ar + 64 * h;
+        x1r[h] = nullptr; x2r[h] = nullptr;
+        if (grow < a.M) {
+            x1r[h] = a.x1 + (size_t)grow * a.k1;
+            if (a.k2) {
+                size_t r2 = (size_t)grow;
+                if (a.idx2) r2 = (size_t)(grow / a.m_per_batch) * a.x2_rows_per_batch + (size_t)a.idx2[grow];
+                x2r[h] = a.x2 + r2 * a.k2;
+            }
         }
     }
     const int bk = tid >> 3, bc = (tid & 7) * 8;
-    f32x4 acc[4];
+    float ra[2][8], rb[8];
+    auto fetch = [&](int kc) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < 2; ++h) {
+            if (VEC) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int gk = kc + ak + 4 * q;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (x1r[h] && gk < K) v = (gk < a.k1) ? *reinterpret_cast<const float4*>(x1r[h] + gk) : *reinterpret_cast<const float4*>(x2r[h] + (gk - a.k1));
+                    ra[h][4 * q] = v.x; ra[h][4 * q + 1] = v.y; ra[h][4 * q + 2] = v.z; ra[h][4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int gk = kc + ak + j;
+                    float v = 0.f;
+                    if (x1r[h]) { if (gk < a.k1) v = x1r[h][gk]; else if (gk < K) v = x2r[h][gk - a.k1]; }
+                    ra[h][j] = v;
+                }
+            }
+        }
+        const int gk = kc + bk;
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int gc = col0 + bc + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < K && gc < a.N) v = *reinterpret_cast<const float4*>(a.W + (size_t)gk * a.N + gc);
+                rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int gc = col0 + bc + j; rb[j] = (gk < K && gc < a.N) ? a.W[(size_t)gk * a.N + gc] : 0.f; }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) As[(ar + 64 * h) * DAS + ak + j] = ra[h][j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[bk * DBS + bc + j] = rb[j];
+    };
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(0);
     for (int kc = 0; kc < K; kc += DKC) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int gk = kc + ak + j;
-            float v = 0.f;
-            if (x1r) { if (gk < a.k1) v = x1r[gk]; else if (gk < K) v = x2r[gk - a.k1]; }
-            As[ar * DAS + ak + j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int gk = kc + bk, gc = col0 + bc + j;
-            Bs[bk * DBS + bc + j] = (gk < K && gc < a.N) ? a.W[(size_t)gk * a.N + gc] : 0.f;
-        }
+        stash();
         __syncthreads();
+        if (kc + DKC < K) fetch(kc + DKC);          // in flight while the MFMAs below run
 #pragma unroll
         for (int ks = 0; ks < DKC / 4; ++ks) {
-            const float av = As[(w * 16 + (lane & 15)) * DAS + ks * 4 + (lane >> 4)];
+            float av[2], bv[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma16(av, Bs[(ks * 4 + (lane >> 4)) * DBS + c * 16 + (lane & 15)], acc[c]);
+            for (int r = 0; r < 2; ++r) av[r] = As[(w * 32 + r * 16 + (lane & 15)) * DAS + ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = Bs[(ks * 4 + (lane >> 4)) * DBS + c * 16 + (lane & 15)];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = mfma16(av[r], bv[c], acc[r][c]);
         }
         __syncthreads();
     }
@@ -82,12 +133,14 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     for (int c = 0; c < 4; ++c) {
         const int col = col0 + c * 16 + (lane & 15);
         if (col >= a.N) continue;
-        const float bv = a.b ? a.b[col] : 0.f;
+        const float bias = a.b ? a.b[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + w * 16 + (lane >> 4) * 4 + r;
-            if (row < a.M) { float v = acc[c][r] + bv; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
-        }
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row0 + w * 32 + r * 16 + (lane >> 4) * 4 + q;
+                if (row < a.M) { float v = acc[r][c][q] + bias; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
+            }
     }
 }
 
@@ -279,9 +332,11 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
 // ---- launchers ---------------------------------------------------------------------------------------
 int launch_dense(const DenseArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
-    dim3 grid((unsigned)((a.M + DT - 1) / DT), (unsigned)((a.N + DT - 1) / DT));
+    dim3 grid((unsigned)((a.M + DTM - 1) / DTM), (unsigned)((a.N + DTN - 1) / DTN));
     ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
-    hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, s, a);
+    const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && a.N % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && ((uintptr_t)a.W & 15) == 0;
+    if (vec) hipLaunchKernelGGL((dense_kernel<true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dense_kernel<false>), grid, dim3(256), 0, s, a);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

@@ -204,9 +204,8 @@ constexpr int CH_TILE = 1536;   // target points staged per step (36 KiB of floa
 // One workgroup per target superpoint j: its centred points are staged in LDS once and re-used against every
 // source superpoint i (one wave per i, one lane per source point).  The mean is a wave tree sum, so it can differ
 // from NumPy's pairwise np.mean in the last ulp (the min distances themselves are exact).
-__global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir) {
-    __shared__ double tb[CH_TILE * 3];
+__device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                 const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, double* tb) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int j = blockIdx.x; j < nsel; j += gridDim.x) {
         const int sj = sel[j], loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
@@ -261,10 +260,24 @@ __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir) {
+    __shared__ double tb[CH_TILE * 3];
+    chamfer_dir_body(xyz, sp_off, sp_pts, sel, nsel, centres, dir, tb);
+}
+// all clouds of a batch in one launch: blockIdx.z = cloud, coff[c] = first row of cloud c in sel / centres, boff[c] = first
+// element of its n_c x n_c blocks in dir / adj
+__global__ __launch_bounds__(256) void sel_chamfer_dir_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                             const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
+                                                             const double* __restrict__ centres, double* dir) {
+    __shared__ double tb[CH_TILE * 3];
+    const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
+    chamfer_dir_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], tb);
+}
+
 // adj = exp(-(ED + CD)) - I (fps_gcn_cpu.py:102-104); rowsum (:106)
-__global__ __launch_bounds__(256) void sel_adj_build(const double* __restrict__ centres, const double* __restrict__ dir, int n, double* adj, double* rowsum) {
+__device__ void adj_build_body(const double* __restrict__ centres, const double* __restrict__ dir, int n, double* adj, double* rowsum, double* part) {
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        __shared__ double part[256];
         double acc = 0.0;
         for (int j = threadIdx.x; j < n; j += 256) {
             const double dx = centres[3 * i] - centres[3 * j], dy = centres[3 * i + 1] - centres[3 * j + 1], dz = centres[3 * i + 2] - centres[3 * j + 2];
@@ -281,8 +294,18 @@ __global__ __launch_bounds__(256) void sel_adj_build(const double* __restrict__ 
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void sel_adj_build(const double* __restrict__ centres, const double* __restrict__ dir, int n, double* adj, double* rowsum) {
+    __shared__ double part[256];
+    adj_build_body(centres, dir, n, adj, rowsum, part);
+}
+__global__ __launch_bounds__(256) void sel_adj_build_batch(const double* __restrict__ centres, const double* __restrict__ dir, const int* __restrict__ coff,
+                                                           const long long* __restrict__ boff, double* adj, double* rowsum) {
+    __shared__ double part[256];
+    const int c = blockIdx.z, lo = coff[c];
+    adj_build_body(centres + 3 * (size_t)lo, dir + boff[c], coff[c + 1] - lo, adj + boff[c], rowsum + lo, part);
+}
 // adj = adj * diag(1/rowsum) + I (:108-115): column j scaled by 1/rowsum[j], inf -> 0
-__global__ __launch_bounds__(256) void sel_adj_norm(const double* __restrict__ rowsum, int n, double* adj) {
+__device__ void adj_norm_body(const double* __restrict__ rowsum, int n, double* adj) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n * n; e += (size_t)gridDim.x * 256) {
         const int i = (int)(e / n), j = (int)(e % n);
         double dinv = 1.0 / rowsum[j];
@@ -290,8 +313,13 @@ __global__ __launch_bounds__(256) void sel_adj_norm(const double* __restrict__ r
         adj[e] = adj[e] * dinv + (i == j ? 1.0 : 0.0);
     }
 }
+__global__ __launch_bounds__(256) void sel_adj_norm(const double* __restrict__ rowsum, int n, double* adj) { adj_norm_body(rowsum, n, adj); }
+__global__ __launch_bounds__(256) void sel_adj_norm_batch(const double* __restrict__ rowsum, const int* __restrict__ coff, const long long* __restrict__ boff, double* adj) {
+    const int c = blockIdx.z, lo = coff[c];
+    adj_norm_body(rowsum + lo, coff[c + 1] - lo, adj + boff[c]);
+}
 // keep the gcn_top largest entries of every row (fps_gcn_cpu.py:153-160); ties keep the higher column index
-__global__ __launch_bounds__(256) void sel_adj_topk(double* adj, int n, int top) {
+__device__ void adj_topk_body(double* adj, int n, int top) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         double* row = adj + (size_t)i * n;
         for (int j = 0; j < n; ++j) {
@@ -303,8 +331,13 @@ __global__ __launch_bounds__(256) void sel_adj_topk(double* adj, int n, int top)
     }
 }
 // Vout[rows[i]] = sum_j adj[i][j] * Vin[rows[j]]  (one hop of fps_gcn_cpu.py:164-165), comb[rows[i]] += Vout
-__global__ __launch_bounds__(256) void sel_propagate(const double* __restrict__ adj, int n, const int* __restrict__ rows, const double* __restrict__ vin, int D,
-                                                     double* vout, double* comb) {
+__global__ __launch_bounds__(256) void sel_adj_topk(double* adj, int n, int top) { adj_topk_body(adj, n, top); }
+__global__ __launch_bounds__(256) void sel_adj_topk_batch(double* adj, const int* __restrict__ coff, const long long* __restrict__ boff, int top) {
+    const int c = blockIdx.z;
+    adj_topk_body(adj + boff[c], coff[c + 1] - coff[c], top);
+}
+__device__ void propagate_body(const double* __restrict__ adj, int n, const int* __restrict__ rows, const double* __restrict__ vin, int D,
+                               double* vout, double* comb) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n * D; e += gridDim.x * 256) {
         const int i = e / D, c = e % D;
         double acc = 0.0;
@@ -312,6 +345,13 @@ __global__ __launch_bounds__(256) void sel_propagate(const double* __restrict__ 
         vout[(size_t)rows[i] * D + c] = acc;
         comb[(size_t)rows[i] * D + c] += acc;
     }
+}
+__global__ __launch_bounds__(256) void sel_propagate(const double* __restrict__ adj, int n, const int* __restrict__ rows, const double* __restrict__ vin, int D,
+                                                     double* vout, double* comb) { propagate_body(adj, n, rows, vin, D, vout, comb); }
+__global__ __launch_bounds__(256) void sel_propagate_batch(const double* __restrict__ adj, const int* __restrict__ coff, const long long* __restrict__ boff,
+                                                           const int* __restrict__ rows, const double* __restrict__ vin, int D, double* vout, double* comb) {
+    const int c = blockIdx.z, lo = coff[c];
+    propagate_body(adj + boff[c], coff[c + 1] - lo, rows + lo, vin, D, vout, comb);
 }
 
 // ---- F4: farthest_features_sample (fps_gcn_cpu.py:119-147) / F5: kCenterGreedy (kcenterGreedy.py:84-128) --------
@@ -444,10 +484,9 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
 template <int DF, int PPT>
 __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ f, int n, int from_partials, int start, int use_sqrt,
                                                      const Part* __restrict__ pin, int npart, const double* __restrict__ mind, int count, int* out) {
-    __shared__ double s_v[8];
-    __shared__ int s_i[8];
-    __shared__ int s_c;
-    __shared__ double s_fc[DF];
+    __shared__ double s_v[2][8];
+    __shared__ int s_i[2][8];
+    __shared__ double s_fc[2][DF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double reg[PPT][DF], rmin[PPT];
 #pragma unroll
@@ -457,7 +496,8 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
 #pragma unroll
         for (int k = 0; k < DF; ++k) reg[q][k] = i < n ? f[(size_t)i * DF + k] : 0.0;
     }
-    auto block_argmax = [&](double v, int i) {
+    // publishes this thread's best into s_v/s_i[par]; after the barrier every thread reduces the 8 wave results itself
+    auto block_argmax = [&](double v, int i, int par) -> int {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const long long b = __double_as_longlong(v);
@@ -466,30 +506,28 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
             const int oi = __shfl_xor(i, o);
             if (better(ov, oi, v, i)) { v = ov; i = oi; }
         }
-        if (lane == 0) { s_v[wid] = v; s_i[wid] = i; }
+        if (lane == 0) { s_v[par][wid] = v; s_i[par][wid] = i; }
         __syncthreads();
-        if (tid == 0) {
-            double bv = s_v[0]; int bi = s_i[0];
+        double bv = s_v[par][0]; int bi = s_i[par][0];
 #pragma unroll
-            for (int w = 1; w < 8; ++w) if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
-            s_c = bi;
-        }
-        __syncthreads();
+        for (int w = 1; w < 8; ++w) if (better(s_v[par][w], s_i[par][w], bv, bi)) { bv = s_v[par][w]; bi = s_i[par][w]; }
+        return bi;
     };
-    if (!from_partials) { if (tid == 0) s_c = start; __syncthreads(); }
+    int c;
+    if (!from_partials) c = start;
     else {
         double v = -1.0; int i = 0x7fffffff;
         for (int k = tid; k < npart; k += 512) if (better(pin[k].v, pin[k].i, v, i)) { v = pin[k].v; i = pin[k].i; }
-        block_argmax(v, i);
+        c = block_argmax(v, i, 1);
     }
     for (int it = 0; it < count; ++it) {
-        const int c = s_c;
+        const int par = it & 1;
         if (tid == 0) out[it] = c;
         if (it + 1 == count) break;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) if (c == tid + q * 512) {
 #pragma unroll
-            for (int k = 0; k < DF; ++k) s_fc[k] = reg[q][k];
+            for (int k = 0; k < DF; ++k) s_fc[par][k] = reg[q][k];
         }
         __syncthreads();
         double bv = -1.0; int bi = 0x7fffffff;
@@ -497,13 +535,13 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
         for (int q = 0; q < PPT; ++q) {
             const int i = tid + q * 512;
             if (i < n) {
-                double dist = np_pairwise_fixed<DF>([&](int k) { const double d = reg[q][k] - s_fc[k]; return d * d; });
+                double dist = np_pairwise_fixed<DF>([&](int k) { const double d = reg[q][k] - s_fc[par][k]; return d * d; });
                 if (use_sqrt) dist = sqrt(dist);
                 if (dist < rmin[q]) rmin[q] = dist;
                 if (better(rmin[q], i, bv, bi)) { bv = rmin[q]; bi = i; }
             }
         }
-        block_argmax(bv, bi);     // its first barrier also orders the s_fc reads before the next overwrite
+        c = block_argmax(bv, bi, par);       // two barriers per iteration; parity double-buffering covers the reuse
     }
 }
 
@@ -645,6 +683,36 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(grid_for(n)), dim3(256), 0, s, d_adj, n, gcn_top);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel, const int32_t* d_coff,
+                               const int64_t* d_boff, size_t num_clouds, size_t n_total, size_t n_max, int gcn_top,
+                               double* d_centres, double* d_cd_dir, double* d_adj, void* stream) {
+    if (!d_xyz || !d_sp_off || !d_sp_pts || !d_sel || !d_coff || !d_boff || !d_centres || !d_cd_dir || !d_adj || num_clouds > 65535) { set_error("cloud_graph_batch: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (num_clouds == 0 || n_total == 0 || n_max == 0) return SSDR_OK;
+    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    const int nt = (int)n_total, nm = (int)n_max; const unsigned nc = (unsigned)num_clouds;
+    SSDR_TRY(Q.rowsum.reserve(8 * n_total));
+    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, nt, d_centres);
+    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel,
+                       d_coff, (const long long*)d_boff, d_centres, d_cd_dir);
+    hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, d_centres, d_cd_dir, d_coff, (const long long*)d_boff, d_adj, Q.rowsum.as<double>());
+    hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), d_coff, (const long long*)d_boff, d_adj);
+    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(grid_for(nm), 1, nc), dim3(256), 0, s, d_adj, d_coff, (const long long*)d_boff, gcn_top);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_propagate_batch_dev(const double* d_adj, const int32_t* d_coff, const int64_t* d_boff, size_t num_clouds, size_t n_max, const int32_t* d_rows,
+                             const double* d_vin, int feat_dim, double* d_vout, double* d_comb, void* stream) {
+    if (!d_adj || !d_coff || !d_boff || !d_rows || !d_vin || !d_vout || !d_comb || feat_dim < 1 || num_clouds > 65535) { set_error("propagate_batch: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (num_clouds == 0 || n_max == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_propagate_batch, dim3(grid_for((long)n_max * feat_dim, 256), 1, (unsigned)num_clouds), dim3(256), 0, pick_stream(stream), d_adj, d_coff,
+                       (const long long*)d_boff, d_rows, d_vin, feat_dim, d_vout, d_comb);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

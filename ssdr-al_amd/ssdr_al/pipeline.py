@@ -187,22 +187,24 @@ class HotPath:
         V = d_mf.to_host().astype(np.float64)                # float32 -> float64 as np.concatenate/np.matmul promote it
         d_v = DevArray.from_host(V); d_comb = DevArray.from_host(V)
         d_tmp = [DevArray(V.shape, np.float64), DevArray(V.shape, np.float64)]
-        blocks = []
-        for b in sorted(set(c for c, _ in refs)):
-            rows = np.array([i for i, (c, _) in enumerate(refs) if c == b], np.int32)
-            ssel = sel[rows]
-            n = len(rows)
-            d = dict(s=DevArray.from_host(ssel), r=DevArray.from_host(rows), c=DevArray((n, 3), np.float64), d=DevArray((n, n), np.float64),
-                     a=DevArray((n, n), np.float64), n=n)
-            _lib.check(L.ssdr_cloud_graph_dev(self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr, d["s"].ptr, n, int(self.sp_size_h[ssel].max()), int(self.gcn_top),
-                                              d["c"].ptr, d["d"].ptr, d["a"].ptr, None))
-            blocks.append(d)
+        # every cloud's chamfer graph and propagation hop in one batched call (rows grouped cloud by cloud)
+        clouds = sorted(set(c for c, _ in refs))
+        order = np.concatenate([[i for i, (c, _) in enumerate(refs) if c == b] for b in clouds]).astype(np.int32)
+        counts = np.array([sum(1 for c, _ in refs if c == b) for b in clouds], np.int64)
+        coff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        boff = np.concatenate([[0], np.cumsum(counts * counts)]).astype(np.int64)
+        d_gsel = DevArray.from_host(sel[order]); d_rows = DevArray.from_host(order)
+        d_coff = DevArray.from_host(coff); d_boff = DevArray.from_host(boff)
+        ntot, nmax, nsq = int(coff[-1]), int(counts.max()), int(boff[-1])
+        d_cen = DevArray((ntot, 3), np.float64); d_dir = DevArray((nsq,), np.float64); d_adj = DevArray((nsq,), np.float64)
+        _lib.check(L.ssdr_cloud_graph_batch_dev(self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_gsel.ptr, d_coff.ptr, d_boff.ptr, len(clouds), ntot, nmax,
+                                                int(self.gcn_top), d_cen.ptr, d_dir.ptr, d_adj.ptr, None))
         src = d_v
         for hop in range(int(self.gcn_number)):
             dst = d_tmp[hop & 1]
-            for d in blocks:
-                _lib.check(L.ssdr_propagate_dev(d["a"].ptr, d["n"], d["r"].ptr, src.ptr, 32, dst.ptr, d_comb.ptr, None))
+            _lib.check(L.ssdr_propagate_batch_dev(d_adj.ptr, d_coff.ptr, d_boff.ptr, len(clouds), nmax, d_rows.ptr, src.ptr, 32, dst.ptr, d_comb.ptr, None))
             src = dst
+        blocks = (d_gsel, d_rows, d_coff, d_boff, d_cen, d_dir, d_adj)
         n_unl = len(unl)
         self.unl_cloud_ids = np.array([self.room_ids[b] for b, _ in unl], np.int64)
         self.unl_sp = np.array([s - self.sp_base[b] for b, s in unl], np.int64)       # superpoint index inside its room
