@@ -42,6 +42,11 @@ const char* ssdr_last_error(void);
 int  ssdr_init(int device);              /* idempotent; selects the HIP device, creates stream + workspace */
 void ssdr_shutdown(void);
 int  ssdr_stream_sync(void* stream);     /* NULL = library stream */
+/* Extra streams for callers that overlap independent work (e.g. the per-room front end); every *_dev entry point
+ * keeps its workspaces per stream, so calls on different streams may run concurrently. */
+int  ssdr_stream_create(void** out_stream);
+int  ssdr_stream_destroy(void* stream);
+int  ssdr_stream_wait(void* waiter, void* waited);   /* waiter continues after what is enqueued on waited so far */
 /* Optional per-launch timing (HIP events on the launch stream) of the instrumented kernels; used by bench.py for
  * the roofline line.  ssdr_prof_report() synchronises and returns "name calls total_ms total_work\n" lines, where
  * total_work is the summed algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels) of those launches. */

@@ -43,7 +43,7 @@ int ensure_init() { return ctx().ready ? SSDR_OK : do_init(0); }
 
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return SSDR_OK;
-    if (p) { SSDR_HIP(hipStreamSynchronize(ctx().stream)); SSDR_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    if (p) { SSDR_HIP(hipDeviceSynchronize()); SSDR_HIP(hipFree(p)); p = nullptr; cap = 0; }   // any stream may still use it
     size_t want = bytes + bytes / 4 + 256;
     SSDR_HIP(hipMalloc(&p, want));
     cap = want;
@@ -104,6 +104,25 @@ int ssdr_stream_sync(void* stream) {
     return SSDR_OK;
 }
 float ssdr_last_gpu_ms(void) { return ssdr::ctx().last_ms; }
+int ssdr_stream_create(void** out_stream) {
+    if (!out_stream) { ssdr::set_error("stream_create: NULL"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ssdr::ensure_init());
+    hipStream_t s = nullptr;
+    SSDR_HIP(hipStreamCreate(&s));
+    *out_stream = s;
+    return SSDR_OK;
+}
+int ssdr_stream_destroy(void* stream) { if (stream) SSDR_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream))); return SSDR_OK; }
+/* work enqueued on `waiter` after this call starts only after everything enqueued on `waited` so far has finished */
+int ssdr_stream_wait(void* waiter, void* waited) {
+    SSDR_TRY(ssdr::ensure_init());
+    hipEvent_t e = nullptr;
+    SSDR_HIP(hipEventCreate(&e));
+    SSDR_HIP(hipEventRecord(e, ssdr::pick_stream(waited)));
+    SSDR_HIP(hipStreamWaitEvent(ssdr::pick_stream(waiter), e, 0));
+    SSDR_HIP(hipEventDestroy(e));
+    return SSDR_OK;
+}
 int ssdr_dev_alloc(size_t bytes, void** d_ptr) {
     if (!d_ptr) { ssdr::set_error("dev_alloc: NULL"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ssdr::ensure_init());

@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 // ---- fused local-feature-aggregation attention half -----------------------------------------------------
 template <int D> struct LfaCfg {
     static constexpr int H = D / 2;
-    static constexpr int PTS = (1024 / D) < 32 ? (1024 / D) : 32;     // points per workgroup
+    // points per workgroup: small enough that 3-5 workgroups share a CU's LDS at the low levels (their phases are
+    // latency-bound gathers), large enough at d >= 256 that a W element fetched from L2 serves several points
+    static constexpr int PTS = D == 16 ? 16 : (D == 64 ? 8 : (D == 128 ? 4 : (D == 256 ? 4 : 2)));
     static constexpr int ROWS = PTS * 16;
     static constexpr int LD = D + 2;                                   // LDS row stride == 2 (mod 32): conflict-free A reads
     static constexpr int NCT = D / 16;                                 // column tiles of the attention GEMM
@@ -194,12 +196,18 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     // Second half: into columns [0,H) as the A operand of the LFAmlp2 GEMM below.
     {
         constexpr int XOFF = SECOND ? 0 : H;
+        static_assert(256 % H == 0, "a thread keeps one output channel");
+        const int c = tid % H;                         // e += 256 never changes e % H: the 10 weights live in registers
+        float wreg[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) wreg[q] = a.w_l1[q * H + c];
+        const float breg = a.b_l1[c];
         for (int e = tid; e < ROWS * H; e += 256) {
-            const int row = e / H, c = e % H;
+            const int row = e / H;
             float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < 10; ++q) s += REL[row * 10 + q] * a.w_l1[q * H + c];
-            F[row * LD + XOFF + c] = lrelu(s + a.b_l1[c]);
+            for (int q = 0; q < 10; ++q) s += REL[row * 10 + q] * wreg[q];
+            F[row * LD + XOFF + c] = lrelu(s + breg);
         }
     }
     __syncthreads();
@@ -210,16 +218,25 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
         f32x4 acc2[T2W];
 #pragma unroll
         for (int t = 0; t < T2W; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // k outer, tiles inner, operands of the next k-step requested before this step's MFMAs (as in the main GEMM)
+        float a2[T2W], b2[T2W], a2n[T2W], b2n[T2W];
+        auto load2 = [&](int kb, float (&av)[T2W], float (&bv)[T2W]) {
+            const int k = kb + (lane >> 4);
 #pragma unroll
-        for (int t = 0; t < T2W; ++t) {
-            const int tile = w * T2W + t, p = tile / NCT2, ct = tile % NCT2;
-            const int col = ct * 16 + (lane & 15);
-            for (int kb = 0; kb < H; kb += 4) {
-                const int k = kb + (lane >> 4);
-                const float av = (k < H) ? F[(p * 16 + (lane & 15)) * LD + k] : 0.f;
-                const float bv = (k < H && col < H) ? a.w_l2[k * H + col] : 0.f;
-                acc2[t] = mfma16(av, bv, acc2[t]);
+            for (int t = 0; t < T2W; ++t) {
+                const int tile = w * T2W + t, p = tile / NCT2, ct = tile % NCT2;
+                const int col = ct * 16 + (lane & 15);
+                av[t] = (k < H) ? F[(p * 16 + (lane & 15)) * LD + k] : 0.f;
+                bv[t] = (k < H && col < H) ? a.w_l2[k * H + col] : 0.f;
             }
+        };
+        load2(0, a2, b2);
+        for (int kb = 0; kb < H; kb += 4) {
+            if (kb + 4 < H) load2(kb + 4, a2n, b2n);
+#pragma unroll
+            for (int t = 0; t < T2W; ++t) acc2[t] = mfma16(a2[t], b2[t], acc2[t]);
+#pragma unroll
+            for (int t = 0; t < T2W; ++t) { a2[t] = a2n[t]; b2[t] = b2n[t]; }
         }
 #pragma unroll
         for (int t = 0; t < T2W; ++t) {
@@ -253,17 +270,31 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     for (int p = 0; p < NP_W; ++p)
 #pragma unroll
         for (int c = 0; c < NC_W; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < D; kb += 4) {
-        const int k = kb + (lane >> 4);
-        float av[NP_W], bv[NC_W];
+    // software pipeline: the operands of k-step kb+4 (A from LDS, W from L2) are requested before the MFMAs of kb issue
+    float av[NP_W], bv[NC_W], an[NP_W], bn[NC_W];
+    {
+        const int k = lane >> 4;
 #pragma unroll
         for (int p = 0; p < NP_W; ++p) av[p] = F[((p0 + p) * 16 + (lane & 15)) * LD + k];
 #pragma unroll
         for (int c = 0; c < NC_W; ++c) bv[c] = a.w_fc[(size_t)k * D + (ct0 + c) * 16 + (lane & 15)];
+    }
+    for (int kb = 0; kb < D; kb += 4) {
+        const int kn = kb + 4 + (lane >> 4);
+        if (kb + 4 < D) {
+#pragma unroll
+            for (int p = 0; p < NP_W; ++p) an[p] = F[((p0 + p) * 16 + (lane & 15)) * LD + kn];
+#pragma unroll
+            for (int c = 0; c < NC_W; ++c) bn[c] = a.w_fc[(size_t)kn * D + (ct0 + c) * 16 + (lane & 15)];
+        }
 #pragma unroll
         for (int p = 0; p < NP_W; ++p)
 #pragma unroll
             for (int c = 0; c < NC_W; ++c) acc[p][c] = mfma16(av[p], bv[c], acc[p][c]);
+#pragma unroll
+        for (int p = 0; p < NP_W; ++p) av[p] = an[p];
+#pragma unroll
+        for (int c = 0; c < NC_W; ++c) bv[c] = bn[c];
     }
 
     // softmax over the 16 neighbours (:579) and weighted sum (:580-581)

@@ -18,6 +18,7 @@
 //            iteration order of the reference's unordered_map<size_t,...> (subsample_order.hip).
 #include "ssdr_internal.hpp"
 #include "block_prims.hpp"
+#include <map>
 
 namespace ssdr {
 namespace {
@@ -228,7 +229,7 @@ struct GsState {
     DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row;
     size_t last_m = 0, last_fdim = 0, last_ldim = 0;
 };
-GsState& gs() { static GsState s; return s; }
+GsState& gs(hipStream_t st = nullptr) { static std::map<hipStream_t, GsState> m; return m[st ? st : ctx().stream]; }
 
 }  // namespace
 
@@ -237,7 +238,7 @@ int subsample_order_reference(const uint64_t* d_ks, const uint32_t* d_vs, const 
 
 int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t fdim, const int32_t* d_c, size_t ldim, float dl,
                           int order, float* d_op, float* d_of, int32_t* d_oc, int64_t* d_om, hipStream_t s) {
-    GsState& S = gs();
+    GsState& S = gs(s);
     const int ni = (int)n;
     const int gmm = std::max(1, std::min((ni + BS - 1) / BS, 1024));
     const int nb = (ni + CHUNK - 1) / CHUNK;

@@ -20,6 +20,7 @@
 // reference build row by row.
 #include "ssdr_internal.hpp"
 #include "block_prims.hpp"
+#include <map>
 
 namespace ssdr {
 namespace {
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(BS) void ord_store_list(OrdPtrs o, int r) {
 }
 
 struct OrdState { RadixSorter sorter; DevBuf skey, sval, kt, seq, L, pfirst, tfirst, cnt, major; };
-OrdState& ost() { static OrdState s; return s; }
+OrdState& ost(hipStream_t st) { static std::map<hipStream_t, OrdState> m; return m[st]; }
 
 }  // namespace
 
 int subsample_order_reference(const uint64_t* d_ks, const uint32_t* d_vs, const int* d_seg_start, const int* d_m, int n_host,
                               int* d_row_of_voxel, hipStream_t s) {
-    OrdState& S = ost();
+    OrdState& S = ost(s);
     const size_t n = (size_t)n_host;
     int nph = 0;   // phases that can be needed for up to n_host voxels
     while (nph < NSCHED && (nph == 0 || BKT_SCHED_H[nph - 1] < (unsigned long long)n_host)) ++nph;

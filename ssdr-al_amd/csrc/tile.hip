@@ -8,6 +8,7 @@
 // as the reference draws it from np.random on the host.
 #include "ssdr_internal.hpp"
 #include "block_prims.hpp"
+#include <map>
 
 namespace ssdr {
 namespace {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts
 }
 
 struct TileState { RadixSorter sorter; DevBuf keys, vals, count; };
-TileState& tst() { static TileState s; return s; }
+TileState& tst(hipStream_t st) { static std::map<hipStream_t, TileState> m; return m[st]; }
 
 }  // namespace
 }  // namespace ssdr
@@ -74,7 +75,7 @@ extern "C" int ssdr_tile_select_dev(const float* d_points, const float* d_colors
     if (!d_points || !d_m || !center || !d_perm || !d_dup_u || !d_out_xyz || n_max == 0 || num_points == 0 || n_max > 0x3fffffff) { set_error("tile_select: bad arguments"); return SSDR_ERR_INVALID; }
     if (d_out_feat && color_dim > 0 && !d_colors) { set_error("tile_select: colors missing"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
-    TileState& T = tst(); hipStream_t s = pick_stream(stream);
+    hipStream_t s = pick_stream(stream); TileState& T = tst(s);
     SSDR_TRY(T.keys.reserve(8 * n_max)); SSDR_TRY(T.vals.reserve(4 * n_max)); SSDR_TRY(T.count.reserve(16));
     const int g = (int)std::max<size_t>(1, std::min<size_t>((n_max + 255) / 256, (size_t)ctx().num_cu * 8));
     hipLaunchKernelGGL(tile_keys, dim3(g), dim3(256), 0, s, d_points, (const long long*)d_m, (int)n_max, center[0], center[1], center[2],

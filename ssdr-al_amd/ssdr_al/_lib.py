@@ -52,6 +52,9 @@ def lib():
         L.ssdr_last_gpu_ms.restype = C.c_float
         L.ssdr_init.argtypes = [i32]
         L.ssdr_stream_sync.argtypes = [vp]
+        L.ssdr_stream_create.argtypes = [C.POINTER(vp)]
+        L.ssdr_stream_destroy.argtypes = [vp]
+        L.ssdr_stream_wait.argtypes = [vp, vp]
         L.ssdr_knn.argtypes = [vp, sz, sz, vp, sz, sz, vp]
         L.ssdr_knn_batch.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
         L.ssdr_knn_batch_i32.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]

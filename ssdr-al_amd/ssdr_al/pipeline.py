@@ -23,6 +23,7 @@ class HotPath:
         self.gcn_number, self.gcn_top = gcn_number, gcn_top
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
         self.seed = seed
+        self.num_streams = 4
         self.global_order = None
         self.rooms = []
         self.timing = None
@@ -86,13 +87,27 @@ class HotPath:
 
     # ---- stages ------------------------------------------------------------------------------------------------
     def _front_end(self):
+        """Rooms are independent until the batch arrays: their subsample + tile chains (many small kernels each) are
+        spread over a few HIP streams so they overlap; the main stream then waits for all of them."""
         cfg, L = self.cfg, _lib.lib()
         N = cfg.num_points
+        if not getattr(self, "_streams", None) or self._streams_lib is not L:
+            self._streams = []
+            for _ in range(self.num_streams):
+                s = C.c_void_p()
+                _lib.check(L.ssdr_stream_create(C.byref(s)))
+                self._streams.append(s.value)
+            self._streams_lib = L
+        for st in self._streams:
+            _lib.check(L.ssdr_stream_wait(st, None))      # the previous step's consumers of xyz / feat are done
         for b, r in enumerate(self.rooms):
+            st = self._streams[b % len(self._streams)]
             _lib.check(L.ssdr_grid_subsample_dev(r["pts"].ptr, r["n"], r["col"].ptr, 3, r["lab"].ptr, 1, cfg.sub_grid_size, _lib.ORDER_KEY,
-                                                 r["sp"].ptr, r["sc"].ptr, r["sl"].ptr, r["m"].ptr, None))
+                                                 r["sp"].ptr, r["sc"].ptr, r["sl"].ptr, r["m"].ptr, st))
             _lib.check(L.ssdr_tile_select_dev(r["sp"].ptr, r["sc"].ptr, 3, r["m"].ptr, r["n"], _lib.ptr(r["center"]), N, r["perm"].ptr, r["dup"].ptr,
-                                              1.0 / 255.0, self.xyz.ptr + b * N * 12, self.feat.ptr + b * N * 24, None, None))
+                                              1.0 / 255.0, self.xyz.ptr + b * N * 12, self.feat.ptr + b * N * 24, None, st))
+        for st in self._streams:
+            _lib.check(L.ssdr_stream_wait(None, st))
 
     def _pyramid(self):
         cfg = self.cfg
