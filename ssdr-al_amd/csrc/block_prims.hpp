@@ -26,7 +26,8 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 // min/max of 3 coordinates over the workgroup; result broadcast to every thread.
-__device__ inline void block_minmax3(float (&mn)[3], float (&mx)[3], float* s /* [4][6] */) {
+template <int NT = BS>
+__device__ inline void block_minmax3(float (&mn)[3], float (&mx)[3], float* s /* [NT/64][6] */) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -38,36 +39,37 @@ __device__ inline void block_minmax3(float (&mn)[3], float (&mx)[3], float* s /*
     for (int d = 0; d < 3; ++d) {
         float a = s[d], b = s[3 + d];
 #pragma unroll
-        for (int w = 1; w < BS / 64; ++w) { a = fminf(a, s[w * 6 + d]); b = fmaxf(b, s[w * 6 + 3 + d]); }
+        for (int w = 1; w < NT / 64; ++w) { a = fminf(a, s[w * 6 + d]); b = fmaxf(b, s[w * 6 + 3 + d]); }
         mn[d] = a; mx[d] = b;
     }
     __syncthreads();
 }
 
-__device__ inline void block_sum2(int& a, int& b, int* s /* [4][2] */) {
+template <int NT = BS>
+__device__ inline void block_sum2(int& a, int& b, int* s /* [NT/64][2] */) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int x = wave_sum(a), y = wave_sum(b);
     if (lane == 0) { s[wid * 2] = x; s[wid * 2 + 1] = y; }
     __syncthreads();
     x = 0; y = 0;
 #pragma unroll
-    for (int w = 0; w < BS / 64; ++w) { x += s[w * 2]; y += s[w * 2 + 1]; }
+    for (int w = 0; w < NT / 64; ++w) { x += s[w * 2]; y += s[w * 2 + 1]; }
     a = x; b = y;
     __syncthreads();
 }
 
 // Writes every position i in [lo,hi) with pred(i) to dst(rank) where rank counts matches in increasing i.
 // Returns the number of matches (uniform).  All threads of the workgroup must call it.
-template <class Pred, class Dst>
-__device__ int block_compact(int lo, int hi, Pred pred, Dst dst, int (*s_w)[U][BS / 64] /* [2][U][4] */) {
+template <int NT = BS, class Pred, class Dst>
+__device__ int block_compact(int lo, int hi, Pred pred, Dst dst, int (*s_w)[U][NT / 64] /* [2][U][NT/64] */) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int running = 0, par = 0;
-    for (int base = lo; base < hi; base += CHUNK, par ^= 1) {
+    for (int base = lo; base < hi; base += NT * U, par ^= 1) {
         bool p[U]; unsigned long long m[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            int i = base + u * BS + tid;
+            int i = base + u * NT + tid;
             p[u] = (i < hi) && pred(i);
             m[u] = __ballot(p[u]);
             if (lane == 0) s_w[par][u][wid] = __popcll(m[u]);
@@ -78,8 +80,8 @@ __device__ int block_compact(int lo, int hi, Pred pred, Dst dst, int (*s_w)[U][B
         for (int u = 0; u < U; ++u) {
             int wbase = 0, tot = 0;
 #pragma unroll
-            for (int w = 0; w < BS / 64; ++w) { int c = s_w[par][u][w]; if (w < wid) wbase += c; tot += c; }
-            if (p[u]) dst(off + wbase + __popcll(m[u] & lt), base + u * BS + tid);
+            for (int w = 0; w < NT / 64; ++w) { int c = s_w[par][u][w]; if (w < wid) wbase += c; tot += c; }
+            if (p[u]) dst(off + wbase + __popcll(m[u] & lt), base + u * NT + tid);
             off += tot;
         }
         running = off;

@@ -39,15 +39,15 @@ constexpr int ST_QUEUE_OVF = 1, ST_NODE_OVF = 2, ST_DEPTH_OVF = 4;
 // The two-pointer sweep of nanoflann.hpp:951-961 (and :966-973) in closed form: positions [start,end)
 // hold `lim - start` elements with left(i) == true; the k-th left-side element with !left swaps with the
 // k-th right-side element (counted from the right end) with left.
-template <class Left>
+template <int NT, class Left>
 __device__ void hoare_sweep(int* ind, float* val, int* tmp, int start, int end, int lim, Left left,
-                            int (*s_w)[U][BS / 64]) {
-    int m = block_compact(start, lim, [&](int i) { return !left(i); },
-                          [&](int k, int i) { tmp[start + k] = i; }, s_w);
+                            int (*s_w)[U][NT / 64]) {
+    int m = block_compact<NT>(start, lim, [&](int i) { return !left(i); },
+                              [&](int k, int i) { tmp[start + k] = i; }, s_w);
     if (m == 0) return;   // uniform
-    block_compact(lim, end, [&](int i) { return left(i); },
-                  [&](int k, int i) { tmp[start + m + (m - 1 - k)] = i; }, s_w);
-    for (int k = threadIdx.x; k < m; k += BS) {
+    block_compact<NT>(lim, end, [&](int i) { return left(i); },
+                      [&](int k, int i) { tmp[start + m + (m - 1 - k)] = i; }, s_w);
+    for (int k = threadIdx.x; k < m; k += NT) {
         int a = tmp[start + k], b = tmp[start + m + k];
         int ia = ind[a], ib = ind[b]; ind[a] = ib; ind[b] = ia;
         float va = val[a], vb = val[b]; val[a] = vb; val[b] = va;
@@ -94,10 +94,11 @@ __device__ __forceinline__ int level_node_base(const ForestPtrs& f, int level, i
 }
 
 // One level of divideTree (nanoflann.hpp:848-896) for every open node.
-__global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
-    __shared__ float s_mm[(BS / 64) * 6];
-    __shared__ int s_sum[(BS / 64) * 2];
-    __shared__ int s_w[2][U][BS / 64];
+template <int NT>
+__global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
+    __shared__ float s_mm[(NT / 64) * 6];
+    __shared__ int s_sum[(NT / 64) * 2];
+    __shared__ int s_w[2][U][NT / 64];
     __shared__ int s_child;
     const int tid = threadIdx.x;
     const int nq = min(f.ctr[CTR_QUEUE0 + level], f.queue_cap);
@@ -120,12 +121,12 @@ __global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
 
         // computeMinMax (:837-846) for all three dimensions at once
         float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int i = tid; i < count; i += BS) {
+        for (int i = tid; i < count; i += NT) {
             const size_t p = (size_t)ind[i] * 3;
 #pragma unroll
             for (int d = 0; d < 3; ++d) { float v = P[p + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
         }
-        block_minmax3(mn, mx, s_mm);
+        block_minmax3<NT>(mn, mx, s_mm);
 
         // middleSplit_ (:898-937)
         const float EPS = 0.00001f;
@@ -147,26 +148,26 @@ __global__ __launch_bounds__(BS) void kd_split_kernel(ForestPtrs f, int level) {
 
         // stage the cut coordinate by position; count "< cut" and "== cut"
         int cL = 0, cE = 0;
-        for (int i = tid; i < count; i += BS) {
+        for (int i = tid; i < count; i += NT) {
             float v = P[(size_t)ind[i] * 3 + cf];
             val[i] = v; cL += v < cut; cE += v == cut;
         }
-        block_sum2(cL, cE, s_sum);   // barrier inside also publishes val[]
+        block_sum2<NT>(cL, cE, s_sum);   // barrier inside also publishes val[]
 
         // planeSplit (:948-975)
         const int lim1 = cL, lim2 = cL + cE;
-        hoare_sweep(ind, val, tmp, 0, count, lim1, [&](int i) { return val[i] < cut; }, s_w);
-        if (cE > 0) hoare_sweep(ind, val, tmp, lim1, count, lim2, [&](int i) { return val[i] <= cut; }, s_w);
+        hoare_sweep<NT>(ind, val, tmp, 0, count, lim1, [&](int i) { return val[i] < cut; }, s_w);
+        if (cE > 0) hoare_sweep<NT>(ind, val, tmp, lim1, count, lim2, [&](int i) { return val[i] <= cut; }, s_w);
         int idx;
         if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
 
         // tight child boxes along the cut dimension (:878-882): divlow = max over left, divhigh = min over right
         float m3n[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, m3x[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int i = tid; i < count; i += BS) {
+        for (int i = tid; i < count; i += NT) {
             float v = val[i];
             if (i < idx) m3x[0] = fmaxf(m3x[0], v); else m3n[0] = fminf(m3n[0], v);
         }
-        block_minmax3(m3n, m3x, s_mm);
+        block_minmax3<NT>(m3n, m3x, s_mm);
 
         if (tid == 0) {
             int c = level_node_base(f, level, f.ntrees) + 2 * qi;
@@ -521,7 +522,11 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     int maxn0 = 0; for (auto& t : trees) maxn0 = std::max(maxn0, t.n);
     const int gsmall = std::max(1, std::min(f.queue_cap / 16 + 1, ctx().num_cu * 2));
     for (int level = 0; level < MAX_LEVELS; ++level) {
-        if (level < BIG_LEVELS && maxn0 > SMALL_MAX) hipLaunchKernelGGL(kd_split_kernel, dim3(grid), dim3(BS), 0, s, p, level);
+        if (level < BIG_LEVELS && maxn0 > SMALL_MAX) {
+            // the first levels have few, large nodes: 16 waves per node; later 4
+            if ((maxn0 >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<1024>), dim3(grid), dim3(1024), 0, s, p, level);
+            else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);
+        }
         hipLaunchKernelGGL(kd_split_small_kernel, dim3(gsmall), dim3(SBS), 0, s, p, level);
     }
     int maxn = 0; for (auto& t : trees) maxn = std::max(maxn, t.n);

@@ -82,6 +82,9 @@ class HotPath:
             self.labeled[b] = set(rng.choice(ids, min(self.labeled_per_tile, len(ids)), replace=False).tolist())
         self.selected_class_list = DevArray.from_host(np.random.default_rng([self.seed, 999983]).integers(0, cfg.num_classes, 4000).astype(np.int32))
         self.hist = DevArray((64,), np.int32)
+        self.labeled_mask = np.zeros(self.S, bool)
+        for b in self.labeled:
+            self.labeled_mask[list(self.labeled[b])] = True
         self.sp_size_h = np.diff(self.sp_off_h)
         return self
 
@@ -158,35 +161,29 @@ class HotPath:
         """create_file_top_and_all + the candidate rule of sampling() (sampler2.py:533-552, :745-753) on index lists.
         Candidate order is canonical (cloud ascending, then descending uncertainty): the reference's own order depends
         on a shuffled DataLoader (sampler2.py:323) and carries no meaning."""
-        top, allc = {}, {}
         if self.global_order is None:
-            batch_size = min(self.select_per_tile * self.B, len(sorted_inds))
-            rank = 0
-            for s in sorted_inds:
-                b = int(self.sp_cloud_h[s])
-                if s in self.labeled[b]:
-                    continue
-                if rank < batch_size:
-                    top.setdefault(b, []).append(int(s))
-                allc.setdefault(b, []).append(int(s))
-                rank += 1
+            order = np.asarray(sorted_inds, np.int64)
+            keep = ~self.labeled_mask[order]                 # labelled regions never compete
+            cand = order[keep]
+            batch_size = min(self.select_per_tile * self.B, len(order))
+            local = cand                                      # all candidates are local
+            in_top = np.arange(len(cand)) < batch_size
         else:
             order, allu, base, batch_size = self.global_order
-            rank = 0
-            for g in order:
-                if allu[g] == -np.inf:
-                    break                                   # labelled regions sort last
-                s = int(g) - base
-                if 0 <= s < self.S:
-                    b = int(self.sp_cloud_h[s])
-                    if rank < batch_size:
-                        top.setdefault(b, []).append(s)
-                    allc.setdefault(b, []).append(s)
-                rank += 1
-        unl, sampling_batch = [], 0
-        for b in sorted(top):
-            k = len(top[b]); sampling_batch += k
-            unl += [(b, s) for s in allc[b][:2 * k]]
+            order = np.asarray(order, np.int64)
+            cand_g = order[allu[order] != -np.inf]           # labelled regions were masked to -inf and sort last
+            in_top_g = np.arange(len(cand_g)) < batch_size
+            mine = (cand_g >= base) & (cand_g < base + self.S)
+            local, in_top = cand_g[mine] - base, in_top_g[mine]
+        cloud = self.sp_cloud_h[local]
+        grp = np.argsort(cloud, kind="stable")               # cloud ascending, descending uncertainty inside a cloud
+        local, in_top, cloud = local[grp], in_top[grp], cloud[grp]
+        ntop = np.bincount(cloud[in_top], minlength=self.B)  # selected_num per cloud (len(file_list_top[cloud]))
+        first = np.searchsorted(cloud, np.arange(self.B))
+        pos = np.arange(len(local)) - first[cloud]
+        take = pos < 2 * ntop[cloud]                          # candidates = first 2 x selected_num of the cloud (:748)
+        unl = [(int(b), int(s)) for b, s in zip(cloud[take], local[take])]
+        sampling_batch = int(ntop.sum())
         lab = [(b, s) for b in sorted(self.labeled) for s in sorted(self.labeled[b])]
         return unl, lab, sampling_batch
 
@@ -203,9 +200,10 @@ class HotPath:
         d_v = DevArray.from_host(V); d_comb = DevArray.from_host(V)
         d_tmp = [DevArray(V.shape, np.float64), DevArray(V.shape, np.float64)]
         # every cloud's chamfer graph and propagation hop in one batched call (rows grouped cloud by cloud)
-        clouds = sorted(set(c for c, _ in refs))
-        order = np.concatenate([[i for i, (c, _) in enumerate(refs) if c == b] for b in clouds]).astype(np.int32)
-        counts = np.array([sum(1 for c, _ in refs if c == b) for b in clouds], np.int64)
+        ref_cloud = np.fromiter((c for c, _ in refs), np.int64, len(refs))
+        order = np.argsort(ref_cloud, kind="stable").astype(np.int32)
+        clouds, counts = np.unique(ref_cloud, return_counts=True)
+        counts = counts.astype(np.int64)
         coff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         boff = np.concatenate([[0], np.cumsum(counts * counts)]).astype(np.int64)
         d_gsel = DevArray.from_host(sel[order]); d_rows = DevArray.from_host(order)
