@@ -107,8 +107,12 @@ __global__ __launch_bounds__(RS_BS) void rs_scan(SortPtrs s, int p) {
     if (tid == 0) s.tot[blockIdx.x] = carry_s;
 }
 
+// Tile layout for ranking: wave w owns the 512 consecutive pairs [w*512, w*512+512) of the tile and walks them in 8
+// rounds of 64, so "tile order" == (wave, round, lane) order.  Each wave ranks its pairs with wave-private digit
+// counters (no workgroup barrier inside the rounds); one barrier later the waves' digit totals are prefixed in wave
+// order.  Two barriers per tile instead of three per round.
 __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
-    __shared__ unsigned s_cnt[RS_BS / 64][256];
+    __shared__ unsigned s_cnt[RS_BS / 64][256];      // per wave: running count of each digit
     __shared__ unsigned s_run[256];
     int par; if (!pass_runs(s, p, par)) return;
     const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
@@ -136,11 +140,13 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
 #pragma unroll
         for (int w = 0; w < RS_BS / 64; ++w) s_cnt[w][tid] = 0;
         __syncthreads();
+        uint64_t key[RS_ITEMS]; uint32_t val[RS_ITEMS]; unsigned rk[RS_ITEMS];
+#pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
-            const int i = b * RS_TILE + j * RS_BS + tid;
+            const int i = b * RS_TILE + wid * (RS_TILE / (RS_BS / 64)) + j * 64 + lane;
             const bool valid = i < n;
-            uint64_t key = 0; uint32_t val = 0; unsigned d = 0;
-            if (valid) { key = K[i]; val = V[i]; d = (unsigned)((key >> (8 * p)) & 0xff); }
+            key[j] = 0; val[j] = 0; unsigned d = 0;
+            if (valid) { key[j] = K[i]; val[j] = V[i]; d = (unsigned)((key[j] >> (8 * p)) & 0xff); }
             unsigned long long m = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
@@ -148,23 +154,22 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
                 const unsigned long long bal = __ballot(valid && one);
                 m &= one ? bal : ~bal;
             }
-            const int rank = __popcll(m & lt);
-            if (valid && rank == 0) s_cnt[wid][d] = (unsigned)__popcll(m);
-            __syncthreads();
-            if (valid) {
-                unsigned pos = s_run[d] + rank;
-                for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
-                KO[pos] = key; VO[pos] = val;
-            }
-            __syncthreads();
-            {
-                unsigned t = 0;
-#pragma unroll
-                for (int w = 0; w < RS_BS / 64; ++w) { t += s_cnt[w][tid]; s_cnt[w][tid] = 0; }
-                s_run[tid] += t;
-            }
-            __syncthreads();
+            const unsigned before = valid ? s_cnt[wid][d] : 0u;         // this digit's count in the wave's earlier rounds
+            rk[j] = valid ? before + (unsigned)__popcll(m & lt) : 0xffffffffu;
+            (void)__ballot(1);                                            // every lane has read `before` ...
+            if (valid && (m & lt) == 0) s_cnt[wid][d] = before + (unsigned)__popcll(m);   // ... then the group leader adds
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            if (rk[j] != 0xffffffffu) {
+                const unsigned d = (unsigned)((key[j] >> (8 * p)) & 0xff);
+                unsigned pos = s_run[d] + rk[j];
+                for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
+                KO[pos] = key[j]; VO[pos] = val[j];
+            }
+        }
+        __syncthreads();
     }
 }
 
