@@ -196,6 +196,9 @@ int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, con
                        double* d_comb, void* stream);
 /* farthest_features_sample (fps_gcn_cpu.py:119-147); `start` is the reference's np.random.randint draw */
 int ssdr_fps_dev(const double* d_feat, size_t n, int feat_dim, int start, size_t count, int32_t* d_out, void* stream);
+/* farthest_superpoint_sample (sampler2.py:49-80, "edcd" branch) over one cloud's superpoints, from the centres and
+ * directed chamfer means ssdr_cloud_graph_dev produced: distance = |centre_i - centre_c|^2 + CD(i,c); n <= 8192 */
+int ssdr_fps_superpoint_dev(const double* d_centres, const double* d_cd_dir, size_t n, int start, size_t count, int32_t* d_out, void* stream);
 /* kCenterGreedy.select_batch_ (kcenterGreedy.py:84-128) with direct float64 Euclidean distances */
 int ssdr_kcenter_dev(const double* d_feat, size_t n, int feat_dim, const int32_t* d_already_selected, size_t n_already, size_t count,
                      int32_t* d_out, void* stream);

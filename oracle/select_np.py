@@ -151,6 +151,23 @@ def farthest_features_sample(features, sample_number, start):   # fps_gcn_cpu.py
     return cent
 
 
+def farthest_superpoint_sample(xyz, offsets, points, sel, sample_number, trigger_idx):
+    """sampler2.py:49-80 (the "edcd" branch): FPS over superpoints with distance |centre_i - centre_c|^2 + CD(i, c)."""
+    sub_off = np.concatenate([[0], np.cumsum(offsets[np.asarray(sel) + 1] - offsets[np.asarray(sel)])]).astype(np.int32)
+    sub_pts = np.concatenate([points[offsets[s]:offsets[s + 1]] for s in sel])
+    cen = bbox_centres(xyz, sub_off, sub_pts)
+    cd = create_cd(xyz, sub_off, sub_pts, cen)
+    n = len(sel)
+    cent = np.zeros(sample_number, np.int32); cent[0] = trigger_idx
+    distance = np.ones(n) * 1e10
+    for i in range(sample_number - 1):
+        dist = np.sum((cen - cen[cent[i]]) ** 2, axis=-1) + cd[cent[i]]
+        mask = dist < distance
+        distance[mask] = dist[mask]
+        cent[i + 1] = np.argmax(distance)
+    return cent
+
+
 def kcenter_greedy(features, already_selected, n):          # kcenterGreedy.py:60-128 (direct distances)
     f = np.asarray(features, np.float64)
     md = None

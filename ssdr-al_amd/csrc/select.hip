@@ -545,6 +545,37 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
     }
 }
 
+// farthest_superpoint_sample (sampler2.py:49-80, the "edcd" branch): FPS over one cloud's superpoints with the
+// distance |centre_i - centre_c|^2 + CD(i, c), CD = dir + dir^T from sel_chamfer_dir.  One workgroup, n <= a few thousand.
+__global__ __launch_bounds__(256) void fps_superpoint(const double* __restrict__ centres, const double* __restrict__ dir, int n, int start, int count, int* out) {
+    __shared__ double s_v[256];
+    __shared__ int s_i[256];
+    SSDR_DYN_SHARED(double, mind);          // [n]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) mind[i] = 1.0e10;
+    int c = start;
+    __syncthreads();
+    for (int it = 0; it < count; ++it) {
+        if (tid == 0) out[it] = c;
+        if (it + 1 == count) break;
+        double bv = -1.0; int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 256) {
+            const double dx = centres[3 * i] - centres[3 * c], dy = centres[3 * i + 1] - centres[3 * c + 1], dz = centres[3 * i + 2] - centres[3 * c + 2];
+            const double ed = (dx * dx + dy * dy) + dz * dz;                                  // np.sum(.., axis=-1) over 3 terms
+            const double cd = (i == c) ? 0.0 : dir[(size_t)c * n + i] + dir[(size_t)i * n + c];   // chamfer_distance(..)[i]: av_dist1 + av_dist2
+            const double dist = ed + cd;
+            double m = mind[i];
+            if (dist < m) { m = dist; mind[i] = m; }
+            if (better(m, i, bv, bi)) { bv = m; bi = i; }
+        }
+        s_v[tid] = bv; s_i[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o && better(s_v[tid + o], s_i[tid + o], s_v[tid], s_i[tid])) { s_v[tid] = s_v[tid + o]; s_i[tid] = s_i[tid + o]; } __syncthreads(); }
+        c = s_i[0];
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_double(double* p, int n, double v) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = v;
 }
@@ -756,6 +787,15 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
                            last ? (Part*)nullptr : pout, Q.mind.as<double>(), d_out + it);
         (void)pin;
     }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_fps_superpoint_dev(const double* d_centres, const double* d_cd_dir, size_t n, int start, size_t count, int32_t* d_out, void* stream) {
+    if (!d_centres || !d_cd_dir || !d_out || start < 0 || (size_t)start >= n || count > n || n > 8192) { set_error("fps_superpoint: bad arguments (n <= 8192)"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (count == 0) return SSDR_OK;
+    hipLaunchKernelGGL(fps_superpoint, dim3(1), dim3(256), 8 * n, pick_stream(stream), d_centres, d_cd_dir, (int)n, start, (int)count, d_out);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

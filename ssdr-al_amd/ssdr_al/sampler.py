@@ -128,6 +128,22 @@ def farthest_features_sample(feature_list, sample_number, start):
     return d_o.to_host()
 
 
+def farthest_superpoint_sample(xyz, offsets, points, sel, sample_number, trigger_idx):
+    """sampler2.py:49-80 (the "edcd" branch) for the superpoints `sel` of one cloud (CSR instead of point lists)."""
+    xyz = np.ascontiguousarray(xyz, np.float32); sel = np.ascontiguousarray(sel, np.int32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    n = len(sel)
+    d_x = DevArray.from_host(xyz); d_o = DevArray.from_host(offsets); d_p = DevArray.from_host(np.ascontiguousarray(points, np.int32))
+    d_s = DevArray.from_host(sel)
+    d_c = DevArray((n, 3), np.float64); d_dir = DevArray((n, n), np.float64); d_a = DevArray((n, n), np.float64)
+    d_out = DevArray((sample_number,), np.int32)
+    L = _lib.lib()
+    _lib.check(L.ssdr_cloud_graph_dev(d_x.ptr, d_o.ptr, d_p.ptr, d_s.ptr, n, int((offsets[sel + 1] - offsets[sel]).max()), 0, d_c.ptr, d_dir.ptr, d_a.ptr, None))
+    _lib.check(L.ssdr_fps_superpoint_dev(d_c.ptr, d_dir.ptr, n, int(trigger_idx), sample_number, d_out.ptr, None))
+    _lib.sync()
+    return d_out.to_host()
+
+
 class kCenterGreedy:
     """kcenterGreedy.py:46-128 (the part the AL loop calls: select_batch_ with a non-empty already_selected)."""
 

@@ -124,6 +124,10 @@ def main():
     kc = kcenterGreedy.kCenterGreedy(kf)
     g["kc/feat"], g["kc/already"] = kf.astype(np.float32), already.astype(np.int32)
     g["kc/seq"] = np.array(kc.select_batch_(already, 30), np.int32)
+    # F6: the "edcd" branch's farthest_superpoint_sample (sampler2.py:49-80) on cloudA's superpoints
+    xyzA, compsA = clouds["cloudA"]
+    cenA = np.stack([(xyzA[c].min(0) + xyzA[c].max(0)).astype(np.float64) / 2.0 for c in compsA])
+    g["f6/seq"] = sampler2.farthest_superpoint_sample([xyzA[c] for c in compsA], cenA, 5, 0)
     np.savez_compressed(os.path.join(HERE, "select_golden.npz"), **g)
     print("select_golden.npz", os.path.getsize(os.path.join(HERE, "select_golden.npz")) // 1024, "KiB")
 

@@ -68,6 +68,17 @@ def test_fps_and_kcenter_golden(backend, golden):
     assert kc.select_batch_(g["kc/already"], 30) == list(g["kc/seq"])
 
 
+def test_edcd_farthest_superpoint_sample_golden(backend, golden):
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    xyz, off, pts = g["f/cloudA/xyz"], g["f/cloudA/offsets"], g["f/cloudA/points"]
+    seq = sampler.farthest_superpoint_sample(xyz, off, pts, np.arange(len(off) - 1), 5, 0)
+    assert np.array_equal(seq, g["f6/seq"])
+    rng = np.random.default_rng(8)
+    sel = rng.permutation(len(off) - 1)[:6]
+    assert np.array_equal(sampler.farthest_superpoint_sample(xyz, off, pts, sel, 4, 2), O.farthest_superpoint_sample(xyz, off, pts, sel, 4, 2))
+
+
 def test_selection_fresh_inputs_against_oracle(backend):
     from ssdr_al import sampler
     rng = np.random.default_rng(21)
