@@ -24,6 +24,7 @@ class HotPath:
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
         self.seed = seed
         self.num_streams = 4
+        self.stream = None          # stream of the front end .. scoring stages (None = the library's main stream)
         self.global_order = None
         self.rooms = []
         self.timing = None
@@ -102,7 +103,7 @@ class HotPath:
                 self._streams.append(s.value)
             self._streams_lib = L
         for st in self._streams:
-            _lib.check(L.ssdr_stream_wait(st, None))      # the previous step's consumers of xyz / feat are done
+            _lib.check(L.ssdr_stream_wait(st, self.stream))      # the previous step's consumers of xyz / feat are done
         for b, r in enumerate(self.rooms):
             st = self._streams[b % len(self._streams)]
             _lib.check(L.ssdr_grid_subsample_dev(r["pts"].ptr, r["n"], r["col"].ptr, 3, r["lab"].ptr, 1, cfg.sub_grid_size, _lib.ORDER_KEY,
@@ -110,31 +111,32 @@ class HotPath:
             _lib.check(L.ssdr_tile_select_dev(r["sp"].ptr, r["sc"].ptr, 3, r["m"].ptr, r["n"], _lib.ptr(r["center"]), N, r["perm"].ptr, r["dup"].ptr,
                                               1.0 / 255.0, self.xyz.ptr + b * N * 12, self.feat.ptr + b * N * 24, None, st))
         for st in self._streams:
-            _lib.check(L.ssdr_stream_wait(None, st))
+            _lib.check(L.ssdr_stream_wait(self.stream, st))
 
     def _pyramid(self):
         cfg = self.cfg
         arr = C.c_void_p * cfg.num_layers
         r = np.asarray(cfg.sub_sampling_ratio, np.int32)
         _lib.check(_lib.lib().ssdr_knn_pyramid_dev(self.xyz.ptr, self.B, cfg.num_points, cfg.num_layers, _lib.ptr(r), cfg.k_n,
-                                                   arr(*[a.ptr for a in self.neigh]), None, arr(*[a.ptr for a in self.interp]), None))
+                                                   arr(*[a.ptr for a in self.neigh]), None, arr(*[a.ptr for a in self.interp]), self.stream))
 
     def _infer(self):
         self.net.infer_dev(self.B, self.cfg.num_points, self.feat.ptr, self.xyz.ptr, [a.ptr for a in self.neigh], [a.ptr for a in self.interp],
-                           self.probs.ptr, self.f32.ptr)
+                           self.probs.ptr, self.f32.ptr, self.stream)
 
     def _score(self, comm=None):
         cfg, L = self.cfg, _lib.lib()
         n = self.B * cfg.num_points
         um = {"lc": 0, "entropy": 1, "sb": 2}[[a for a in self.sampler_args if a in ("lc", "entropy", "sb")][0]]
         rm = {"mean": 0, "sum_weight": 1, "WetSU": 2}[[a for a in self.sampler_args if a in ("mean", "sum_weight", "WetSU")][0]]
-        _lib.check(L.ssdr_point_uncertainty_dev(self.probs.ptr, n, cfg.num_classes, um, self.unc.ptr, self.cls.ptr, None))
+        st = self.stream
+        _lib.check(L.ssdr_point_uncertainty_dev(self.probs.ptr, n, cfg.num_classes, um, self.unc.ptr, self.cls.ptr, st))
         _lib.check(L.ssdr_region_stats_dev(self.unc.ptr, self.cls.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, cfg.num_classes, rm,
-                                           self.region_unc.ptr, self.dom.ptr, self.dom_cnt.ptr, None))
+                                           self.region_unc.ptr, self.dom.ptr, self.dom_cnt.ptr, st))
         nsel = self.selected_class_list.shape[0]
         if "clsbal" in self.sampler_args:
             if comm is None:
-                _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, None))
+                _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, st))
             else:       # exchange 1: the class histogram is global (the already-selected list is counted once, on rank 0)
                 _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, None))
                 _lib.sync()
@@ -142,7 +144,7 @@ class HotPath:
                 self.hist = DevArray.from_host(h[:64].astype(np.int32))
                 _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, int(h[64]) + nsel, self.region_unc.ptr, None))
         if comm is None:
-            _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, None))
+            _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, st))
             self.global_order = None
         else:           # exchange 2: rank the regions of ALL ranks; labelled regions are taken out before the cut
             _lib.sync()
@@ -252,4 +254,36 @@ class HotPath:
         out = self._select(comm); mark()
         if timed_stages:
             self.timing = dict(zip(("subsample+tile", "knn_pyramid", "randla_infer", "score", "select"), np.diff(t) * 1e3))
+        return out
+
+
+class Pipelined:
+    """Two buffer sets of the same batch: while the selection stage of batch k (latency-bound: host decisions, one
+    workgroup of FPS) runs on the main stream, the front end .. scoring of batch k+1 is already running on a second
+    stream.  Every batch still goes through every stage; K calls to `run` finish K selections."""
+
+    def __init__(self, make_hot_path):
+        L = _lib.lib()
+        s = C.c_void_p()
+        _lib.check(L.ssdr_stream_create(C.byref(s)))
+        self.s1 = s.value
+        self.hp = [make_hot_path(), make_hot_path()]
+        for h in self.hp:
+            h.stream = self.s1
+        _lib.sync(); _lib.sync(self.s1)
+
+    def _enqueue(self, h):
+        h._front_end(); h._pyramid(); h._infer(); h._score()
+
+    def run(self, steps):
+        L = _lib.lib()
+        out = None
+        self._enqueue(self.hp[0])
+        for k in range(steps):
+            cur, nxt = self.hp[k & 1], self.hp[(k + 1) & 1]
+            _lib.check(L.ssdr_stream_wait(None, self.s1))       # main stream: wait for batch k's scores (all of s1 so far)
+            if k + 1 < steps:
+                self._enqueue(nxt)                               # batch k+1 starts now, next to batch k's selection
+            out = cur._select()
+        _lib.sync(); _lib.sync(self.s1)
         return out

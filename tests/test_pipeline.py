@@ -55,3 +55,23 @@ def test_small_room_is_padded_by_duplication(backend):
     assert ref["m"][0] < hp.cfg.num_points
     assert_bits_equal(hp.xyz.to_host(), ref["xyz"], "padded tile")
     assert_bits_equal(hp.feat.to_host(), ref["feat"], "padded tile features")
+
+
+def test_overlapped_batches_give_the_same_selection(backend):
+    """bench.py overlaps the selection of batch k with the front end .. scoring of batch k+1 (two buffer sets, two
+    streams); the result of every batch must not change."""
+    from oracle import randla_np as R
+    from ssdr_al import pipeline, synthetic
+    from ssdr_al.helper_tool import ConfigS3DIS
+
+    class Cfg(ConfigS3DIS):
+        pass
+    Cfg.num_points = 1024 if backend == "emu" else 40960
+    W = R.init_weights(0)
+    rooms = [synthetic.make_room(5000 + i, density=80.0 if backend == "emu" else 2500.0) for i in range(2)]
+    make = lambda: pipeline.HotPath(W, Cfg, select_per_tile=6, labeled_per_tile=3).load_rooms(rooms)
+    one, _ = make().step()
+    pipe = pipeline.Pipelined(make)
+    for k in (1, 2, 5):
+        sel, _ = pipe.run(k)
+        assert np.array_equal(sel, one)
