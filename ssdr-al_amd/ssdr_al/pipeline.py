@@ -24,7 +24,8 @@ class HotPath:
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
         self.seed = seed
         self.num_streams = 4
-        self.stream = None          # stream of the front end .. scoring stages (None = the library's main stream)
+        self.stream = None          # stream of the pyramid .. scoring stages (None = the library's main stream)
+        self.front_stream = None    # stream the per-room front end forks from / joins to
         self.global_order = None
         self.rooms = []
         self.timing = None
@@ -103,7 +104,7 @@ class HotPath:
                 self._streams.append(s.value)
             self._streams_lib = L
         for st in self._streams:
-            _lib.check(L.ssdr_stream_wait(st, self.stream))      # the previous step's consumers of xyz / feat are done
+            _lib.check(L.ssdr_stream_wait(st, self.front_stream))      # the previous step's consumers of xyz / feat are done
         for b, r in enumerate(self.rooms):
             st = self._streams[b % len(self._streams)]
             _lib.check(L.ssdr_grid_subsample_dev(r["pts"].ptr, r["n"], r["col"].ptr, 3, r["lab"].ptr, 1, cfg.sub_grid_size, _lib.ORDER_KEY,
@@ -111,7 +112,7 @@ class HotPath:
             _lib.check(L.ssdr_tile_select_dev(r["sp"].ptr, r["sc"].ptr, 3, r["m"].ptr, r["n"], _lib.ptr(r["center"]), N, r["perm"].ptr, r["dup"].ptr,
                                               1.0 / 255.0, self.xyz.ptr + b * N * 12, self.feat.ptr + b * N * 24, None, st))
         for st in self._streams:
-            _lib.check(L.ssdr_stream_wait(self.stream, st))
+            _lib.check(L.ssdr_stream_wait(self.front_stream, st))
 
     def _pyramid(self):
         cfg = self.cfg
@@ -258,32 +259,45 @@ class HotPath:
 
 
 class Pipelined:
-    """Two buffer sets of the same batch: while the selection stage of batch k (latency-bound: host decisions, one
-    workgroup of FPS) runs on the main stream, the front end .. scoring of batch k+1 is already running on a second
-    stream.  Every batch still goes through every stage; K calls to `run` finish K selections."""
+    """Three buffer sets of the same batch and three streams: while the selection of batch k (latency-bound: host
+    decisions, one workgroup of FPS) runs on the main stream, the KNN pyramid + network + scoring of batch k+1 run on a
+    second stream and the per-room front end (many small kernels) of batch k+2 on a third.  Every batch still goes
+    through every stage; `run(K)` finishes K selections."""
 
     def __init__(self, make_hot_path):
         L = _lib.lib()
-        s = C.c_void_p()
-        _lib.check(L.ssdr_stream_create(C.byref(s)))
-        self.s1 = s.value
-        self.hp = [make_hot_path(), make_hot_path()]
+        self.sf, self.sc = C.c_void_p(), C.c_void_p()
+        _lib.check(L.ssdr_stream_create(C.byref(self.sf)))
+        _lib.check(L.ssdr_stream_create(C.byref(self.sc)))
+        self.sf, self.sc = self.sf.value, self.sc.value
+        self.hp = [make_hot_path() for _ in range(3)]
         for h in self.hp:
-            h.stream = self.s1
-        _lib.sync(); _lib.sync(self.s1)
+            h.stream, h.front_stream = self.sc, self.sf
+        self._drain()
 
-    def _enqueue(self, h):
-        h._front_end(); h._pyramid(); h._infer(); h._score()
+    def _drain(self):
+        _lib.sync(); _lib.sync(self.sf); _lib.sync(self.sc)
+
+    def _front(self, h):
+        h._front_end()
+
+    def _compute(self, h):
+        _lib.check(_lib.lib().ssdr_stream_wait(self.sc, self.sf))      # this batch's tiles (everything on sf so far)
+        h._pyramid(); h._infer(); h._score()
 
     def run(self, steps):
         L = _lib.lib()
         out = None
-        self._enqueue(self.hp[0])
+        hp = self.hp
+        self._front(hp[0]); self._compute(hp[0])
+        if steps > 1:
+            self._front(hp[1])
         for k in range(steps):
-            cur, nxt = self.hp[k & 1], self.hp[(k + 1) & 1]
-            _lib.check(L.ssdr_stream_wait(None, self.s1))       # main stream: wait for batch k's scores (all of s1 so far)
+            _lib.check(L.ssdr_stream_wait(None, self.sc))               # main stream: batch k's scores are ready
             if k + 1 < steps:
-                self._enqueue(nxt)                               # batch k+1 starts now, next to batch k's selection
-            out = cur._select()
-        _lib.sync(); _lib.sync(self.s1)
+                self._compute(hp[(k + 1) % 3])                            # batch k+1: pyramid + network + scoring
+            if k + 2 < steps:
+                self._front(hp[(k + 2) % 3])                              # batch k+2: subsample + tiles (its set was last read by select(k-1))
+            out = hp[k % 3]._select()                                     # batch k: selection (host-synchronous)
+        self._drain()
         return out
