@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the batches strictly one after the other")
+    ap.add_argument("--pipeline-depth", type=int, default=2, choices=(2, 3))
+    ap.add_argument("--front-streams", type=int, default=4)
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
     args = ap.parse_args()
 
@@ -78,7 +80,11 @@ def main():
     pipe = None
     if world == 1 and not args.no_pipeline:
         ids = [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)]
-        pipe = pipeline.Pipelined(lambda: pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms, ids))
+        def mk():
+            h = pipeline.HotPath(weights, ConfigS3DIS)
+            h.num_streams = args.front_streams
+            return h.load_rooms(rooms, ids)
+        pipe = pipeline.Pipelined(mk, args.pipeline_depth)
     if pipe is not None:
         pipe.run(max(args.warmup, 1))
     else:

@@ -259,18 +259,24 @@ class HotPath:
 
 
 class Pipelined:
-    """Three buffer sets of the same batch and three streams: while the selection of batch k (latency-bound: host
-    decisions, one workgroup of FPS) runs on the main stream, the KNN pyramid + network + scoring of batch k+1 run on a
-    second stream and the per-room front end (many small kernels) of batch k+2 on a third.  Every batch still goes
-    through every stage; `run(K)` finishes K selections."""
+    """Overlap consecutive batches on separate buffer sets and HIP streams.
+    depth 2: the selection of batch k (latency-bound: host decisions, one workgroup of FPS) on the main stream next to
+             front end + KNN pyramid + network + scoring of batch k+1 on a second stream;
+    depth 3: additionally the per-room front end of batch k+2 on a third stream.
+    Every batch still goes through every stage; `run(K)` finishes K selections."""
 
-    def __init__(self, make_hot_path):
+    def __init__(self, make_hot_path, depth=2):
+        assert depth in (2, 3)
         L = _lib.lib()
-        self.sf, self.sc = C.c_void_p(), C.c_void_p()
-        _lib.check(L.ssdr_stream_create(C.byref(self.sf)))
-        _lib.check(L.ssdr_stream_create(C.byref(self.sc)))
-        self.sf, self.sc = self.sf.value, self.sc.value
-        self.hp = [make_hot_path() for _ in range(3)]
+        self.depth = depth
+        sc = C.c_void_p()
+        _lib.check(L.ssdr_stream_create(C.byref(sc)))
+        self.sc = self.sf = sc.value
+        if depth == 3:
+            sf = C.c_void_p()
+            _lib.check(L.ssdr_stream_create(C.byref(sf)))
+            self.sf = sf.value
+        self.hp = [make_hot_path() for _ in range(depth)]
         for h in self.hp:
             h.stream, h.front_stream = self.sc, self.sf
         self._drain()
@@ -282,22 +288,25 @@ class Pipelined:
         h._front_end()
 
     def _compute(self, h):
-        _lib.check(_lib.lib().ssdr_stream_wait(self.sc, self.sf))      # this batch's tiles (everything on sf so far)
+        if self.sf != self.sc:
+            _lib.check(_lib.lib().ssdr_stream_wait(self.sc, self.sf))  # this batch's tiles (everything on sf so far)
         h._pyramid(); h._infer(); h._score()
 
     def run(self, steps):
         L = _lib.lib()
         out = None
-        hp = self.hp
+        hp, d = self.hp, self.depth
         self._front(hp[0]); self._compute(hp[0])
-        if steps > 1:
+        if d == 3 and steps > 1:
             self._front(hp[1])
         for k in range(steps):
             _lib.check(L.ssdr_stream_wait(None, self.sc))               # main stream: batch k's scores are ready
             if k + 1 < steps:
-                self._compute(hp[(k + 1) % 3])                            # batch k+1: pyramid + network + scoring
-            if k + 2 < steps:
-                self._front(hp[(k + 2) % 3])                              # batch k+2: subsample + tiles (its set was last read by select(k-1))
-            out = hp[k % 3]._select()                                     # batch k: selection (host-synchronous)
+                if d == 2:
+                    self._front(hp[(k + 1) % d])
+                self._compute(hp[(k + 1) % d])                            # batch k+1: (front end,) pyramid + network + scoring
+            if d == 3 and k + 2 < steps:
+                self._front(hp[(k + 2) % d])                              # batch k+2: subsample + tiles (its set was last read by select(k-1))
+            out = hp[k % d]._select()                                     # batch k: selection (host-synchronous)
         self._drain()
         return out
