@@ -523,8 +523,8 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     const int gsmall = std::max(1, std::min(f.queue_cap / 16 + 1, ctx().num_cu * 2));
     for (int level = 0; level < MAX_LEVELS; ++level) {
         if (level < BIG_LEVELS && maxn0 > SMALL_MAX) {
-            // the first levels have few, large nodes: 16 waves per node; later 4
-            if ((maxn0 >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<1024>), dim3(grid), dim3(1024), 0, s, p, level);
+            // the first levels have few, large nodes: 8 waves per node (16 would spill at the 128-VGPR cap); later 4
+            if ((maxn0 >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<512>), dim3(grid), dim3(512), 0, s, p, level);
             else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);
         }
         hipLaunchKernelGGL(kd_split_small_kernel, dim3(gsmall), dim3(SBS), 0, s, p, level);
