@@ -127,8 +127,17 @@ def main():
         mfma = name in ("dense_kernel", "lfa_att_kernel")
         achieved = work / (ms * 1e-3) / (1e12 if mfma else 1e9)
         peak = PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBS
+        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes); null when that file
+        # has no entry for the kernel.  bench.py cannot collect PMC counters itself.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"]
+            traffic = pmc[name]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roofline = {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
-                    "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2),
                     "others": {r[0]: {"ms_per_step": round(r[2] / 3, 3), "launches_per_step": r[1] // 3} for r in rows}}
         hp.step(gather if world == 1 else None, timed_stages=True)

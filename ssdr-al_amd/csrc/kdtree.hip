@@ -416,6 +416,9 @@ __device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& t
             else                     { best = na.w; other = na.z; cut = (val - nb.x) * (val - nb.x); }
             const float dst = cf == 0 ? d0 : (cf == 1 ? d1 : d2);
             const float m2 = mind + cut - dst;
+            // nanoflann tests `mindistsq <= worstDist` when it comes back to the far child (:1319); worstDist only
+            // shrinks, so a far child that already fails the test now can never pass it later: do not even stack it
+            if (!(m2 <= rs.worst())) { node = best; na = a.node_a[node]; continue; }
             if (sp < MAX_LEVELS) {
                 stk_node[sp] = other; stk_m[sp] = m2;
                 stk_0[sp] = cf == 0 ? cut : d0; stk_1[sp] = cf == 1 ? cut : d1; stk_2[sp] = cf == 2 ? cut : d2;
