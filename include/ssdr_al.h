@@ -209,6 +209,19 @@ int ssdr_kcenter_dev(const double* d_feat, size_t n, int feat_dim, const int32_t
 int ssdr_chamfer3d_forward_dev(const float* d_xyz1, const float* d_xyz2, size_t batch, size_t n, size_t m,
                                float* d_dist1, float* d_dist2, int32_t* d_idx1, int32_t* d_idx2, void* stream);
 
+/* ---- evaluation tail ("next" row N2: S3/RandLANet.py:326-334, 353-411; S3/helper_tool.py:237-262) ------------------
+ * ssdr_vote_smooth_dev: test_probs[point_idx] = smooth*test_probs[point_idx] + (1-smooth)*probs with NumPy's rule for
+ *   repeated indices (old row on the right-hand side, last occurrence wins).  d_owner_scratch: int32, one entry per
+ *   row of test_probs, initialised to -1 by the caller once (the call restores it).
+ * ssdr_confusion_dev: preds = argmax(probs[proj_idx[i]]) (proj_idx may be NULL: row i), confusion[label][pred] += 1
+ *   accumulated into d_confusion uint64 [C,C] (caller zeroes it), optional d_pred int32 [n] and d_iou float64 [C] =
+ *   DP.IoU_from_confusions of the accumulated matrix.  Re-projection to the raw cloud is proj_idx = ssdr_knn(sub_xyz,
+ *   raw_xyz, K=1) (utils/data_prepare_s3dis.py:69). */
+int ssdr_vote_smooth_dev(float* d_test_probs, const int32_t* d_point_idx, const float* d_probs, size_t n, int num_classes, double smooth,
+                         int32_t* d_owner_scratch, void* stream);
+int ssdr_confusion_dev(const float* d_probs, int num_classes, const int32_t* d_proj_idx, const int32_t* d_labels, size_t n, int32_t* d_pred,
+                       uint64_t* d_confusion, double* d_iou, void* stream);
+
 /* ---- plain device memory for callers without their own allocator (tests, the ctypes mirror) ---------- */
 int ssdr_dev_alloc(size_t bytes, void** d_ptr);
 int ssdr_dev_free(void* d_ptr);
