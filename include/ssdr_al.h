@@ -126,6 +126,14 @@ int ssdr_tile_select_dev(const float* d_points, const float* d_colors, int color
                          const float* center, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
                          float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream);
 
+/* Test-time variant (S3/s3dis_dataset_test.py:105-143): the same tile, plus the possibility-map update
+ * possibility[idx] += (1 - dists/max(dists))^2 over the tile's (un-padded) points (float64 map, float32 dists) and,
+ * optionally, min / argmin of the updated map (the next pick: :106-108). */
+int ssdr_tile_select_possibility_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, size_t n_max,
+                                     const float* center, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
+                                     float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx,
+                                     double* d_possibility, double* d_out_min_possibility, int32_t* d_out_argmin, void* stream);
+
 /* ---- RandLA-Net inference (replaces the TF1 graph of S3/RandLANet.py:140-180, 505-585 run by
  *      model.sess.run([prob_logits, last_second_features, ...]) in S3/sampler2.py:598 / :327) ----------
  * fp32 throughout (exact-f32 MFMA).  Weights are handed over per layer with batch-norm already folded

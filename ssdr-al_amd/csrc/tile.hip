@@ -61,6 +61,37 @@ __global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts
     }
 }
 
+// Possibility map of the test-time generator (S3/s3dis_dataset_test.py:140-143): for the `avail` points of the tile,
+// dists = (dx*dx + dy*dy) + dz*dz in float32, delta = (1 - dists / max(dists))^2, possibility[idx] += delta (float64).
+// The tile's points are the first `avail` entries of the distance-sorted list, so max(dists) is the key of the last one.
+__global__ __launch_bounds__(256) void tile_possibility(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sorted, const int* __restrict__ d_count,
+                                                        int num_points, double* possibility) {
+    const int avail = min(*d_count, num_points);
+    if (avail <= 0) return;
+    const float dmax = __uint_as_float((unsigned)keys[avail - 1]);
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < avail; r += gridDim.x * 256) {
+        const float d = __uint_as_float((unsigned)keys[r]);
+        const float q = 1 - d / dmax;
+        possibility[sorted[r]] += (double)(q * q);
+    }
+}
+
+// min / argmin of the possibility map (np.min, np.argmin: first minimum), one workgroup
+__global__ __launch_bounds__(1024) void possibility_min(const double* __restrict__ possibility, const long long* __restrict__ d_m, int n_host, double* out_min, int* out_arg) {
+    __shared__ double s_v[1024];
+    __shared__ int s_i[1024];
+    const int m = (int)min((long long)n_host, *d_m), tid = threadIdx.x;
+    double bv = 1.0e300; int bi = 0x7fffffff;
+    for (int i = tid; i < m; i += 1024) { const double v = possibility[i]; if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; } }
+    s_v[tid] = bv; s_i[tid] = bi;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o && (s_v[tid + o] < s_v[tid] || (s_v[tid + o] == s_v[tid] && s_i[tid + o] < s_i[tid]))) { s_v[tid] = s_v[tid + o]; s_i[tid] = s_i[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { *out_min = s_v[0]; *out_arg = s_i[0]; }
+}
+
 struct TileState { RadixSorter sorter; DevBuf keys, vals, count; };
 TileState& tst(hipStream_t st) { static std::map<hipStream_t, TileState> m; return m[st]; }
 
@@ -69,9 +100,20 @@ TileState& tst(hipStream_t st) { static std::map<hipStream_t, TileState> m; retu
 
 using namespace ssdr;
 
+extern "C" int ssdr_tile_select_possibility_dev(const float*, const float*, int, const int64_t*, size_t, const float*, size_t, const int32_t*, const float*, float,
+                                                float*, float*, int32_t*, double*, double*, int32_t*, void*);
+
 extern "C" int ssdr_tile_select_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, size_t n_max,
                                     const float* center, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
                                     float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream) {
+    return ssdr_tile_select_possibility_dev(d_points, d_colors, color_dim, d_m, n_max, center, num_points, d_perm, d_dup_u, color_scale, d_out_xyz, d_out_feat,
+                                            d_out_idx, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int ssdr_tile_select_possibility_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, size_t n_max,
+                                                const float* center, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
+                                                float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx,
+                                                double* d_possibility, double* d_out_min_possibility, int32_t* d_out_argmin, void* stream) {
     if (!d_points || !d_m || !center || !d_perm || !d_dup_u || !d_out_xyz || n_max == 0 || num_points == 0 || n_max > 0x3fffffff) { set_error("tile_select: bad arguments"); return SSDR_ERR_INVALID; }
     if (d_out_feat && color_dim > 0 && !d_colors) { set_error("tile_select: colors missing"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
@@ -84,6 +126,11 @@ extern "C" int ssdr_tile_select_dev(const float* d_points, const float* d_colors
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 1024));
     hipLaunchKernelGGL(tile_gather, dim3(g2), dim3(256), 0, s, d_points, d_colors, d_colors ? color_dim : 0, T.vals.as<uint32_t>(), T.count.as<int>(),
                        d_perm, d_dup_u, (int)num_points, center[0], center[1], center[2], color_scale, d_out_xyz, d_out_feat, d_out_idx);
+    if (d_possibility) {
+        hipLaunchKernelGGL(tile_possibility, dim3(g2), dim3(256), 0, s, T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), T.count.as<int>(), (int)num_points, d_possibility);
+        if (d_out_min_possibility && d_out_argmin)
+            hipLaunchKernelGGL(possibility_min, dim3(1), dim3(1024), 0, s, d_possibility, (const long long*)d_m, (int)n_max, d_out_min_possibility, d_out_argmin);
+    }
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
