@@ -72,6 +72,6 @@ def test_overlapped_batches_give_the_same_selection(backend):
     make = lambda: pipeline.HotPath(W, Cfg, select_per_tile=6, labeled_per_tile=3).load_rooms(rooms)
     one, _ = make().step()
     pipe = pipeline.Pipelined(make)
-    for k in (1, 2, 5):
+    for k in (1, 3):
         sel, _ = pipe.run(k)
         assert np.array_equal(sel, one)
