@@ -115,6 +115,14 @@ int ssdr_grid_subsample_dev(const float* d_points, size_t n,
                             float* d_out_points, float* d_out_features, int32_t* d_out_classes,
                             int64_t* d_out_m, void* stream);
 
+/* All clouds of a batch in one call (the per-cloud chain is ~45 small launches; batching divides that by the batch).
+ * The clouds are concatenated: cloud r owns rows [cloud_offsets[r], cloud_offsets[r+1]) (host int64 [num_clouds+1]) of
+ * d_points / d_features / d_classes; its M_r output rows are written from row cloud_offsets[r] of the output arrays and
+ * M_r to d_out_m[r].  Rows by ascending voxel key (SSDR_ORDER_KEY).  At most 64 clouds per call. */
+int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features, size_t fdim, const int32_t* d_classes, size_t ldim,
+                                  const int64_t* cloud_offsets, size_t num_clouds, float sampleDl,
+                                  float* d_out_points, float* d_out_features, int32_t* d_out_classes, int64_t* d_out_m, void* stream);
+
 /* ---- tile generator (spatially_regular_gen, S3/s3dis_dataset.py:115-154; data_aug, S3/helper_tool.py:185-199) --
  * From a (sub-sampled) cloud resident on the device — d_points [*,3], d_colors [*,color_dim], live row count
  * *d_m (device int64, as written by ssdr_grid_subsample_dev; n_max bounds it) — take the num_points points nearest
@@ -126,6 +134,11 @@ int ssdr_tile_select_dev(const float* d_points, const float* d_colors, int color
                          const float* center, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
                          float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream);
 
+/* Batch form: cloud r = rows [cloud_offsets[r], cloud_offsets[r+1]) with live count d_m[r]; centers host [num_clouds,3];
+ * d_perm / d_dup_u [num_clouds, num_points]; outputs [num_clouds, num_points, ...]. */
+int ssdr_tile_select_batch_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, const int64_t* cloud_offsets,
+                               size_t num_clouds, const float* centers, size_t num_points, const int32_t* d_perm, const float* d_dup_u,
+                               float color_scale, float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream);
 /* Test-time variant (S3/s3dis_dataset_test.py:105-143): the same tile, plus the possibility-map update
  * possibility[idx] += (1 - dists/max(dists))^2 over the tile's (un-padded) points (float64 map, float32 dists) and,
  * optionally, min / argmin of the updated map (the next pick: :106-108). */

@@ -39,7 +39,7 @@ def run(hp, rooms, weights, threads=1, net_outputs=None, stop_after=None):
     o = _c()
     N = cfg.num_points
     t = [time.perf_counter()]
-    tiles = [front_end(r, hr["center"], hr["perm"].to_host(), hr["dup"].to_host(), N, cfg.sub_grid_size) for r, hr in zip(rooms, hp.rooms)]
+    tiles = [front_end(r, hr["center"], hr["perm"], hr["dup"], N, cfg.sub_grid_size) for r, hr in zip(rooms, hp.rooms)]
     xyz0 = np.stack([a[0] for a in tiles]); feat = np.stack([a[1] for a in tiles])
     t.append(time.perf_counter())
     out = {"xyz": xyz0, "feat": feat, "m": [a[2] for a in tiles]}

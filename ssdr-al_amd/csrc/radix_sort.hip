@@ -1,32 +1,53 @@
-// Stable LSD radix sort of (u64 key, u32 value) pairs for gfx950, 8 bits per pass.
+// Stable LSD radix sort of (u64 key, u32 value) pairs for gfx950, 8 bits per pass, over one or several independent
+// SEGMENTS of one buffer in the same launches (the 16 rooms of a batch sort together: launch count, not bytes, bounds
+// sorts of 0.1-1 M pairs).
 //
-// Used by the voxel-grid subsampling (sort points by voxel key, ties keep input order) and by the
-// emulation of the reference's output order.  HBM-bound integer work: per executed pass each pair is
-// read twice and written once (histogram, scatter).  Passes whose digit is identical in every key are
-// skipped on the device without a host round-trip: a pre-pass accumulates AND / OR of all keys and
-// every kernel of pass p derives "executed?" and its ping-pong parity from those two words.
+// Used by the voxel-grid subsampling (sort points by voxel key, ties keep input order), the tile generator (sort by
+// distance), the region ranking and the emulation of the reference's output order.  HBM-bound integer work: per
+// executed pass each pair is read twice and written once (histogram, scatter).  Passes whose digit is identical in
+// every key of every segment are skipped on the device without a host round-trip: a pre-pass accumulates AND / OR of
+// the keys per segment and every kernel of pass p derives "executed?" and its ping-pong parity from those words.
 //
-// Stability inside a 2048-pair tile comes from wave-level digit matching: 8 ballots give every lane
-// the mask of lanes holding the same digit; its rank is the popcount of the lower lanes, and per-wave
-// digit counts are combined through LDS in wave order.
+// Layout: segment s owns the slots [off[s], off[s+1]) of keys / vals (off[] multiples of the 2048-pair tile, so a tile
+// never straddles segments); its live pairs are the first cnt[s] slots, cnt[s] = min(d_cnt[s], n_host[s]) when a
+// device count is given.  Stability inside a tile: wave w owns 512 consecutive pairs and ranks them with wave-private
+// digit counters (8 ballots give every lane the mask of lanes holding the same digit), two barriers per tile.
 #include "ssdr_internal.hpp"
 
 namespace ssdr {
 namespace {
 
 constexpr int RS_BS = 256, RS_ITEMS = 8, RS_TILE = RS_BS * RS_ITEMS;
+static_assert(RS_TILE == RADIX_TILE, "RADIX_TILE in ssdr_internal.hpp");
+
+struct SegTab { int nseg; int off[RADIX_MAX_SEG + 1]; int n_host[RADIX_MAX_SEG]; };
 
 struct SortPtrs {
     uint64_t* k[2]; uint32_t* v[2];
-    unsigned long long* andor;   // [0] = AND of keys, [1] = OR of keys
+    unsigned long long* andor;   // [nseg][2] = AND, OR of the segment's keys
     unsigned* hist;              // [256][nblocks_max]
-    unsigned* tot;               // [256] digit totals of the current pass
-    const int* d_n; int n_host; int nblocks_max;
+    unsigned* tot;               // [nseg][256] digit totals of the current pass
+    const int* d_cnt;            // optional device counts per segment
+    int nblocks_max;
+    SegTab seg;
 };
 
-__device__ __forceinline__ int sort_n(const SortPtrs& s) { return s.d_n ? min(*s.d_n, s.n_host) : s.n_host; }
+__device__ __forceinline__ int seg_count(const SortPtrs& s, int sg) { return s.d_cnt ? min(s.d_cnt[sg], s.seg.n_host[sg]) : s.seg.n_host[sg]; }
+__device__ __forceinline__ int seg_of_tile(const SortPtrs& s, int b) {
+    int sg = 0;
+    while (sg + 1 < s.seg.nseg && b * RS_TILE >= s.seg.off[sg + 1]) ++sg;
+    return sg;
+}
+__device__ __forceinline__ unsigned long long union_diff(const SortPtrs& s) {
+    unsigned long long diff = 0ull;
+    for (int sg = 0; sg < s.seg.nseg; ++sg) {
+        const unsigned long long a = s.andor[2 * sg], o = s.andor[2 * sg + 1];
+        if (!(a == ~0ull && o == 0ull)) diff |= a ^ o;        // an empty segment contributes nothing
+    }
+    return diff;
+}
 __device__ __forceinline__ bool pass_runs(const SortPtrs& s, int p, int& parity) {
-    const unsigned long long diff = s.andor[0] ^ s.andor[1];
+    const unsigned long long diff = union_diff(s);
     int par = 0;
     for (int q = 0; q < p; ++q) par ^= ((diff >> (8 * q)) & 0xffull) != 0;
     parity = par;
@@ -34,14 +55,17 @@ __device__ __forceinline__ bool pass_runs(const SortPtrs& s, int p, int& parity)
 }
 
 __global__ __launch_bounds__(RS_BS) void rs_andor_init(SortPtrs s) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { s.andor[0] = ~0ull; s.andor[1] = 0ull; }
+    const int i = blockIdx.x * RS_BS + threadIdx.x;
+    if (i < s.seg.nseg) { s.andor[2 * i] = ~0ull; s.andor[2 * i + 1] = 0ull; }
 }
 
+// grid.y = segment
 __global__ __launch_bounds__(RS_BS) void rs_andor(SortPtrs s) {
     __shared__ unsigned long long sa[RS_BS / 64], so[RS_BS / 64];
-    const int n = sort_n(s);
+    const int sg = blockIdx.y, n = seg_count(s, sg);
+    const uint64_t* K = s.k[0] + s.seg.off[sg];
     unsigned long long a = ~0ull, o = 0ull;
-    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { unsigned long long k = s.k[0][i]; a &= k; o |= k; }
+    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { unsigned long long k = K[i]; a &= k; o |= k; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         unsigned lo = __shfl_xor((unsigned)a, off), hi = __shfl_xor((unsigned)(a >> 32), off);
@@ -54,22 +78,23 @@ __global__ __launch_bounds__(RS_BS) void rs_andor(SortPtrs s) {
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < RS_BS / 64; ++w) { a &= sa[w]; o |= so[w]; }
-        atomicAnd(&s.andor[0], a); atomicOr(&s.andor[1], o);
+        if (n > 0) { atomicAnd(&s.andor[2 * sg], a); atomicOr(&s.andor[2 * sg + 1], o); }
     }
 }
 
 __global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
     __shared__ unsigned h[256];
     int par; if (!pass_runs(s, p, par)) return;
-    const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
+    const int nb = s.seg.off[s.seg.nseg] / RS_TILE;
     const uint64_t* K = s.k[par];
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int sg = seg_of_tile(s, b), end = s.seg.off[sg] + seg_count(s, sg);
         h[threadIdx.x] = 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             int i = b * RS_TILE + j * RS_BS + threadIdx.x;
-            if (i < n) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
+            if (i < end) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
         }
         __syncthreads();
         s.hist[(size_t)threadIdx.x * s.nblocks_max + b] = h[threadIdx.x];
@@ -77,14 +102,15 @@ __global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
     }
 }
 
-// per digit d (one workgroup each): exclusive scan of hist[d][0..nb) over the tile axis, digit total to tot[d]
+// block (d, segment): exclusive scan of hist[d][tiles of the segment] over the tile axis, digit total to tot[segment][d]
 __global__ __launch_bounds__(RS_BS) void rs_scan(SortPtrs s, int p) {
     __shared__ unsigned wsum[RS_BS / 64];
     __shared__ unsigned carry_s;
     int par; if (!pass_runs(s, p, par)) return;
-    const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
+    const int sg = blockIdx.y;
+    const int b0 = s.seg.off[sg] / RS_TILE, nb = s.seg.off[sg + 1] / RS_TILE - b0;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    unsigned* row = s.hist + (size_t)blockIdx.x * s.nblocks_max;
+    unsigned* row = s.hist + (size_t)blockIdx.x * s.nblocks_max + b0;
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < nb; base += RS_BS) {
@@ -104,39 +130,33 @@ __global__ __launch_bounds__(RS_BS) void rs_scan(SortPtrs s, int p) {
         if (tid == 0) carry_s = carry + tot;
         __syncthreads();
     }
-    if (tid == 0) s.tot[blockIdx.x] = carry_s;
+    if (tid == 0) s.tot[sg * 256 + blockIdx.x] = carry_s;
 }
 
-// Tile layout for ranking: wave w owns the 512 consecutive pairs [w*512, w*512+512) of the tile and walks them in 8
-// rounds of 64, so "tile order" == (wave, round, lane) order.  Each wave ranks its pairs with wave-private digit
-// counters (no workgroup barrier inside the rounds); one barrier later the waves' digit totals are prefixed in wave
-// order.  Two barriers per tile instead of three per round.
 __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
     __shared__ unsigned s_cnt[RS_BS / 64][256];      // per wave: running count of each digit
     __shared__ unsigned s_run[256];
+    __shared__ unsigned s_wt[RS_BS / 64];
     int par; if (!pass_runs(s, p, par)) return;
-    const int n = sort_n(s), nb = (n + RS_TILE - 1) / RS_TILE;
+    const int nb = s.seg.off[s.seg.nseg] / RS_TILE;
     const uint64_t* K = s.k[par]; const uint32_t* V = s.v[par];
     uint64_t* KO = s.k[par ^ 1]; uint32_t* VO = s.v[par ^ 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // exclusive scan of the 256 digit totals (thread tid owns digit tid)
-    __shared__ unsigned s_wt[RS_BS / 64];
-    unsigned dbase;
-    {
-        const unsigned x = s.tot[tid];
-        unsigned incl = x;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off); if (lane >= off) incl += y; }
-        if (lane == 63) s_wt[wid] = incl;
-        __syncthreads();
-        unsigned wbase = 0;
-#pragma unroll
-        for (int w = 0; w < RS_BS / 64; ++w) if (w < wid) wbase += s_wt[w];
-        dbase = wbase + incl - x;
-    }
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
-        s_run[tid] = dbase + s.hist[(size_t)tid * s.nblocks_max + b];
+        const int sg = seg_of_tile(s, b), end = s.seg.off[sg] + seg_count(s, sg);
+        {   // exclusive scan of the segment's 256 digit totals (thread tid owns digit tid)
+            const unsigned x = s.tot[sg * 256 + tid];
+            unsigned incl = x;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+            if (lane == 63) s_wt[wid] = incl;
+            __syncthreads();
+            unsigned wbase = 0;
+#pragma unroll
+            for (int w = 0; w < RS_BS / 64; ++w) if (w < wid) wbase += s_wt[w];
+            s_run[tid] = (unsigned)s.seg.off[sg] + wbase + incl - x + s.hist[(size_t)tid * s.nblocks_max + b];
+        }
 #pragma unroll
         for (int w = 0; w < RS_BS / 64; ++w) s_cnt[w][tid] = 0;
         __syncthreads();
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             const int i = b * RS_TILE + wid * (RS_TILE / (RS_BS / 64)) + j * 64 + lane;
-            const bool valid = i < n;
+            const bool valid = i < end;
             key[j] = 0; val[j] = 0; unsigned d = 0;
             if (valid) { key[j] = K[i]; val[j] = V[i]; d = (unsigned)((key[j] >> (8 * p)) & 0xff); }
             unsigned long long m = __ballot(valid);
@@ -181,85 +201,105 @@ __global__ __launch_bounds__(1024) void rs_high_passes(SortPtrs s) {
     __shared__ unsigned s_cnt[16][256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int n = sort_n(s);
     for (int p = 4; p < 8; ++p) {
         int par; if (!pass_runs(s, p, par)) continue;      // uniform
-        const uint64_t* K = s.k[par]; const uint32_t* V = s.v[par];
-        uint64_t* KO = s.k[par ^ 1]; uint32_t* VO = s.v[par ^ 1];
-        if (tid < 256) h[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += 1024) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
-        __syncthreads();
-        if (tid == 0) { unsigned run = 0; for (int d = 0; d < 256; ++d) { unsigned c = h[d]; h[d] = run; run += c; } }
-        __syncthreads();
-        for (int base = 0; base < n; base += 1024) {        // stable: tiles in order, waves in order, lanes in order
-            const int i = base + tid;
-            const bool valid = i < n;
-            uint64_t key = 0; uint32_t val = 0; unsigned d = 0;
-            if (valid) { key = K[i]; val = V[i]; d = (unsigned)((key >> (8 * p)) & 0xff); }
-            for (int w = 0; w < 16; ++w) if (tid < 256) s_cnt[w][tid] = 0;
+        for (int sg = 0; sg < s.seg.nseg; ++sg) {
+            const int n = seg_count(s, sg), so = s.seg.off[sg];
+            const uint64_t* K = s.k[par] + so; const uint32_t* V = s.v[par] + so;
+            uint64_t* KO = s.k[par ^ 1] + so; uint32_t* VO = s.v[par ^ 1] + so;
+            if (tid < 256) h[tid] = 0;
             __syncthreads();
-            unsigned long long m = __ballot(valid);
+            for (int i = tid; i < n; i += 1024) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
+            __syncthreads();
+            if (tid == 0) { unsigned run = 0; for (int d = 0; d < 256; ++d) { unsigned c = h[d]; h[d] = run; run += c; } }
+            __syncthreads();
+            for (int base = 0; base < n; base += 1024) {        // stable: tiles in order, waves in order, lanes in order
+                const int i = base + tid;
+                const bool valid = i < n;
+                uint64_t key = 0; uint32_t val = 0; unsigned d = 0;
+                if (valid) { key = K[i]; val = V[i]; d = (unsigned)((key >> (8 * p)) & 0xff); }
+                for (int w = 0; w < 16; ++w) if (tid < 256) s_cnt[w][tid] = 0;
+                __syncthreads();
+                unsigned long long m = __ballot(valid);
 #pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const bool one = (d >> bit) & 1;
-                const unsigned long long bal = __ballot(valid && one);
-                m &= one ? bal : ~bal;
+                for (int bit = 0; bit < 8; ++bit) {
+                    const bool one = (d >> bit) & 1;
+                    const unsigned long long bal = __ballot(valid && one);
+                    m &= one ? bal : ~bal;
+                }
+                const int rank = __popcll(m & lt);
+                if (valid && rank == 0) s_cnt[wid][d] = (unsigned)__popcll(m);
+                __syncthreads();
+                if (valid) {
+                    unsigned pos = h[d] + rank;
+                    for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
+                    KO[pos] = key; VO[pos] = val;
+                }
+                __syncthreads();
+                if (tid < 256) { unsigned t = 0; for (int w = 0; w < 16; ++w) t += s_cnt[w][tid]; h[tid] += t; }
+                __syncthreads();
             }
-            const int rank = __popcll(m & lt);
-            if (valid && rank == 0) s_cnt[wid][d] = (unsigned)__popcll(m);
-            __syncthreads();
-            if (valid) {
-                unsigned pos = h[d] + rank;
-                for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
-                KO[pos] = key; VO[pos] = val;
-            }
-            __syncthreads();
-            if (tid < 256) { unsigned t = 0; for (int w = 0; w < 16; ++w) t += s_cnt[w][tid]; h[tid] += t; }
             __syncthreads();
         }
-        __syncthreads();
     }
 }
 
-// after the last pass the result may sit in buffer 1: bring it home to buffer 0
+// after the last pass the result may sit in buffer 1: bring it home to buffer 0 (grid.y = segment)
 __global__ __launch_bounds__(RS_BS) void rs_finish(SortPtrs s) {
-    const unsigned long long diff = s.andor[0] ^ s.andor[1];
+    const unsigned long long diff = union_diff(s);
     int par = 0;
     for (int q = 0; q < 8; ++q) par ^= ((diff >> (8 * q)) & 0xffull) != 0;
     if (!par) return;
-    const int n = sort_n(s);
-    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { s.k[0][i] = s.k[1][i]; s.v[0][i] = s.v[1][i]; }
+    const int sg = blockIdx.y, n = seg_count(s, sg), so = s.seg.off[sg];
+    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { s.k[0][so + i] = s.k[1][so + i]; s.v[0][so + i] = s.v[1][so + i]; }
 }
 
 }  // namespace
 
-int RadixSorter::reserve(size_t n_max) {
-    nblocks_max = (int)((n_max + RS_TILE - 1) / RS_TILE) + 1;
-    SSDR_TRY(k1.reserve(8 * n_max + 16)); SSDR_TRY(v1.reserve(4 * n_max + 16));
-    SSDR_TRY(hist.reserve(4 * 256 * (size_t)nblocks_max + 4 * 256)); SSDR_TRY(andor.reserve(16));
+int RadixSorter::reserve(size_t slots) {
+    nblocks_max = (int)((slots + RS_TILE - 1) / RS_TILE) + 1;
+    SSDR_TRY(k1.reserve(8 * slots + 16)); SSDR_TRY(v1.reserve(4 * slots + 16));
+    SSDR_TRY(hist.reserve(4 * 256 * (size_t)nblocks_max + 4 * 256 * (size_t)RADIX_MAX_SEG)); SSDR_TRY(andor.reserve(16 * RADIX_MAX_SEG));
+    return SSDR_OK;
+}
+
+int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t st, int key_bits) {
+    if (nseg <= 0) return SSDR_OK;
+    if (nseg > RADIX_MAX_SEG) { set_error("radix sort: more than %d segments", RADIX_MAX_SEG); return SSDR_ERR_INVALID; }
+    const int slots = off[nseg];
+    if (slots <= 0) return SSDR_OK;
+    SSDR_TRY(reserve((size_t)slots));
+    SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>();
+    s.andor = andor.as<unsigned long long>(); s.hist = hist.as<unsigned>(); s.tot = hist.as<unsigned>() + 256 * (size_t)nblocks_max;
+    s.d_cnt = d_cnt; s.nblocks_max = nblocks_max; s.seg.nseg = nseg;
+    int maxn = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (off[i] % RS_TILE || off[i + 1] < off[i] + n_host[i]) { set_error("radix sort: segment offsets must be tile-aligned and hold the segment"); return SSDR_ERR_INVALID; }
+        s.seg.off[i] = off[i]; s.seg.n_host[i] = n_host[i]; maxn = std::max(maxn, n_host[i]);
+    }
+    s.seg.off[nseg] = off[nseg];
+    const int nb = (slots + RS_TILE - 1) / RS_TILE;
+    const int g = std::max(1, std::min(nb, ctx().num_cu * 8));
+    const int gseg = std::max(1, std::min((maxn + RS_BS * 8 - 1) / (RS_BS * 8), ctx().num_cu * 4));
+    hipLaunchKernelGGL(rs_andor_init, dim3(1), dim3(RS_BS), 0, st, s);
+    hipLaunchKernelGGL(rs_andor, dim3(gseg, nseg), dim3(RS_BS), 0, st, s);
+    const int npass = std::min(4, (std::max(key_bits, 1) + 7) / 8);      // wide passes for the low 32 bits ...
+    for (int p = 0; p < npass; ++p) {
+        hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
+        hipLaunchKernelGGL(rs_scan, dim3(256, nseg), dim3(RS_BS), 0, st, s, p);
+        hipLaunchKernelGGL(rs_scatter, dim3(g), dim3(RS_BS), 0, st, s, p);
+    }
+    if (key_bits > 32) hipLaunchKernelGGL(rs_high_passes, dim3(1), dim3(1024), 0, st, s);   // ... one kernel for the rest
+    hipLaunchKernelGGL(rs_finish, dim3(gseg, nseg), dim3(RS_BS), 0, st, s);
+    SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
 
 int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t st, int key_bits) {
     if (n_host <= 0) return SSDR_OK;
-    SSDR_TRY(reserve((size_t)n_host));
-    SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>();
-    s.andor = andor.as<unsigned long long>(); s.hist = hist.as<unsigned>(); s.tot = hist.as<unsigned>() + 256 * (size_t)nblocks_max; s.d_n = d_n; s.n_host = n_host; s.nblocks_max = nblocks_max;
-    const int nb = (n_host + RS_TILE - 1) / RS_TILE;
-    const int g = std::max(1, std::min(nb, ctx().num_cu * 8));
-    hipLaunchKernelGGL(rs_andor_init, dim3(1), dim3(RS_BS), 0, st, s);
-    hipLaunchKernelGGL(rs_andor, dim3(g), dim3(RS_BS), 0, st, s);
-    const int npass = std::min(4, (std::max(key_bits, 1) + 7) / 8);      // wide passes for the low 32 bits ...
-    for (int p = 0; p < npass; ++p) {
-        hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
-        hipLaunchKernelGGL(rs_scan, dim3(256), dim3(RS_BS), 0, st, s, p);
-        hipLaunchKernelGGL(rs_scatter, dim3(g), dim3(RS_BS), 0, st, s, p);
-    }
-    if (key_bits > 32) hipLaunchKernelGGL(rs_high_passes, dim3(1), dim3(1024), 0, st, s);   // ... one kernel for the rest
-    hipLaunchKernelGGL(rs_finish, dim3(g), dim3(RS_BS), 0, st, s);
-    SSDR_HIP(hipGetLastError());
-    return SSDR_OK;
+    // one segment; the tail of its last tile is never touched, so a buffer of exactly n_host slots is enough
+    const int off[2] = {0, (n_host + RS_TILE - 1) / RS_TILE * RS_TILE};
+    return sort_segments(keys, vals, 1, off, &n_host, d_n, st, key_bits);
 }
 
 }  // namespace ssdr

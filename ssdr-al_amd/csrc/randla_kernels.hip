@@ -270,31 +270,36 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     for (int p = 0; p < NP_W; ++p)
 #pragma unroll
         for (int c = 0; c < NC_W; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // software pipeline: the operands of k-step kb+4 (A from LDS, W from L2) are requested before the MFMAs of kb issue
-    float av[NP_W], bv[NC_W], an[NP_W], bn[NC_W];
-    {
-        const int k = lane >> 4;
+    // software pipeline: the operands of the NEXT two k-steps (A from LDS, W from L2) are requested before the 2 x 16
+    // MFMAs of the current two issue, i.e. ~1000 MFMA cycles of cover for an L2 round trip
+    constexpr int KS = (D >= 8) ? 2 : 1;           // k-steps (of 4) per pipeline stage
+    float av[KS][NP_W], bv[KS][NC_W], an[KS][NP_W], bn[KS][NC_W];
+    auto fetch = [&](int kb, float (&fa)[KS][NP_W], float (&fb)[KS][NC_W]) {
 #pragma unroll
-        for (int p = 0; p < NP_W; ++p) av[p] = F[((p0 + p) * 16 + (lane & 15)) * LD + k];
+        for (int u = 0; u < KS; ++u) {
+            const int k = kb + 4 * u + (lane >> 4);
 #pragma unroll
-        for (int c = 0; c < NC_W; ++c) bv[c] = a.w_fc[(size_t)k * D + (ct0 + c) * 16 + (lane & 15)];
-    }
-    for (int kb = 0; kb < D; kb += 4) {
-        const int kn = kb + 4 + (lane >> 4);
-        if (kb + 4 < D) {
+            for (int p = 0; p < NP_W; ++p) fa[u][p] = F[((p0 + p) * 16 + (lane & 15)) * LD + k];
 #pragma unroll
-            for (int p = 0; p < NP_W; ++p) an[p] = F[((p0 + p) * 16 + (lane & 15)) * LD + kn];
-#pragma unroll
-            for (int c = 0; c < NC_W; ++c) bn[c] = a.w_fc[(size_t)kn * D + (ct0 + c) * 16 + (lane & 15)];
+            for (int c = 0; c < NC_W; ++c) fb[u][c] = a.w_fc[(size_t)k * D + (ct0 + c) * 16 + (lane & 15)];
         }
+    };
+    fetch(0, av, bv);
+    for (int kb = 0; kb < D; kb += 4 * KS) {
+        if (kb + 4 * KS < D) fetch(kb + 4 * KS, an, bn);
 #pragma unroll
-        for (int p = 0; p < NP_W; ++p)
+        for (int u = 0; u < KS; ++u)
 #pragma unroll
-            for (int c = 0; c < NC_W; ++c) acc[p][c] = mfma16(av[p], bv[c], acc[p][c]);
+            for (int p = 0; p < NP_W; ++p)
 #pragma unroll
-        for (int p = 0; p < NP_W; ++p) av[p] = an[p];
+                for (int c = 0; c < NC_W; ++c) acc[p][c] = mfma16(av[u][p], bv[u][c], acc[p][c]);
 #pragma unroll
-        for (int c = 0; c < NC_W; ++c) bv[c] = bn[c];
+        for (int u = 0; u < KS; ++u) {
+#pragma unroll
+            for (int p = 0; p < NP_W; ++p) av[u][p] = an[u][p];
+#pragma unroll
+            for (int c = 0; c < NC_W; ++c) bv[u][c] = bn[u][c];
+        }
     }
 
     // softmax over the 16 neighbours (:579) and weighted sum (:580-581)

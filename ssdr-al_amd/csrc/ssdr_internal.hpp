@@ -66,12 +66,17 @@ struct ProfScope {
 // ---- radix sort (radix_sort.hip) ----------------------------------------------------------------
 // Stable sort of (u64 key, u32 value) pairs, in place (result in keys/vals).  d_n (optional) is a device
 // int holding the live count (<= n_host); n_host sizes the launches.
+constexpr int RADIX_TILE = 2048;       // pairs per sort tile; segment offsets must be multiples of it
+constexpr int RADIX_MAX_SEG = 64;
 struct RadixSorter {
     DevBuf k1, v1, hist, andor;
     int nblocks_max = 0;
-    int reserve(size_t n_max);
+    int reserve(size_t slots);
     // key_bits: upper bound on the significant key bits when the caller knows one (skips launching higher passes)
     int sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t s, int key_bits = 64);
+    // nseg independent segments in the same launches: segment i lives in slots [off[i], off[i+1]) (tile-aligned), holds
+    // n_host[i] pairs (d_cnt[i] when given, device side).  off has nseg + 1 entries.
+    int sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t s, int key_bits = 64);
 };
 
 // ---- kd-tree forest (kdtree.hip) ----------------------------------------------------------------

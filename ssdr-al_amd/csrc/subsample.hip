@@ -32,7 +32,7 @@ struct GsParams {
     int status;       // 1 = more than LAB_CAP distinct labels in one voxel
 };
 
-__global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict__ P, int n, float* partial) {
+__device__ __forceinline__ void gs_minmax_partial_body(const float* __restrict__ P, int n, float* partial) {
     __shared__ float s_mm[(BS / 64) * 6];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts, float dl, GsParams* prm) {
+__device__ __forceinline__ void gs_params_body(const float* partial, int nparts, float dl, GsParams* prm) {
     __shared__ float s_mm[(BS / 64) * 6];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = threadIdx.x; i < nparts; i += BS) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts
     }
 }
 
-__global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals) {
+__device__ __forceinline__ void gs_keys_body(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals) {
     const float ox = prm->org[0], oy = prm->org[1], oz = prm->org[2], dl = prm->dl;
     const unsigned long long nx = prm->nx, ny = prm->ny;
     for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n
 }
 
 // ---- segment heads: 3-step compaction -------------------------------------------------------------
-__global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict__ ks, int n, int* bsum) {
+__device__ __forceinline__ void gs_heads_count_body(const uint64_t* __restrict__ ks, int n, int* bsum) {
     __shared__ int s_sum[(BS / 64) * 2];
     const int base = blockIdx.x * CHUNK;
     int c = 0, z = 0;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict_
     if (threadIdx.x == 0) bsum[blockIdx.x] = c;
 }
 
-__global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParams* prm, int* seg_start, int n) {
+__device__ __forceinline__ void gs_heads_scan_body(int* bsum, int nb, GsParams* prm, int* seg_start, int n) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParam
     if (tid == 0) { prm->m = carry_s; seg_start[carry_s] = n; }
 }
 
-__global__ __launch_bounds__(BS) void gs_heads_write(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) {
+__device__ __forceinline__ void gs_heads_write_body(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) {
     __shared__ int s_w[2][U][BS / 64];
     const int base = blockIdx.x * CHUNK, off = bsum[blockIdx.x];
     const int hi = min(n, base + CHUNK);
@@ -180,7 +180,7 @@ __device__ __forceinline__ int voxel_label_fast(const int* __restrict__ cls, int
     return best;
 }
 
-__global__ __launch_bounds__(BS) void gs_reduce_labels(const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start,
+__device__ __forceinline__ void gs_reduce_labels_body(const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start,
                                                        GsParams* prm, const int* __restrict__ row_of_voxel, int* out_c) {
     const long long total = (long long)prm->m * ldim;
     for (long long e = (long long)blockIdx.x * BS + threadIdx.x; e < total; e += (long long)gridDim.x * BS) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(BS) void gs_reduce_labels(const int* __restrict__ c
     }
 }
 
-__global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, const float* __restrict__ F, int fdim,
+__device__ __forceinline__ void gs_reduce_body(const float* __restrict__ P, const float* __restrict__ F, int fdim,
                                                 const int* __restrict__ cls, int ldim,
                                                 const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
                                                 const int* __restrict__ row_of_voxel,
@@ -222,6 +222,60 @@ __global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, con
             out_f[(size_t)row * fdim + f] = acc / (float)count;      // :90-94
         }
     }
+}
+
+
+// ---- kernel entry points: one cloud, or all clouds of a batch (blockIdx.y = cloud) -----------------------------
+__global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict__ P, int n, float* partial) { gs_minmax_partial_body(P, n, partial); }
+__global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts, float dl, GsParams* prm) { gs_params_body(partial, nparts, dl, prm); }
+__global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals) { gs_keys_body(P, n, prm, keys, vals); }
+__global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict__ ks, int n, int* bsum) { gs_heads_count_body(ks, n, bsum); }
+__global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParams* prm, int* seg_start, int n) { gs_heads_scan_body(bsum, nb, prm, seg_start, n); }
+__global__ __launch_bounds__(BS) void gs_heads_write(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) { gs_heads_write_body(ks, n, bsum, seg_start); }
+__global__ __launch_bounds__(BS) void gs_reduce_labels(const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, int* out_c) { gs_reduce_labels_body(cls, ldim, vs, seg_start, prm, row_of_voxel, out_c); }
+__global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m, uint64_t* out_first, const uint64_t* ks) { gs_reduce_body(P, F, fdim, cls, ldim, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m, out_first, ks); }
+
+// Per-cloud tables of a batch, passed by value.  Cloud r: input rows [off[r], off[r+1]) of the concatenated arrays,
+// sort slots [toff[r], toff[r+1]) (tile-aligned), segment-start slots from toff[r] + r.
+struct CloudTab { int nr; int off[RADIX_MAX_SEG + 1]; int toff[RADIX_MAX_SEG + 1]; };
+constexpr int PB = 64;      // partial min/max blocks per cloud
+
+__global__ __launch_bounds__(BS) void gs_minmax_partial_b(CloudTab t, const float* __restrict__ P, float* partial) {
+    const int r = blockIdx.y;
+    gs_minmax_partial_body(P + 3 * (size_t)t.off[r], t.off[r + 1] - t.off[r], partial + (size_t)r * PB * 6);
+}
+__global__ __launch_bounds__(BS) void gs_params_b(const float* partial, float dl, GsParams* prm) {
+    gs_params_body(partial + (size_t)blockIdx.x * PB * 6, PB, dl, prm + blockIdx.x);
+}
+__global__ __launch_bounds__(BS) void gs_keys_b(CloudTab t, const float* __restrict__ P, const GsParams* prm, uint64_t* keys, uint32_t* vals) {
+    const int r = blockIdx.y;
+    gs_keys_body(P + 3 * (size_t)t.off[r], t.off[r + 1] - t.off[r], prm + r, keys + t.toff[r], vals + t.toff[r]);
+}
+__global__ __launch_bounds__(BS) void gs_heads_count_b(CloudTab t, const uint64_t* __restrict__ ks, int* bsum, int nb_max) {
+    const int r = blockIdx.y, n = t.off[r + 1] - t.off[r];
+    if ((int)blockIdx.x * CHUNK >= n) { if (threadIdx.x == 0) bsum[(size_t)r * nb_max + blockIdx.x] = 0; return; }
+    gs_heads_count_body(ks + t.toff[r], n, bsum + (size_t)r * nb_max);
+}
+__global__ __launch_bounds__(1024) void gs_heads_scan_b(CloudTab t, int* bsum, int nb_max, GsParams* prm, int* seg_start) {
+    const int r = blockIdx.x, n = t.off[r + 1] - t.off[r];
+    gs_heads_scan_body(bsum + (size_t)r * nb_max, (n + CHUNK - 1) / CHUNK, prm + r, seg_start + t.toff[r] + r, n);
+}
+__global__ __launch_bounds__(BS) void gs_heads_write_b(CloudTab t, const uint64_t* __restrict__ ks, const int* bsum, int nb_max, int* seg_start) {
+    const int r = blockIdx.y, n = t.off[r + 1] - t.off[r];
+    if ((int)blockIdx.x * CHUNK >= n) return;
+    gs_heads_write_body(ks + t.toff[r], n, bsum + (size_t)r * nb_max, seg_start + t.toff[r] + r);
+}
+__global__ __launch_bounds__(BS) void gs_reduce_b(CloudTab t, const float* __restrict__ P, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim,
+                                                  const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
+                                                  float* out_p, float* out_f, int* out_c, long long* out_m) {
+    const int r = blockIdx.y; const size_t o = (size_t)t.off[r];
+    gs_reduce_body(P + 3 * o, F ? F + o * fdim : nullptr, fdim, cls ? cls + o * ldim : nullptr, ldim, vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr,
+                   out_p + 3 * o, out_f ? out_f + o * fdim : nullptr, out_c ? out_c + o * ldim : nullptr, out_m ? out_m + r : nullptr, nullptr, nullptr);
+}
+__global__ __launch_bounds__(BS) void gs_reduce_labels_b(CloudTab t, const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start,
+                                                         GsParams* prm, int* out_c) {
+    const int r = blockIdx.y; const size_t o = (size_t)t.off[r];
+    gs_reduce_labels_body(cls + o * ldim, ldim, vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr, out_c + o * ldim);
 }
 
 struct GsState {
@@ -267,6 +321,40 @@ int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t f
     return SSDR_OK;
 }
 
+int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim, const int32_t* d_c, size_t ldim, const int64_t* room_off, size_t nr, float dl,
+                                float* d_op, float* d_of, int32_t* d_oc, int64_t* d_om, hipStream_t s) {
+    GsState& S = gs(s);
+    CloudTab t; t.nr = (int)nr;
+    int toff = 0, maxn = 0; std::vector<int> n_host(nr);
+    for (size_t r = 0; r < nr; ++r) {
+        const long n = (long)(room_off[r + 1] - room_off[r]);
+        if (n <= 0 || room_off[r + 1] > 0x3fffffff) { set_error("grid_subsample_batch: every cloud needs >= 1 point"); return n <= 0 ? SSDR_ERR_EMPTY : SSDR_ERR_INVALID; }
+        t.off[r] = (int)room_off[r]; t.toff[r] = toff; n_host[r] = (int)n; maxn = std::max(maxn, (int)n);
+        toff += ((int)n + RADIX_TILE - 1) / RADIX_TILE * RADIX_TILE;
+        if (toff > 0x3fffffff) { set_error("grid_subsample_batch: too many points"); return SSDR_ERR_INVALID; }
+    }
+    t.off[nr] = (int)room_off[nr]; t.toff[nr] = toff;
+    const int nb_max = (maxn + CHUNK - 1) / CHUNK;
+    SSDR_TRY(S.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(S.vals.reserve(4 * (size_t)toff + 16));
+    SSDR_TRY(S.partial.reserve(24 * (size_t)PB * nr)); SSDR_TRY(S.params.reserve(sizeof(GsParams) * nr));
+    SSDR_TRY(S.bsum.reserve(4 * (size_t)nb_max * nr + 16)); SSDR_TRY(S.seg.reserve(4 * ((size_t)toff + nr + 2)));
+    GsParams* prm = S.params.as<GsParams>();
+    const unsigned R = (unsigned)nr;
+    hipLaunchKernelGGL(gs_minmax_partial_b, dim3(PB, R), dim3(BS), 0, s, t, d_p, S.partial.as<float>());
+    hipLaunchKernelGGL(gs_params_b, dim3(R), dim3(BS), 0, s, S.partial.as<float>(), dl, prm);
+    const int g = std::max(1, std::min((maxn + BS - 1) / BS, 256));
+    hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, S.keys.as<uint64_t>(), S.vals.as<uint32_t>());
+    SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), (int)nr, t.toff, n_host.data(), nullptr, s));
+    hipLaunchKernelGGL(gs_heads_count_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max);
+    hipLaunchKernelGGL(gs_heads_scan_b, dim3(R), dim3(1024), 0, s, t, S.bsum.as<int>(), nb_max, prm, S.seg.as<int>());
+    hipLaunchKernelGGL(gs_heads_write_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, S.seg.as<int>());
+    hipLaunchKernelGGL(gs_reduce_b, dim3(g, R), dim3(BS), 0, s, t, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
+                       d_op, d_of, d_oc, (long long*)d_om);
+    if (d_c) hipLaunchKernelGGL(gs_reduce_labels_b, dim3(g, R), dim3(BS), 0, s, t, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, d_oc);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
 }  // namespace ssdr
 
 using namespace ssdr;
@@ -284,6 +372,18 @@ int ssdr_grid_subsample_dev(const float* d_points, size_t n, const float* d_feat
     SSDR_TRY(ensure_init());
     return grid_subsample_device(d_points, n, d_features, d_features ? fdim : 0, d_classes, d_classes ? ldim : 0, sampleDl, order,
                                  d_out_points, d_out_features, d_out_classes, d_out_m, pick_stream(stream));
+}
+
+int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features, size_t fdim, const int32_t* d_classes, size_t ldim,
+                                  const int64_t* cloud_offsets, size_t num_clouds, float sampleDl,
+                                  float* d_out_points, float* d_out_features, int32_t* d_out_classes, int64_t* d_out_m, void* stream) {
+    if (!d_points || !d_out_points || !cloud_offsets || !d_out_m || num_clouds == 0 || num_clouds > RADIX_MAX_SEG) { set_error("grid_subsample_batch: bad arguments (1..%d clouds)", RADIX_MAX_SEG); return SSDR_ERR_INVALID; }
+    if (!(sampleDl > 0.f)) { set_error("grid_subsample_batch: sampleDl must be > 0"); return SSDR_ERR_INVALID; }
+    if (d_features && (!fdim || !d_out_features)) { set_error("grid_subsample_batch: features given without fdim / output"); return SSDR_ERR_INVALID; }
+    if (d_classes && (!ldim || !d_out_classes)) { set_error("grid_subsample_batch: classes given without ldim / output"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    return grid_subsample_batch_device(d_points, d_features, d_features ? fdim : 0, d_classes, d_classes ? ldim : 0, cloud_offsets, num_clouds, sampleDl,
+                                       d_out_points, d_out_features, d_out_classes, d_out_m, pick_stream(stream));
 }
 
 int ssdr_grid_subsample(const float* points, size_t n, const float* features, size_t fdim, const int32_t* classes, size_t ldim,

@@ -9,11 +9,12 @@
 #include "ssdr_internal.hpp"
 #include "block_prims.hpp"
 #include <map>
+#include <vector>
 
 namespace ssdr {
 namespace {
 
-__global__ __launch_bounds__(256) void tile_keys(const float* __restrict__ pts, const long long* __restrict__ d_m, int n_host, float cx, float cy, float cz,
+__device__ __forceinline__ void tile_keys_body(const float* __restrict__ pts, const long long* __restrict__ d_m, int n_host, float cx, float cy, float cz,
                                                  uint64_t* keys, uint32_t* vals, int* d_count) {
     const int m = (int)min((long long)n_host, *d_m);
     if (blockIdx.x == 0 && threadIdx.x == 0) *d_count = m;
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void tile_keys(const float* __restrict__ pts, 
 
 // out row r takes sorted position perm[r] when that position exists (< min(m, num_points)); a cloud smaller than
 // num_points is padded: rows >= m duplicate point floor(dup_u[r] * m) of the *shuffled* list (data_aug).
-__global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts, const float* __restrict__ colors, int cdim,
+__device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, const float* __restrict__ colors, int cdim,
                                                    const uint32_t* __restrict__ sorted, const int* __restrict__ d_count,
                                                    const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
                                                    float cx, float cy, float cz, float color_scale,
@@ -59,6 +60,25 @@ __global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts
         }
         if (out_idx) out_idx[r] = (int)id;
     }
+}
+
+
+// kernel entry points: one cloud, or all clouds of a batch (blockIdx.y = cloud)
+__global__ __launch_bounds__(256) void tile_keys(const float* __restrict__ pts, const long long* __restrict__ d_m, int n_host, float cx, float cy, float cz, uint64_t* keys, uint32_t* vals, int* d_count) { tile_keys_body(pts, d_m, n_host, cx, cy, cz, keys, vals, d_count); }
+__global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted, const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points, float cx, float cy, float cz, float color_scale, float* out_xyz, float* out_feat, int* out_idx) { tile_gather_body(pts, colors, cdim, sorted, d_count, perm, dup_u, num_points, cx, cy, cz, color_scale, out_xyz, out_feat, out_idx); }
+
+struct TileTab { int nr; int off[RADIX_MAX_SEG + 1]; int toff[RADIX_MAX_SEG + 1]; float cx[RADIX_MAX_SEG], cy[RADIX_MAX_SEG], cz[RADIX_MAX_SEG]; };
+
+__global__ __launch_bounds__(256) void tile_keys_b(TileTab t, const float* __restrict__ pts, const long long* __restrict__ d_m, uint64_t* keys, uint32_t* vals, int* d_count) {
+    const int r = blockIdx.y;
+    tile_keys_body(pts + 3 * (size_t)t.off[r], d_m + r, t.off[r + 1] - t.off[r], t.cx[r], t.cy[r], t.cz[r], keys + t.toff[r], vals + t.toff[r], d_count + r);
+}
+__global__ __launch_bounds__(256) void tile_gather_b(TileTab t, const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted,
+                                                     const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
+                                                     float color_scale, float* out_xyz, float* out_feat, int* out_idx) {
+    const int r = blockIdx.y; const size_t o = (size_t)t.off[r], q = (size_t)r * num_points;
+    tile_gather_body(pts + 3 * o, colors ? colors + o * cdim : nullptr, cdim, sorted + t.toff[r], d_count + r, perm + q, dup_u + q, num_points, t.cx[r], t.cy[r], t.cz[r],
+                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr);
 }
 
 // Possibility map of the test-time generator (S3/s3dis_dataset_test.py:140-143): for the `avail` points of the tile,
@@ -131,6 +151,35 @@ extern "C" int ssdr_tile_select_possibility_dev(const float* d_points, const flo
         if (d_out_min_possibility && d_out_argmin)
             hipLaunchKernelGGL(possibility_min, dim3(1), dim3(1024), 0, s, d_possibility, (const long long*)d_m, (int)n_max, d_out_min_possibility, d_out_argmin);
     }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, const int64_t* cloud_offsets, size_t num_clouds,
+                                          const float* centers, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
+                                          float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream) {
+    if (!d_points || !d_m || !cloud_offsets || !centers || !d_perm || !d_dup_u || !d_out_xyz || num_clouds == 0 || num_clouds > RADIX_MAX_SEG || num_points == 0) { set_error("tile_select_batch: bad arguments (1..%d clouds)", RADIX_MAX_SEG); return SSDR_ERR_INVALID; }
+    if (d_out_feat && color_dim > 0 && !d_colors) { set_error("tile_select_batch: colors missing"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream); TileState& T = tst(s);
+    TileTab t; t.nr = (int)num_clouds;
+    int toff = 0, maxn = 0; std::vector<int> n_host(num_clouds);
+    for (size_t r = 0; r < num_clouds; ++r) {
+        const long n = (long)(cloud_offsets[r + 1] - cloud_offsets[r]);
+        if (n <= 0 || cloud_offsets[r + 1] > 0x3fffffff) { set_error("tile_select_batch: bad cloud offsets"); return SSDR_ERR_INVALID; }
+        t.off[r] = (int)cloud_offsets[r]; t.toff[r] = toff; n_host[r] = (int)n; maxn = std::max(maxn, (int)n);
+        t.cx[r] = centers[3 * r]; t.cy[r] = centers[3 * r + 1]; t.cz[r] = centers[3 * r + 2];
+        toff += ((int)n + RADIX_TILE - 1) / RADIX_TILE * RADIX_TILE;
+    }
+    t.off[num_clouds] = (int)cloud_offsets[num_clouds]; t.toff[num_clouds] = toff;
+    SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.vals.reserve(4 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
+    const unsigned R = (unsigned)num_clouds;
+    const int g = std::max(1, std::min((maxn + 255) / 256, 256));
+    hipLaunchKernelGGL(tile_keys_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), T.count.as<int>());
+    SSDR_TRY(T.sorter.sort_segments(T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), (int)num_clouds, t.toff, n_host.data(), T.count.as<int>(), s, 32));
+    const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
+    hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, T.vals.as<uint32_t>(), T.count.as<int>(), d_perm, d_dup_u,
+                       (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

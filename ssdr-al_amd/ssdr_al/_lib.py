@@ -88,6 +88,8 @@ def lib():
         L.ssdr_fps_superpoint_dev.argtypes = [vp, vp, sz, i32, sz, vp, vp]
         L.ssdr_kcenter_dev.argtypes = [vp, sz, i32, vp, sz, sz, vp, vp]
         L.ssdr_tile_select_dev.argtypes = [vp, vp, i32, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp]
+        L.ssdr_grid_subsample_batch_dev.argtypes = [vp, vp, sz, vp, sz, vp, sz, f32, vp, vp, vp, vp, vp]
+        L.ssdr_tile_select_batch_dev.argtypes = [vp, vp, i32, vp, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp]
         L.ssdr_tile_select_possibility_dev.argtypes = [vp, vp, i32, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
         L.ssdr_chamfer3d_forward_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
         L.ssdr_vote_smooth_dev.argtypes = [vp, vp, vp, sz, i32, f64, vp, vp]

@@ -39,17 +39,26 @@ class HotPath:
         self.B = len(rooms)
         self.room_ids = list(range(len(rooms))) if room_ids is None else list(room_ids)
         self.rooms = []
+        centers, perms, dups = [], [], []
         for (xyz, rgb, lab), rid in zip(rooms, self.room_ids):
             self.rng = np.random.default_rng([self.seed, rid])
             n = len(xyz)
-            r = dict(n=n, pts=DevArray.from_host(xyz.astype(np.float32)), col=DevArray.from_host(rgb.astype(np.float32)),
-                     lab=DevArray.from_host(lab.astype(np.int32).reshape(-1, 1)),
-                     sp=DevArray((n, 3), np.float32), sc=DevArray((n, 3), np.float32), sl=DevArray((n, 1), np.int32), m=DevArray((2,), np.int64))
             pick = xyz[self.rng.integers(0, n)] + self.rng.normal(0, cfg.noise_init / 10, 3)      # s3dis_dataset.py:119-126
-            r["center"] = np.ascontiguousarray(pick, np.float32)
-            r["perm"] = DevArray.from_host(self.rng.permutation(N).astype(np.int32))              # DP.shuffle_idx :137
-            r["dup"] = DevArray.from_host(self.rng.random(N).astype(np.float32))                  # DP.data_aug's np.random.choice
+            r = dict(n=n, center=np.ascontiguousarray(pick, np.float32),
+                     perm=self.rng.permutation(N).astype(np.int32),                             # DP.shuffle_idx :137
+                     dup=self.rng.random(N).astype(np.float32))                                 # DP.data_aug's np.random.choice
+            centers.append(r["center"]); perms.append(r["perm"]); dups.append(r["dup"])
             self.rooms.append(r)
+        # the rooms of the batch live concatenated in HBM: one batched call per front-end stage
+        self.room_off = np.concatenate([[0], np.cumsum([len(r[0]) for r in rooms])]).astype(np.int64)
+        nt = int(self.room_off[-1])
+        self.raw_p = DevArray.from_host(np.concatenate([r[0] for r in rooms]).astype(np.float32))
+        self.raw_c = DevArray.from_host(np.concatenate([r[1] for r in rooms]).astype(np.float32))
+        self.raw_l = DevArray.from_host(np.concatenate([r[2] for r in rooms]).astype(np.int32).reshape(-1, 1))
+        self.sub_p = DevArray((nt, 3), np.float32); self.sub_c = DevArray((nt, 3), np.float32); self.sub_l = DevArray((nt, 1), np.int32)
+        self.sub_m = DevArray((len(rooms) + 1,), np.int64)
+        self.centers = np.ascontiguousarray(np.stack(centers), np.float32)
+        self.perm = DevArray.from_host(np.stack(perms)); self.dup = DevArray.from_host(np.stack(dups))
         B = self.B
         self.xyz = DevArray((B, N, 3), np.float32); self.feat = DevArray((B, N, 6), np.float32)
         L, K = cfg.num_layers, cfg.k_n
@@ -92,27 +101,13 @@ class HotPath:
 
     # ---- stages ------------------------------------------------------------------------------------------------
     def _front_end(self):
-        """Rooms are independent until the batch arrays: their subsample + tile chains (many small kernels each) are
-        spread over a few HIP streams so they overlap; the main stream then waits for all of them."""
+        """grid-subsample + tile of every room of the batch, one batched launch sequence per stage (on front_stream)."""
         cfg, L = self.cfg, _lib.lib()
-        N = cfg.num_points
-        if not getattr(self, "_streams", None) or self._streams_lib is not L:
-            self._streams = []
-            for _ in range(self.num_streams):
-                s = C.c_void_p()
-                _lib.check(L.ssdr_stream_create(C.byref(s)))
-                self._streams.append(s.value)
-            self._streams_lib = L
-        for st in self._streams:
-            _lib.check(L.ssdr_stream_wait(st, self.front_stream))      # the previous step's consumers of xyz / feat are done
-        for b, r in enumerate(self.rooms):
-            st = self._streams[b % len(self._streams)]
-            _lib.check(L.ssdr_grid_subsample_dev(r["pts"].ptr, r["n"], r["col"].ptr, 3, r["lab"].ptr, 1, cfg.sub_grid_size, _lib.ORDER_KEY,
-                                                 r["sp"].ptr, r["sc"].ptr, r["sl"].ptr, r["m"].ptr, st))
-            _lib.check(L.ssdr_tile_select_dev(r["sp"].ptr, r["sc"].ptr, 3, r["m"].ptr, r["n"], _lib.ptr(r["center"]), N, r["perm"].ptr, r["dup"].ptr,
-                                              1.0 / 255.0, self.xyz.ptr + b * N * 12, self.feat.ptr + b * N * 24, None, st))
-        for st in self._streams:
-            _lib.check(L.ssdr_stream_wait(self.front_stream, st))
+        st = self.front_stream
+        _lib.check(L.ssdr_grid_subsample_batch_dev(self.raw_p.ptr, self.raw_c.ptr, 3, self.raw_l.ptr, 1, _lib.ptr(self.room_off), self.B, cfg.sub_grid_size,
+                                                   self.sub_p.ptr, self.sub_c.ptr, self.sub_l.ptr, self.sub_m.ptr, st))
+        _lib.check(L.ssdr_tile_select_batch_dev(self.sub_p.ptr, self.sub_c.ptr, 3, self.sub_m.ptr, _lib.ptr(self.room_off), self.B, _lib.ptr(self.centers),
+                                                cfg.num_points, self.perm.ptr, self.dup.ptr, 1.0 / 255.0, self.xyz.ptr, self.feat.ptr, None, st))
 
     def _pyramid(self):
         cfg = self.cfg

@@ -75,3 +75,30 @@ def test_subsample_fresh_inputs_against_oracle(backend, orc):
         exp = orc.grid_subsampling(pts, col, lab, dl, order=order)
         for x, y in zip(got, exp):
             assert_bits_equal(x, y, order)
+
+
+def test_subsample_batch_matches_per_cloud_oracle(backend, orc):
+    """ssdr_grid_subsample_batch_dev: ragged clouds (one of a single point, one exactly a sort tile) in one call."""
+    from ssdr_al import _lib
+    from ssdr_al._lib import DevArray
+    rng = np.random.default_rng(31)
+    sizes = [1, 2048, 700, 5000, 33] if backend == "emu" else [1, 2048, 300000, 812345, 33, 40960]
+    clouds = []
+    for i, n in enumerate(sizes):
+        p = (rng.random((n, 3), dtype=np.float32) * np.array([6, 5, 3], np.float32) + np.float32(i)).astype(np.float32)
+        clouds.append((p, rng.integers(0, 256, (n, 3)).astype(np.float32), rng.integers(0, 13, (n, 1)).astype(np.int32)))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    P = np.concatenate([c[0] for c in clouds]); Fe = np.concatenate([c[1] for c in clouds]); Lb = np.concatenate([c[2] for c in clouds])
+    d_p, d_f, d_l = DevArray.from_host(P), DevArray.from_host(Fe), DevArray.from_host(Lb)
+    o_p, o_f, o_l = DevArray(P.shape, np.float32), DevArray(Fe.shape, np.float32), DevArray(Lb.shape, np.int32)
+    d_m = DevArray((len(sizes),), np.int64)
+    _lib.check(_lib.lib().ssdr_grid_subsample_batch_dev(d_p.ptr, d_f.ptr, 3, d_l.ptr, 1, _lib.ptr(off), len(sizes), 0.04, o_p.ptr, o_f.ptr, o_l.ptr, d_m.ptr, None))
+    _lib.sync()
+    m = d_m.to_host(); gp, gf, gl = o_p.to_host(), o_f.to_host(), o_l.to_host()
+    for r, (p, f, l) in enumerate(clouds):
+        ep, ef, el = orc.grid_subsampling(p, f, l, 0.04, order="key")
+        assert m[r] == len(ep)
+        s = int(off[r])
+        assert_bits_equal(gp[s:s + m[r]], ep, "cloud %d points" % r)
+        assert_bits_equal(gf[s:s + m[r]], ef, "cloud %d features" % r)
+        assert_bits_equal(gl[s:s + m[r]], el, "cloud %d labels" % r)
