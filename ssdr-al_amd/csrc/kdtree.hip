@@ -31,9 +31,9 @@ namespace {
 
 constexpr int LEAF_MAX = 10;         // knn_.cxx:28 / KDTreeTableAdaptor.h:134
 constexpr int MAX_LEVELS = 40;       // levels launched per build == search stack depth
-constexpr int BIG_LEVELS = 28;       // levels at which nodes above 64 points are still split
-constexpr int CTR_NODES = 0, CTR_STATUS = 1, CTR_DEPTH = 2, CTR_QUEUE0 = 8, CTR_SQUEUE0 = 8 + MAX_LEVELS + 8, CTR_TOTAL = CTR_SQUEUE0 + MAX_LEVELS + 8;
-constexpr int SMALL_MAX = 64;        // nodes up to one wavefront of points are split by a single wave (kd_split_small_kernel)
+constexpr int BIG_LEVELS = 24;       // levels at which nodes above 64 points are still split
+constexpr int CTR_NODES = 0, CTR_STATUS = 1, CTR_DEPTH = 2, CTR_SQ = 3, CTR_QUEUE0 = 8, CTR_TOTAL = CTR_QUEUE0 + MAX_LEVELS + 8;
+constexpr int SMALL_MAX = 64;        // a node of at most one wavefront of points: its whole subtree is built by one wave (kd_small_subtree_kernel)
 constexpr int ST_QUEUE_OVF = 1, ST_NODE_OVF = 2, ST_DEPTH_OVF = 4;
 
 // The two-pointer sweep of nanoflann.hpp:951-961 (and :966-973) in closed form: positions [start,end)
@@ -80,19 +80,13 @@ __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
         f.node_b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         f.node_tree[t] = t;
         if (n > SMALL_MAX) { int q = atomicAdd(&f.ctr[CTR_QUEUE0], 1); f.queue[q] = t; }
-        else if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_SQUEUE0], 1); f.squeue[q] = t; }
+        else if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_SQ], 1); f.squeue[q] = t; }
     }
 }
 
-// Children get node ids without atomics: level l hands out ids base(l) + 2*slot, where base(l) = ntrees + 2 * (number of
-// nodes split at the levels above), big nodes first, then small ones (tens of thousands of waves adding to one counter
-// serialise at ~10 ns each).
-__device__ __forceinline__ int level_node_base(const ForestPtrs& f, int level, int ntrees) {
-    int b = ntrees;
-    for (int j = 0; j < level; ++j) b += 2 * (min(f.ctr[CTR_QUEUE0 + j], f.queue_cap) + min(f.ctr[CTR_SQUEUE0 + j], f.queue_cap));
-    return b;
-}
-
+// Children get node ids without atomics: a node split at absolute vind position m hands its children the ids
+// ntrees + 2*m and ntrees + 2*m + 1 (split positions are unique in the forest; tens of thousands of waves adding to one
+// counter would serialise at ~10 ns each).
 // One level of divideTree (nanoflann.hpp:848-896) for every open node.
 template <int NT>
 __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
@@ -170,7 +164,7 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
         block_minmax3<NT>(m3n, m3x, s_mm);
 
         if (tid == 0) {
-            int c = level_node_base(f, level, f.ntrees) + 2 * qi;
+            int c = f.ntrees + 2 * (left + idx);
             if (c + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c = -1; }
             s_child = c;
         }
@@ -192,8 +186,9 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
                 int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
                 if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
             } else if (cr - cl > LEAF_MAX) {
-                int q = atomicAdd(&f.ctr[CTR_SQUEUE0 + level + 1], 1);
-                if (q < f.queue_cap) f.squeue[((level + 1) & 1) * f.queue_cap + q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+                f.node_b[c] = make_float4(0.f, 0.f, 0.f, __int_as_float(level + 1));      // depth of this small root
+                int q = atomicAdd(&f.ctr[CTR_SQ], 1);
+                if (q < 2 * f.queue_cap) f.squeue[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
             }
         }
         if (c1 >= 0 && tid == 0) {
@@ -204,138 +199,134 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
     }
 }
 
-// The same split for nodes of at most 64 points: one wavefront per node, one lane per point.  min/max are wave
-// reductions, the counts are ballots, and the two-pointer sweeps of planeSplit become two LDS permutations whose
-// destinations come from ballot prefix counts (left-side misplaced k <-> right-side misplaced k from the right).
-constexpr int SBS = 1024;            // 16 nodes per workgroup step
-__global__ __launch_bounds__(SBS) void kd_split_small_kernel(ForestPtrs f, int level) {
-    __shared__ int s_pos[SBS / 64][2][64];     // [wave][side][rank] -> position
-    __shared__ int s_ind[SBS / 64][64];
-    __shared__ float s_xyz[SBS / 64][3][64];
-    __shared__ int s_npush[SBS / 64];
-    __shared__ int s_qbase;
+// Nodes of at most 64 points: ONE wavefront builds the node's whole subtree (one lane per point, the points stay in
+// registers / LDS).  min/max are wave reductions, the counts are ballots, and the two-pointer sweeps of planeSplit
+// become two LDS permutations whose destinations come from ballot prefix counts (left-side misplaced k <-> right-side
+// misplaced k from the right).  Open children go to a per-wave stack in LDS; one launch covers every small subtree of
+// the forest.
+constexpr int SUB_STACK = 64;
+struct SubEntry { int l, r, node, depth; float lo[3], hi[3]; };
+
+__global__ __launch_bounds__(BS) void kd_small_subtree_kernel(ForestPtrs f) {
+    __shared__ int s_pos[BS / 64][2][64];     // [wave][side][rank] -> position
+    __shared__ int s_ind[BS / 64][64];
+    __shared__ float s_xyz[BS / 64][3][64];
+    __shared__ SubEntry s_stk[BS / 64][SUB_STACK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int nq = min(f.ctr[CTR_SQUEUE0 + level], f.queue_cap);
-    const int* qin = f.squeue + (level & 1) * f.queue_cap;
-    if (blockIdx.x == 0 && tid == 0 && nq > 0) {
-        atomicMax(&f.ctr[CTR_DEPTH], level + 1);
-        if (level + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
-    }
-    const int nwg = (nq + SBS / 64 - 1) / (SBS / 64);
-    const int idbase = level_node_base(f, level, f.ntrees) + 2 * min(f.ctr[CTR_QUEUE0 + level], f.queue_cap);
-    for (int g = blockIdx.x; g < nwg; g += gridDim.x) {          // uniform trip count inside a workgroup
-        const int qi = g * (SBS / 64) + wid;
-        const bool have = qi < nq;
-        int node = 0, left = 0, count = 0, tree = 0;
-        float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
-        if (have) {
-            node = qin[qi];
-            const int4 na = f.node_a[node];
-            left = na.x; count = na.y - na.x; tree = f.node_tree[node];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { lo[d] = f.node_box[6 * (size_t)node + d]; hi[d] = f.node_box[6 * (size_t)node + 3 + d]; }
-        }
-        const bool act = have && lane < count;
+    const int nq = min(f.ctr[CTR_SQ], 2 * f.queue_cap);
+    for (int qi = blockIdx.x * (BS / 64) + wid; qi < nq; qi += gridDim.x * (BS / 64)) {     // waves are independent: no workgroup barrier below
+        const int root = f.squeue[qi];
+        const int4 ra = f.node_a[root];
+        const int left = ra.x, rcount = ra.y - ra.x, tree = f.node_tree[root];
         int id = 0; float c[3] = {0.f, 0.f, 0.f};
-        if (act) {
+        if (lane < rcount) {
             id = f.vind[left + lane];
             const float* P = f.desc[tree].pts;
 #pragma unroll
             for (int d = 0; d < 3; ++d) c[d] = P[(size_t)id * 3 + d];
         }
-        float mn[3], mx[3];
+        if (lane == 0) {
+            SubEntry e; e.l = 0; e.r = rcount; e.node = root; e.depth = __float_as_int(f.node_b[root].w);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { mn[d] = wave_min(act ? c[d] : FLT_MAX); mx[d] = wave_max(act ? c[d] : -FLT_MAX); }
-        // middleSplit_ (:898-937)
-        const float EPS = 0.00001f;
-        float max_span = hi[0] - lo[0];
-#pragma unroll
-        for (int d = 1; d < 3; ++d) { float sp = hi[d] - lo[d]; if (sp > max_span) max_span = sp; }
-        float max_spread = -1.f; int cf = 0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float sp = hi[d] - lo[d];
-            if (sp > (1 - EPS) * max_span) { float spread = mx[d] - mn[d]; if (spread > max_spread) { cf = d; max_spread = spread; } }
+            for (int d = 0; d < 3; ++d) { e.lo[d] = f.node_box[6 * (size_t)root + d]; e.hi[d] = f.node_box[6 * (size_t)root + 3 + d]; }
+            s_stk[wid][0] = e;
         }
-        const float lo_c = cf == 0 ? lo[0] : (cf == 1 ? lo[1] : lo[2]);
-        const float hi_c = cf == 0 ? hi[0] : (cf == 1 ? hi[1] : hi[2]);
-        const float mn_c = cf == 0 ? mn[0] : (cf == 1 ? mn[1] : mn[2]);
-        const float mx_c = cf == 0 ? mx[0] : (cf == 1 ? mx[1] : mx[2]);
-        const float split_val = (lo_c + hi_c) / 2;
-        const float cut = split_val < mn_c ? mn_c : (split_val > mx_c ? mx_c : split_val);
-
-        int lim1 = 0, lim2 = 0;
+        int sp = 1, maxdepth = 0;
+        while (sp > 0) {
+            (void)__ballot(1);                               // stack writes of lane 0 are visible to the wave
+            const SubEntry e = s_stk[wid][--sp];
+            const int l = e.l, r = e.r, node = e.node, cnt = r - l;
+            const bool act = lane >= l && lane < r;
+            float mn[3], mx[3];
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {                   // planeSplit (:948-975): "< cut", then "<= cut" on the rest
-            const float v = cf == 0 ? c[0] : (cf == 1 ? c[1] : c[2]);
-            const int start = pass == 0 ? 0 : lim1;
-            const bool in = act && lane >= start;
-            const bool isleft = pass == 0 ? (v < cut) : (v <= cut);
-            const unsigned long long ml = __ballot(in && isleft);
-            const int lim = start + __popcll(ml);
-            if (pass == 0) lim1 = lim; else lim2 = lim;
-            const bool badl = in && lane < lim && !isleft;       // misplaced on the left, k-th from the left
-            const bool badr = in && lane >= lim && isleft;       // misplaced on the right, k-th from the right
-            const unsigned long long mbl = __ballot(badl), mbr = __ballot(badr);
-            if (badl) s_pos[wid][0][__popcll(mbl & lt)] = lane;
-            if (badr) s_pos[wid][1][__popcll(mbr & ~lt & ~(1ull << lane))] = lane;
-            __syncthreads();
-            int dest = lane;
-            if (badl) dest = s_pos[wid][1][__popcll(mbl & lt)];
-            if (badr) dest = s_pos[wid][0][__popcll(mbr & ~lt & ~(1ull << lane))];
-            s_ind[wid][dest] = id;
+            for (int d = 0; d < 3; ++d) { mn[d] = wave_min(act ? c[d] : FLT_MAX); mx[d] = wave_max(act ? c[d] : -FLT_MAX); }
+            // middleSplit_ (:898-937)
+            const float EPS = 0.00001f;
+            float max_span = e.hi[0] - e.lo[0];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) s_xyz[wid][d][dest] = c[d];
-            __syncthreads();
-            id = s_ind[wid][lane];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) c[d] = s_xyz[wid][d][lane];
-            __syncthreads();
-        }
-        int idx;
-        if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
-        const float v = cf == 0 ? c[0] : (cf == 1 ? c[1] : c[2]);
-        const float divlow = wave_max((act && lane < idx) ? v : -FLT_MAX);
-        const float divhigh = wave_min((act && lane >= idx) ? v : FLT_MAX);
-        if (act) f.vind[left + lane] = id;
-        int c1 = -1;
-        if (have) {
-            c1 = idbase + 2 * qi;
-            if (c1 + 2 > f.node_cap) { if (lane == 0) atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c1 = -1; }
-        }
-        // queue slots for the children that stay open: one atomic per workgroup step instead of one per child
-        const int open0 = (have && c1 >= 0 && idx > LEAF_MAX) ? 1 : 0, open1 = (have && c1 >= 0 && count - idx > LEAF_MAX) ? 1 : 0;
-        if (lane == 0) s_npush[wid] = open0 + open1;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < SBS / 64; ++w) tot += s_npush[w];
-            s_qbase = tot ? atomicAdd(&f.ctr[CTR_SQUEUE0 + level + 1], tot) : 0;
-        }
-        __syncthreads();
-        int qslot = s_qbase;
-        for (int w = 0; w < wid; ++w) qslot += s_npush[w];
-        if (have && c1 >= 0 && lane < 2) {
-            const int cn = c1 + lane;
-            const int cl = lane == 0 ? left : left + idx, cr = lane == 0 ? left + idx : left + count;
-            f.node_a[cn] = make_int4(cl, cr, -1, -1);
-            f.node_b[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
-            f.node_tree[cn] = tree;
+            for (int d = 1; d < 3; ++d) { float spn = e.hi[d] - e.lo[d]; if (spn > max_span) max_span = spn; }
+            float max_spread = -1.f; int cf = 0;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                f.node_box[6 * (size_t)cn + d] = (lane == 1 && d == cf) ? cut : lo[d];
-                f.node_box[6 * (size_t)cn + 3 + d] = (lane == 0 && d == cf) ? cut : hi[d];
+                float spn = e.hi[d] - e.lo[d];
+                if (spn > (1 - EPS) * max_span) { float spread = mx[d] - mn[d]; if (spread > max_spread) { cf = d; max_spread = spread; } }
             }
-            if (cr - cl > LEAF_MAX) {
-                const int q = qslot + (lane == 1 ? open0 : 0);
-                if (q < f.queue_cap) f.squeue[((level + 1) & 1) * f.queue_cap + q] = cn; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+            const float lo_c = cf == 0 ? e.lo[0] : (cf == 1 ? e.lo[1] : e.lo[2]);
+            const float hi_c = cf == 0 ? e.hi[0] : (cf == 1 ? e.hi[1] : e.hi[2]);
+            const float mn_c = cf == 0 ? mn[0] : (cf == 1 ? mn[1] : mn[2]);
+            const float mx_c = cf == 0 ? mx[0] : (cf == 1 ? mx[1] : mx[2]);
+            const float split_val = (lo_c + hi_c) / 2;
+            const float cut = split_val < mn_c ? mn_c : (split_val > mx_c ? mx_c : split_val);
+
+            int lim1 = l, lim2 = l;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {               // planeSplit (:948-975): "< cut", then "<= cut" on the rest
+                const float v = cf == 0 ? c[0] : (cf == 1 ? c[1] : c[2]);
+                const int start = pass == 0 ? l : lim1;
+                const bool in = act && lane >= start;
+                const bool isleft = pass == 0 ? (v < cut) : (v <= cut);
+                const unsigned long long ml = __ballot(in && isleft);
+                const int lim = start + __popcll(ml);
+                if (pass == 0) lim1 = lim; else lim2 = lim;
+                const bool badl = in && lane < lim && !isleft;   // misplaced on the left, k-th from the left
+                const bool badr = in && lane >= lim && isleft;   // misplaced on the right, k-th from the right
+                const unsigned long long mbl = __ballot(badl), mbr = __ballot(badr);
+                if (badl) s_pos[wid][0][__popcll(mbl & lt)] = lane;
+                if (badr) s_pos[wid][1][__popcll(mbr & ~lt & ~(1ull << lane))] = lane;
+                (void)__ballot(1);
+                int dest = lane;
+                if (badl) dest = s_pos[wid][1][__popcll(mbl & lt)];
+                if (badr) dest = s_pos[wid][0][__popcll(mbr & ~lt & ~(1ull << lane))];
+                s_ind[wid][dest] = id;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) s_xyz[wid][d][dest] = c[d];
+                (void)__ballot(1);
+                id = s_ind[wid][lane];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) c[d] = s_xyz[wid][d][lane];
+                (void)__ballot(1);
             }
+            int idx;
+            if (lim1 - l > cnt / 2) idx = lim1 - l; else if (lim2 - l < cnt / 2) idx = lim2 - l; else idx = cnt / 2;
+            const int m = l + idx;
+            const float v = cf == 0 ? c[0] : (cf == 1 ? c[1] : c[2]);
+            const float divlow = wave_max((act && lane < m) ? v : -FLT_MAX);
+            const float divhigh = wave_min((act && lane >= m) ? v : FLT_MAX);
+            const int c1 = f.ntrees + 2 * (left + m);
+            const bool fits = c1 + 2 <= f.node_cap;
+            if (!fits && lane == 0) atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF);
+            if (fits && lane < 2) {
+                const int cn = c1 + lane;
+                const int cl = lane == 0 ? l : m, cr = lane == 0 ? m : r;
+                f.node_a[cn] = make_int4(left + cl, left + cr, -1, -1);
+                f.node_b[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (fits && lane == 0) {
+                f.node_a[node] = make_int4(left + l, left + r, c1, c1 + 1);
+                f.node_b[node] = make_float4(divlow, divhigh, __int_as_float(cf), 0.f);
+                maxdepth = max(maxdepth, e.depth + 1);
+                // open children: right first, so the left one is split next (order is irrelevant for the result)
+                if (r - m > LEAF_MAX && sp < SUB_STACK) {
+                    SubEntry ch; ch.l = m; ch.r = r; ch.node = c1 + 1; ch.depth = e.depth + 1;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { ch.lo[d] = d == cf ? cut : e.lo[d]; ch.hi[d] = e.hi[d]; }
+                    s_stk[wid][sp] = ch;
+                }
+                if (m - l > LEAF_MAX && sp + (r - m > LEAF_MAX ? 1 : 0) < SUB_STACK) {
+                    SubEntry ch; ch.l = l; ch.r = m; ch.node = c1; ch.depth = e.depth + 1;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { ch.lo[d] = e.lo[d]; ch.hi[d] = d == cf ? cut : e.hi[d]; }
+                    s_stk[wid][sp + (r - m > LEAF_MAX ? 1 : 0)] = ch;
+                }
+            }
+            if (fits) sp += (r - m > LEAF_MAX ? 1 : 0) + (m - l > LEAF_MAX ? 1 : 0);
+            if (sp > SUB_STACK) { sp = SUB_STACK; if (lane == 0) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF); }
         }
-        __syncthreads();       // s_npush / s_qbase are reused by the next step
-        if (have && c1 >= 0 && lane == 0) {
-            f.node_a[node] = make_int4(left, left + count, c1, c1 + 1);
-            f.node_b[node] = make_float4(divlow, divhigh, __int_as_float(cf), 0.f);
+        if (lane < rcount) f.vind[left + lane] = id;
+        if (lane == 0) {
+            atomicMax(&f.ctr[CTR_DEPTH], maxdepth);
+            if (maxdepth >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
         }
     }
 }
@@ -520,18 +511,15 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     ForestPtrs p = ptrs(f);
     hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(BS), 0, s, p);
     const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
-    // nodes above 64 points: one workgroup each; deeper than BIG_LEVELS a node that large means a degenerate cloud
-    // (flagged, not mis-built).  Nodes of at most 64 points: one wavefront each.
+    // nodes above 64 points: one workgroup each, level by level; deeper than BIG_LEVELS a node that large means a
+    // degenerate cloud (flagged, not mis-built).  Everything at or below 64 points: one launch, one wavefront per subtree.
     int maxn0 = 0; for (auto& t : trees) maxn0 = std::max(maxn0, t.n);
-    const int gsmall = std::max(1, std::min(f.queue_cap / 16 + 1, ctx().num_cu * 2));
-    for (int level = 0; level < MAX_LEVELS; ++level) {
-        if (level < BIG_LEVELS && maxn0 > SMALL_MAX) {
-            // the first levels have few, large nodes: 8 waves per node (16 would spill at the 128-VGPR cap); later 4
-            if ((maxn0 >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<512>), dim3(grid), dim3(512), 0, s, p, level);
-            else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);
-        }
-        hipLaunchKernelGGL(kd_split_small_kernel, dim3(gsmall), dim3(SBS), 0, s, p, level);
+    for (int level = 0; level < BIG_LEVELS && maxn0 > SMALL_MAX; ++level) {
+        // the first levels have few, large nodes: 8 waves per node (16 would spill at the 128-VGPR cap); later 4
+        if ((maxn0 >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<512>), dim3(grid), dim3(512), 0, s, p, level);
+        else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);
     }
+    hipLaunchKernelGGL(kd_small_subtree_kernel, dim3(std::max(1, std::min(f.queue_cap / 2 + 1, ctx().num_cu * 16))), dim3(BS), 0, s, p);
     int maxn = 0; for (auto& t : trees) maxn = std::max(maxn, t.n);
     dim3 g((unsigned)std::max(1, std::min((maxn + 255) / 256, 64)), (unsigned)std::min(f.ntrees, 65535));
     hipLaunchKernelGGL(kd_sort_points_kernel, g, dim3(256), 0, s, p, f.ntrees);
