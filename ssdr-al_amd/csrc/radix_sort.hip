@@ -25,6 +25,7 @@ struct SegTab { int nseg; int off[RADIX_MAX_SEG + 1]; int n_host[RADIX_MAX_SEG];
 struct SortPtrs {
     uint64_t* k[2]; uint32_t* v[2];
     unsigned long long* andor;   // [nseg][2] = AND, OR of the segment's keys
+    unsigned long long* andor_part;   // [nseg][RS_ANDOR_G][2] partials
     unsigned* hist;              // [256][nblocks_max]
     unsigned* tot;               // [nseg][256] digit totals of the current pass
     const int* d_cnt;            // optional device counts per segment
@@ -54,18 +55,21 @@ __device__ __forceinline__ bool pass_runs(const SortPtrs& s, int p, int& parity)
     return ((diff >> (8 * p)) & 0xffull) != 0;
 }
 
-__global__ __launch_bounds__(RS_BS) void rs_andor_init(SortPtrs s) {
-    const int i = blockIdx.x * RS_BS + threadIdx.x;
-    if (i < s.seg.nseg) { s.andor[2 * i] = ~0ull; s.andor[2 * i + 1] = 0ull; }
-}
-
-// grid.y = segment
+// grid (RS_ANDOR_G, segment): partial AND / OR of a slice of the segment's keys -> part[segment][block][2].  (Thousands
+// of workgroups folding into one word per segment with atomics serialise at ~10 ns each; a second tiny kernel folds.)
+constexpr int RS_ANDOR_G = 256;
 __global__ __launch_bounds__(RS_BS) void rs_andor(SortPtrs s) {
     __shared__ unsigned long long sa[RS_BS / 64], so[RS_BS / 64];
     const int sg = blockIdx.y, n = seg_count(s, sg);
     const uint64_t* K = s.k[0] + s.seg.off[sg];
     unsigned long long a = ~0ull, o = 0ull;
-    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { unsigned long long k = K[i]; a &= k; o |= k; }
+    const int stride = gridDim.x * RS_BS;
+    int i = blockIdx.x * RS_BS + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const unsigned long long k0 = K[i], k1 = K[i + stride], k2 = K[i + 2 * stride], k3 = K[i + 3 * stride];
+        a &= k0 & k1 & k2 & k3; o |= k0 | k1 | k2 | k3;
+    }
+    for (; i < n; i += stride) { unsigned long long k = K[i]; a &= k; o |= k; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         unsigned lo = __shfl_xor((unsigned)a, off), hi = __shfl_xor((unsigned)(a >> 32), off);
@@ -78,8 +82,23 @@ __global__ __launch_bounds__(RS_BS) void rs_andor(SortPtrs s) {
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < RS_BS / 64; ++w) { a &= sa[w]; o |= so[w]; }
-        if (n > 0) { atomicAnd(&s.andor[2 * sg], a); atomicOr(&s.andor[2 * sg + 1], o); }
+        s.andor_part[2 * ((size_t)sg * RS_ANDOR_G + blockIdx.x)] = a;
+        s.andor_part[2 * ((size_t)sg * RS_ANDOR_G + blockIdx.x) + 1] = o;
     }
+}
+// one wavefront per segment folds the partials (an empty segment keeps AND = ~0, OR = 0)
+__global__ __launch_bounds__(64) void rs_andor_fold(SortPtrs s, int nparts) {
+    const int sg = blockIdx.x, lane = threadIdx.x;
+    unsigned long long a = ~0ull, o = 0ull;
+    for (int j = lane; j < nparts; j += 64) { a &= s.andor_part[2 * ((size_t)sg * RS_ANDOR_G + j)]; o |= s.andor_part[2 * ((size_t)sg * RS_ANDOR_G + j) + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)a, off), hi = __shfl_xor((unsigned)(a >> 32), off);
+        a &= ((unsigned long long)hi << 32) | lo;
+        lo = __shfl_xor((unsigned)o, off); hi = __shfl_xor((unsigned)(o >> 32), off);
+        o |= ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0) { s.andor[2 * sg] = a; s.andor[2 * sg + 1] = o; }
 }
 
 __global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
@@ -89,6 +108,7 @@ __global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
     const uint64_t* K = s.k[par];
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
         const int sg = seg_of_tile(s, b), end = s.seg.off[sg] + seg_count(s, sg);
+        if (b * RS_TILE >= end) continue;                 // tile past the segment's live pairs: rs_scan never reads its row
         h[threadIdx.x] = 0;
         __syncthreads();
 #pragma unroll
@@ -108,7 +128,7 @@ __global__ __launch_bounds__(RS_BS) void rs_scan(SortPtrs s, int p) {
     __shared__ unsigned carry_s;
     int par; if (!pass_runs(s, p, par)) return;
     const int sg = blockIdx.y;
-    const int b0 = s.seg.off[sg] / RS_TILE, nb = s.seg.off[sg + 1] / RS_TILE - b0;
+    const int b0 = s.seg.off[sg] / RS_TILE, nb = (seg_count(s, sg) + RS_TILE - 1) / RS_TILE;     // live tiles only
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     unsigned* row = s.hist + (size_t)blockIdx.x * s.nblocks_max + b0;
     if (tid == 0) carry_s = 0;
@@ -133,40 +153,41 @@ __global__ __launch_bounds__(RS_BS) void rs_scan(SortPtrs s, int p) {
     if (tid == 0) s.tot[sg * 256 + blockIdx.x] = carry_s;
 }
 
+// The tile is first ordered by digit in LDS (stable: waves in order, rounds in order, lanes in order), then written
+// out position by position, so consecutive threads store consecutive pairs of one digit's run: whole 64-128 B pieces
+// of a cache line per run instead of 64 isolated 8-byte stores per wave.
 __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
-    __shared__ unsigned s_cnt[RS_BS / 64][256];      // per wave: running count of each digit
-    __shared__ unsigned s_run[256];
-    __shared__ unsigned s_wt[RS_BS / 64];
+    constexpr int NW = RS_BS / 64;
+    __shared__ unsigned s_cnt[NW][256];      // per wave: running count of each digit, then the wave's start inside the tile
+    __shared__ unsigned s_run[256];          // global position of the digit's run of this tile minus its start inside the tile
+    __shared__ unsigned s_wt[2][NW];
+    __shared__ uint64_t s_key[RS_TILE];
+    __shared__ uint32_t s_val[RS_TILE];
     int par; if (!pass_runs(s, p, par)) return;
     const int nb = s.seg.off[s.seg.nseg] / RS_TILE;
     const uint64_t* K = s.k[par]; const uint32_t* V = s.v[par];
     uint64_t* KO = s.k[par ^ 1]; uint32_t* VO = s.v[par ^ 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s_cnt[w][tid] = 0;
+    __syncthreads();
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
         const int sg = seg_of_tile(s, b), end = s.seg.off[sg] + seg_count(s, sg);
-        {   // exclusive scan of the segment's 256 digit totals (thread tid owns digit tid)
-            const unsigned x = s.tot[sg * 256 + tid];
-            unsigned incl = x;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(incl, off); if (lane >= off) incl += y; }
-            if (lane == 63) s_wt[wid] = incl;
-            __syncthreads();
-            unsigned wbase = 0;
-#pragma unroll
-            for (int w = 0; w < RS_BS / 64; ++w) if (w < wid) wbase += s_wt[w];
-            s_run[tid] = (unsigned)s.seg.off[sg] + wbase + incl - x + s.hist[(size_t)tid * s.nblocks_max + b];
-        }
-#pragma unroll
-        for (int w = 0; w < RS_BS / 64; ++w) s_cnt[w][tid] = 0;
-        __syncthreads();
+        if (b * RS_TILE >= end) continue;
+        const int ntile = min(RS_TILE, end - b * RS_TILE);
         uint64_t key[RS_ITEMS]; uint32_t val[RS_ITEMS]; unsigned rk[RS_ITEMS];
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
-            const int i = b * RS_TILE + wid * (RS_TILE / (RS_BS / 64)) + j * 64 + lane;
+            const int i = b * RS_TILE + wid * (RS_TILE / NW) + j * 64 + lane;
+            key[j] = 0; val[j] = 0;
+            if (i < end) { key[j] = K[i]; val[j] = V[i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const int i = b * RS_TILE + wid * (RS_TILE / NW) + j * 64 + lane;
             const bool valid = i < end;
-            key[j] = 0; val[j] = 0; unsigned d = 0;
-            if (valid) { key[j] = K[i]; val[j] = V[i]; d = (unsigned)((key[j] >> (8 * p)) & 0xff); }
+            const unsigned d = valid ? (unsigned)((key[j] >> (8 * p)) & 0xff) : 0u;
             unsigned long long m = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
@@ -180,13 +201,47 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
             if (valid && (m & lt) == 0) s_cnt[wid][d] = before + (unsigned)__popcll(m);   // ... then the group leader adds
         }
         __syncthreads();
+        {   // thread tid owns digit tid: start of the digit inside the tile and in the segment (two exclusive scans)
+            unsigned cw[NW], tcount = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { cw[w] = s_cnt[w][tid]; tcount += cw[w]; }
+            const unsigned gtot = s.tot[sg * 256 + tid];
+            unsigned inc_t = tcount, inc_g = gtot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                unsigned y = __shfl_up(inc_t, off), z = __shfl_up(inc_g, off);
+                if (lane >= off) { inc_t += y; inc_g += z; }
+            }
+            if (lane == 63) { s_wt[0][wid] = inc_t; s_wt[1][wid] = inc_g; }
+            __syncthreads();
+            unsigned base_t = 0, base_g = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) if (w < wid) { base_t += s_wt[0][w]; base_g += s_wt[1][w]; }
+            const unsigned lstart = base_t + inc_t - tcount;
+            s_run[tid] = (unsigned)s.seg.off[sg] + base_g + inc_g - gtot + s.hist[(size_t)tid * s.nblocks_max + b] - lstart;
+            unsigned run = lstart;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { s_cnt[w][tid] = run; run += cw[w]; }
+        }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             if (rk[j] != 0xffffffffu) {
                 const unsigned d = (unsigned)((key[j] >> (8 * p)) & 0xff);
-                unsigned pos = s_run[d] + rk[j];
-                for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
-                KO[pos] = key[j]; VO[pos] = val[j];
+                const unsigned l = s_cnt[wid][d] + rk[j];
+                s_key[l] = key[j]; s_val[l] = val[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s_cnt[w][tid] = 0;            // for the next tile (read again only after the next barrier)
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const int l = j * RS_BS + tid;
+            if (l < ntile) {
+                const uint64_t k = s_key[l];
+                const unsigned pos = s_run[(unsigned)((k >> (8 * p)) & 0xff)] + (unsigned)l;
+                KO[pos] = k; VO[pos] = s_val[l];
             }
         }
         __syncthreads();
@@ -259,7 +314,7 @@ __global__ __launch_bounds__(RS_BS) void rs_finish(SortPtrs s) {
 int RadixSorter::reserve(size_t slots) {
     nblocks_max = (int)((slots + RS_TILE - 1) / RS_TILE) + 1;
     SSDR_TRY(k1.reserve(8 * slots + 16)); SSDR_TRY(v1.reserve(4 * slots + 16));
-    SSDR_TRY(hist.reserve(4 * 256 * (size_t)nblocks_max + 4 * 256 * (size_t)RADIX_MAX_SEG)); SSDR_TRY(andor.reserve(16 * RADIX_MAX_SEG));
+    SSDR_TRY(hist.reserve(4 * 256 * (size_t)nblocks_max + 4 * 256 * (size_t)RADIX_MAX_SEG)); SSDR_TRY(andor.reserve(16 * RADIX_MAX_SEG * (size_t)(RS_ANDOR_G + 1)));
     return SSDR_OK;
 }
 
@@ -270,7 +325,7 @@ int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const i
     if (slots <= 0) return SSDR_OK;
     SSDR_TRY(reserve((size_t)slots));
     SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>();
-    s.andor = andor.as<unsigned long long>(); s.hist = hist.as<unsigned>(); s.tot = hist.as<unsigned>() + 256 * (size_t)nblocks_max;
+    s.andor = andor.as<unsigned long long>(); s.andor_part = s.andor + 2 * RADIX_MAX_SEG; s.hist = hist.as<unsigned>(); s.tot = hist.as<unsigned>() + 256 * (size_t)nblocks_max;
     s.d_cnt = d_cnt; s.nblocks_max = nblocks_max; s.seg.nseg = nseg;
     int maxn = 0;
     for (int i = 0; i < nseg; ++i) {
@@ -281,8 +336,9 @@ int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const i
     const int nb = (slots + RS_TILE - 1) / RS_TILE;
     const int g = std::max(1, std::min(nb, ctx().num_cu * 8));
     const int gseg = std::max(1, std::min((maxn + RS_BS * 8 - 1) / (RS_BS * 8), ctx().num_cu * 4));
-    hipLaunchKernelGGL(rs_andor_init, dim3(1), dim3(RS_BS), 0, st, s);
-    hipLaunchKernelGGL(rs_andor, dim3(gseg, nseg), dim3(RS_BS), 0, st, s);
+    const int gao = std::max(1, std::min(std::min(gseg, RS_ANDOR_G), std::max(1, ctx().num_cu * 16 / nseg)));
+    hipLaunchKernelGGL(rs_andor, dim3(gao, nseg), dim3(RS_BS), 0, st, s);
+    hipLaunchKernelGGL(rs_andor_fold, dim3(nseg), dim3(64), 0, st, s, gao);
     const int npass = std::min(4, (std::max(key_bits, 1) + 7) / 8);      // wide passes for the low 32 bits ...
     for (int p = 0; p < npass; ++p) {
         hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
