@@ -24,6 +24,7 @@ namespace ssdr {
 namespace {
 
 constexpr int LAB_CAP = 29;
+constexpr int GS_UNROLL = 8;    // gathers in flight per lane in the voxel reductions (a lane's loop is a latency chain otherwise)
 
 struct GsParams {
     float org[3]; float dl;
@@ -168,11 +169,19 @@ __device__ __forceinline__ int voxel_label_fast(const int* __restrict__ cls, int
     int cnt[13], seen[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) { cnt[k] = 0; seen[k] = -1; }
-    for (int j = s; j < e; ++j) {
-        const int L = cls[(size_t)vs[j] * ldim + col];
-        if (L < 0 || L >= 13) return -1;
+    for (int j0 = s; j0 < e; j0 += GS_UNROLL) {
+        int lv[GS_UNROLL];
 #pragma unroll
-        for (int k = 0; k < 13; ++k) if (L == k) { if (cnt[k] == 0) seen[k] = j; cnt[k]++; }
+        for (int u = 0; u < GS_UNROLL; ++u) lv[u] = cls[(size_t)vs[min(j0 + u, e - 1)] * ldim + col];
+#pragma unroll
+        for (int u = 0; u < GS_UNROLL; ++u) {
+            const int j = j0 + u, L = lv[u];
+            if (j < e) {
+                if (L < 0 || L >= 13) return -1;
+#pragma unroll
+                for (int k = 0; k < 13; ++k) if (L == k) { if (cnt[k] == 0) seen[k] = j; cnt[k]++; }
+            }
+        }
     }
     int best = 0;
 #pragma unroll
@@ -211,14 +220,26 @@ __device__ __forceinline__ void gs_reduce_body(const float* __restrict__ P, cons
         const int row = row_of_voxel ? row_of_voxel[v] : v;
         if (c < 3) {
             float sum = 0.f;
-            for (int j = s; j < en; ++j) sum += P[3 * (size_t)vs[j] + c];
+            for (int j0 = s; j0 < en; j0 += GS_UNROLL) {               // GS_UNROLL gathers in flight, then the adds in input order
+                float wv[GS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < GS_UNROLL; ++u) wv[u] = P[3 * (size_t)vs[min(j0 + u, en - 1)] + c];
+#pragma unroll
+                for (int u = 0; u < GS_UNROLL; ++u) if (j0 + u < en) sum += wv[u];
+            }
             const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
             out_p[3 * (size_t)row + c] = sum * a;
             if (c == 0 && out_first) out_first[v] = ks[s];
         } else {
             const int f = c - 3;
             float acc = 0.f;
-            for (int j = s; j < en; ++j) acc += F[(size_t)vs[j] * fdim + f];
+            for (int j0 = s; j0 < en; j0 += GS_UNROLL) {
+                float wv[GS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < GS_UNROLL; ++u) wv[u] = F[(size_t)vs[min(j0 + u, en - 1)] * fdim + f];
+#pragma unroll
+                for (int u = 0; u < GS_UNROLL; ++u) if (j0 + u < en) acc += wv[u];
+            }
             out_f[(size_t)row * fdim + f] = acc / (float)count;      // :90-94
         }
     }

@@ -102,3 +102,21 @@ def test_subsample_batch_matches_per_cloud_oracle(backend, orc):
         assert_bits_equal(gp[s:s + m[r]], ep, "cloud %d points" % r)
         assert_bits_equal(gf[s:s + m[r]], ef, "cloud %d features" % r)
         assert_bits_equal(gl[s:s + m[r]], el, "cloud %d labels" % r)
+
+
+@pytest.mark.parametrize("fdim,ldim,nlab", [(6, 2, 13), (3, 2, 40), (1, 1, 300), (4, 1, 13)])
+def test_subsample_row_layouts(backend, orc, fdim, ldim, nlab):
+    """Other feature / label widths than the hot path's (3, 1); labels outside [0,13) leave the fast majority-vote
+    path (a 40/300-label voxel walks the unordered_map emulation, rehash included)."""
+    from ssdr_al import subsampling
+    rng = np.random.default_rng(100 * fdim + ldim)
+    n = 6000 if backend == "emu" else 200000
+    pts = (rng.random((n, 3), dtype=np.float32) * np.array([3, 2, 1], np.float32)).astype(np.float32)
+    feat = rng.normal(0, 50, (n, fdim)).astype(np.float32)
+    lab = (rng.integers(0, nlab, (n, ldim)) - (5 if nlab > 13 else 0)).astype(np.int32)
+    dl = (0.2 if backend == "emu" else 0.065) if nlab > 13 else 0.08      # <= 29 distinct labels per voxel (LAB_CAP)
+    for order in ("reference", "key"):
+        got = subsampling.compute(pts, features=feat, classes=lab, sampleDl=dl, order=order)
+        exp = orc.grid_subsampling(pts, feat, lab, dl, order=order)
+        for x, y in zip(got, exp):
+            assert_bits_equal(x, y, "%s fdim %d ldim %d" % (order, fdim, ldim))
