@@ -251,12 +251,25 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
         __syncthreads();
     }
 
-    // gather_neighbour (:519 / :524): neighbour features into columns [0,H)
+    // gather_neighbour (:519 / :524): neighbour features into columns [0,H).  Every thread first requests ALL of its
+    // 16-byte pieces and only then stores them to LDS (a load -> wait -> store loop is one memory round trip per
+    // iteration, 32 of them at d = 512).
     {
         const float* fin = a.fin + (size_t)b * a.n * H;
-        for (int e = tid; e < ROWS * H; e += 256) {
-            const int row = e / H, c = e % H;
-            F[row * LD + c] = (pt0 + (row >> 4) < a.n) ? fin[(size_t)NBR[row] * H + c] : 0.f;
+        constexpr int H4 = H / 4, NV = ROWS * H4 / 256;
+        static_assert(ROWS * H4 % 256 == 0 && NV >= 1, "gather tiling");
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + 256 * i, row = e / H4, c4 = e % H4;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pt0 + (row >> 4) < a.n) v[i] = *reinterpret_cast<const float4*>(fin + (size_t)NBR[row] * H + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + 256 * i, row = e / H4, c4 = e % H4;
+            float2* dst = reinterpret_cast<float2*>(&F[row * LD + 4 * c4]);      // LD is even: 8-byte aligned
+            dst[0] = make_float2(v[i].x, v[i].y); dst[1] = make_float2(v[i].z, v[i].w);
         }
     }
     __syncthreads();
