@@ -192,22 +192,31 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     }
     __syncthreads();
 
-    // LocSE conv 10 -> H (LFAmlp1, :518).  First half: straight into the f_xyz columns [H,2H).
-    // Second half: into columns [0,H) as the A operand of the LFAmlp2 GEMM below.
+    // LocSE conv 10 -> H (LFAmlp1, :518) on the matrix cores: [16 neighbour rows] x [10 (padded to 12)] x [16 channels]
+    // tiles, 3 MFMAs each (the per-output VALU loop costs more than the whole attention GEMM at d <= 64).
+    // First half: straight into the f_xyz columns [H,2H).  Second half: into columns [0,H) as the A operand of the
+    // LFAmlp2 GEMM below.
     {
         constexpr int XOFF = SECOND ? 0 : H;
-        static_assert(256 % H == 0, "a thread keeps one output channel");
-        const int c = tid % H;                         // e += 256 never changes e % H: the 10 weights live in registers
-        float wreg[10];
+        constexpr int NCT1 = C::NCT2, T1W = PTS * NCT1 / 4;
+        static_assert(PTS * NCT1 % 4 == 0, "LocSE tiles split evenly over the 4 waves");
 #pragma unroll
-        for (int q = 0; q < 10; ++q) wreg[q] = a.w_l1[q * H + c];
-        const float breg = a.b_l1[c];
-        for (int e = tid; e < ROWS * H; e += 256) {
-            const int row = e / H;
-            float s = 0.f;
+        for (int t = 0; t < T1W; ++t) {
+            const int tile = w * T1W + t, p = tile / NCT1, ct = tile % NCT1;
+            const int col = ct * 16 + (lane & 15);
+            f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 10; ++q) s += REL[row * 10 + q] * wreg[q];
-            F[row * LD + XOFF + c] = lrelu(s + breg);
+            for (int ks = 0; ks < 3; ++ks) {
+                const int k = ks * 4 + (lane >> 4);
+                const float av1 = (k < 10) ? REL[(p * 16 + (lane & 15)) * 10 + k] : 0.f;
+                const float bv1 = (k < 10 && col < H) ? a.w_l1[k * H + col] : 0.f;
+                acc1 = mfma16(av1, bv1, acc1);
+            }
+            if (col < H) {
+                const float bias = a.b_l1[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) F[(p * 16 + (lane >> 4) * 4 + r) * LD + XOFF + col] = lrelu(acc1[r] + bias);
+            }
         }
     }
     __syncthreads();
@@ -327,11 +336,12 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
             m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
             float e[4], s = 0.f, v = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { e[r] = expf(acc[p][c][r] - m); s += e[r]; }
+            for (int r = 0; r < 4; ++r) { e[r] = __expf(acc[p][c][r] - m); s += e[r]; }    // v_exp_f32; within 2 ulp, far inside the 1e-3 feature tolerance
             s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v += F[((p0 + p) * 16 + (lane >> 4) * 4 + r) * LD + col] * (e[r] / s);
+            for (int r = 0; r < 4; ++r) v += F[((p0 + p) * 16 + (lane >> 4) * 4 + r) * LD + col] * e[r];
             v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            v = v / s;                                                   // sum_k f_k e_k / sum_k e_k: one division per output
             if ((lane >> 4) == 0 && n < a.n) out[(size_t)n * D + col] = v;
         }
     }
