@@ -394,42 +394,54 @@ __device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& t
     if (qy > td.hi[1]) { d1 = (qy - td.hi[1]) * (qy - td.hi[1]); mind += d1; }
     if (qz < td.lo[2]) { d2 = (qz - td.lo[2]) * (qz - td.lo[2]); mind += d2; }
     if (qz > td.hi[2]) { d2 = (qz - td.hi[2]) * (qz - td.hi[2]); mind += d2; }
+    // Both halves of a node record are requested together (one memory round trip per level, not two) and the points
+    // of a leaf four at a time: the walk is a chain of dependent loads, its latency is the whole cost.
     int node = td.root;
+    int4 na = a.node_a[node]; float4 nb = a.node_b[node];
     for (;;) {
-        int4 na = a.node_a[node];
         while (na.z >= 0) {   // internal: take the near child, defer the far one (:1292-1326)
-            const float4 nb = a.node_b[node];
             const int cf = __float_as_int(nb.z);
             const float val = cf == 0 ? qx : (cf == 1 ? qy : qz);
             const float diff1 = val - nb.x, diff2 = val - nb.y;
             int best, other; float cut;
             if ((diff1 + diff2) < 0) { best = na.z; other = na.w; cut = (val - nb.y) * (val - nb.y); }
             else                     { best = na.w; other = na.z; cut = (val - nb.x) * (val - nb.x); }
+            node = best; na = a.node_a[node]; nb = a.node_b[node];
             const float dst = cf == 0 ? d0 : (cf == 1 ? d1 : d2);
             const float m2 = mind + cut - dst;
             // nanoflann tests `mindistsq <= worstDist` when it comes back to the far child (:1319); worstDist only
             // shrinks, so a far child that already fails the test now can never pass it later: do not even stack it
-            if (!(m2 <= rs.worst())) { node = best; na = a.node_a[node]; continue; }
+            if (!(m2 <= rs.worst())) continue;
             if (sp < MAX_LEVELS) {
                 stk_node[sp] = other; stk_m[sp] = m2;
                 stk_0[sp] = cf == 0 ? cut : d0; stk_1[sp] = cf == 1 ? cut : d1; stk_2[sp] = cf == 2 ? cut : d2;
                 ++sp;
             } else atomicOr(&a.ctr[CTR_STATUS], ST_DEPTH_OVF);
-            node = best; na = a.node_a[node];
         }
         {   // leaf (:1275-1289)
             const float worst = rs.worst();
-            for (int i = na.x; i < na.y; ++i) {
-                const float4 p = a.sorted[i];
-                const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
-                if (dist < worst && dist < rs.worst()) rs.add(dist, __float_as_int(p.w));   // addPoint keeps nothing >= the current worst
+            for (int i0 = na.x; i0 < na.y; i0 += 4) {
+                float4 pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pv[u] = a.sorted[min(i0 + u, na.y - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + u < na.y) {
+                        const float4 p = pv[u];
+                        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                        float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+                        if (dist < worst && dist < rs.worst()) rs.add(dist, __float_as_int(p.w));   // addPoint keeps nothing >= the current worst
+                    }
+                }
             }
         }
         bool found = false;
         while (sp > 0) {
             --sp;
-            if (stk_m[sp] <= rs.worst()) { node = stk_node[sp]; mind = stk_m[sp]; d0 = stk_0[sp]; d1 = stk_1[sp]; d2 = stk_2[sp]; found = true; break; }
+            if (stk_m[sp] <= rs.worst()) {
+                node = stk_node[sp]; na = a.node_a[node]; nb = a.node_b[node];
+                mind = stk_m[sp]; d0 = stk_0[sp]; d1 = stk_1[sp]; d2 = stk_2[sp]; found = true; break;
+            }
         }
         if (!found) break;
     }
