@@ -76,8 +76,8 @@ __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
     if (tid == 0) {
         for (int d = 0; d < 3; ++d) { f.desc[t].lo[d] = mn[d]; f.desc[t].hi[d] = mx[d]; f.node_box[6 * t + d] = mn[d]; f.node_box[6 * t + 3 + d] = mx[d]; }
         f.desc[t].root = t;
-        f.node_a[t] = make_int4(voff, voff + n, -1, -1);
-        f.node_b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        f.node_a[2 * (size_t)(t)] = make_int4(voff, voff + n, -1, -1);
+        f.node_b[2 * (size_t)(t)] = make_float4(0.f, 0.f, 0.f, 0.f);
         f.node_tree[t] = t;
         if (n > SMALL_MAX) { int q = atomicAdd(&f.ctr[CTR_QUEUE0], 1); f.queue[q] = t; }
         else if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_SQ], 1); f.squeue[q] = t; }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
     }
     for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
         const int node = qin[qi];
-        const int4 na = f.node_a[node];
+        const int4 na = f.node_a[2 * (size_t)(node)];
         const int left = na.x, count = na.y - na.x;
         const int tree = f.node_tree[node];
         const float* P = f.desc[tree].pts;
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
         if (c1 >= 0 && tid < 2) {
             const int c = c1 + tid;
             const int cl = tid == 0 ? left : left + idx, cr = tid == 0 ? left + idx : left + count;
-            f.node_a[c] = make_int4(cl, cr, -1, -1);
-            f.node_b[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f.node_a[2 * (size_t)(c)] = make_int4(cl, cr, -1, -1);
+            f.node_b[2 * (size_t)(c)] = make_float4(0.f, 0.f, 0.f, 0.f);
             f.node_tree[c] = tree;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -186,14 +186,14 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
                 int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
                 if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
             } else if (cr - cl > LEAF_MAX) {
-                f.node_b[c] = make_float4(0.f, 0.f, 0.f, __int_as_float(level + 1));      // depth of this small root
+                f.node_b[2 * (size_t)(c)] = make_float4(0.f, 0.f, 0.f, __int_as_float(level + 1));      // depth of this small root
                 int q = atomicAdd(&f.ctr[CTR_SQ], 1);
                 if (q < 2 * f.queue_cap) f.squeue[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
             }
         }
         if (c1 >= 0 && tid == 0) {
-            f.node_a[node] = make_int4(na.x, na.y, c1, c1 + 1);
-            f.node_b[node] = make_float4(m3x[0], m3n[0], __int_as_float(cf), 0.f);
+            f.node_a[2 * (size_t)(node)] = make_int4(na.x, na.y, c1, c1 + 1);
+            f.node_b[2 * (size_t)(node)] = make_float4(m3x[0], m3n[0], __int_as_float(cf), 0.f);
         }
         __syncthreads();
     }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(BS) void kd_small_subtree_kernel(ForestPtrs f) {
     const int nq = min(f.ctr[CTR_SQ], 2 * f.queue_cap);
     for (int qi = blockIdx.x * (BS / 64) + wid; qi < nq; qi += gridDim.x * (BS / 64)) {     // waves are independent: no workgroup barrier below
         const int root = f.squeue[qi];
-        const int4 ra = f.node_a[root];
+        const int4 ra = f.node_a[2 * (size_t)(root)];
         const int left = ra.x, rcount = ra.y - ra.x, tree = f.node_tree[root];
         int id = 0; float c[3] = {0.f, 0.f, 0.f};
         if (lane < rcount) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(BS) void kd_small_subtree_kernel(ForestPtrs f) {
             for (int d = 0; d < 3; ++d) c[d] = P[(size_t)id * 3 + d];
         }
         if (lane == 0) {
-            SubEntry e; e.l = 0; e.r = rcount; e.node = root; e.depth = __float_as_int(f.node_b[root].w);
+            SubEntry e; e.l = 0; e.r = rcount; e.node = root; e.depth = __float_as_int(f.node_b[2 * (size_t)(root)].w);
 #pragma unroll
             for (int d = 0; d < 3; ++d) { e.lo[d] = f.node_box[6 * (size_t)root + d]; e.hi[d] = f.node_box[6 * (size_t)root + 3 + d]; }
             s_stk[wid][0] = e;
@@ -299,12 +299,12 @@ __global__ __launch_bounds__(BS) void kd_small_subtree_kernel(ForestPtrs f) {
             if (fits && lane < 2) {
                 const int cn = c1 + lane;
                 const int cl = lane == 0 ? l : m, cr = lane == 0 ? m : r;
-                f.node_a[cn] = make_int4(left + cl, left + cr, -1, -1);
-                f.node_b[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
+                f.node_a[2 * (size_t)(cn)] = make_int4(left + cl, left + cr, -1, -1);
+                f.node_b[2 * (size_t)(cn)] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (fits && lane == 0) {
-                f.node_a[node] = make_int4(left + l, left + r, c1, c1 + 1);
-                f.node_b[node] = make_float4(divlow, divhigh, __int_as_float(cf), 0.f);
+                f.node_a[2 * (size_t)(node)] = make_int4(left + l, left + r, c1, c1 + 1);
+                f.node_b[2 * (size_t)(node)] = make_float4(divlow, divhigh, __int_as_float(cf), 0.f);
                 maxdepth = max(maxdepth, e.depth + 1);
                 // open children: right first, so the left one is split next (order is irrelevant for the result)
                 if (r - m > LEAF_MAX && sp < SUB_STACK) {
@@ -397,7 +397,7 @@ __device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& t
     // Both halves of a node record are requested together (one memory round trip per level, not two) and the points
     // of a leaf four at a time: the walk is a chain of dependent loads, its latency is the whole cost.
     int node = td.root;
-    int4 na = a.node_a[node]; float4 nb = a.node_b[node];
+    int4 na = a.node_a[2 * (size_t)(node)]; float4 nb = a.node_b[2 * (size_t)(node)];
     for (;;) {
         while (na.z >= 0) {   // internal: take the near child, defer the far one (:1292-1326)
             const int cf = __float_as_int(nb.z);
@@ -406,7 +406,7 @@ __device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& t
             int best, other; float cut;
             if ((diff1 + diff2) < 0) { best = na.z; other = na.w; cut = (val - nb.y) * (val - nb.y); }
             else                     { best = na.w; other = na.z; cut = (val - nb.x) * (val - nb.x); }
-            node = best; na = a.node_a[node]; nb = a.node_b[node];
+            node = best; na = a.node_a[2 * (size_t)(node)]; nb = a.node_b[2 * (size_t)(node)];
             const float dst = cf == 0 ? d0 : (cf == 1 ? d1 : d2);
             const float m2 = mind + cut - dst;
             // nanoflann tests `mindistsq <= worstDist` when it comes back to the far child (:1319); worstDist only
@@ -439,7 +439,7 @@ __device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& t
         while (sp > 0) {
             --sp;
             if (stk_m[sp] <= rs.worst()) {
-                node = stk_node[sp]; na = a.node_a[node]; nb = a.node_b[node];
+                node = stk_node[sp]; na = a.node_a[2 * (size_t)(node)]; nb = a.node_b[2 * (size_t)(node)];
                 mind = stk_m[sp]; d0 = stk_0[sp]; d1 = stk_1[sp]; d2 = stk_2[sp]; found = true; break;
             }
         }
@@ -484,7 +484,8 @@ __global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) 
 ForestPtrs ptrs(const KdForest& f) {
     ForestPtrs p;
     p.desc = f.desc.as<KdTreeDesc>(); p.vind = f.vind.as<int>(); p.sorted = f.sorted.as<float4>();
-    p.node_a = f.node_a.as<int4>(); p.node_b = f.node_b.as<float4>(); p.node_box = f.node_box.as<float>();
+    p.node_a = f.node_a.as<int4>(); p.node_b = f.node_a.as<float4>() + 1;      // one 32-byte record per node: {int4 a; float4 b}, both pointers stride 2
+    p.node_box = f.node_box.as<float>();
     p.node_tree = f.node_tree.as<int>(); p.queue = f.queue.as<int>(); p.ctr = f.counters.as<int>();
     p.tmp = f.tmp.as<int>(); p.val = f.val.as<float>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
     p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap; p.ntrees = f.ntrees;
@@ -504,7 +505,7 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     SSDR_TRY(f.desc.reserve(sizeof(KdTreeDesc) * (trees.size() + 1)));
     SSDR_TRY(f.vind.reserve(4 * tp)); SSDR_TRY(f.sorted.reserve(16 * tp));
     SSDR_TRY(f.tmp.reserve(4 * tp)); SSDR_TRY(f.val.reserve(4 * tp));
-    SSDR_TRY(f.node_a.reserve(16 * (size_t)f.node_cap)); SSDR_TRY(f.node_b.reserve(16 * (size_t)f.node_cap));
+    SSDR_TRY(f.node_a.reserve(32 * (size_t)f.node_cap));
     SSDR_TRY(f.node_box.reserve(24 * (size_t)f.node_cap)); SSDR_TRY(f.node_tree.reserve(4 * (size_t)f.node_cap));
     SSDR_TRY(f.queue.reserve(16 * (size_t)f.queue_cap));
     SSDR_TRY(f.counters.reserve(4 * CTR_TOTAL));

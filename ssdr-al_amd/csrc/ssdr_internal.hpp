@@ -89,7 +89,7 @@ struct KdTreeDesc {      // one independent support set
 };
 
 struct KdForest {
-    DevBuf desc, vind, sorted, node_a, node_b, node_box, node_tree, queue, counters, tmp, val;
+    DevBuf desc, vind, sorted, node_a, node_box, node_tree, queue, counters, tmp, val;     // node_a: 32-byte records {int4 range+children; float4 divlow, divhigh, dim, -}
     KdTreeDesc* staging = nullptr; size_t staging_cap = 0; hipEvent_t staging_ev = nullptr;
     int ntrees = 0;
     int total_pts = 0;
