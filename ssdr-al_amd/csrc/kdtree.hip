@@ -11,8 +11,9 @@
 //           planeSplit sweeps (:948-975) are replaced by an equivalent closed form: the k-th
 //           misplaced element from the left swaps with the k-th misplaced element from the right,
 //           which wavefront ballots + prefix sums compute in parallel and which yields the same
-//           permutation of `vind` (tests/test_kdtree_*.py compare it with the oracle element by
-//           element).
+//           permutation of `vind` (tests/test_knn.py compares it with the oracle element by element).
+//           vind is not stored as such: every position holds a 16-byte record (x, y, z, index) that is
+//           permuted as a whole, so all build passes stream and leaf scans are contiguous loads.
 //   search  one lane per query, explicit stack, the visiting order of searchLevel (:1271-1329) and
 //           the insertion rule of KNNResultSet::addPoint (:63-92).  Queries are taken in tree order
 //           so the 64 lanes of a wavefront walk neighbouring leaves.
@@ -40,24 +41,22 @@ constexpr int ST_QUEUE_OVF = 1, ST_NODE_OVF = 2, ST_DEPTH_OVF = 4;
 // hold `lim - start` elements with left(i) == true; the k-th left-side element with !left swaps with the
 // k-th right-side element (counted from the right end) with left.
 template <int NT, class Left>
-__device__ void hoare_sweep(int* ind, float* val, int* tmp, int start, int end, int lim, Left left,
-                            int (*s_w)[U][NT / 64]) {
+__device__ void hoare_sweep(float4* rec, int* tmp, int start, int end, int lim, Left left, int (*s_w)[U][NT / 64]) {
     int m = block_compact<NT>(start, lim, [&](int i) { return !left(i); },
                               [&](int k, int i) { tmp[start + k] = i; }, s_w);
     if (m == 0) return;   // uniform
     block_compact<NT>(lim, end, [&](int i) { return left(i); },
                       [&](int k, int i) { tmp[start + m + (m - 1 - k)] = i; }, s_w);
     for (int k = threadIdx.x; k < m; k += NT) {
-        int a = tmp[start + k], b = tmp[start + m + k];
-        int ia = ind[a], ib = ind[b]; ind[a] = ib; ind[b] = ia;
-        float va = val[a], vb = val[b]; val[a] = vb; val[b] = va;
+        const int a = tmp[start + k], b = tmp[start + m + k];
+        const float4 ra = rec[a], rb = rec[b]; rec[a] = rb; rec[b] = ra;
     }
     __syncthreads();
 }
 
 struct ForestPtrs {
-    KdTreeDesc* desc; int* vind; float4* sorted; int4* node_a; float4* node_b; float* node_box; int* node_tree;
-    int* queue; int* ctr; int* tmp; float* val; int node_cap; int queue_cap;
+    KdTreeDesc* desc; float4* sorted; int4* node_a; float4* node_b; float* node_box; int* node_tree;
+    int* queue; int* ctr; int* tmp; int node_cap; int queue_cap;
     int* squeue;     // open nodes with <= SMALL_MAX points, [2][queue_cap]
     int ntrees;
 };
@@ -68,9 +67,9 @@ __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
     const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = tid; i < n; i += BS) {
-        f.vind[voff + i] = i;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { float v = P[3 * (size_t)i + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+        const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+        f.sorted[voff + i] = make_float4(x, y, z, __int_as_float(i));      // vind[i] = i, the point travels with its index
+        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x); mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y); mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
     }
     block_minmax3(mn, mx, s_mm);
     if (tid == 0) {
@@ -107,18 +106,24 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
         const int4 na = f.node_a[2 * (size_t)(node)];
         const int left = na.x, count = na.y - na.x;
         const int tree = f.node_tree[node];
-        const float* P = f.desc[tree].pts;
-        int* ind = f.vind + left; float* val = f.val + left; int* tmp = f.tmp + left;
+        float4* S = f.sorted + left; int* tmp = f.tmp + left;
+        const float* Sf = reinterpret_cast<const float*>(S);
         float lo[3], hi[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) { lo[d] = f.node_box[6 * (size_t)node + d]; hi[d] = f.node_box[6 * (size_t)node + 3 + d]; }
 
-        // computeMinMax (:837-846) for all three dimensions at once
+        // computeMinMax (:837-846) for all three dimensions at once; the records are in position order, so every pass
+        // streams (four 16-byte loads in flight per thread)
         float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int i = tid; i < count; i += NT) {
-            const size_t p = (size_t)ind[i] * 3;
+        for (int i0 = tid; i0 < count; i0 += 4 * NT) {
+            float4 v[4];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { float v = P[p + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+            for (int u = 0; u < 4; ++u) v[u] = S[min(i0 + u * NT, count - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mn[0] = fminf(mn[0], v[u].x); mx[0] = fmaxf(mx[0], v[u].x); mn[1] = fminf(mn[1], v[u].y); mx[1] = fmaxf(mx[1], v[u].y);
+                mn[2] = fminf(mn[2], v[u].z); mx[2] = fmaxf(mx[2], v[u].z);
+            }
         }
         block_minmax3<NT>(mn, mx, s_mm);
 
@@ -140,26 +145,35 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
         const float split_val = (lo_c + hi_c) / 2;
         const float cut = split_val < mn_c ? mn_c : (split_val > mx_c ? mx_c : split_val);
 
-        // stage the cut coordinate by position; count "< cut" and "== cut"
+        // count "< cut" and "== cut"
         int cL = 0, cE = 0;
-        for (int i = tid; i < count; i += NT) {
-            float v = P[(size_t)ind[i] * 3 + cf];
-            val[i] = v; cL += v < cut; cE += v == cut;
+        for (int i0 = tid; i0 < count; i0 += 4 * NT) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = Sf[4 * (size_t)min(i0 + u * NT, count - 1) + cf];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + u * NT < count) { cL += v[u] < cut; cE += v[u] == cut; }
         }
-        block_sum2<NT>(cL, cE, s_sum);   // barrier inside also publishes val[]
+        block_sum2<NT>(cL, cE, s_sum);
 
         // planeSplit (:948-975)
         const int lim1 = cL, lim2 = cL + cE;
-        hoare_sweep<NT>(ind, val, tmp, 0, count, lim1, [&](int i) { return val[i] < cut; }, s_w);
-        if (cE > 0) hoare_sweep<NT>(ind, val, tmp, lim1, count, lim2, [&](int i) { return val[i] <= cut; }, s_w);
+        hoare_sweep<NT>(S, tmp, 0, count, lim1, [&](int i) { return Sf[4 * (size_t)i + cf] < cut; }, s_w);
+        if (cE > 0) hoare_sweep<NT>(S, tmp, lim1, count, lim2, [&](int i) { return Sf[4 * (size_t)i + cf] <= cut; }, s_w);
         int idx;
         if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
 
         // tight child boxes along the cut dimension (:878-882): divlow = max over left, divhigh = min over right
         float m3n[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, m3x[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int i = tid; i < count; i += NT) {
-            float v = val[i];
-            if (i < idx) m3x[0] = fmaxf(m3x[0], v); else m3n[0] = fminf(m3n[0], v);
+        for (int i0 = tid; i0 < count; i0 += 4 * NT) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = Sf[4 * (size_t)min(i0 + u * NT, count - 1) + cf];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT;
+                if (i < idx) m3x[0] = fmaxf(m3x[0], v[u]); else if (i < count) m3n[0] = fminf(m3n[0], v[u]);
+            }
         }
         block_minmax3<NT>(m3n, m3x, s_mm);
 
@@ -218,14 +232,9 @@ __global__ __launch_bounds__(BS) void kd_small_subtree_kernel(ForestPtrs f) {
     for (int qi = blockIdx.x * (BS / 64) + wid; qi < nq; qi += gridDim.x * (BS / 64)) {     // waves are independent: no workgroup barrier below
         const int root = f.squeue[qi];
         const int4 ra = f.node_a[2 * (size_t)(root)];
-        const int left = ra.x, rcount = ra.y - ra.x, tree = f.node_tree[root];
+        const int left = ra.x, rcount = ra.y - ra.x;
         int id = 0; float c[3] = {0.f, 0.f, 0.f};
-        if (lane < rcount) {
-            id = f.vind[left + lane];
-            const float* P = f.desc[tree].pts;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) c[d] = P[(size_t)id * 3 + d];
-        }
+        if (lane < rcount) { const float4 r4 = f.sorted[left + lane]; c[0] = r4.x; c[1] = r4.y; c[2] = r4.z; id = __float_as_int(r4.w); }
         if (lane == 0) {
             SubEntry e; e.l = 0; e.r = rcount; e.node = root; e.depth = __float_as_int(f.node_b[2 * (size_t)(root)].w);
 #pragma unroll
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(BS) void kd_small_subtree_kernel(ForestPtrs f) {
             if (fits) sp += (r - m > LEAF_MAX ? 1 : 0) + (m - l > LEAF_MAX ? 1 : 0);
             if (sp > SUB_STACK) { sp = SUB_STACK; if (lane == 0) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF); }
         }
-        if (lane < rcount) f.vind[left + lane] = id;
+        if (lane < rcount) f.sorted[left + lane] = make_float4(c[0], c[1], c[2], __int_as_float(id));
         if (lane == 0) {
             atomicMax(&f.ctr[CTR_DEPTH], maxdepth);
             if (maxdepth >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
@@ -331,20 +340,9 @@ __global__ __launch_bounds__(BS) void kd_small_subtree_kernel(ForestPtrs f) {
     }
 }
 
-// Points re-ordered by vind, index in .w: leaf scans become contiguous 16-byte loads.
-__global__ void kd_sort_points_kernel(ForestPtrs f, int ntrees) {
-    for (int t = blockIdx.y; t < ntrees; t += gridDim.y) {
-        const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-            int id = f.vind[voff + i];
-            f.sorted[voff + i] = make_float4(P[3 * (size_t)id], P[3 * (size_t)id + 1], P[3 * (size_t)id + 2], __int_as_float(id));
-        }
-    }
-}
-
 // ---- search -------------------------------------------------------------------------------------
 struct SearchArgs {
-    const KdTreeDesc* desc; const int* vind; const float4* sorted; const int4* node_a; const float4* node_b;
+    const KdTreeDesc* desc; const float4* sorted; const int4* node_a; const float4* node_b;
     int tree0; const float* queries; size_t q_stride; int nq; int qorder_tree0; void* out; size_t out_stride; int* ctr;
 };
 
@@ -454,7 +452,7 @@ __global__ __launch_bounds__(256) void kd_search_kernel(SearchArgs a) {
     if (qi >= a.nq) return;
     const KdTreeDesc td = a.desc[a.tree0 + t];
     int q = qi;
-    if (a.qorder_tree0 >= 0) q = a.vind[a.desc[a.qorder_tree0 + t].voff + qi];
+    if (a.qorder_tree0 >= 0) q = __float_as_int(a.sorted[a.desc[a.qorder_tree0 + t].voff + qi].w);
     const float* Q = a.queries + (size_t)t * a.q_stride + 3 * (size_t)q;
     const float qx = Q[0], qy = Q[1], qz = Q[2];
     RegSet<K> rs; rs.init();
@@ -472,7 +470,7 @@ __global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) 
     if (qi >= a.nq) return;
     const KdTreeDesc td = a.desc[a.tree0 + t];
     int q = qi;
-    if (a.qorder_tree0 >= 0) q = a.vind[a.desc[a.qorder_tree0 + t].voff + qi];
+    if (a.qorder_tree0 >= 0) q = __float_as_int(a.sorted[a.desc[a.qorder_tree0 + t].voff + qi].w);
     const float* Q = a.queries + (size_t)t * a.q_stride + 3 * (size_t)q;
     LdsSet rs; rs.K = K; rs.d = s_dyn + threadIdx.x; rs.id = reinterpret_cast<int*>(s_dyn + 64 * K) + threadIdx.x;
     rs.init();
@@ -483,11 +481,11 @@ __global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) 
 
 ForestPtrs ptrs(const KdForest& f) {
     ForestPtrs p;
-    p.desc = f.desc.as<KdTreeDesc>(); p.vind = f.vind.as<int>(); p.sorted = f.sorted.as<float4>();
+    p.desc = f.desc.as<KdTreeDesc>(); p.sorted = f.sorted.as<float4>();
     p.node_a = f.node_a.as<int4>(); p.node_b = f.node_a.as<float4>() + 1;      // one 32-byte record per node: {int4 a; float4 b}, both pointers stride 2
     p.node_box = f.node_box.as<float>();
     p.node_tree = f.node_tree.as<int>(); p.queue = f.queue.as<int>(); p.ctr = f.counters.as<int>();
-    p.tmp = f.tmp.as<int>(); p.val = f.val.as<float>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
+    p.tmp = f.tmp.as<int>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
     p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap; p.ntrees = f.ntrees;
     return p;
 }
@@ -503,8 +501,7 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     f.queue_cap = (int)(total / (LEAF_MAX + 1)) + f.ntrees + 16;
     const size_t tp = (size_t)(total ? total : 1);
     SSDR_TRY(f.desc.reserve(sizeof(KdTreeDesc) * (trees.size() + 1)));
-    SSDR_TRY(f.vind.reserve(4 * tp)); SSDR_TRY(f.sorted.reserve(16 * tp));
-    SSDR_TRY(f.tmp.reserve(4 * tp)); SSDR_TRY(f.val.reserve(4 * tp));
+    SSDR_TRY(f.sorted.reserve(16 * tp)); SSDR_TRY(f.tmp.reserve(4 * tp));
     SSDR_TRY(f.node_a.reserve(32 * (size_t)f.node_cap));
     SSDR_TRY(f.node_box.reserve(24 * (size_t)f.node_cap)); SSDR_TRY(f.node_tree.reserve(4 * (size_t)f.node_cap));
     SSDR_TRY(f.queue.reserve(16 * (size_t)f.queue_cap));
@@ -533,9 +530,6 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
         else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);
     }
     hipLaunchKernelGGL(kd_small_subtree_kernel, dim3(std::max(1, std::min(f.queue_cap / 2 + 1, ctx().num_cu * 16))), dim3(BS), 0, s, p);
-    int maxn = 0; for (auto& t : trees) maxn = std::max(maxn, t.n);
-    dim3 g((unsigned)std::max(1, std::min((maxn + 255) / 256, 64)), (unsigned)std::min(f.ntrees, 65535));
-    hipLaunchKernelGGL(kd_sort_points_kernel, g, dim3(256), 0, s, p, f.ntrees);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
@@ -545,7 +539,7 @@ int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, 
     if (ntrees <= 0 || nq <= 0 || K <= 0) return SSDR_OK;
     if (K > 256) { set_error("K=%d > 256 is not supported", K); return SSDR_ERR_UNSUPPORTED; }
     ForestPtrs p = ptrs(f);
-    SearchArgs a{p.desc, p.vind, p.sorted, p.node_a, p.node_b, tree0, d_queries, q_stride, nq, qorder_tree0, d_out, out_stride, p.ctr};
+    SearchArgs a{p.desc, p.sorted, p.node_a, p.node_b, tree0, d_queries, q_stride, nq, qorder_tree0, d_out, out_stride, p.ctr};
     dim3 grid((unsigned)((nq + 255) / 256), (unsigned)ntrees);
     // algorithmic bytes: support + query coordinates read once, indices written once
     long support = 0;   // not known on the host per tree without the descriptors; callers pass uniform trees

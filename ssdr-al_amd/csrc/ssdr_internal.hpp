@@ -83,13 +83,13 @@ struct RadixSorter {
 struct KdTreeDesc {      // one independent support set
     const float* pts;    // device pointer, n x 3 row-major
     int n;
-    int voff;            // offset of this tree's slice in vind / sorted
+    int voff;            // offset of this tree's slice in `sorted` (position-ordered point records: x, y, z, index)
     int root;            // node id of the root
     float lo[3], hi[3];  // tight root box
 };
 
 struct KdForest {
-    DevBuf desc, vind, sorted, node_a, node_box, node_tree, queue, counters, tmp, val;     // node_a: 32-byte records {int4 range+children; float4 divlow, divhigh, dim, -}
+    DevBuf desc, sorted, node_a, node_box, node_tree, queue, counters, tmp;     // node_a: 32-byte records {int4 range+children; float4 divlow, divhigh, dim, -}
     KdTreeDesc* staging = nullptr; size_t staging_cap = 0; hipEvent_t staging_ev = nullptr;
     int ntrees = 0;
     int total_pts = 0;
