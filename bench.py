@@ -39,8 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the batches strictly one after the other")
-    ap.add_argument("--pipeline-depth", type=int, default=2, choices=(2, 3))
-    ap.add_argument("--front-streams", type=int, default=4)
+    ap.add_argument("--pipeline-depth", type=int, default=5, choices=(2, 3, 4, 5), help="batches in flight (stages on separate HIP streams)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
     args = ap.parse_args()
 
@@ -75,25 +74,24 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    # N = 1: consecutive batches are software-pipelined (selection of batch k next to the front end .. scoring of
-    # batch k+1, two buffer sets); every batch runs every stage and all K selections finish inside the timed region.
+    # Consecutive batches are software-pipelined over the stages (front end | KNN pyramid | network | scoring | selection
+    # on separate HIP streams, one buffer set per batch in flight); every batch runs every stage and all K selections
+    # finish inside the timed region.  N > 1: the three small exchanges stay host-synchronous, in the same order on every rank.
     pipe = None
-    if world == 1 and not args.no_pipeline:
+    if not args.no_pipeline:
         ids = [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)]
         def mk():
-            h = pipeline.HotPath(weights, ConfigS3DIS)
-            h.num_streams = args.front_streams
-            return h.load_rooms(rooms, ids)
+            return pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms, ids)
         pipe = pipeline.Pipelined(mk, args.pipeline_depth)
     if pipe is not None:
-        pipe.run(max(args.warmup, 1))
+        pipe.run(max(args.warmup, 1), gather)
     else:
         for _ in range(args.warmup):
             hp.step(gather)
     barrier()
     t0 = time.perf_counter()
     if pipe is not None:
-        pipe.run(args.steps)
+        pipe.run(args.steps, gather)
     else:
         for _ in range(args.steps):
             hp.step(gather)
@@ -188,7 +186,7 @@ def main():
                                       "ranking -> FPS-GCN select (gcn_number=1)" % TILES_PER_GPU,
                           "tiles_per_gpu": TILES_PER_GPU, "tile_points": ConfigS3DIS.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
                           "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * TILES_PER_GPU * world), "sharding": "tiles",
-                          "batches_overlapped": bool(pipe is not None)},
+                          "batches_in_flight": args.pipeline_depth if pipe is not None else 1},
                "stage_ms": stage_ms, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

@@ -23,9 +23,10 @@ class HotPath:
         self.gcn_number, self.gcn_top = gcn_number, gcn_top
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
         self.seed = seed
-        self.num_streams = 4
         self.stream = None          # stream of the pyramid .. scoring stages (None = the library's main stream)
-        self.front_stream = None    # stream the per-room front end forks from / joins to
+        self.front_stream = None    # stream of the front end (grid-subsample + tiles)
+        self.knn_stream = None      # stream of the KNN pyramid (None = self.stream)
+        self.score_stream = None    # stream of the scoring stage (None = self.stream)
         self.global_order = None
         self.rooms = []
         self.timing = None
@@ -114,7 +115,8 @@ class HotPath:
         arr = C.c_void_p * cfg.num_layers
         r = np.asarray(cfg.sub_sampling_ratio, np.int32)
         _lib.check(_lib.lib().ssdr_knn_pyramid_dev(self.xyz.ptr, self.B, cfg.num_points, cfg.num_layers, _lib.ptr(r), cfg.k_n,
-                                                   arr(*[a.ptr for a in self.neigh]), None, arr(*[a.ptr for a in self.interp]), self.stream))
+                                                   arr(*[a.ptr for a in self.neigh]), None, arr(*[a.ptr for a in self.interp]),
+                                                   self.knn_stream if self.knn_stream is not None else self.stream))
 
     def _infer(self):
         self.net.infer_dev(self.B, self.cfg.num_points, self.feat.ptr, self.xyz.ptr, [a.ptr for a in self.neigh], [a.ptr for a in self.interp],
@@ -125,7 +127,7 @@ class HotPath:
         n = self.B * cfg.num_points
         um = {"lc": 0, "entropy": 1, "sb": 2}[[a for a in self.sampler_args if a in ("lc", "entropy", "sb")][0]]
         rm = {"mean": 0, "sum_weight": 1, "WetSU": 2}[[a for a in self.sampler_args if a in ("mean", "sum_weight", "WetSU")][0]]
-        st = self.stream
+        st = self.score_stream if self.score_stream is not None else self.stream
         _lib.check(L.ssdr_point_uncertainty_dev(self.probs.ptr, n, cfg.num_classes, um, self.unc.ptr, self.cls.ptr, st))
         _lib.check(L.ssdr_region_stats_dev(self.unc.ptr, self.cls.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, cfg.num_classes, rm,
                                            self.region_unc.ptr, self.dom.ptr, self.dom_cnt.ptr, st))
@@ -134,24 +136,24 @@ class HotPath:
             if comm is None:
                 _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, st))
             else:       # exchange 1: the class histogram is global (the already-selected list is counted once, on rank 0)
-                _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, None))
-                _lib.sync()
+                _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, st))
+                _lib.sync(st)
                 h = comm.allreduce_sum(np.concatenate([self.hist.to_host().astype(np.int64), [self.S]]))
                 self.hist = DevArray.from_host(h[:64].astype(np.int32))
-                _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, int(h[64]) + nsel, self.region_unc.ptr, None))
+                _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, int(h[64]) + nsel, self.region_unc.ptr, st))
         if comm is None:
             _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, st))
             self.global_order = None
         else:           # exchange 2: rank the regions of ALL ranks; labelled regions are taken out before the cut
-            _lib.sync()
+            _lib.sync(st)
             u = self.region_unc.to_host()
             lab = np.zeros(self.S, bool)
             for b in self.labeled:
                 lab[list(self.labeled[b])] = True
             allu, counts = comm.allgather_var(np.where(lab, -np.inf, u))
             d_all = DevArray.from_host(allu); d_ord = DevArray((len(allu),), np.int32)
-            _lib.check(L.ssdr_rank_regions_dev(d_all.ptr, len(allu), d_ord.ptr, None))
-            _lib.sync()
+            _lib.check(L.ssdr_rank_regions_dev(d_all.ptr, len(allu), d_ord.ptr, st))
+            _lib.sync(st)
             base = int(sum(counts[: comm.rank]))
             self.global_order = (d_ord.to_host(), allu, base, self.select_per_tile * self.B * comm.world)
 
@@ -254,54 +256,69 @@ class HotPath:
 
 
 class Pipelined:
-    """Overlap consecutive batches on separate buffer sets and HIP streams.
-    depth 2: the selection of batch k (latency-bound: host decisions, one workgroup of FPS) on the main stream next to
-             front end + KNN pyramid + network + scoring of batch k+1 on a second stream;
-    depth 3: additionally the per-room front end of batch k+2 on a third stream.
+    """Overlap consecutive batches on separate buffer sets and HIP streams (software pipeline over the stages
+    front end | KNN pyramid | network | scoring | selection).  `depth` batches are in flight:
+    depth 2: selection of batch k (latency-bound: host decisions, one workgroup of FPS) on the main stream next to
+             everything else of batch k+1 on a second stream;
+    depth 3: front end (subsample + tiles) on its own stream, one batch further ahead;
+    depth 4: KNN pyramid on its own stream too;   depth 5: and scoring apart from the network.
     Every batch still goes through every stage; `run(K)` finishes K selections."""
+    STAGES = ("front", "knn", "infer", "score")
+    GROUPS = {2: (0, 0, 0, 0), 3: (0, 1, 1, 1), 4: (0, 1, 2, 2), 5: (0, 1, 2, 3)}     # stage -> stream group
 
-    def __init__(self, make_hot_path, depth=2):
-        assert depth in (2, 3)
+    def __init__(self, make_hot_path, depth=5):
+        assert depth in self.GROUPS
         L = _lib.lib()
         self.depth = depth
-        sc = C.c_void_p()
-        _lib.check(L.ssdr_stream_create(C.byref(sc)))
-        self.sc = self.sf = sc.value
-        if depth == 3:
-            sf = C.c_void_p()
-            _lib.check(L.ssdr_stream_create(C.byref(sf)))
-            self.sf = sf.value
+        self.group = dict(zip(self.STAGES, self.GROUPS[depth]))
+        # The first stream created after the library's own shares its hardware queue on this runtime (measured on
+        # MI355X / ROCm 7.2: whatever stage sat on it serialised with the selection kernels of the main stream, 67 vs
+        # 81 Mpoints/s at depth 4, for any GPU_MAX_HW_QUEUES): leave that one unused.
+        self._spare = C.c_void_p()
+        _lib.check(L.ssdr_stream_create(C.byref(self._spare)))
+        self.streams = []
+        for _ in range(depth - 1):
+            st = C.c_void_p()
+            _lib.check(L.ssdr_stream_create(C.byref(st)))
+            self.streams.append(st.value)
+        self.lead = {n: depth - 1 - g for n, g in self.group.items()}      # batches ahead of the selection
         self.hp = [make_hot_path() for _ in range(depth)]
         for h in self.hp:
-            h.stream, h.front_stream = self.sc, self.sf
+            h.front_stream, h.knn_stream = self.streams[self.group["front"]], self.streams[self.group["knn"]]
+            h.stream, h.score_stream = self.streams[self.group["infer"]], self.streams[self.group["score"]]
         self._drain()
 
     def _drain(self):
-        _lib.sync(); _lib.sync(self.sf); _lib.sync(self.sc)
+        _lib.sync()
+        for st in self.streams:
+            _lib.sync(st)
 
-    def _front(self, h):
-        h._front_end()
+    def _stage(self, name, b):
+        """enqueue one stage of batch b; a consumer stream first waits for everything its producer stream holds so far"""
+        h = self.hp[b % self.depth]
+        i = self.STAGES.index(name)
+        if i > 0 and self.group[name] != self.group[self.STAGES[i - 1]]:
+            _lib.check(_lib.lib().ssdr_stream_wait(self.streams[self.group[name]], self.streams[self.group[self.STAGES[i - 1]]]))
+        if name == "score":
+            h._score(self.comm)       # with a communicator: host-synchronous (two small exchanges), same order on every rank
+        else:
+            {"front": h._front_end, "knn": h._pyramid, "infer": h._infer}[name]()
 
-    def _compute(self, h):
-        if self.sf != self.sc:
-            _lib.check(_lib.lib().ssdr_stream_wait(self.sc, self.sf))  # this batch's tiles (everything on sf so far)
-        h._pyramid(); h._infer(); h._score()
-
-    def run(self, steps):
+    def run(self, steps, comm=None):
+        self.comm = comm
         L = _lib.lib()
         out = None
-        hp, d = self.hp, self.depth
-        self._front(hp[0]); self._compute(hp[0])
-        if d == 3 and steps > 1:
-            self._front(hp[1])
+        lead, first = self.lead, self.lead["front"]
+        for b in range(min(steps, first)):                   # prologue: fill the pipe
+            for name in self.STAGES:
+                if b < lead[name]:
+                    self._stage(name, b)
         for k in range(steps):
-            _lib.check(L.ssdr_stream_wait(None, self.sc))               # main stream: batch k's scores are ready
-            if k + 1 < steps:
-                if d == 2:
-                    self._front(hp[(k + 1) % d])
-                self._compute(hp[(k + 1) % d])                            # batch k+1: (front end,) pyramid + network + scoring
-            if d == 3 and k + 2 < steps:
-                self._front(hp[(k + 2) % d])                              # batch k+2: subsample + tiles (its set was last read by select(k-1))
-            out = hp[k % d]._select()                                     # batch k: selection (host-synchronous)
+            _lib.check(L.ssdr_stream_wait(None, self.streams[self.group["score"]]))    # main stream: batch k's scores are ready
+            for b in range(k + 1, min(steps, k + first + 1)):
+                for name in self.STAGES:
+                    if b == k + lead[name]:
+                        self._stage(name, b)                 # the buffer set of batch b was last read by select(b - depth), done
+            out = self.hp[k % self.depth]._select(comm)      # batch k: selection (host-synchronous)
         self._drain()
         return out

@@ -27,8 +27,12 @@ def main():
     all_rooms = [synthetic.make_room(7000 + i, density=80.0) for i in range(per * world)]
     mine = list(range(rank * per, (rank + 1) * per))
     hp = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine)
-    sel, unl = hp.step(Comm(dist, "cpu"))
-    res = {"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
+    comm = Comm(dist, "cpu")
+    sel, unl = hp.step(comm)
+    # the same batches kept in flight on separate streams, exchanges included (what bench.py runs for N > 1)
+    pipe = pipeline.Pipelined(lambda: pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine), 3)
+    psel, _ = pipe.run(2, comm)
+    res = {"pipelined_equal": bool(np.array_equal(psel, sel)), "pipelined_selected": pipe.hp[1].selected,"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
            "expect": [int(x) for x in S.farthest_features_sample(hp.comb_all, len(sel), 0)]}
     if rank == 0:      # the same job in ONE process over the union of the rooms
         one = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms(all_rooms, list(range(per * world)))

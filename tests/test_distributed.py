@@ -20,3 +20,4 @@ def test_two_rank_sharded_selection_equals_single_process(tmp_path, emu_lib):
     assert len(r[0]["selected"]) == 20 and len(set(map(tuple, r[0]["selected"]))) == 20
     assert {c for c, _ in r[0]["selected"]} <= {0, 1, 2, 3}
     assert r[0]["selected"] == r[0]["single"]          # sharded == single process, index for index
+    assert all(x["pipelined_equal"] and x["pipelined_selected"] == x["selected"] for x in r)    # batches in flight: same result
