@@ -24,6 +24,7 @@ namespace ssdr {
 namespace {
 
 constexpr int LAB_CAP = 29;
+constexpr int REC_W = 8;        // words of a packed point record (rows of at most 8 words: the hot path's 3 + 3 + 1)
 constexpr int GS_UNROLL = 8;    // gathers in flight per lane in the voxel reductions (a lane's loop is a latency chain otherwise)
 
 struct GsParams {
@@ -68,16 +69,35 @@ __device__ __forceinline__ void gs_params_body(const float* partial, int nparts,
     }
 }
 
-__device__ __forceinline__ void gs_keys_body(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals) {
+// With `rec` the kernel also packs every point's row (xyz, features, labels; at most REC_W words) into one 32-byte
+// record: the per-voxel reduction then gathers ONE memory sector per point in sorted order instead of one from each of
+// three arrays (PMC: the three-array reduction fetched 6-11x its algorithmic bytes, a random 4-12 byte read pays for a
+// whole sector).
+__device__ __forceinline__ void gs_keys_body(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals,
+                                              const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) {
     const float ox = prm->org[0], oy = prm->org[1], oz = prm->org[2], dl = prm->dl;
     const unsigned long long nx = prm->nx, ny = prm->ny;
     for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
+        const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
         // grid_subsampling.cpp:53-56 (size_t arithmetic wraps)
-        const unsigned long long ix = (unsigned long long)(long long)floorf((P[3 * (size_t)i] - ox) / dl);
-        const unsigned long long iy = (unsigned long long)(long long)floorf((P[3 * (size_t)i + 1] - oy) / dl);
-        const unsigned long long iz = (unsigned long long)(long long)floorf((P[3 * (size_t)i + 2] - oz) / dl);
+        const unsigned long long ix = (unsigned long long)(long long)floorf((x - ox) / dl);
+        const unsigned long long iy = (unsigned long long)(long long)floorf((y - oy) / dl);
+        const unsigned long long iz = (unsigned long long)(long long)floorf((z - oz) / dl);
         keys[i] = ix + nx * iy + nx * ny * iz;
         vals[i] = (uint32_t)i;
+        if (rec) {
+            uint32_t w[REC_W];
+            w[0] = __float_as_uint(x); w[1] = __float_as_uint(y); w[2] = __float_as_uint(z);
+#pragma unroll
+            for (int k = 3; k < REC_W; ++k) {
+                uint32_t v = 0;
+                if (k - 3 < fdim) v = __float_as_uint(F[(size_t)i * fdim + (k - 3)]);
+                else if (k - 3 - fdim < ldim) v = (uint32_t)cls[(size_t)i * ldim + (k - 3 - fdim)];
+                w[k] = v;
+            }
+            uint4* r4 = reinterpret_cast<uint4*>(rec + (size_t)i * REC_W);
+            r4[0] = make_uint4(w[0], w[1], w[2], w[3]); r4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
     }
 }
 
@@ -246,10 +266,73 @@ __device__ __forceinline__ void gs_reduce_body(const float* __restrict__ P, cons
 }
 
 
+// The same reduction from packed records: 8 lanes per voxel, lane c owns word c of the record (coordinates and features
+// are summed in input order, label columns vote); one loop, one record gather per point serves all of them.  The vote
+// of a label lane is a packed byte-counter add per point (labels 0..12, at most 255 points); only a voxel whose
+// maximum is shared by two labels (the tie goes by first-seen order), or one outside those limits, is re-scanned by
+// the exact routines above.
+__device__ __forceinline__ void gs_reduce_packed_body(const uint32_t* __restrict__ rec, int fdim, int ldim,
+                                                       const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
+                                                       const int* __restrict__ row_of_voxel,
+                                                       float* out_p, float* out_f, int* out_c, long long* out_m) {
+    const int m = prm->m;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out_m) *out_m = m;
+    const int CH = 3 + fdim;
+    const long long total = (long long)m * REC_W;
+    for (long long e = (long long)blockIdx.x * BS + threadIdx.x; e < total; e += (long long)gridDim.x * BS) {
+        const int v = (int)(e / REC_W), c = (int)(e % REC_W);
+        if (c >= CH + ldim) continue;
+        const int s = seg_start[v], en = seg_start[v + 1];
+        const int count = en - s;
+        const int row = row_of_voxel ? row_of_voxel[v] : v;
+        const bool is_label = c >= CH;
+        float sum = 0.f;
+        unsigned long long pk0 = 0ull, pk1 = 0ull;          // byte counters of labels 0..7 / 8..15
+        bool exact = count > 255;                           // needs the exact routines
+        for (int j0 = s; j0 < en; j0 += GS_UNROLL) {        // GS_UNROLL gathers in flight, then the adds in input order
+            uint32_t wv[GS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < GS_UNROLL; ++u) wv[u] = rec[(size_t)vs[min(j0 + u, en - 1)] * REC_W + c];
+#pragma unroll
+            for (int u = 0; u < GS_UNROLL; ++u) {
+                if (j0 + u < en) {
+                    if (!is_label) sum += __uint_as_float(wv[u]);
+                    else {
+                        const unsigned L = wv[u];
+                        const unsigned long long inc = 1ull << ((L & 7u) * 8u);
+                        exact |= L >= 13u;
+                        pk0 += L < 8u ? inc : 0ull; pk1 += (L >= 8u && L < 16u) ? inc : 0ull;
+                    }
+                }
+            }
+        }
+        if (c < 3) {
+            const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
+            out_p[3 * (size_t)row + c] = sum * a;
+        } else if (!is_label) {
+            out_f[(size_t)row * fdim + (c - 3)] = sum / (float)count;      // :90-94
+        } else {
+            int best = 0, bestc = -1, nbest = 0;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                const int ck = (int)(((k < 8 ? pk0 : pk1) >> ((k & 7) * 8)) & 0xffull);
+                if (ck > bestc) { bestc = ck; best = k; nbest = 1; } else if (ck == bestc) ++nbest;
+            }
+            if (exact || nbest > 1) {
+                const int* rc = reinterpret_cast<const int*>(rec);
+                best = voxel_label_fast(rc, REC_W, c, vs, s, en);
+                if (best < 0) best = voxel_label(rc, REC_W, c, vs, s, en, &prm->status);
+            }
+            out_c[(size_t)row * ldim + (c - CH)] = best;
+        }
+    }
+}
+
 // ---- kernel entry points: one cloud, or all clouds of a batch (blockIdx.y = cloud) -----------------------------
 __global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict__ P, int n, float* partial) { gs_minmax_partial_body(P, n, partial); }
 __global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts, float dl, GsParams* prm) { gs_params_body(partial, nparts, dl, prm); }
-__global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals) { gs_keys_body(P, n, prm, keys, vals); }
+__global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) { gs_keys_body(P, n, prm, keys, vals, F, fdim, cls, ldim, rec); }
+__global__ __launch_bounds__(BS) void gs_reduce_packed(const uint32_t* __restrict__ rec, int fdim, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m) { gs_reduce_packed_body(rec, fdim, ldim, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m); }
 __global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict__ ks, int n, int* bsum) { gs_heads_count_body(ks, n, bsum); }
 __global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParams* prm, int* seg_start, int n) { gs_heads_scan_body(bsum, nb, prm, seg_start, n); }
 __global__ __launch_bounds__(BS) void gs_heads_write(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) { gs_heads_write_body(ks, n, bsum, seg_start); }
@@ -268,9 +351,17 @@ __global__ __launch_bounds__(BS) void gs_minmax_partial_b(CloudTab t, const floa
 __global__ __launch_bounds__(BS) void gs_params_b(const float* partial, float dl, GsParams* prm) {
     gs_params_body(partial + (size_t)blockIdx.x * PB * 6, PB, dl, prm + blockIdx.x);
 }
-__global__ __launch_bounds__(BS) void gs_keys_b(CloudTab t, const float* __restrict__ P, const GsParams* prm, uint64_t* keys, uint32_t* vals) {
-    const int r = blockIdx.y;
-    gs_keys_body(P + 3 * (size_t)t.off[r], t.off[r + 1] - t.off[r], prm + r, keys + t.toff[r], vals + t.toff[r]);
+__global__ __launch_bounds__(BS) void gs_keys_b(CloudTab t, const float* __restrict__ P, const GsParams* prm, uint64_t* keys, uint32_t* vals,
+                                                const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) {
+    const int r = blockIdx.y; const size_t o = (size_t)t.off[r];
+    gs_keys_body(P + 3 * o, t.off[r + 1] - t.off[r], prm + r, keys + t.toff[r], vals + t.toff[r],
+                 F ? F + o * fdim : nullptr, fdim, cls ? cls + o * ldim : nullptr, ldim, rec ? rec + o * REC_W : nullptr);
+}
+__global__ __launch_bounds__(BS) void gs_reduce_packed_b(CloudTab t, const uint32_t* __restrict__ rec, int fdim, int ldim, const uint32_t* __restrict__ vs,
+                                                         const int* __restrict__ seg_start, GsParams* prm, float* out_p, float* out_f, int* out_c, long long* out_m) {
+    const int r = blockIdx.y; const size_t o = (size_t)t.off[r];
+    gs_reduce_packed_body(rec + o * REC_W, fdim, ldim, vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr,
+                          out_p + 3 * o, out_f ? out_f + o * fdim : nullptr, out_c ? out_c + o * ldim : nullptr, out_m ? out_m + r : nullptr);
 }
 __global__ __launch_bounds__(BS) void gs_heads_count_b(CloudTab t, const uint64_t* __restrict__ ks, int* bsum, int nb_max) {
     const int r = blockIdx.y, n = t.off[r + 1] - t.off[r];
@@ -301,7 +392,7 @@ __global__ __launch_bounds__(BS) void gs_reduce_labels_b(CloudTab t, const int* 
 
 struct GsState {
     RadixSorter sorter;
-    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row;
+    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec;
     size_t last_m = 0, last_fdim = 0, last_ldim = 0;
 };
 GsState& gs(hipStream_t st = nullptr) { static std::map<hipStream_t, GsState> m; return m[st ? st : ctx().stream]; }
@@ -324,7 +415,10 @@ int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t f
     hipLaunchKernelGGL(gs_minmax_partial, dim3(gmm), dim3(BS), 0, s, d_p, ni, S.partial.as<float>());
     hipLaunchKernelGGL(gs_params, dim3(1), dim3(BS), 0, s, S.partial.as<float>(), gmm, dl, prm);
     const int g = std::max(1, std::min((ni + BS - 1) / BS, ctx().num_cu * 16));
-    hipLaunchKernelGGL(gs_keys, dim3(g), dim3(BS), 0, s, d_p, ni, prm, S.keys.as<uint64_t>(), S.vals.as<uint32_t>());
+    const bool packed = 3 + fdim + ldim <= (size_t)REC_W;      // rows of at most 8 words reduce from packed records
+    uint32_t* rec = nullptr;
+    if (packed) { SSDR_TRY(S.rec.reserve(4 * (size_t)REC_W * n + 16)); rec = S.rec.as<uint32_t>(); }
+    hipLaunchKernelGGL(gs_keys, dim3(g), dim3(BS), 0, s, d_p, ni, prm, S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), d_f, (int)fdim, (const int*)d_c, (int)ldim, rec);
     SSDR_TRY(S.sorter.sort(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), ni, nullptr, s));
     hipLaunchKernelGGL(gs_heads_count, dim3(nb), dim3(BS), 0, s, S.keys.as<uint64_t>(), ni, S.bsum.as<int>());
     hipLaunchKernelGGL(gs_heads_scan, dim3(1), dim3(1024), 0, s, S.bsum.as<int>(), nb, prm, S.seg.as<int>(), ni);
@@ -335,9 +429,13 @@ int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t f
         SSDR_TRY(subsample_order_reference(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), S.seg.as<int>(), &prm->m, ni, S.row.as<int>(), s));
         row = S.row.as<int>();
     }
-    hipLaunchKernelGGL(gs_reduce, dim3(g), dim3(BS), 0, s, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
-                       row, d_op, d_of, d_oc, (long long*)d_om, (uint64_t*)nullptr, S.keys.as<uint64_t>());
-    if (d_c) hipLaunchKernelGGL(gs_reduce_labels, dim3(g), dim3(BS), 0, s, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_oc);
+    if (packed) {
+        hipLaunchKernelGGL(gs_reduce_packed, dim3(g), dim3(BS), 0, s, rec, (int)fdim, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_op, d_of, d_oc, (long long*)d_om);
+    } else {
+        hipLaunchKernelGGL(gs_reduce, dim3(g), dim3(BS), 0, s, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
+                           row, d_op, d_of, d_oc, (long long*)d_om, (uint64_t*)nullptr, S.keys.as<uint64_t>());
+        if (d_c) hipLaunchKernelGGL(gs_reduce_labels, dim3(g), dim3(BS), 0, s, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_oc);
+    }
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
@@ -364,14 +462,21 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
     hipLaunchKernelGGL(gs_minmax_partial_b, dim3(PB, R), dim3(BS), 0, s, t, d_p, S.partial.as<float>());
     hipLaunchKernelGGL(gs_params_b, dim3(R), dim3(BS), 0, s, S.partial.as<float>(), dl, prm);
     const int g = std::max(1, std::min((maxn + BS - 1) / BS, 256));
-    hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, S.keys.as<uint64_t>(), S.vals.as<uint32_t>());
+    const bool packed = 3 + fdim + ldim <= (size_t)REC_W;
+    uint32_t* rec = nullptr;
+    if (packed) { SSDR_TRY(S.rec.reserve(4 * (size_t)REC_W * (size_t)room_off[nr] + 16)); rec = S.rec.as<uint32_t>(); }
+    hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), d_f, (int)fdim, (const int*)d_c, (int)ldim, rec);
     SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), (int)nr, t.toff, n_host.data(), nullptr, s));
     hipLaunchKernelGGL(gs_heads_count_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max);
     hipLaunchKernelGGL(gs_heads_scan_b, dim3(R), dim3(1024), 0, s, t, S.bsum.as<int>(), nb_max, prm, S.seg.as<int>());
     hipLaunchKernelGGL(gs_heads_write_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, S.seg.as<int>());
-    hipLaunchKernelGGL(gs_reduce_b, dim3(g, R), dim3(BS), 0, s, t, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
-                       d_op, d_of, d_oc, (long long*)d_om);
-    if (d_c) hipLaunchKernelGGL(gs_reduce_labels_b, dim3(g, R), dim3(BS), 0, s, t, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, d_oc);
+    if (packed) {
+        hipLaunchKernelGGL(gs_reduce_packed_b, dim3(g, R), dim3(BS), 0, s, t, rec, (int)fdim, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, d_op, d_of, d_oc, (long long*)d_om);
+    } else {
+        hipLaunchKernelGGL(gs_reduce_b, dim3(g, R), dim3(BS), 0, s, t, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
+                           d_op, d_of, d_oc, (long long*)d_om);
+        if (d_c) hipLaunchKernelGGL(gs_reduce_labels_b, dim3(g, R), dim3(BS), 0, s, t, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, d_oc);
+    }
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
