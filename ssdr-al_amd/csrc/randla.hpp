@@ -28,6 +28,8 @@ struct LfaArgs {
 int launch_dense(const DenseArgs& a, hipStream_t s);
 int launch_lfa(int D, const LfaArgs& a, bool second, int B, hipStream_t s);
 int launch_gather_max(const float* f, const int* idx, int n_in, int n_out, int idx_rows, int C, float* out, int B, hipStream_t s);
+int launch_tail(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                int M, int C, float* feat32, float* probs, hipStream_t s);
 int launch_head(const float* x, const float* W, const float* b, int M, int C, float* probs, hipStream_t s);
 
 }  // namespace ssdr

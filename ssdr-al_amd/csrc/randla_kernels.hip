@@ -31,6 +31,14 @@ static inline f32x4 mfma16(float a, float b, f32x4 c) { return hipemu_mfma_f32_1
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * 0.2f; }
 
+// In the fully unrolled row-per-lane layers the scheduler would otherwise hoist every weight read of the layer to the top
+// (hundreds of live registers, spills): a fence per k keeps one k-slice of weights live at a time.
+#ifndef HIPEMU
+#define SSDR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SSDR_SCHED_FENCE() ((void)0)
+#endif
+
 // ---- dense --------------------------------------------------------------------------------------------
 // 128 x 64 output tile per workgroup, K in chunks of 32; wave w owns rows [32w, 32w+32) x all 64 columns as 2 x 4
 // MFMA tiles.  The next K chunk is fetched into registers (float4 when every row segment is 16-byte aligned) while
@@ -149,7 +157,7 @@ template <int D> struct LfaCfg {
     static constexpr int H = D / 2;
     // points per workgroup: small enough that 3-5 workgroups share a CU's LDS at the low levels (their phases are
     // latency-bound gathers), large enough at d >= 256 that a W element fetched from L2 serves several points
-    static constexpr int PTS = D == 16 ? 16 : (D == 64 ? 8 : (D == 128 ? 4 : (D == 256 ? 4 : 2)));
+    static constexpr int PTS = D == 16 ? 16 : (D == 64 ? 8 : (D == 128 ? 4 : (D == 256 ? 4 : 2)));      // re-measured after the gather fix: 8/4/2/2 variants within 2 %
     static constexpr int ROWS = PTS * 16;
     static constexpr int LD = D + 2;                                   // LDS row stride == 2 (mod 32): conflict-free A reads
     static constexpr int NCT = D / 16;                                 // column tiles of the attention GEMM
@@ -388,12 +396,128 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
     }
 }
 
+// ---- thin layers: one row per lane -------------------------------------------------------------------------
+// For k1 <= 16 and N = 8 (fc0 and the level-0 encoder convs into 8 channels) the 128 x 64 MFMA tile is
+// mostly padding and a workgroup lives for one latency-bound K chunk; these layers are pure HBM streams (a few hundred
+// FLOP per row).  One lane = one row: the row in registers, the weights broadcast from LDS, fused multiply-adds.
+template <int K1, int K2, int N>
+__global__ __launch_bounds__(256) void dense_rows_kernel(DenseArgs a) {
+    constexpr int K = K1 + K2;
+    __shared__ float Ws[K * N + N];
+    for (int i = threadIdx.x; i < K * N; i += 256) Ws[i] = a.W[i];
+    for (int i = threadIdx.x; i < N; i += 256) Ws[K * N + i] = a.b ? a.b[i] : 0.f;
+    __syncthreads();
+    // one row per thread, no row loop: the weight reads would be hoisted out of it as loop invariants (K*N live registers)
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row < a.M) {
+        float x[K];
+        const float* r1 = a.x1 + (size_t)row * K1;
+        if (K1 % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < K1 / 4; ++q) { const float4 v = reinterpret_cast<const float4*>(r1)[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K1; ++k) x[k] = r1[k];
+        }
+        if (K2 > 0) {
+            size_t r2 = (size_t)row;
+            if (a.idx2) r2 = (size_t)(row / a.m_per_batch) * a.x2_rows_per_batch + (size_t)a.idx2[row];
+            const float4* p2 = reinterpret_cast<const float4*>(a.x2 + r2 * K2);
+#pragma unroll
+            for (int q = 0; q < K2 / 4; ++q) { const float4 v = p2[q]; x[K1 + 4 * q] = v.x; x[K1 + 4 * q + 1] = v.y; x[K1 + 4 * q + 2] = v.z; x[K1 + 4 * q + 3] = v.w; }
+        }
+        float acc[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = Ws[K * N + n];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = fmaf(x[k], Ws[k * N + n], acc[n]);
+            SSDR_SCHED_FENCE();
+        }
+        float4* yo = reinterpret_cast<float4*>(a.y + (size_t)row * N);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            if (a.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+            yo[q] = v;
+        }
+    }
+}
+
+// fc1 (32 -> 64) + fc2 (64 -> 32 = last_second_features) + fc (32 -> C) + softmax (:174-178, :84) in one pass over the
+// points: 128 bytes in, 128 + 4C bytes out per point instead of three round trips through HBM.
+template <int C>
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                   const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3,
+                                                   const float* __restrict__ b3, int M, float* __restrict__ feat32, float* __restrict__ probs) {
+    __shared__ float S1[32 * 64 + 64], S2[64 * 32 + 32], S3[32 * C + C];
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) { S1[i] = W1[i]; S2[i] = W2[i]; }
+    for (int i = threadIdx.x; i < 64; i += 256) S1[32 * 64 + i] = b1[i];
+    for (int i = threadIdx.x; i < 32; i += 256) S2[64 * 32 + i] = b2[i];
+    for (int i = threadIdx.x; i < 32 * C; i += 256) S3[i] = W3[i];
+    for (int i = threadIdx.x; i < C; i += 256) S3[32 * C + i] = b3[i];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;          // one row per thread (see dense_rows_kernel)
+    if (row < M) {
+        float xin[32], h1[64], f[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 v = reinterpret_cast<const float4*>(x + (size_t)row * 32)[q]; xin[4 * q] = v.x; xin[4 * q + 1] = v.y; xin[4 * q + 2] = v.z; xin[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int n = 0; n < 64; ++n) h1[n] = S1[32 * 64 + n];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)                 // 32 outputs at a time: 32 weights live per k
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+#pragma unroll
+                for (int n = 0; n < 32; ++n) h1[32 * half + n] = fmaf(xin[k], S1[k * 64 + 32 * half + n], h1[32 * half + n]);
+                SSDR_SCHED_FENCE();
+            }
+#pragma unroll
+        for (int n = 0; n < 32; ++n) f[n] = S2[64 * 32 + n];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float hk = lrelu(h1[k]);
+#pragma unroll
+            for (int n = 0; n < 32; ++n) f[n] = fmaf(hk, S2[k * 32 + n], f[n]);
+            SSDR_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int n = 0; n < 32; ++n) f[n] = lrelu(f[n]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) reinterpret_cast<float4*>(feat32 + (size_t)row * 32)[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+        float logit[C]; float m = -3.402823466e+38f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) logit[c] = S3[32 * C + c];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) logit[c] = fmaf(f[k], S3[k * C + c], logit[c]);
+            SSDR_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) m = fmaxf(m, logit[c]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { logit[c] = expf(logit[c] - m); sum += logit[c]; }
+#pragma unroll
+        for (int c = 0; c < C; ++c) probs[(size_t)row * C + c] = logit[c] / sum;
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 int launch_dense(const DenseArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
     dim3 grid((unsigned)((a.M + DTM - 1) / DTM), (unsigned)((a.N + DTN - 1) / DTN));
     ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
     const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && a.N % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && ((uintptr_t)a.W & 15) == 0;
+    // thin layers over many rows: one row per lane (x2 / y rows must be 16-byte aligned, x1 too unless k1 % 4 != 0)
+    if (a.M >= 1024 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && (a.k1 % 4 != 0 || ((uintptr_t)a.x1 & 15) == 0)) {
+        const dim3 g((unsigned)((a.M + 255) / 256));
+#define SSDR_ROWS(K1_, K2_, N_) if (a.k1 == K1_ && a.k2 == K2_ && a.N == N_) { hipLaunchKernelGGL((dense_rows_kernel<K1_, K2_, N_>), g, dim3(256), 0, s, a); SSDR_HIP(hipGetLastError()); return SSDR_OK; }
+        SSDR_ROWS(6, 0, 8) SSDR_ROWS(8, 0, 8) SSDR_ROWS(16, 0, 8)      // wider outputs: register allocation degrades, the MFMA tile wins
+#undef SSDR_ROWS
+    }
     if (vec) hipLaunchKernelGGL((dense_kernel<true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((dense_kernel<false>), grid, dim3(256), 0, s, a);
     SSDR_HIP(hipGetLastError());
@@ -435,6 +559,19 @@ int launch_gather_max(const float* f, const int* idx, int n_in, int n_out, int i
     const size_t total = (size_t)n_out * C;
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 4096)), (unsigned)B);
     hipLaunchKernelGGL(gather_max_kernel, grid, dim3(256), 0, s, f, idx, n_in, n_out, idx_rows, C, out);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+// fused fc1 + fc2 + fc + softmax; returns SSDR_ERR_UNSUPPORTED (without setting an error) when C has no instantiation
+int launch_tail(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                int M, int C, float* feat32, float* probs, hipStream_t s) {
+    if (M <= 0) return SSDR_OK;
+    if ((C != 13 && C != 8) || ((uintptr_t)x & 15) || ((uintptr_t)feat32 & 15)) return SSDR_ERR_UNSUPPORTED;
+    ProfScope prof("tail_kernel", s, (double)M * 4.0 * (32 + 32 + C));
+    const dim3 g((unsigned)((M + 255) / 256));
+    if (C == 13) hipLaunchKernelGGL((tail_kernel<13>), g, dim3(256), 0, s, x, W1, b1, W2, b2, W3, b3, M, feat32, probs);
+    else hipLaunchKernelGGL((tail_kernel<8>), g, dim3(256), 0, s, x, W1, b1, W2, b2, W3, b3, M, feat32, probs);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

@@ -164,11 +164,17 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         SSDR_TRY(launch_dense(a, s));
         feat = y; feat_c = skip_c; feat_n = n;
     }
-    float* f1 = buf(6 * L + 4, B * (size_t)N[0] * 64); if (!f1) return SSDR_ERR_HIP;
-    SSDR_TRY(launch_dense(dense(feat, feat_c, m->layers[li++], f1, Bi * N[0], 1), s));                       // fc1
-    SSDR_TRY(launch_dense(dense(f1, 64, m->layers[li++], d_feat32, Bi * N[0], 1), s));                       // fc2 = last_second_features
-    const Layer& fc = m->layers[li++];
-    SSDR_TRY(launch_head(d_feat32, fc.W.as<float>(), fc.b.as<float>(), Bi * N[0], m->C, d_probs, s));        // fc + softmax
+    const Layer& l1 = m->layers[li]; const Layer& l2 = m->layers[li + 1]; const Layer& fc = m->layers[li + 2];
+    int fused = SSDR_ERR_UNSUPPORTED;
+    if (feat_c == 32 && l1.out == 64 && l2.out == 32 && l1.has_b && l2.has_b)                                // fc1 + fc2 + fc + softmax in one pass
+        fused = launch_tail(feat, l1.W.as<float>(), l1.b.as<float>(), l2.W.as<float>(), l2.b.as<float>(), fc.W.as<float>(), fc.b.as<float>(),
+                            Bi * N[0], m->C, d_feat32, d_probs, s);
+    if (fused == SSDR_ERR_UNSUPPORTED) {
+        float* f1 = buf(6 * L + 4, B * (size_t)N[0] * 64); if (!f1) return SSDR_ERR_HIP;
+        SSDR_TRY(launch_dense(dense(feat, feat_c, l1, f1, Bi * N[0], 1), s));                                 // fc1
+        SSDR_TRY(launch_dense(dense(f1, 64, l2, d_feat32, Bi * N[0], 1), s));                                 // fc2 = last_second_features
+        SSDR_TRY(launch_head(d_feat32, fc.W.as<float>(), fc.b.as<float>(), Bi * N[0], m->C, d_probs, s));     // fc + softmax
+    } else SSDR_TRY(fused);
     return SSDR_OK;
 }
 
