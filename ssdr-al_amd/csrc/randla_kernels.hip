@@ -152,6 +152,79 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     }
 }
 
+// ---- dense, few rows ----------------------------------------------------------------------------------------
+// The deep levels have 1280-10240 rows: 128-row tiles leave most of the 256 CUs without a workgroup and every
+// workgroup walks K = 512-1536 as a serial chain of chunks.  32 x 64 tiles give 4x the workgroups; wave w owns the
+// 16 columns [16w, 16w+16) of both 16-row tiles.  Same staging / prefetch scheme as dense_kernel (VEC only).
+constexpr int STM = 32;
+__global__ __launch_bounds__(256) void dense_small_kernel(DenseArgs a) {
+    __shared__ float As[STM * DAS];
+    __shared__ float Bs[DKC * DBS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = blockIdx.x * STM, col0 = blockIdx.y * DTN;
+    const int K = a.k1 + a.k2;
+    const int ar = tid >> 3, ak = (tid & 7) * 4;           // A staging: row ar, 4 consecutive k
+    const float* x1r = nullptr; const float* x2r = nullptr;
+    {
+        const int grow = row0 + ar;
+        if (grow < a.M) {
+            x1r = a.x1 + (size_t)grow * a.k1;
+            if (a.k2) {
+                size_t r2 = (size_t)grow;
+                if (a.idx2) r2 = (size_t)(grow / a.m_per_batch) * a.x2_rows_per_batch + (size_t)a.idx2[grow];
+                x2r = a.x2 + r2 * a.k2;
+            }
+        }
+    }
+    const int bk = tid >> 3, bc = (tid & 7) * 8;           // B staging: k row bk, 8 consecutive columns
+    float ra[4], rb[8];
+    auto fetch = [&](int kc) {
+        const int gk = kc + ak;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x1r && gk < K) v = (gk < a.k1) ? *reinterpret_cast<const float4*>(x1r + gk) : *reinterpret_cast<const float4*>(x2r + (gk - a.k1));
+        ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+        const int gkb = kc + bk;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int gc = col0 + bc + 4 * q;
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gkb < K && gc < a.N) u = *reinterpret_cast<const float4*>(a.W + (size_t)gkb * a.N + gc);
+            rb[4 * q] = u.x; rb[4 * q + 1] = u.y; rb[4 * q + 2] = u.z; rb[4 * q + 3] = u.w;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[ar * DAS + ak + j] = ra[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[bk * DBS + bc + j] = rb[j];
+    };
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    fetch(0);
+    for (int kc = 0; kc < K; kc += DKC) {
+        stash();
+        __syncthreads();
+        if (kc + DKC < K) fetch(kc + DKC);          // in flight while the MFMAs below run
+#pragma unroll
+        for (int ks = 0; ks < DKC / 4; ++ks) {
+            const float bv = Bs[(ks * 4 + (lane >> 4)) * DBS + w * 16 + (lane & 15)];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[r] = mfma16(As[(r * 16 + (lane & 15)) * DAS + ks * 4 + (lane >> 4)], bv, acc[r]);
+        }
+        __syncthreads();
+    }
+    const int col = col0 + w * 16 + (lane & 15);
+    if (col < a.N) {
+        const float bias = a.b ? a.b[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row0 + r * 16 + (lane >> 4) * 4 + q;
+                if (row < a.M) { float v = acc[r][q] + bias; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
+            }
+    }
+}
+
 // ---- fused local-feature-aggregation attention half -----------------------------------------------------
 template <int D> struct LfaCfg {
     static constexpr int H = D / 2;
@@ -518,7 +591,10 @@ int launch_dense(const DenseArgs& a, hipStream_t s) {
         SSDR_ROWS(6, 0, 8) SSDR_ROWS(8, 0, 8) SSDR_ROWS(16, 0, 8)      // wider outputs: register allocation degrades, the MFMA tile wins
 #undef SSDR_ROWS
     }
-    if (vec) hipLaunchKernelGGL((dense_kernel<true>), grid, dim3(256), 0, s, a);
+    if (vec && a.M <= 16384) {      // too few 128-row tiles to fill the chip
+        dim3 gs((unsigned)((a.M + STM - 1) / STM), (unsigned)((a.N + DTN - 1) / DTN));
+        hipLaunchKernelGGL(dense_small_kernel, gs, dim3(256), 0, s, a);
+    } else if (vec) hipLaunchKernelGGL((dense_kernel<true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((dense_kernel<false>), grid, dim3(256), 0, s, a);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
