@@ -5,6 +5,7 @@ This is the sequencing the reference spreads over data_prepare_s3dis.py:58, s3di
 sampler2.py:580-642 (prediction) and :736-781 (the gcn_fps branch of sampling); files, pickles and the label
 simulation are out of scope.  All arithmetic happens in libssdr_al.so; the host only moves small index lists."""
 import ctypes as C
+import os
 import time
 
 import numpy as np

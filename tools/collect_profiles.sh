@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the round's judged profiles on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+# then copy gpurun_out/profiles_$1/* into profiles/ (tools/pmc_summary.py builds the PMC summary).
+R=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# 1. the bench line itself (default flags = what the driver runs)
+python3 bench.py > $OUT/${R}_bench_line.json 2> $OUT/${R}_bench_line.err
+# 2. kernel trace + stats of the same command (batches in flight) and of the strictly sequential variant
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kts -o kts -- python3 bench.py --no-cpu-baseline --no-pipeline > $OUT/${R}_bench_seq_under_rocprof.json 2> $OUT/kts.err
+cp $OUT/kt/kt_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
+cp $OUT/kts/kts_kernel_stats.csv $OUT/${R}_bench_seq_kernel_stats.csv
+# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one pass), sequential, one step
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o pf -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/pf.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o pw -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/pw.err
+cp $OUT/pf/pf_counter_collection.csv $OUT/${R}_pmc_fetch_size.csv
+cp $OUT/pw/pw_counter_collection.csv $OUT/${R}_pmc_write_size.csv
+rm -rf $OUT/kt $OUT/kts $OUT/pf $OUT/pw
+ls -la $OUT
