@@ -253,6 +253,22 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
     const int* neigh = a.neigh + (size_t)b * a.n * 16;
 
+    // LocSE weights of this wave's tiles: requested first, so their latency hides behind the position encoding (inside
+    // the tile loop every tile waited for its own three loads: 100 us of the 280 us level-0 launch)
+    constexpr int NCT1 = C::NCT2, T1W = PTS * NCT1 / 4;
+    static_assert(PTS * NCT1 % 4 == 0, "LocSE tiles split evenly over the 4 waves");
+    float w1[T1W][3], b1[T1W];
+#pragma unroll
+    for (int t = 0; t < T1W; ++t) {
+        const int col = ((w * T1W + t) % NCT1) * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int k = ks * 4 + (lane >> 4);
+            w1[t][ks] = (k < 10 && col < H) ? a.w_l1[k * H + col] : 0.f;
+        }
+        b1[t] = col < H ? a.b_l1[col] : 0.f;
+    }
+
     // relative_pos_encoding (:529-535): [ |d|, d(3), p(3), p_nbr(3) ]
     for (int row = tid; row < ROWS; row += 256) {
         const int n = pt0 + (row >> 4);
@@ -279,8 +295,6 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     // LFAmlp2 GEMM below.
     {
         constexpr int XOFF = SECOND ? 0 : H;
-        constexpr int NCT1 = C::NCT2, T1W = PTS * NCT1 / 4;
-        static_assert(PTS * NCT1 % 4 == 0, "LocSE tiles split evenly over the 4 waves");
 #pragma unroll
         for (int t = 0; t < T1W; ++t) {
             const int tile = w * T1W + t, p = tile / NCT1, ct = tile % NCT1;
@@ -290,13 +304,11 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
             for (int ks = 0; ks < 3; ++ks) {
                 const int k = ks * 4 + (lane >> 4);
                 const float av1 = (k < 10) ? REL[(p * 16 + (lane & 15)) * 10 + k] : 0.f;
-                const float bv1 = (k < 10 && col < H) ? a.w_l1[k * H + col] : 0.f;
-                acc1 = mfma16(av1, bv1, acc1);
+                acc1 = mfma16(av1, w1[t][ks], acc1);
             }
             if (col < H) {
-                const float bias = a.b_l1[col];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) F[(p * 16 + (lane >> 4) * 4 + r) * LD + XOFF + col] = lrelu(acc1[r] + bias);
+                for (int r = 0; r < 4; ++r) F[(p * 16 + (lane >> 4) * 4 + r) * LD + XOFF + col] = lrelu(acc1[r] + b1[t]);
             }
         }
     }
