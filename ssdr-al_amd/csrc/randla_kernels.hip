@@ -29,7 +29,13 @@ typedef hipemu_f32x4 f32x4;
 static inline f32x4 mfma16(float a, float b, f32x4 c) { return hipemu_mfma_f32_16x16x4f32(a, b, c); }
 #endif
 
-__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * 0.2f; }
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.2f); }     // = v > 0 ? v : 0.2 v, one instruction less
+
+#ifndef HIPEMU
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ulp
+#else
+static inline float fast_rcp(float x) { return 1.0f / x; }
+#endif
 
 // In the fully unrolled row-per-lane layers the scheduler would otherwise hoist every weight read of the layer to the top
 // (hundreds of live registers, spills): a fence per k keeps one k-slice of weights live at a time.
@@ -257,16 +263,21 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     // the tile loop every tile waited for its own three loads: 100 us of the 280 us level-0 launch)
     constexpr int NCT1 = C::NCT2, T1W = PTS * NCT1 / 4;
     static_assert(PTS * NCT1 % 4 == 0, "LocSE tiles split evenly over the 4 waves");
-    float w1[T1W][3], b1[T1W];
+    constexpr int NB1 = T1W < NCT1 ? T1W : NCT1;       // distinct column tiles among this wave's tiles (tile t uses slot t % NB1)
+    static_assert(T1W % NB1 == 0 && (T1W >= NCT1 ? T1W % NCT1 == 0 : NCT1 % T1W == 0), "slot rule");
+    float w1[NB1][3], b1[NB1];
 #pragma unroll
-    for (int t = 0; t < T1W; ++t) {
+    for (int t = 0; t < NB1; ++t) {
         const int col = ((w * T1W + t) % NCT1) * 16 + (lane & 15);
+        const int colc = col < H ? col : H - 1;            // clamped, no divergent loads; masked below
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const int k = ks * 4 + (lane >> 4);
-            w1[t][ks] = (k < 10 && col < H) ? a.w_l1[k * H + col] : 0.f;
+            const float v = a.w_l1[(k < 10 ? k : 9) * H + colc];
+            w1[t][ks] = (k < 10 && col < H) ? v : 0.f;
         }
-        b1[t] = col < H ? a.b_l1[col] : 0.f;
+        const float bv = a.b_l1[colc];
+        b1[t] = col < H ? bv : 0.f;
     }
 
     // relative_pos_encoding (:529-535): [ |d|, d(3), p(3), p_nbr(3) ]
@@ -304,11 +315,11 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
             for (int ks = 0; ks < 3; ++ks) {
                 const int k = ks * 4 + (lane >> 4);
                 const float av1 = (k < 10) ? REL[(p * 16 + (lane & 15)) * 10 + k] : 0.f;
-                acc1 = mfma16(av1, w1[t][ks], acc1);
+                acc1 = mfma16(av1, w1[t % NB1][ks], acc1);
             }
             if (col < H) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) F[(p * 16 + (lane >> 4) * 4 + r) * LD + XOFF + col] = lrelu(acc1[r] + b1[t]);
+                for (int r = 0; r < 4; ++r) F[(p * 16 + (lane >> 4) * 4 + r) * LD + XOFF + col] = lrelu(acc1[r] + b1[t % NB1]);
             }
         }
     }
@@ -434,7 +445,7 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v += F[((p0 + p) * 16 + (lane >> 4) * 4 + r) * LD + col] * e[r];
             v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            v = v / s;                                                   // sum_k f_k e_k / sum_k e_k: one division per output
+            v = v * fast_rcp(s);                                         // sum_k f_k e_k / sum_k e_k: one reciprocal (1 ulp) per output
             if ((lane >> 4) == 0 && n < a.n) out[(size_t)n * D + col] = v;
         }
     }
