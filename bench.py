@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the batches strictly one after the other")
-    ap.add_argument("--pipeline-depth", type=int, default=5, choices=(2, 3, 4, 5), help="batches in flight (stages on separate HIP streams)")
+    ap.add_argument("--pipeline-depth", type=int, default=0, choices=(0, 2, 3, 4, 5),
+                    help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 3 with the exchanges of N > 1")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
     args = ap.parse_args()
 
@@ -47,11 +48,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("SSDR_BENCH_FORCE_DIST"))      # the latter: exercise the RCCL path on one GPU
+    if args.pipeline_depth == 0:
+        # With the exchanges the host loop (selection + 3 host-synchronous collectives) is what bounds a step, and every extra
+        # stream in flight lengthens those waits: measured on one GPU through RCCL, 72 Mpoints/s at depth 3 vs 58 at depth 5.
+        args.pipeline_depth = 3 if use_dist else 5
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the exchanges are small and host-synchronous: a high-priority RCCL stream gets a hardware queue of its own instead of
+        # waiting behind the queued kernels of whichever pipeline stream it would otherwise share one with
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=not os.environ.get("SSDR_NCCL_NORMAL_PRIO"))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
     from oracle import randla_np as R          # only the weight initialiser here; the oracle proper runs in cpu_baseline
     from ssdr_al import _lib, pipeline, synthetic
@@ -63,13 +72,13 @@ def main():
     hp = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
 
     gather = None
-    if world > 1:
+    if use_dist:
         from ssdr_al.distributed import Comm
         gather = Comm(dist, "cuda")             # the three small exchanges of the selection stage (RCCL)
 
     def barrier():
         _lib.sync()
-        if world > 1:
+        if use_dist:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
@@ -97,7 +106,7 @@ def main():
             hp.step(gather)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,7 +215,7 @@ def main():
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1},
                "stage_ms": stage_ms, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -198,6 +198,9 @@ int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorte
 int ssdr_segment_mean_features_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom,
                                    const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel, size_t nsel,
                                    float* d_out, void* stream);
+/* y0[i] = (y1[i] =) (double)x[i]: what np.concatenate / np.matmul do to the float32 features when they meet the float64
+ * adjacency (sampler2.py:760-770, fps_gcn_cpu.py:162-166); y1 may be NULL. */
+int ssdr_widen_f32_f64_dev(const float* d_x, size_t n, double* d_y0, double* d_y1, void* stream);
 /* One cloud's block of fps_adj_all (fps_gcn_cpu.py:40-117) for its superpoints d_sel[0..nsel): bbox centres
  * [nsel,3], directed chamfer means [nsel,nsel] (cd = dir + dir^T, create_cd :12-38) and the normalised adjacency
  * (S-I)D^-1 + I [nsel,nsel]; gcn_top > 0 keeps the top entries per row (:153-160).  max_sp_size >= largest

@@ -30,7 +30,7 @@ static int do_init(int device) {
     if (device < 0) device = 0;
     if (device >= n) { set_error("device %d out of range (%d devices)", device, n); return SSDR_ERR_INVALID; }
     SSDR_HIP(hipSetDevice(device));
-    SSDR_HIP(hipStreamCreate(&c.stream));
+    SSDR_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));     // no implicit ordering against the legacy NULL stream (a host framework's default stream would serialise every stream of the pipeline)
     SSDR_HIP(hipEventCreate(&c.ev0));
     SSDR_HIP(hipEventCreate(&c.ev1));
     int cu = 0;
@@ -108,7 +108,7 @@ int ssdr_stream_create(void** out_stream) {
     if (!out_stream) { ssdr::set_error("stream_create: NULL"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ssdr::ensure_init());
     hipStream_t s = nullptr;
-    SSDR_HIP(hipStreamCreate(&s));
+    SSDR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *out_stream = s;
     return SSDR_OK;
 }

@@ -576,6 +576,9 @@ __global__ __launch_bounds__(256) void fps_superpoint(const double* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void widen_f32_f64(const float* __restrict__ x, size_t n, double* y0, double* y1) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const double v = (double)x[i]; y0[i] = v; if (y1) y1[i] = v; }
+}
 __global__ __launch_bounds__(256) void fill_double(double* p, int n, double v) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = v;
 }
@@ -697,6 +700,15 @@ int ssdr_segment_mean_features_dev(const float* d_feat, int feat_dim, const int3
     if (nsel == 0) return SSDR_OK;
     hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nsel * feat_dim)), dim3(256), 0, pick_stream(stream), d_feat, feat_dim, d_cls, d_dom, d_sp_off, d_sp_pts, d_sel,
                        (int)nsel, d_out);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_widen_f32_f64_dev(const float* d_x, size_t n, double* d_y0, double* d_y1, void* stream) {
+    if (!d_x || !d_y0) { set_error("widen_f32_f64: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (n == 0) return SSDR_OK;
+    hipLaunchKernelGGL(widen_f32_f64, dim3(grid_for((long)n)), dim3(256), 0, pick_stream(stream), d_x, n, d_y0, d_y1);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

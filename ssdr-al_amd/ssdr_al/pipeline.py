@@ -124,6 +124,11 @@ class HotPath:
                            self.probs.ptr, self.f32.ptr, self.stream)
 
     def _score(self, comm=None):
+        self._score_async(comm)
+        self._score_finish(comm)
+
+    def _score_async(self, comm=None):
+        """device part of the scoring: enqueued, never waits (with a communicator: up to the local class histogram)"""
         cfg, L = self.cfg, _lib.lib()
         n = self.B * cfg.num_points
         um = {"lc": 0, "entropy": 1, "sb": 2}[[a for a in self.sampler_args if a in ("lc", "entropy", "sb")][0]]
@@ -136,27 +141,36 @@ class HotPath:
         if "clsbal" in self.sampler_args:
             if comm is None:
                 _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, st))
-            else:       # exchange 1: the class histogram is global (the already-selected list is counted once, on rank 0)
+            else:       # the already-selected list is counted once, on rank 0
                 _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, st))
-                _lib.sync(st)
-                h = comm.allreduce_sum(np.concatenate([self.hist.to_host().astype(np.int64), [self.S]]))
-                self.hist = DevArray.from_host(h[:64].astype(np.int32))
-                _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, int(h[64]) + nsel, self.region_unc.ptr, st))
         if comm is None:
             _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, st))
             self.global_order = None
-        else:           # exchange 2: rank the regions of ALL ranks; labelled regions are taken out before the cut
+
+    def _score_finish(self, comm=None):
+        """host-synchronous part (communicator only): exchanges 1 and 2, then the global ranking"""
+        if comm is None:
+            return
+        L = _lib.lib()
+        st = self.score_stream if self.score_stream is not None else self.stream
+        nsel = self.selected_class_list.shape[0]
+        if "clsbal" in self.sampler_args:       # exchange 1: the class histogram is global
             _lib.sync(st)
-            u = self.region_unc.to_host()
-            lab = np.zeros(self.S, bool)
-            for b in self.labeled:
-                lab[list(self.labeled[b])] = True
-            allu, counts = comm.allgather_var(np.where(lab, -np.inf, u))
-            d_all = DevArray.from_host(allu); d_ord = DevArray((len(allu),), np.int32)
-            _lib.check(L.ssdr_rank_regions_dev(d_all.ptr, len(allu), d_ord.ptr, st))
-            _lib.sync(st)
-            base = int(sum(counts[: comm.rank]))
-            self.global_order = (d_ord.to_host(), allu, base, self.select_per_tile * self.B * comm.world)
+            h = comm.allreduce_sum(np.concatenate([self.hist.to_host().astype(np.int64), [self.S]]))
+            self.hist = DevArray.from_host(h[:64].astype(np.int32))
+            _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, int(h[64]) + nsel, self.region_unc.ptr, st))
+        # exchange 2: rank the regions of ALL ranks; labelled regions are taken out before the cut
+        _lib.sync(st)
+        u = self.region_unc.to_host()
+        lab = np.zeros(self.S, bool)
+        for b in self.labeled:
+            lab[list(self.labeled[b])] = True
+        allu, counts = comm.allgather_var(np.where(lab, -np.inf, u))
+        d_all = DevArray.from_host(allu); d_ord = DevArray((len(allu),), np.int32)
+        _lib.check(L.ssdr_rank_regions_dev(d_all.ptr, len(allu), d_ord.ptr, st))
+        _lib.sync(st)
+        base = int(sum(counts[: comm.rank]))
+        self.global_order = (d_ord.to_host(), allu, base, self.select_per_tile * self.B * comm.world)
 
     def _candidates(self, sorted_inds):
         """create_file_top_and_all + the candidate rule of sampling() (sampler2.py:533-552, :745-753) on index lists.
@@ -194,12 +208,6 @@ class HotPath:
         unl, lab, sampling_batch = self._candidates(sorted_inds)
         refs = unl + lab
         sel = np.array([s for _, s in refs], np.int32)
-        d_sel = DevArray.from_host(sel); d_mf = DevArray((len(sel), 32), np.float32)
-        _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel.ptr, len(sel), d_mf.ptr, None))
-        _lib.sync()
-        V = d_mf.to_host().astype(np.float64)                # float32 -> float64 as np.concatenate/np.matmul promote it
-        d_v = DevArray.from_host(V); d_comb = DevArray.from_host(V)
-        d_tmp = [DevArray(V.shape, np.float64), DevArray(V.shape, np.float64)]
         # every cloud's chamfer graph and propagation hop in one batched call (rows grouped cloud by cloud)
         ref_cloud = np.fromiter((c for c, _ in refs), np.int64, len(refs))
         order = np.argsort(ref_cloud, kind="stable").astype(np.int32)
@@ -207,18 +215,30 @@ class HotPath:
         counts = counts.astype(np.int64)
         coff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         boff = np.concatenate([[0], np.cumsum(counts * counts)]).astype(np.int64)
-        d_gsel = DevArray.from_host(sel[order]); d_rows = DevArray.from_host(order)
-        d_coff = DevArray.from_host(coff); d_boff = DevArray.from_host(boff)
         ntot, nmax, nsq = int(coff[-1]), int(counts.max()), int(boff[-1])
+        # ONE upload for all the small index tables (each separate copy is a host round trip behind the kernels in flight)
+        parts = [sel, sel[order], order, coff, boff.view(np.int32)]
+        offs = np.cumsum([0] + [(len(p) + 3) // 4 * 4 for p in parts])           # 16-byte aligned pieces
+        pack = np.zeros(offs[-1], np.int32)
+        for p, o in zip(parts, offs):
+            pack[o:o + len(p)] = p
+        d_pack = DevArray.from_host(pack)
+        d_sel, d_gsel, d_rows, d_coff, d_boff = (d_pack.ptr + 4 * int(o) for o in offs[:-1])
+        d_mf = DevArray((len(sel), 32), np.float32)
+        d_v = DevArray((len(sel), 32), np.float64); d_comb = DevArray((len(sel), 32), np.float64)
+        d_tmp = [DevArray(d_v.shape, np.float64), DevArray(d_v.shape, np.float64)]
+        _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel, len(sel), d_mf.ptr, None))
+        # float32 -> float64 as np.concatenate / np.matmul promote it (V and the running sum comb start as the same values)
+        _lib.check(L.ssdr_widen_f32_f64_dev(d_mf.ptr, len(sel) * 32, d_v.ptr, d_comb.ptr, None))
         d_cen = DevArray((ntot, 3), np.float64); d_dir = DevArray((nsq,), np.float64); d_adj = DevArray((nsq,), np.float64)
-        _lib.check(L.ssdr_cloud_graph_batch_dev(self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_gsel.ptr, d_coff.ptr, d_boff.ptr, len(clouds), ntot, nmax,
+        _lib.check(L.ssdr_cloud_graph_batch_dev(self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_gsel, d_coff, d_boff, len(clouds), ntot, nmax,
                                                 int(self.gcn_top), d_cen.ptr, d_dir.ptr, d_adj.ptr, None))
         src = d_v
         for hop in range(int(self.gcn_number)):
             dst = d_tmp[hop & 1]
-            _lib.check(L.ssdr_propagate_batch_dev(d_adj.ptr, d_coff.ptr, d_boff.ptr, len(clouds), nmax, d_rows.ptr, src.ptr, 32, dst.ptr, d_comb.ptr, None))
+            _lib.check(L.ssdr_propagate_batch_dev(d_adj.ptr, d_coff, d_boff, len(clouds), nmax, d_rows, src.ptr, 32, dst.ptr, d_comb.ptr, None))
             src = dst
-        blocks = (d_gsel, d_rows, d_coff, d_boff, d_cen, d_dir, d_adj)
+        blocks = (d_pack, d_cen, d_dir, d_adj)
         n_unl = len(unl)
         self.unl_cloud_ids = np.array([self.room_ids[b] for b, _ in unl], np.int64)
         self.unl_sp = np.array([s - self.sp_base[b] for b, s in unl], np.int64)       # superpoint index inside its room
@@ -234,7 +254,7 @@ class HotPath:
         start = 0                                            # np.random.randint(0, n) in the reference (:133); fixed here
         _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
         _lib.sync()
-        self._keep = (blocks, d_v, d_tmp, d_sel, d_mf)
+        self._keep = (blocks, d_v, d_tmp, d_mf)
         sel = d_out.to_host()
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
         return sel, unl
@@ -301,7 +321,7 @@ class Pipelined:
         if i > 0 and self.group[name] != self.group[self.STAGES[i - 1]]:
             _lib.check(_lib.lib().ssdr_stream_wait(self.streams[self.group[name]], self.streams[self.group[self.STAGES[i - 1]]]))
         if name == "score":
-            h._score(self.comm)       # with a communicator: host-synchronous (two small exchanges), same order on every rank
+            h._score_async(self.comm)
         else:
             {"front": h._front_end, "knn": h._pyramid, "infer": h._infer}[name]()
 
@@ -314,12 +334,19 @@ class Pipelined:
             for name in self.STAGES:
                 if b < lead[name]:
                     self._stage(name, b)
+                    if name == "score":
+                        self.hp[b % self.depth]._score_finish(comm)
         for k in range(steps):
             _lib.check(L.ssdr_stream_wait(None, self.streams[self.group["score"]]))    # main stream: batch k's scores are ready
+            late = []
             for b in range(k + 1, min(steps, k + first + 1)):
                 for name in self.STAGES:
                     if b == k + lead[name]:
                         self._stage(name, b)                 # the buffer set of batch b was last read by select(b - depth), done
+                        if name == "score":
+                            late.append(b)
             out = self.hp[k % self.depth]._select(comm)      # batch k: selection (host-synchronous)
+            for b in late:                                   # with a communicator: exchanges 1 + 2 of batch k+1, host-synchronous, after the
+                self.hp[b % self.depth]._score_finish(comm)  # selection, by when that batch's scoring kernels have long finished
         self._drain()
         return out
