@@ -266,65 +266,129 @@ __device__ __forceinline__ void gs_reduce_body(const float* __restrict__ P, cons
 }
 
 
-// The same reduction from packed records: 8 lanes per voxel, lane c owns word c of the record (coordinates and features
-// are summed in input order, label columns vote); one loop, one record gather per point serves all of them.  The vote
-// of a label lane is a packed byte-counter add per point (labels 0..12, at most 255 points); only a voxel whose
-// maximum is shared by two labels (the tie goes by first-seen order), or one outside those limits, is re-scanned by
-// the exact routines above.
-__device__ __forceinline__ void gs_reduce_packed_body(const uint32_t* __restrict__ rec, int fdim, int ldim,
-                                                       const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
-                                                       const int* __restrict__ row_of_voxel,
-                                                       float* out_p, float* out_f, int* out_c, long long* out_m) {
-    const int m = prm->m;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && out_m) *out_m = m;
-    const int CH = 3 + fdim;
-    const long long total = (long long)m * REC_W;
-    for (long long e = (long long)blockIdx.x * BS + threadIdx.x; e < total; e += (long long)gridDim.x * BS) {
-        const int v = (int)(e / REC_W), c = (int)(e % REC_W);
-        if (c >= CH + ldim) continue;
-        const int s = seg_start[v], en = seg_start[v + 1];
-        const int count = en - s;
-        const int row = row_of_voxel ? row_of_voxel[v] : v;
-        const bool is_label = c >= CH;
-        float sum = 0.f;
-        unsigned long long pk0 = 0ull, pk1 = 0ull;          // byte counters of labels 0..7 / 8..15
-        bool exact = count > 255;                           // needs the exact routines
-        for (int j0 = s; j0 < en; j0 += GS_UNROLL) {        // GS_UNROLL gathers in flight, then the adds in input order
-            uint32_t wv[GS_UNROLL];
+// Reduction from packed records: 8 lanes per voxel, lane c owns word c of the record (coordinates and features are summed
+// in input order, label columns vote).  The vote of a label lane is a packed byte-counter add per point (labels 0..12, at
+// most 255 points); only a voxel whose maximum is shared by two labels (the tie goes by first-seen order), or one
+// outside those limits, is re-scanned by the exact routines above.
+// The reduction of one voxel (lane c = word c of the record) from a record source `get(j, c)`, j in [s, en): shared by the
+// staged kernel below (records in LDS) and its fallback (records gathered from global memory).
+template <class Get>
+__device__ __forceinline__ void gs_reduce_voxel(Get get, int s, int en, int c, int fdim, int ldim, int row, const uint32_t* __restrict__ rec,
+                                                const uint32_t* __restrict__ vs, int gs0, int gen, GsParams* prm, float* out_p, float* out_f, int* out_c) {
+    const int CH = 3 + fdim, count = en - s;
+    const bool is_label = c >= CH;
+    float sum = 0.f;
+    unsigned long long pk0 = 0ull, pk1 = 0ull;          // byte counters of labels 0..7 / 8..15
+    bool exact = count > 255;                           // needs the exact routines
+    for (int j0 = s; j0 < en; j0 += GS_UNROLL) {
+        uint32_t wv[GS_UNROLL];
 #pragma unroll
-            for (int u = 0; u < GS_UNROLL; ++u) wv[u] = rec[(size_t)vs[min(j0 + u, en - 1)] * REC_W + c];
+        for (int u = 0; u < GS_UNROLL; ++u) wv[u] = get(min(j0 + u, en - 1), c);
 #pragma unroll
-            for (int u = 0; u < GS_UNROLL; ++u) {
-                if (j0 + u < en) {
-                    if (!is_label) sum += __uint_as_float(wv[u]);
-                    else {
-                        const unsigned L = wv[u];
-                        const unsigned long long inc = 1ull << ((L & 7u) * 8u);
-                        exact |= L >= 13u;
-                        pk0 += L < 8u ? inc : 0ull; pk1 += (L >= 8u && L < 16u) ? inc : 0ull;
-                    }
+        for (int u = 0; u < GS_UNROLL; ++u) {
+            if (j0 + u < en) {
+                if (!is_label) sum += __uint_as_float(wv[u]);
+                else {
+                    const unsigned L = wv[u];
+                    const unsigned long long inc = 1ull << ((L & 7u) * 8u);
+                    exact |= L >= 13u;
+                    pk0 += L < 8u ? inc : 0ull; pk1 += (L >= 8u && L < 16u) ? inc : 0ull;
                 }
             }
         }
-        if (c < 3) {
-            const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
-            out_p[3 * (size_t)row + c] = sum * a;
-        } else if (!is_label) {
-            out_f[(size_t)row * fdim + (c - 3)] = sum / (float)count;      // :90-94
-        } else {
-            int best = 0, bestc = -1, nbest = 0;
+    }
+    if (c < 3) {
+        const float a = (float)(1.0 / (double)count);          // cloud.h:120 via grid_subsampling.cpp:87
+        out_p[3 * (size_t)row + c] = sum * a;
+    } else if (!is_label) {
+        out_f[(size_t)row * fdim + (c - 3)] = sum / (float)count;      // :90-94
+    } else {
+        int best = 0, bestc = -1, nbest = 0;
 #pragma unroll
-            for (int k = 0; k < 13; ++k) {
-                const int ck = (int)(((k < 8 ? pk0 : pk1) >> ((k & 7) * 8)) & 0xffull);
-                if (ck > bestc) { bestc = ck; best = k; nbest = 1; } else if (ck == bestc) ++nbest;
-            }
-            if (exact || nbest > 1) {
-                const int* rc = reinterpret_cast<const int*>(rec);
-                best = voxel_label_fast(rc, REC_W, c, vs, s, en);
-                if (best < 0) best = voxel_label(rc, REC_W, c, vs, s, en, &prm->status);
-            }
-            out_c[(size_t)row * ldim + (c - CH)] = best;
+        for (int k = 0; k < 13; ++k) {
+            const int ck = (int)(((k < 8 ? pk0 : pk1) >> ((k & 7) * 8)) & 0xffull);
+            if (ck > bestc) { bestc = ck; best = k; nbest = 1; } else if (ck == bestc) ++nbest;
         }
+        if (exact || nbest > 1) {
+            const int* rc = reinterpret_cast<const int*>(rec);
+            best = voxel_label_fast(rc, REC_W, c, vs, gs0, gen);
+            if (best < 0) best = voxel_label(rc, REC_W, c, vs, gs0, gen, &prm->status);
+        }
+        out_c[(size_t)row * ldim + (c - CH)] = best;
+    }
+}
+
+// Staged version of the packed reduction.  A workgroup owns the voxels that START inside one tile of GS_T sorted
+// positions; it first gathers all their points' records into LDS with every thread loading (a flat, fully parallel
+// random gather runs at 2x the rate of per-voxel loops that chase seg_start -> index -> record), then the per-voxel
+// sequential sums read LDS.  A tile whose voxels span more than GS_CAP points falls back to global gathers.
+constexpr int GS_T = 512, GS_CAP = 1024, GS_LD = REC_W + 1;
+__device__ __forceinline__ int gs_lower_bound(const int* __restrict__ seg_start, int m, int target, int lane) {
+    int lo = 0, hi = m;                                  // first v in [0, m] with seg_start[v] >= target (seg_start[m] = n >= target)
+    while (hi > lo) {
+        const int step = (hi - lo + 63) / 64;
+        const int p = lo + lane * step;
+        const bool ge = p < hi ? seg_start[p] >= target : true;
+        const unsigned long long mask = __ballot(ge);
+        const int first = mask ? __ffsll((long long)mask) - 1 : 64;     // first probe at or past the answer (64: all 64 probes are below it)
+        if (first == 0) hi = lo;
+        else { const int nlo = lo + (first - 1) * step + 1, nhi = min(hi, lo + first * step); lo = nlo; hi = nhi; }
+    }
+    return lo;
+}
+__device__ __forceinline__ void gs_reduce_staged_body(const uint32_t* __restrict__ rec, int fdim, int ldim, int n,
+                                                       const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
+                                                       const int* __restrict__ row_of_voxel,
+                                                       float* out_p, float* out_f, int* out_c, long long* out_m) {
+    __shared__ uint32_t s_rec[GS_CAP * GS_LD];
+    __shared__ int s_seg[GS_T + 2];
+    __shared__ int s_v[2];
+    const int m = prm->m, tid = threadIdx.x, lane = tid & 63;
+    if (blockIdx.x == 0 && tid == 0 && out_m) *out_m = m;
+    const int ntiles = (n + GS_T - 1) / GS_T;
+    for (int b = blockIdx.x; b < ntiles; b += gridDim.x) {
+        if (tid < 64) { const int v = gs_lower_bound(seg_start, m, b * GS_T, lane); if (lane == 0) s_v[0] = v; }
+        else if (tid < 128) { const int v = gs_lower_bound(seg_start, m, min((b + 1) * GS_T, n), lane); if (lane == 0) s_v[1] = v; }
+        __syncthreads();
+        const int vfirst = s_v[0], vend = s_v[1], nv = vend - vfirst;
+        const int p0 = seg_start[vfirst], np = seg_start[vend] - p0;
+        if (nv > 0 && np <= GS_CAP) {
+            for (int i = tid; i <= nv; i += BS) s_seg[i] = seg_start[vfirst + i] - p0;
+            uint4 r0[GS_CAP / BS], r1[GS_CAP / BS];
+#pragma unroll
+            for (int u = 0; u < GS_CAP / BS; ++u) {                 // all record gathers of the tile in flight together
+                const int i = tid + u * BS;
+                if (i < np) {
+                    const uint4* src = reinterpret_cast<const uint4*>(rec + (size_t)vs[p0 + i] * REC_W);
+                    r0[u] = src[0]; r1[u] = src[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GS_CAP / BS; ++u) {
+                const int i = tid + u * BS;
+                if (i < np) {
+                    uint32_t* d = s_rec + i * GS_LD;
+                    d[0] = r0[u].x; d[1] = r0[u].y; d[2] = r0[u].z; d[3] = r0[u].w; d[4] = r1[u].x; d[5] = r1[u].y; d[6] = r1[u].z; d[7] = r1[u].w;
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < nv * REC_W; e += BS) {
+                const int vl = e / REC_W, c = e % REC_W;
+                if (c >= 3 + fdim + ldim) continue;
+                const int v = vfirst + vl, sl = s_seg[vl], el = s_seg[vl + 1];
+                gs_reduce_voxel([&](int j, int cc) { return s_rec[j * GS_LD + cc]; }, sl, el, c, fdim, ldim, row_of_voxel ? row_of_voxel[v] : v,
+                                rec, vs, p0 + sl, p0 + el, prm, out_p, out_f, out_c);
+            }
+        } else if (nv > 0) {                                         // a tile with a very large voxel: gather from global memory
+            for (int e = tid; e < nv * REC_W; e += BS) {
+                const int vl = e / REC_W, c = e % REC_W;
+                if (c >= 3 + fdim + ldim) continue;
+                const int v = vfirst + vl, sg = seg_start[v], eg = seg_start[v + 1];
+                gs_reduce_voxel([&](int j, int cc) { return rec[(size_t)vs[j] * REC_W + cc]; }, sg, eg, c, fdim, ldim, row_of_voxel ? row_of_voxel[v] : v,
+                                rec, vs, sg, eg, prm, out_p, out_f, out_c);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -332,7 +396,7 @@ __device__ __forceinline__ void gs_reduce_packed_body(const uint32_t* __restrict
 __global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict__ P, int n, float* partial) { gs_minmax_partial_body(P, n, partial); }
 __global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts, float dl, GsParams* prm) { gs_params_body(partial, nparts, dl, prm); }
 __global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) { gs_keys_body(P, n, prm, keys, vals, F, fdim, cls, ldim, rec); }
-__global__ __launch_bounds__(BS) void gs_reduce_packed(const uint32_t* __restrict__ rec, int fdim, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m) { gs_reduce_packed_body(rec, fdim, ldim, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m); }
+__global__ __launch_bounds__(BS) void gs_reduce_packed(const uint32_t* __restrict__ rec, int fdim, int ldim, int n, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m) { gs_reduce_staged_body(rec, fdim, ldim, n, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m); }
 __global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict__ ks, int n, int* bsum) { gs_heads_count_body(ks, n, bsum); }
 __global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParams* prm, int* seg_start, int n) { gs_heads_scan_body(bsum, nb, prm, seg_start, n); }
 __global__ __launch_bounds__(BS) void gs_heads_write(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) { gs_heads_write_body(ks, n, bsum, seg_start); }
@@ -360,7 +424,7 @@ __global__ __launch_bounds__(BS) void gs_keys_b(CloudTab t, const float* __restr
 __global__ __launch_bounds__(BS) void gs_reduce_packed_b(CloudTab t, const uint32_t* __restrict__ rec, int fdim, int ldim, const uint32_t* __restrict__ vs,
                                                          const int* __restrict__ seg_start, GsParams* prm, float* out_p, float* out_f, int* out_c, long long* out_m) {
     const int r = blockIdx.y; const size_t o = (size_t)t.off[r];
-    gs_reduce_packed_body(rec + o * REC_W, fdim, ldim, vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr,
+    gs_reduce_staged_body(rec + o * REC_W, fdim, ldim, t.off[r + 1] - t.off[r], vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr,
                           out_p + 3 * o, out_f ? out_f + o * fdim : nullptr, out_c ? out_c + o * ldim : nullptr, out_m ? out_m + r : nullptr);
 }
 __global__ __launch_bounds__(BS) void gs_heads_count_b(CloudTab t, const uint64_t* __restrict__ ks, int* bsum, int nb_max) {
@@ -430,7 +494,7 @@ int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t f
         row = S.row.as<int>();
     }
     if (packed) {
-        hipLaunchKernelGGL(gs_reduce_packed, dim3(g), dim3(BS), 0, s, rec, (int)fdim, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_op, d_of, d_oc, (long long*)d_om);
+        hipLaunchKernelGGL(gs_reduce_packed, dim3(g), dim3(BS), 0, s, rec, (int)fdim, (int)ldim, ni, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_op, d_of, d_oc, (long long*)d_om);
     } else {
         hipLaunchKernelGGL(gs_reduce, dim3(g), dim3(BS), 0, s, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
                            row, d_op, d_of, d_oc, (long long*)d_om, (uint64_t*)nullptr, S.keys.as<uint64_t>());
