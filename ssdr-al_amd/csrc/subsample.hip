@@ -309,10 +309,17 @@ __device__ __forceinline__ void gs_reduce_voxel(Get get, int s, int en, int c, i
             const int ck = (int)(((k < 8 ? pk0 : pk1) >> ((k & 7) * 8)) & 0xffull);
             if (ck > bestc) { bestc = ck; best = k; nbest = 1; } else if (ck == bestc) ++nbest;
         }
-        if (exact || nbest > 1) {
+        if (exact) {                                         // labels outside [0,13) or more than 255 points: the exact routines
             const int* rc = reinterpret_cast<const int*>(rec);
             best = voxel_label_fast(rc, REC_W, c, vs, gs0, gen);
             if (best < 0) best = voxel_label(rc, REC_W, c, vs, gs0, gen, &prm->status);
+        } else if (nbest > 1) {                              // shared maximum: the label first seen LAST wins (see voxel_label_fast)
+            unsigned seen = 0;
+            for (int j = s; j < en; ++j) {
+                const unsigned L = get(j, c);
+                const int ck = (int)(((L < 8 ? pk0 : pk1) >> ((L & 7) * 8)) & 0xffull);
+                if (ck == bestc && !((seen >> L) & 1u)) { seen |= 1u << L; best = (int)L; }
+            }
         }
         out_c[(size_t)row * ldim + (c - CH)] = best;
     }
@@ -323,34 +330,26 @@ __device__ __forceinline__ void gs_reduce_voxel(Get get, int s, int en, int c, i
 // random gather runs at 2x the rate of per-voxel loops that chase seg_start -> index -> record), then the per-voxel
 // sequential sums read LDS.  A tile whose voxels span more than GS_CAP points falls back to global gathers.
 constexpr int GS_T = 512, GS_CAP = 1024, GS_LD = REC_W + 1;
-__device__ __forceinline__ int gs_lower_bound(const int* __restrict__ seg_start, int m, int target, int lane) {
-    int lo = 0, hi = m;                                  // first v in [0, m] with seg_start[v] >= target (seg_start[m] = n >= target)
-    while (hi > lo) {
-        const int step = (hi - lo + 63) / 64;
-        const int p = lo + lane * step;
-        const bool ge = p < hi ? seg_start[p] >= target : true;
-        const unsigned long long mask = __ballot(ge);
-        const int first = mask ? __ffsll((long long)mask) - 1 : 64;     // first probe at or past the answer (64: all 64 probes are below it)
-        if (first == 0) hi = lo;
-        else { const int nlo = lo + (first - 1) * step + 1, nhi = min(hi, lo + first * step); lo = nlo; hi = nhi; }
+// first_ge[t] = first voxel that starts at or after position t * GS_T (t = 0 .. ntiles; first_ge[ntiles] = m): voxel v writes the
+// entries of the tile boundaries in (start of v-1, start of v], so every entry has exactly one writer
+__device__ __forceinline__ void gs_tile_index_body(const int* __restrict__ seg_start, const GsParams* prm, int n, int* first_ge) {
+    const int m = prm->m, ntiles = (n + GS_T - 1) / GS_T;
+    for (int v = blockIdx.x * BS + threadIdx.x; v <= m; v += gridDim.x * BS) {
+        const int cur = v < m ? seg_start[v] : n + GS_T, prev = v > 0 ? seg_start[v - 1] : -1;     // v == m: sentinel past the end
+        for (int t = prev / GS_T + (prev >= 0 ? 1 : 0); t <= ntiles && t * GS_T <= cur; ++t) if (t * GS_T > prev) first_ge[t] = v;
     }
-    return lo;
 }
-__device__ __forceinline__ void gs_reduce_staged_body(const uint32_t* __restrict__ rec, int fdim, int ldim, int n,
+__device__ __forceinline__ void gs_reduce_staged_body(const uint32_t* __restrict__ rec, int fdim, int ldim, int n, const int* __restrict__ first_ge,
                                                        const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
                                                        const int* __restrict__ row_of_voxel,
                                                        float* out_p, float* out_f, int* out_c, long long* out_m) {
     __shared__ uint32_t s_rec[GS_CAP * GS_LD];
     __shared__ int s_seg[GS_T + 2];
-    __shared__ int s_v[2];
-    const int m = prm->m, tid = threadIdx.x, lane = tid & 63;
+    const int m = prm->m, tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && out_m) *out_m = m;
     const int ntiles = (n + GS_T - 1) / GS_T;
     for (int b = blockIdx.x; b < ntiles; b += gridDim.x) {
-        if (tid < 64) { const int v = gs_lower_bound(seg_start, m, b * GS_T, lane); if (lane == 0) s_v[0] = v; }
-        else if (tid < 128) { const int v = gs_lower_bound(seg_start, m, min((b + 1) * GS_T, n), lane); if (lane == 0) s_v[1] = v; }
-        __syncthreads();
-        const int vfirst = s_v[0], vend = s_v[1], nv = vend - vfirst;
+        const int vfirst = first_ge[b], vend = first_ge[b + 1], nv = vend - vfirst;
         const int p0 = seg_start[vfirst], np = seg_start[vend] - p0;
         if (nv > 0 && np <= GS_CAP) {
             for (int i = tid; i <= nv; i += BS) s_seg[i] = seg_start[vfirst + i] - p0;
@@ -396,7 +395,8 @@ __device__ __forceinline__ void gs_reduce_staged_body(const uint32_t* __restrict
 __global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict__ P, int n, float* partial) { gs_minmax_partial_body(P, n, partial); }
 __global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts, float dl, GsParams* prm) { gs_params_body(partial, nparts, dl, prm); }
 __global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) { gs_keys_body(P, n, prm, keys, vals, F, fdim, cls, ldim, rec); }
-__global__ __launch_bounds__(BS) void gs_reduce_packed(const uint32_t* __restrict__ rec, int fdim, int ldim, int n, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m) { gs_reduce_staged_body(rec, fdim, ldim, n, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m); }
+__global__ __launch_bounds__(BS) void gs_tile_index(const int* __restrict__ seg_start, const GsParams* prm, int n, int* first_ge) { gs_tile_index_body(seg_start, prm, n, first_ge); }
+__global__ __launch_bounds__(BS) void gs_reduce_packed(const uint32_t* __restrict__ rec, int fdim, int ldim, int n, const int* __restrict__ first_ge, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m) { gs_reduce_staged_body(rec, fdim, ldim, n, first_ge, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m); }
 __global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict__ ks, int n, int* bsum) { gs_heads_count_body(ks, n, bsum); }
 __global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParams* prm, int* seg_start, int n) { gs_heads_scan_body(bsum, nb, prm, seg_start, n); }
 __global__ __launch_bounds__(BS) void gs_heads_write(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) { gs_heads_write_body(ks, n, bsum, seg_start); }
@@ -421,10 +421,15 @@ __global__ __launch_bounds__(BS) void gs_keys_b(CloudTab t, const float* __restr
     gs_keys_body(P + 3 * o, t.off[r + 1] - t.off[r], prm + r, keys + t.toff[r], vals + t.toff[r],
                  F ? F + o * fdim : nullptr, fdim, cls ? cls + o * ldim : nullptr, ldim, rec ? rec + o * REC_W : nullptr);
 }
-__global__ __launch_bounds__(BS) void gs_reduce_packed_b(CloudTab t, const uint32_t* __restrict__ rec, int fdim, int ldim, const uint32_t* __restrict__ vs,
+__global__ __launch_bounds__(BS) void gs_tile_index_b(CloudTab t, const int* __restrict__ seg_start, const GsParams* prm, int* first_ge) {
+    const int r = blockIdx.y;
+    gs_tile_index_body(seg_start + t.toff[r] + r, prm + r, t.off[r + 1] - t.off[r], first_ge + t.toff[r] / GS_T + 2 * r);
+}
+__global__ __launch_bounds__(BS) void gs_reduce_packed_b(CloudTab t, const uint32_t* __restrict__ rec, int fdim, int ldim, const int* __restrict__ first_ge,
+                                                         const uint32_t* __restrict__ vs,
                                                          const int* __restrict__ seg_start, GsParams* prm, float* out_p, float* out_f, int* out_c, long long* out_m) {
     const int r = blockIdx.y; const size_t o = (size_t)t.off[r];
-    gs_reduce_staged_body(rec + o * REC_W, fdim, ldim, t.off[r + 1] - t.off[r], vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr,
+    gs_reduce_staged_body(rec + o * REC_W, fdim, ldim, t.off[r + 1] - t.off[r], first_ge + t.toff[r] / GS_T + 2 * r, vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr,
                           out_p + 3 * o, out_f ? out_f + o * fdim : nullptr, out_c ? out_c + o * ldim : nullptr, out_m ? out_m + r : nullptr);
 }
 __global__ __launch_bounds__(BS) void gs_heads_count_b(CloudTab t, const uint64_t* __restrict__ ks, int* bsum, int nb_max) {
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(BS) void gs_reduce_labels_b(CloudTab t, const int* 
 
 struct GsState {
     RadixSorter sorter;
-    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec;
+    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec, tidx;
     size_t last_m = 0, last_fdim = 0, last_ldim = 0;
 };
 GsState& gs(hipStream_t st = nullptr) { static std::map<hipStream_t, GsState> m; return m[st ? st : ctx().stream]; }
@@ -494,7 +499,9 @@ int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t f
         row = S.row.as<int>();
     }
     if (packed) {
-        hipLaunchKernelGGL(gs_reduce_packed, dim3(g), dim3(BS), 0, s, rec, (int)fdim, (int)ldim, ni, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_op, d_of, d_oc, (long long*)d_om);
+        SSDR_TRY(S.tidx.reserve(4 * (n / GS_T + 4)));
+        hipLaunchKernelGGL(gs_tile_index, dim3(g), dim3(BS), 0, s, S.seg.as<int>(), prm, ni, S.tidx.as<int>());
+        hipLaunchKernelGGL(gs_reduce_packed, dim3(g), dim3(BS), 0, s, rec, (int)fdim, (int)ldim, ni, S.tidx.as<int>(), S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_op, d_of, d_oc, (long long*)d_om);
     } else {
         hipLaunchKernelGGL(gs_reduce, dim3(g), dim3(BS), 0, s, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
                            row, d_op, d_of, d_oc, (long long*)d_om, (uint64_t*)nullptr, S.keys.as<uint64_t>());
@@ -535,7 +542,9 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
     hipLaunchKernelGGL(gs_heads_scan_b, dim3(R), dim3(1024), 0, s, t, S.bsum.as<int>(), nb_max, prm, S.seg.as<int>());
     hipLaunchKernelGGL(gs_heads_write_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, S.seg.as<int>());
     if (packed) {
-        hipLaunchKernelGGL(gs_reduce_packed_b, dim3(g, R), dim3(BS), 0, s, t, rec, (int)fdim, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, d_op, d_of, d_oc, (long long*)d_om);
+        SSDR_TRY(S.tidx.reserve(4 * ((size_t)toff / GS_T + 2 * nr + 4)));
+        hipLaunchKernelGGL(gs_tile_index_b, dim3(g, R), dim3(BS), 0, s, t, S.seg.as<int>(), prm, S.tidx.as<int>());
+        hipLaunchKernelGGL(gs_reduce_packed_b, dim3(g, R), dim3(BS), 0, s, t, rec, (int)fdim, (int)ldim, S.tidx.as<int>(), S.vals.as<uint32_t>(), S.seg.as<int>(), prm, d_op, d_of, d_oc, (long long*)d_om);
     } else {
         hipLaunchKernelGGL(gs_reduce_b, dim3(g, R), dim3(BS), 0, s, t, d_p, d_f, (int)fdim, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm,
                            d_op, d_of, d_oc, (long long*)d_om);
