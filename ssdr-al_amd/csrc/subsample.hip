@@ -329,7 +329,7 @@ __device__ __forceinline__ void gs_reduce_voxel(Get get, int s, int en, int c, i
 // positions; it first gathers all their points' records into LDS with every thread loading (a flat, fully parallel
 // random gather runs at 2x the rate of per-voxel loops that chase seg_start -> index -> record), then the per-voxel
 // sequential sums read LDS.  A tile whose voxels span more than GS_CAP points falls back to global gathers.
-constexpr int GS_T = 512, GS_CAP = 1024, GS_LD = REC_W + 1;
+constexpr int GS_T = 256, GS_CAP = 512, GS_LD = REC_W + 1;
 // first_ge[t] = first voxel that starts at or after position t * GS_T (t = 0 .. ntiles; first_ge[ntiles] = m): voxel v writes the
 // entries of the tile boundaries in (start of v-1, start of v], so every entry has exactly one writer
 __device__ __forceinline__ void gs_tile_index_body(const int* __restrict__ seg_start, const GsParams* prm, int n, int* first_ge) {
