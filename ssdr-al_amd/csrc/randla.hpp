@@ -20,7 +20,8 @@ struct LfaArgs {
     const float* fin;                            // [B][n][D/2]  features to gather from the neighbours
     const float* w_l1; const float* b_l1;        // LFAmlp1 10 -> D/2 (BN folded)
     const float* w_l2; const float* b_l2;        // LFAmlp2 D/2 -> D/2 (second half only)
-    const float* w_fc;                           // attention dense D -> D, no bias
+    const float* w_fc;                           // attention dense D -> D, no bias, [k][col]
+    const float* w_fc_t;                         // the same transposed, [col][k]
     float* out;                                  // [B][n][D]   sum_k f * softmax_k(f W)
     int n;
 };

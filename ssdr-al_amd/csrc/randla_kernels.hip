@@ -238,7 +238,8 @@ template <int D> struct LfaCfg {
     // latency-bound gathers), large enough at d >= 256 that a W element fetched from L2 serves several points
     static constexpr int PTS = D == 16 ? 16 : (D == 64 ? 8 : (D == 128 ? 4 : (D == 256 ? 4 : 2)));      // re-measured after the gather fix: 8/4/2/2 variants within 2 %
     static constexpr int ROWS = PTS * 16;
-    static constexpr int LD = D + 2;                                   // LDS row stride == 2 (mod 32): conflict-free A reads
+    static constexpr bool WIDE = D >= 64;                              // 16-byte operand fetches in the attention GEMM
+    static constexpr int LD = WIDE ? D + 4 : D + 2;                    // LDS row stride: 16-byte aligned rows (WIDE) / == 2 (mod 32): conflict-free 4-byte A reads
     static constexpr int NCT = D / 16;                                 // column tiles of the attention GEMM
     static constexpr int NC_W = (D / 64) > 1 ? (D / 64) : 1;           // column tiles per wave
     static constexpr int NP_W = (PTS * NCT / 4) / NC_W;                // point tiles per wave
@@ -381,8 +382,11 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = tid + 256 * i, row = e / H4, c4 = e % H4;
-            float2* dst = reinterpret_cast<float2*>(&F[row * LD + 4 * c4]);      // LD is even: 8-byte aligned
-            dst[0] = make_float2(v[i].x, v[i].y); dst[1] = make_float2(v[i].z, v[i].w);
+            if (C::WIDE) *reinterpret_cast<float4*>(&F[row * LD + 4 * c4]) = v[i];           // rows are 16-byte aligned
+            else {
+                float2* dst = reinterpret_cast<float2*>(&F[row * LD + 4 * c4]);      // LD is even: 8-byte aligned
+                dst[0] = make_float2(v[i].x, v[i].y); dst[1] = make_float2(v[i].z, v[i].w);
+            }
         }
     }
     __syncthreads();
@@ -396,35 +400,74 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     for (int p = 0; p < NP_W; ++p)
 #pragma unroll
         for (int c = 0; c < NC_W; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // software pipeline: the operands of the NEXT two k-steps (A from LDS, W from L2) are requested before the 2 x 16
-    // MFMAs of the current two issue, i.e. ~1000 MFMA cycles of cover for an L2 round trip
-    constexpr int KS = (D >= 8) ? 2 : 1;           // k-steps (of 4) per pipeline stage
-    float av[KS][NP_W], bv[KS][NC_W], an[KS][NP_W], bn[KS][NC_W];
-    auto fetch = [&](int kb, float (&fa)[KS][NP_W], float (&fb)[KS][NC_W]) {
+    if constexpr (C::WIDE) {
+        // k is taken in blocks of 16: in MFMA step u of a block lane group g supplies k = 16 kb + 4 g + u (the sum over k does not
+        // care about the order), so a lane's four A values are 16 contiguous bytes of its LDS row and its four W values 16
+        // contiguous bytes of the transposed weights: one ds_read_b128 + one global dwordx4 feed four MFMAs.  The next block
+        // is requested before the current block's 4 x NP_W x NC_W MFMAs issue.
+        float av[NP_W][4], bv[NC_W][4], an[NP_W][4], bn[NC_W][4];
+        auto fetch16 = [&](int kb, float (&fa)[NP_W][4], float (&fb)[NC_W][4]) {
+            const int k0 = kb * 16 + 4 * (lane >> 4);
 #pragma unroll
-        for (int u = 0; u < KS; ++u) {
-            const int k = kb + 4 * u + (lane >> 4);
+            for (int p = 0; p < NP_W; ++p) {
+                const float4 v = *reinterpret_cast<const float4*>(&F[((p0 + p) * 16 + (lane & 15)) * LD + k0]);
+                fa[p][0] = v.x; fa[p][1] = v.y; fa[p][2] = v.z; fa[p][3] = v.w;
+            }
 #pragma unroll
-            for (int p = 0; p < NP_W; ++p) fa[u][p] = F[((p0 + p) * 16 + (lane & 15)) * LD + k];
+            for (int c = 0; c < NC_W; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(a.w_fc_t + (size_t)((ct0 + c) * 16 + (lane & 15)) * D + k0);
+                fb[c][0] = v.x; fb[c][1] = v.y; fb[c][2] = v.z; fb[c][3] = v.w;
+            }
+        };
+        fetch16(0, av, bv);
+        for (int kb = 0; kb < D / 16; ++kb) {
+            if (kb + 1 < D / 16) fetch16(kb + 1, an, bn);
 #pragma unroll
-            for (int c = 0; c < NC_W; ++c) fb[u][c] = a.w_fc[(size_t)k * D + (ct0 + c) * 16 + (lane & 15)];
-        }
-    };
-    fetch(0, av, bv);
-    for (int kb = 0; kb < D; kb += 4 * KS) {
-        if (kb + 4 * KS < D) fetch(kb + 4 * KS, an, bn);
+            for (int u = 0; u < 4; ++u)                      // consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int u = 0; u < KS; ++u)
+                for (int p = 0; p < NP_W; ++p)
+#pragma unroll
+                    for (int c = 0; c < NC_W; ++c) acc[p][c] = mfma16(av[p][u], bv[c][u], acc[p][c]);
 #pragma unroll
             for (int p = 0; p < NP_W; ++p)
 #pragma unroll
-                for (int c = 0; c < NC_W; ++c) acc[p][c] = mfma16(av[u][p], bv[u][c], acc[p][c]);
+                for (int u = 0; u < 4; ++u) av[p][u] = an[p][u];
 #pragma unroll
-        for (int u = 0; u < KS; ++u) {
+            for (int c = 0; c < NC_W; ++c)
 #pragma unroll
-            for (int p = 0; p < NP_W; ++p) av[u][p] = an[u][p];
+                for (int u = 0; u < 4; ++u) bv[c][u] = bn[c][u];
+        }
+    } else {
+        // software pipeline: the operands of the NEXT two k-steps (A from LDS, W from L2) are requested before the 2 x 16
+        // MFMAs of the current two issue, i.e. ~1000 MFMA cycles of cover for an L2 round trip
+        constexpr int KS = (D >= 8) ? 2 : 1;           // k-steps (of 4) per pipeline stage
+        float av[KS][NP_W], bv[KS][NC_W], an[KS][NP_W], bn[KS][NC_W];
+        auto fetch = [&](int kb, float (&fa)[KS][NP_W], float (&fb)[KS][NC_W]) {
 #pragma unroll
-            for (int c = 0; c < NC_W; ++c) bv[u][c] = bn[u][c];
+            for (int u = 0; u < KS; ++u) {
+                const int k = kb + 4 * u + (lane >> 4);
+#pragma unroll
+                for (int p = 0; p < NP_W; ++p) fa[u][p] = F[((p0 + p) * 16 + (lane & 15)) * LD + k];
+#pragma unroll
+                for (int c = 0; c < NC_W; ++c) fb[u][c] = a.w_fc[(size_t)k * D + (ct0 + c) * 16 + (lane & 15)];
+            }
+        };
+        fetch(0, av, bv);
+        for (int kb = 0; kb < D; kb += 4 * KS) {
+            if (kb + 4 * KS < D) fetch(kb + 4 * KS, an, bn);
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int p = 0; p < NP_W; ++p)
+#pragma unroll
+                    for (int c = 0; c < NC_W; ++c) acc[p][c] = mfma16(av[u][p], bv[u][c], acc[p][c]);
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+#pragma unroll
+                for (int p = 0; p < NP_W; ++p) av[u][p] = an[u][p];
+#pragma unroll
+                for (int c = 0; c < NC_W; ++c) bv[u][c] = bn[u][c];
+            }
         }
     }
 

@@ -14,7 +14,7 @@
 namespace ssdr {
 namespace {
 
-struct Layer { int in = 0, out = 0; bool has_b = true; DevBuf W, b; bool set = false; };
+struct Layer { int in = 0, out = 0; bool has_b = true; DevBuf W, b, Wt; bool set = false; };     // Wt: [out][in] copy for the attention layers
 
 struct Model {
     int L = 5, K = 16, C = 13, in_dim = 6;
@@ -91,6 +91,12 @@ int ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* 
     SSDR_TRY(ly.W.reserve(sizeof(float) * (size_t)ly.in * ly.out));
     SSDR_HIP(hipMemcpy(ly.W.p, W, sizeof(float) * (size_t)ly.in * ly.out, hipMemcpyHostToDevice));
     if (ly.has_b) { SSDR_TRY(ly.b.reserve(sizeof(float) * ly.out)); SSDR_HIP(hipMemcpy(ly.b.p, b, sizeof(float) * ly.out, hipMemcpyHostToDevice)); }
+    if (!ly.has_b && ly.in == ly.out) {      // attention dense (d x d, no bias): the LFA kernel reads four consecutive k of one output column at once
+        std::vector<float> t((size_t)ly.in * ly.out);
+        for (int k = 0; k < ly.in; ++k) for (int c = 0; c < ly.out; ++c) t[(size_t)c * ly.in + k] = W[(size_t)k * ly.out + c];
+        SSDR_TRY(ly.Wt.reserve(sizeof(float) * t.size()));
+        SSDR_HIP(hipMemcpy(ly.Wt.p, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
+    }
     ly.set = true;
     return SSDR_OK;
 }
@@ -98,7 +104,7 @@ int ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* 
 void ssdr_randla_destroy(void* handle) {
     Model* m = static_cast<Model*>(handle);
     if (!m) return;
-    for (auto& l : m->layers) { l.W.release(); l.b.release(); }
+    for (auto& l : m->layers) { l.W.release(); l.b.release(); l.Wt.release(); }
     for (auto& w : m->ws) w.release();
     delete m;
 }
@@ -137,10 +143,10 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         LfaArgs la{}; la.xyz = d_xyz; la.xyz_batch_stride = n0 * 3; la.neigh = d_neigh_idx[i]; la.n = n;
         la.w_l1 = m->layers[base + 1].W.as<float>(); la.b_l1 = m->layers[base + 1].b.as<float>();
         la.w_l2 = m->layers[base + 4].W.as<float>(); la.b_l2 = m->layers[base + 4].b.as<float>();
-        la.fin = f_pc; la.w_fc = m->layers[base + 2].W.as<float>(); la.out = agg;
+        la.fin = f_pc; la.w_fc = m->layers[base + 2].W.as<float>(); la.w_fc_t = m->layers[base + 2].Wt.as<float>(); la.out = agg;
         SSDR_TRY(launch_lfa(d, la, false, Bi, s));                                                          // LocSE + att pool 1
         SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 3], aggm, (int)rows, 1), s));                   // att1 mlp d->h
-        la.fin = aggm; la.w_fc = m->layers[base + 5].W.as<float>(); la.out = agg;
+        la.fin = aggm; la.w_fc = m->layers[base + 5].W.as<float>(); la.w_fc_t = m->layers[base + 5].Wt.as<float>(); la.out = agg;
         SSDR_TRY(launch_lfa(d, la, true, Bi, s));                                                           // LocSE2 + att pool 2
         SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
         DenseArgs r = dense(aggm, d, m->layers[base + 7], out, (int)rows, 1);                               // lrelu(mlp2 + shortcut)
