@@ -252,6 +252,16 @@ int ssdr_dev_free(void* d_ptr);
 int ssdr_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int ssdr_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 
+/* ---- superpoint-graph inputs (the partition itself, cut-pursuit, stays out of scope) -----------------
+ * compute_graph_nn_2 (partition/graphs.py:23-70, voronoi == 0): sklearn's exact float64 k-NN.  source/target/distances
+ * [n*k_nn1] of the adjacency graph (neighbour j of point i at i*k_nn1 + j, the point itself dropped), target2 [n*k_nn2].
+ * Equidistant neighbours (sklearn leaves their order open) come in the order the kd-tree walk meets them. */
+int ssdr_knn_graph_dev(const float* d_xyz, size_t n, size_t k_nn1, size_t k_nn2, uint32_t* d_source, uint32_t* d_target,
+                       float* d_distances, uint32_t* d_target2, void* stream);
+/* libply_c.compute_geof (partition/ply_c/ply_c.cpp:385-455): [n,4] = linearity, planarity, scattering, verticality of
+ * every point and its k_nn neighbours d_target[n*k_nn]. */
+int ssdr_geof_dev(const float* d_xyz, size_t n, const uint32_t* d_target, size_t k_nn, float* d_geof, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

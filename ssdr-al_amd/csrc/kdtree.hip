@@ -479,6 +479,90 @@ __global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) 
     for (int j = 0; j < K; ++j) o[j] = (OutT)rs.get(j);
 }
 
+// ---- float64 search (superpoint graph) ------------------------------------------------------------
+// `compute_graph_nn_2` (partition/graphs.py:23-70) asks sklearn for the k nearest neighbours: float32 coordinates
+// widened to float64, squared distance ((dx*dx + dy*dy) + dz*dz) in float64, neighbours by ascending distance.  Same
+// forest, same walk, with every bound and distance in float64 and the result set in LDS ([slot][lane]).
+struct LdsSetD {
+    double* d; int* id; int K;
+    __device__ __forceinline__ void init() { for (int j = 0; j < K; ++j) { d[j * 64] = 1.7976931348623157e308; id[j * 64] = 0; } }
+    __device__ __forceinline__ double worst() const { return d[(K - 1) * 64]; }
+    __device__ __forceinline__ void add(double dist, int index) {
+        int j = K - 1;
+        for (; j > 0; --j) {
+            if (d[(j - 1) * 64] > dist) { d[j * 64] = d[(j - 1) * 64]; id[j * 64] = id[(j - 1) * 64]; }
+            else break;
+        }
+        d[j * 64] = dist; id[j * 64] = index;
+    }
+};
+
+__device__ __forceinline__ void kd_walk_f64(const SearchArgs& a, const KdTreeDesc& td, double qx, double qy, double qz, LdsSetD& rs) {
+    int stk_node[MAX_LEVELS]; double stk_m[MAX_LEVELS], stk_0[MAX_LEVELS], stk_1[MAX_LEVELS], stk_2[MAX_LEVELS];
+    int sp = 0;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, mind = 0.0;
+    if (qx < td.lo[0]) { d0 = (qx - td.lo[0]) * (qx - td.lo[0]); mind += d0; }
+    if (qx > td.hi[0]) { d0 = (qx - td.hi[0]) * (qx - td.hi[0]); mind += d0; }
+    if (qy < td.lo[1]) { d1 = (qy - td.lo[1]) * (qy - td.lo[1]); mind += d1; }
+    if (qy > td.hi[1]) { d1 = (qy - td.hi[1]) * (qy - td.hi[1]); mind += d1; }
+    if (qz < td.lo[2]) { d2 = (qz - td.lo[2]) * (qz - td.lo[2]); mind += d2; }
+    if (qz > td.hi[2]) { d2 = (qz - td.hi[2]) * (qz - td.hi[2]); mind += d2; }
+    int node = td.root;
+    int4 na = a.node_a[2 * (size_t)node]; float4 nb = a.node_b[2 * (size_t)node];
+    for (;;) {
+        while (na.z >= 0) {
+            const int cf = __float_as_int(nb.z);
+            const double val = cf == 0 ? qx : (cf == 1 ? qy : qz);
+            const double diff1 = val - (double)nb.x, diff2 = val - (double)nb.y;
+            int best, other; double cut;
+            if ((diff1 + diff2) < 0) { best = na.z; other = na.w; cut = diff2 * diff2; }
+            else                     { best = na.w; other = na.z; cut = diff1 * diff1; }
+            node = best; na = a.node_a[2 * (size_t)node]; nb = a.node_b[2 * (size_t)node];
+            const double dst = cf == 0 ? d0 : (cf == 1 ? d1 : d2);
+            const double m2 = mind + cut - dst;
+            if (!(m2 <= rs.worst())) continue;
+            if (sp < MAX_LEVELS) {
+                stk_node[sp] = other; stk_m[sp] = m2;
+                stk_0[sp] = cf == 0 ? cut : d0; stk_1[sp] = cf == 1 ? cut : d1; stk_2[sp] = cf == 2 ? cut : d2;
+                ++sp;
+            } else atomicOr(&a.ctr[CTR_STATUS], ST_DEPTH_OVF);
+        }
+        for (int i = na.x; i < na.y; ++i) {
+            const float4 p = a.sorted[i];
+            const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+            double dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+            if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
+        }
+        bool found = false;
+        while (sp > 0) {
+            --sp;
+            if (stk_m[sp] <= rs.worst()) {
+                node = stk_node[sp]; na = a.node_a[2 * (size_t)node]; nb = a.node_b[2 * (size_t)node];
+                mind = stk_m[sp]; d0 = stk_0[sp]; d1 = stk_1[sp]; d2 = stk_2[sp]; found = true; break;
+            }
+        }
+        if (!found) break;
+    }
+}
+
+// out: int32 ids [nq][K] by ascending distance, d2: float64 squared distances [nq][K]
+__global__ __launch_bounds__(64) void kd_search_f64_kernel(SearchArgs a, int K, double* __restrict__ out_d2) {
+    SSDR_DYN_SHARED(double, s_dyn64);
+    const int t = blockIdx.y;
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= a.nq) return;
+    const KdTreeDesc td = a.desc[a.tree0 + t];
+    int q = qi;
+    if (a.qorder_tree0 >= 0) q = __float_as_int(a.sorted[a.desc[a.qorder_tree0 + t].voff + qi].w);
+    const float* Q = a.queries + (size_t)t * a.q_stride + 3 * (size_t)q;
+    LdsSetD rs; rs.K = K; rs.d = s_dyn64 + threadIdx.x; rs.id = reinterpret_cast<int*>(s_dyn64 + 64 * K) + threadIdx.x;
+    rs.init();
+    if (td.n > 0) kd_walk_f64(a, td, (double)Q[0], (double)Q[1], (double)Q[2], rs);
+    int* o = reinterpret_cast<int*>(a.out) + (size_t)t * a.out_stride + (size_t)q * K;
+    double* od = out_d2 + (size_t)t * a.out_stride + (size_t)q * K;
+    for (int j = 0; j < K; ++j) { o[j] = rs.id[j * 64]; od[j] = rs.d[j * 64]; }
+}
+
 ForestPtrs ptrs(const KdForest& f) {
     ForestPtrs p;
     p.desc = f.desc.as<KdTreeDesc>(); p.sorted = f.sorted.as<float4>();
@@ -558,6 +642,21 @@ int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, 
         if (out_i64) hipLaunchKernelGGL((kd_search_any_kernel<int64_t>), g2, dim3(64), lds, s, a, K);
         else hipLaunchKernelGGL((kd_search_any_kernel<int32_t>), g2, dim3(64), lds, s, a, K);
     }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int kd_search_f64(const KdForest& f, int tree0, int ntrees, const float* d_queries, size_t q_stride, int nq, int K,
+                  int qorder_tree0, int32_t* d_out, double* d_out_d2, size_t out_stride, hipStream_t s) {
+    if (ntrees <= 0 || nq <= 0 || K <= 0) return SSDR_OK;
+    if (K > 128) { set_error("float64 search: K=%d > 128 is not supported", K); return SSDR_ERR_UNSUPPORTED; }
+    ForestPtrs p = ptrs(f);
+    SearchArgs a{p.desc, p.sorted, p.node_a, p.node_b, tree0, d_queries, q_stride, nq, qorder_tree0, d_out, out_stride, p.ctr};
+    dim3 g((unsigned)((nq + 63) / 64), (unsigned)ntrees);
+    const size_t lds = (size_t)64 * K * 12;
+    static bool attr_done = false;
+    if (!attr_done) { SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 128 * 12)); attr_done = true; }
+    hipLaunchKernelGGL(kd_search_f64_kernel, g, dim3(64), lds, s, a, K, d_out_d2);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

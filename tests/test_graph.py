@@ -1,0 +1,74 @@
+"""Superpoint-graph inputs: k-NN structures against the reference's own partition/graphs.py (golden vectors
+made by importing it, tests/golden/make_golden_graph.py) and against the oracle; geometric features against the oracle
+(parity unpinned for those: the reference's ply_c.cpp needs Eigen + Boost, see oracle/graph_np.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def gg():
+    return np.load(os.path.join(HERE, "golden", "graph_golden.npz"))
+
+
+def test_oracle_graph_matches_reference_golden(gg):
+    from oracle import graph_np
+    for name in ("uniform", "room"):
+        g, t2 = graph_np.compute_graph_nn_2(gg[name + "/xyz"], 10, 45)
+        for k in ("source", "target", "distances"):
+            assert_bits_equal(g[k], gg[name + "/" + k], name + " " + k)
+        assert_bits_equal(t2, gg[name + "/target2"], name + " target2")
+
+
+def test_knn_graph_matches_reference_golden(backend, gg):
+    from ssdr_al import graphs
+    for name in ("uniform", "room"):
+        x = gg[name + "/xyz"]
+        g, t2 = graphs.compute_graph_nn_2(x, 10, 45)
+        assert g["is_nn"] is True and g["source"].dtype == np.uint32 and g["distances"].dtype == np.float32 and t2.dtype == np.uint32
+        for k in ("source", "target", "distances"):
+            assert_bits_equal(g[k], gg[name + "/" + k], name + " " + k)
+        assert_bits_equal(t2, gg[name + "/target2"], name + " target2")
+        g1 = graphs.compute_graph_nn(x, 7)
+        assert_bits_equal(g1["target"], gg[name + "/nn7_target"]); assert_bits_equal(g1["distances"], gg[name + "/nn7_distances"])
+    with pytest.raises(AssertionError, match="knn1 must be smaller than knn2"):
+        graphs.compute_graph_nn_2(gg["uniform/xyz"], 12, 10)
+    with pytest.raises(NotImplementedError):
+        graphs.compute_graph_nn_2(gg["uniform/xyz"], 5, 10, voronoi=0.5)
+
+
+def test_knn_graph_fresh_inputs_against_oracle(backend):
+    from oracle import graph_np
+    from ssdr_al import graphs
+    rng = np.random.default_rng(5)
+    n = 700 if backend == "emu" else 6000
+    x = (rng.normal(0, 1, (n, 3)) * np.array([3, 2, 0.05])).astype(np.float32)          # a slab: long kd-tree walks
+    g, t2 = graphs.compute_graph_nn_2(x, 10, 45)
+    eg, et2 = graph_np.compute_graph_nn_2(x, 10, 45)
+    assert_bits_equal(t2, et2); assert_bits_equal(g["target"], eg["target"]); assert_bits_equal(g["distances"], eg["distances"])
+
+
+def test_geof_against_oracle(backend, gg):
+    from oracle import graph_np
+    from ssdr_al import libply_c
+    x = gg["room/xyz"]
+    t2 = gg["room/target2"]
+    got = libply_c.compute_geof(x, t2, 45)
+    exp = graph_np.compute_geof(x, t2, 45)
+    assert got.shape == (len(x), 4) and got.dtype == np.float32
+    # float32 covariance + float64 eigen solve on both sides; the summation order of the covariance differs (1e-4)
+    assert np.abs(got[:, :3] - exp[:, :3]).max() < 2e-4
+    assert np.abs(got[:, 3] - exp[:, 3]).max() < 2e-3            # verticality mixes eigenvectors: looser where two eigenvalues are close
+    assert (got[:, :3] >= -1e-6).all() and (got[:, 0] + got[:, 1] + got[:, 2] < 1 + 1e-4).all()     # linearity + planarity + scattering = 1
+    # a plane: planarity ~ 1, its normal is vertical -> verticality ~ 0 (the weighted |eigenvector| sum lies in the plane)
+    rng = np.random.default_rng(2)
+    p = np.concatenate([rng.random((400, 2)), np.zeros((400, 1))], 1).astype(np.float32)
+    from oracle.graph_np import compute_graph_nn_2
+    _, tp = compute_graph_nn_2(p, 5, 20)
+    gp = libply_c.compute_geof(p, tp, 20)
+    assert (gp[:, 2] < 1e-3).all() and (gp[:, 3] < 1e-3).all()
