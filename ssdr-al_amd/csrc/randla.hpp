@@ -22,6 +22,7 @@ struct LfaArgs {
     const float* w_l2; const float* b_l2;        // LFAmlp2 D/2 -> D/2 (second half only)
     const float* w_fc;                           // attention dense D -> D, no bias, [k][col]
     const float* w_fc_t;                         // the same transposed, [col][k]
+    const float* g;                              // optional [B][n][D]: fin * w_fc[0:D/2] per point (d >= 64): the kernel then only multiplies the position half
     float* out;                                  // [B][n][D]   sum_k f * softmax_k(f W)
     int n;
 };

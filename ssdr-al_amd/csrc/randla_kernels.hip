@@ -401,6 +401,24 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
 #pragma unroll
         for (int c = 0; c < NC_W; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (C::WIDE) {
+        // The neighbour-feature half of the product depends on the neighbour alone: (f_nbr | f_xyz) W = f_nbr W[0:H] + f_xyz W[H:D],
+        // and G = f W[0:H] was computed once per POINT by a plain dense launch (16x fewer rows).  The accumulators start from the
+        // gathered rows of G, the MFMA loop only covers the position half: half the matrix-core work of the attention GEMM.
+        const int kb0 = a.g ? H / 16 : 0;
+        if (a.g) {
+            const float* G = a.g + (size_t)b * a.n * D;
+#pragma unroll
+            for (int p = 0; p < NP_W; ++p) {
+                int nb4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nb4[r] = NBR[(p0 + p) * 16 + (lane >> 4) * 4 + r];
+                const bool ok = pt0 + p0 + p < a.n;
+#pragma unroll
+                for (int c = 0; c < NC_W; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[p][c][r] = ok ? G[(size_t)nb4[r] * D + (ct0 + c) * 16 + (lane & 15)] : 0.f;
+            }
+        }
         // k is taken in blocks of 16: in MFMA step u of a block lane group g supplies k = 16 kb + 4 g + u (the sum over k does not
         // care about the order), so a lane's four A values are 16 contiguous bytes of its LDS row and its four W values 16
         // contiguous bytes of the transposed weights: one ds_read_b128 + one global dwordx4 feed four MFMAs.  The next block
@@ -419,8 +437,8 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
                 fb[c][0] = v.x; fb[c][1] = v.y; fb[c][2] = v.z; fb[c][3] = v.w;
             }
         };
-        fetch16(0, av, bv);
-        for (int kb = 0; kb < D / 16; ++kb) {
+        fetch16(kb0, av, bv);
+        for (int kb = kb0; kb < D / 16; ++kb) {
             if (kb + 1 < D / 16) fetch16(kb + 1, an, bn);
 #pragma unroll
             for (int u = 0; u < 4; ++u)                      // consecutive MFMAs go to different accumulators

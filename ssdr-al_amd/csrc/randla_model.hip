@@ -144,9 +144,20 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         la.w_l1 = m->layers[base + 1].W.as<float>(); la.b_l1 = m->layers[base + 1].b.as<float>();
         la.w_l2 = m->layers[base + 4].W.as<float>(); la.b_l2 = m->layers[base + 4].b.as<float>();
         la.fin = f_pc; la.w_fc = m->layers[base + 2].W.as<float>(); la.w_fc_t = m->layers[base + 2].Wt.as<float>(); la.out = agg;
+        float* gbuf = nullptr;
+        if (d >= 64) {      // neighbour half of the attention product once per point: G = f_pc * W[0:h]  (rows 0..h-1 of the [d][d] weights)
+            gbuf = buf(idxs(i, 5), rows * d); if (!gbuf) return SSDR_ERR_HIP;
+            DenseArgs ga{}; ga.x1 = f_pc; ga.k1 = h; ga.W = la.w_fc; ga.b = nullptr; ga.y = gbuf; ga.M = (int)rows; ga.N = d; ga.act = 0; ga.m_per_batch = 1;
+            SSDR_TRY(launch_dense(ga, s));
+        }
+        la.g = gbuf;
         SSDR_TRY(launch_lfa(d, la, false, Bi, s));                                                          // LocSE + att pool 1
         SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 3], aggm, (int)rows, 1), s));                   // att1 mlp d->h
         la.fin = aggm; la.w_fc = m->layers[base + 5].W.as<float>(); la.w_fc_t = m->layers[base + 5].Wt.as<float>(); la.out = agg;
+        if (gbuf) {
+            DenseArgs ga{}; ga.x1 = aggm; ga.k1 = h; ga.W = la.w_fc; ga.b = nullptr; ga.y = gbuf; ga.M = (int)rows; ga.N = d; ga.act = 0; ga.m_per_batch = 1;
+            SSDR_TRY(launch_dense(ga, s));
+        }
         SSDR_TRY(launch_lfa(d, la, true, Bi, s));                                                           // LocSE2 + att pool 2
         SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
         DenseArgs r = dense(aggm, d, m->layers[base + 7], out, (int)rows, 1);                               // lrelu(mlp2 + shortcut)
