@@ -252,6 +252,12 @@ int ssdr_dev_free(void* d_ptr);
 int ssdr_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int ssdr_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 
+/* cpp_knn_batch_distance_pick (knn_.h:21-23, knn_.cxx:136-203, knn.pyx:111-149): nqueries "least used first" query points
+ * per batch element and their K neighbours.  The reference seeds std::mt19937 with time(0); here the seed is an argument
+ * (the same seed gives the reference's result).  batch_queries [B][nqueries][dim], batch_indices [B][nqueries][K]. */
+int ssdr_knn_batch_distance_pick(const float* batch_data, size_t batch_size, size_t npts, size_t dim, float* batch_queries,
+                                 size_t nqueries, size_t K, int64_t* batch_indices, uint32_t seed);
+
 /* ---- superpoint-graph inputs (the partition itself, cut-pursuit, stays out of scope) -----------------
  * compute_graph_nn_2 (partition/graphs.py:23-70, voronoi == 0): sklearn's exact float64 k-NN.  source/target/distances
  * [n*k_nn1] of the adjacency graph (neighbour j of point i at i*k_nn1 + j, the point itself dropped), target2 [n*k_nn2].

@@ -90,6 +90,15 @@ class _Oracle:
         self.lib.oracle_knn_batch(p, p.shape[0], p.shape[1], p.shape[2], q, q.shape[1], K, out, int(threads))
         return out
 
+    def knn_batch_distance_pick(self, pts, nqueries, K, seed):
+        p = np.ascontiguousarray(pts, np.float32)
+        out = np.zeros((p.shape[0], nqueries, K), np.int64)
+        q = np.zeros((p.shape[0], nqueries, p.shape[2]), np.float32)
+        self.lib.oracle_knn_batch_distance_pick.restype = None
+        self.lib.oracle_knn_batch_distance_pick.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, _i64p, C.c_uint32]
+        self.lib.oracle_knn_batch_distance_pick(p, p.shape[0], p.shape[1], p.shape[2], q, nqueries, K, out, int(seed) & 0xffffffff)
+        return out, q
+
     def kdtree(self, pts, leaf_max=10):
         p = np.ascontiguousarray(pts, np.float32)
         n = p.shape[0]
@@ -153,6 +162,24 @@ class _Ref:
         (self.lib.ref_knn_batch_omp if omp else self.lib.ref_knn_batch)(
             p, p.shape[0], p.shape[1], p.shape[2], q, q.shape[1], K, out)
         return out
+
+    def knn_batch_distance_pick(self, pts, nqueries, K, seed):
+        """cpp_knn_batch_distance_pick with the clock it seeds std::mt19937 from pinned to `seed` (oracle/ref_shim.cpp)."""
+        L = self.lib
+        if not hasattr(L, "ref_knn_batch_distance_pick"):
+            return None                                       # an older prebuilt _ref without the hook
+        L.ref_set_time.restype = None; L.ref_set_time.argtypes = [C.c_long]
+        L.ref_knn_batch_distance_pick.restype = None
+        L.ref_knn_batch_distance_pick.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, _i64p]
+        p = np.ascontiguousarray(pts, np.float32)
+        out = np.zeros((p.shape[0], nqueries, K), np.int64)
+        q = np.zeros((p.shape[0], nqueries, p.shape[2]), np.float32)
+        L.ref_set_time(int(seed))
+        try:
+            L.ref_knn_batch_distance_pick(p, p.shape[0], p.shape[1], p.shape[2], q, nqueries, K, out)
+        finally:
+            L.ref_set_time(-1)
+        return out, q
 
 
 _c = None

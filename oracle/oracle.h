@@ -41,6 +41,11 @@ void oracle_knn_batch(const float* pts, size_t batch, size_t npts, size_t dim,
                       const float* queries, size_t nq, size_t K,
                       int64_t* out_idx, int threads);
 
+/* nearest_neighbors/knn_.cxx:136-203 (cpp_knn_batch_distance_pick) with an explicit std::mt19937 seed (the reference
+ * uses time(0)).  out_queries [batch][nq][dim], out_idx [batch][nq][K]. */
+void oracle_knn_batch_distance_pick(const float* pts, size_t batch, size_t npts, size_t dim, float* out_queries, size_t nq,
+                                    size_t K, int64_t* out_idx, uint32_t seed);
+
 /* Exposes the emulated kd-tree for white-box tests of the GPU builder:
  * vind (npts), and per node: left,right,divfeat,child1,child2 (int32 x5) + divlow,divhigh (float x2).
  * Returns the node count (nodes are numbered in pre-order, root = 0). */

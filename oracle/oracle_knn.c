@@ -274,3 +274,61 @@ long oracle_kdtree_dump(const float* pts, size_t npts, size_t dim, size_t leaf_m
     }
     long nn = (long)t.nnodes; tree_free(&t); return nn;
 }
+
+/* ---- knn_batch_distance_pick (knn_.cxx:136-203) -----------------------------------------------------------------
+ * Sequential "least used points first" query picking; the reference seeds std::mt19937 with time(0) and draws ONE
+ * number per query, batch elements in order.  MT19937 restated below (Matsumoto & Nishimura 1998, the algorithm
+ * std::mt19937 is specified to be); the seed is an argument. */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+static void mt_seed(mt19937_t* g, uint32_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+static uint32_t mt_next(mt19937_t* g)
+{
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+void oracle_knn_batch_distance_pick(const float* pts, size_t batch, size_t npts, size_t dim, float* out_queries, size_t nq,
+                                    size_t K, int64_t* out_idx, uint32_t seed)
+{
+    mt19937_t g; mt_seed(&g, seed);
+    size_t* ids = (size_t*)calloc(K ? K : 1, sizeof(size_t));
+    float* ds = (float*)calloc(K ? K : 1, sizeof(float));
+    int* used = (int*)malloc(sizeof(int) * (npts ? npts : 1));
+    size_t* poss = (size_t*)malloc(sizeof(size_t) * (npts ? npts : 1));
+    for (size_t b = 0; b < batch; ++b) {
+        const float* P = pts + b * npts * dim;
+        ktree t; tree_build(&t, P, npts, dim, 10);
+        for (size_t i = 0; i < npts; ++i) used[i] = 0;
+        int current = 0;
+        for (size_t q = 0; q < nq; ++q) {
+            size_t np_ = 0;
+            while (np_ == 0) {                                           /* :155-165 */
+                for (size_t i = 0; i < npts; ++i) if (used[i] == current) poss[np_++] = i;
+                if (np_ == 0) { current = used[0]; for (size_t i = 1; i < npts; ++i) if (used[i] < current) current = used[i]; }
+            }
+            const size_t index = poss[mt_next(&g) % np_];                /* :168 */
+            /* :177-180: fresh (zeroed) id / dist vectors for every query */
+            for (size_t j = 0; j < K; ++j) { ids[j] = 0; ds[j] = 0.f; }
+            tree_query(&t, P + index * dim, K, ids, ds);
+            for (size_t j = 0; j < K; ++j) used[ids[j]]++;               /* :182-184 */
+            used[index] += 100;                                          /* :185 */
+            for (size_t j = 0; j < K; ++j) out_idx[(b * nq + q) * K + j] = (int64_t)ids[j];
+            for (size_t d = 0; d < dim; ++d) out_queries[(b * nq + q) * dim + d] = P[index * dim + d];
+        }
+        tree_free(&t);
+    }
+    free(ids); free(ds); free(used); free(poss);
+}

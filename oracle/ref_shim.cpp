@@ -10,6 +10,7 @@
 // generators can call the reference cores through ctypes.
 #include <cstddef>
 #include <cstring>
+#include <ctime>
 #include <vector>
 #include "grid_subsampling/grid_subsampling.h"   // -I<ref>/utils/cpp_wrappers/cpp_subsampling
 #include "knn_.h"                                // -I<ref>/utils/nearest_neighbors
@@ -44,5 +45,22 @@ void ref_knn_batch(const float* p, size_t b, size_t np_, size_t dim, const float
 { cpp_knn_batch(p, b, np_, dim, q, nq, K, out); }
 void ref_knn_batch_omp(const float* p, size_t b, size_t np_, size_t dim, const float* q, size_t nq, size_t K, long* out)
 { cpp_knn_batch_omp(p, b, np_, dim, q, nq, K, out); }
+
+
+// cpp_knn_batch_distance_pick seeds std::mt19937 with time(0) (knn_.cxx:141).  The library is linked with
+// -Wl,-Bsymbolic-functions, so the reference object's call to time() binds to this definition: tests pin the clock to get
+// a reproducible run of the UNMODIFIED reference code (ref_set_time(-1) = real clock again).
+static long g_fake_time = -1;
+time_t time(time_t* t)
+{
+    time_t v;
+    if (g_fake_time >= 0) v = (time_t)g_fake_time;
+    else { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); v = ts.tv_sec; }
+    if (t) *t = v;
+    return v;
+}
+void ref_set_time(long v) { g_fake_time = v; }
+void ref_knn_batch_distance_pick(const float* p, size_t b, size_t np_, size_t dim, float* q, size_t nq, size_t K, long* out)
+{ cpp_knn_batch_distance_pick(p, b, np_, dim, q, nq, K, out); }
 
 }

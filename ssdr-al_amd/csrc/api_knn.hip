@@ -1,5 +1,6 @@
 // C-ABI entry points of the KNN ops (include/ssdr_al.h), host and device flavours.
 #include "ssdr_internal.hpp"
+#include <random>
 
 namespace ssdr {
 namespace {
@@ -74,6 +75,34 @@ int ssdr_knn_batch_dev(const float* d_batch_data, size_t batch_size, size_t npts
     if (batch_size == 0 || nqueries == 0 || K == 0) return SSDR_OK;
     return knn_batch_device(d_batch_data, batch_size, npts, d_queries, nqueries, K, d_indices, false,
                             d_batch_data == d_queries && npts == nqueries, pick_stream(stream));
+}
+
+int ssdr_knn_batch_distance_pick(const float* batch_data, size_t batch_size, size_t npts, size_t dim, float* batch_queries, size_t nqueries,
+                                 size_t K, int64_t* batch_indices, uint32_t seed) {
+    if (dim != 3) { set_error("dim=%zu: only dim == 3 is implemented", dim); return SSDR_ERR_UNSUPPORTED; }
+    if (!batch_data || !batch_queries || !batch_indices || npts == 0 || npts > 0x3fffffff) { set_error("knn_batch_distance_pick: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (batch_size == 0 || nqueries == 0 || K == 0) return SSDR_OK;
+    KnnState& S = st(); Context& c = ctx(); hipStream_t s = c.stream;
+    std::mt19937 gen(seed);                                   // the reference: mt19937 mt_rand(time(0)), one draw per query (:141, :168)
+    std::vector<uint32_t> rnd(batch_size * nqueries);
+    for (auto& r : rnd) r = (uint32_t)gen();
+    DevBuf d_rnd, d_used, d_q, d_idx;
+    SSDR_TRY(S.pts.reserve(batch_size * npts * 12 + 16));
+    SSDR_TRY(d_rnd.reserve(4 * rnd.size())); SSDR_TRY(d_used.reserve(4 * batch_size * npts));
+    SSDR_TRY(d_q.reserve(12 * batch_size * nqueries)); SSDR_TRY(d_idx.reserve(8 * batch_size * nqueries * K));
+    SSDR_HIP(hipMemcpyAsync(S.pts.p, batch_data, batch_size * npts * 12, hipMemcpyHostToDevice, s));
+    SSDR_HIP(hipMemcpyAsync(d_rnd.p, rnd.data(), 4 * rnd.size(), hipMemcpyHostToDevice, s));
+    std::vector<KdTreeDesc> trees(batch_size);
+    for (size_t b = 0; b < batch_size; ++b) { trees[b].pts = S.pts.as<float>() + b * npts * 3; trees[b].n = (int)npts; }
+    SSDR_TRY(kd_build(S.forest, trees, s));
+    SSDR_TRY(kd_distance_pick(S.forest, (int)batch_size, (int)npts, d_rnd.as<uint32_t>(), (int)nqueries, (int)K, d_used.as<int>(), d_q.as<float>(),
+                              d_idx.as<int64_t>(), s));
+    SSDR_HIP(hipMemcpyAsync(batch_queries, d_q.p, 12 * batch_size * nqueries, hipMemcpyDeviceToHost, s));
+    SSDR_HIP(hipMemcpyAsync(batch_indices, d_idx.p, 8 * batch_size * nqueries * K, hipMemcpyDeviceToHost, s));
+    SSDR_HIP(hipStreamSynchronize(s));
+    d_rnd.release(); d_used.release(); d_q.release(); d_idx.release();
+    return kd_check(S.forest, s);
 }
 
 int ssdr_knn_pyramid_dev(const float* d_xyz, size_t B, size_t npts, size_t num_layers, const int32_t* ratios, size_t K,

@@ -479,6 +479,68 @@ __global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) 
     for (int j = 0; j < K; ++j) o[j] = (OutT)rs.get(j);
 }
 
+// ---- knn_batch_distance_pick (knn_.cxx:136-203) --------------------------------------------------------------------
+// "Least used points first" query picking: every query is a point whose use count equals the current minimum, chosen
+// by one std::mt19937 draw (pre-generated on the host, one per query, batch elements in order); its K neighbours'
+// counts go up by one, its own by 100.  Sequential by construction (query q+1 depends on the counts query q left):
+// one workgroup per batch element, the count / select steps block-parallel, the single kd walk on one lane.
+__global__ __launch_bounds__(256) void kd_distance_pick_kernel(SearchArgs a, const uint32_t* __restrict__ rnd, int K, int npts, int* used_all,
+                                                               float* out_q, long long* out_idx) {
+    SSDR_DYN_SHARED(float, s_dyn);
+    __shared__ int s_part[256];
+    __shared__ int s_sel[2];          // [0] picked index, [1] current id
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const KdTreeDesc td = a.desc[a.tree0 + b];
+    const float* P = td.pts;
+    int* used = used_all + (size_t)b * npts;
+    for (int i = tid; i < npts; i += 256) used[i] = 0;
+    if (tid == 0) s_sel[1] = 0;
+    __syncthreads();
+    const int chunk = (npts + 255) / 256, lo = min(tid * chunk, npts), hi = min(lo + chunk, npts);
+    for (int q = 0; q < a.nq; ++q) {
+        int total = 0, before = 0, mine = 0;
+        for (;;) {
+            const int cur = s_sel[1];
+            mine = 0;
+            for (int i = lo; i < hi; ++i) mine += used[i] == cur;
+            s_part[tid] = mine;
+            __syncthreads();
+            total = 0; before = 0;
+            for (int t = 0; t < 256; ++t) { const int c = s_part[t]; if (t < tid) before += c; total += c; }
+            __syncthreads();
+            if (total > 0) break;
+            int mn = 0x7fffffff;                              // no point left at this count: continue from the minimum (:160-162)
+            for (int i = lo; i < hi; ++i) mn = min(mn, used[i]);
+            s_part[tid] = mn;
+            __syncthreads();
+            if (tid == 0) { int m = s_part[0]; for (int t = 1; t < 256; ++t) m = min(m, s_part[t]); s_sel[1] = m; }
+            __syncthreads();
+        }
+        const int r = (int)(rnd[(size_t)b * a.nq + q] % (uint32_t)total);     // possible_ids[mt_rand() % size] (:168), ids ascending
+        if (r >= before && r < before + mine) {
+            const int cur = s_sel[1]; int k = r - before;
+            for (int i = lo; i < hi; ++i) if (used[i] == cur && k-- == 0) { s_sel[0] = i; break; }
+        }
+        __syncthreads();
+        const int index = s_sel[0];
+        LdsSet rs; rs.K = K; rs.d = s_dyn; rs.id = reinterpret_cast<int*>(s_dyn + 64 * K);
+        if (tid == 0) {
+            rs.init();
+            if (td.n > 0) kd_walk(a, td, P[3 * (size_t)index], P[3 * (size_t)index + 1], P[3 * (size_t)index + 2], rs);
+        }
+        __syncthreads();
+        if (tid < K) {
+            const int id = rs.id[tid * 64];
+            atomicAdd(&used[id], 1);                                                   // :182-184 (unfilled slots hold id 0)
+            out_idx[((size_t)b * a.nq + q) * K + tid] = id;
+        }
+        if (tid < 3) out_q[((size_t)b * a.nq + q) * 3 + tid] = P[3 * (size_t)index + tid];
+        __syncthreads();
+        if (tid == 0) used[index] += 100;                                              // :185
+        __syncthreads();
+    }
+}
+
 // ---- float64 search (superpoint graph) ------------------------------------------------------------
 // `compute_graph_nn_2` (partition/graphs.py:23-70) asks sklearn for the k nearest neighbours: float32 coordinates
 // widened to float64, squared distance ((dx*dx + dy*dy) + dz*dz) in float64, neighbours by ascending distance.  Same
@@ -657,6 +719,18 @@ int kd_search_f64(const KdForest& f, int tree0, int ntrees, const float* d_queri
     static bool attr_done = false;
     if (!attr_done) { SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 128 * 12)); attr_done = true; }
     hipLaunchKernelGGL(kd_search_f64_kernel, g, dim3(64), lds, s, a, K, d_out_d2);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int kd_distance_pick(const KdForest& f, int ntrees, int npts, const uint32_t* d_rnd, int nq, int K, int* d_used, float* d_out_q,
+                     int64_t* d_out_idx, hipStream_t s) {
+    if (ntrees <= 0 || nq <= 0 || K <= 0) return SSDR_OK;
+    if (K > 256) { set_error("K=%d > 256 is not supported", K); return SSDR_ERR_UNSUPPORTED; }
+    ForestPtrs p = ptrs(f);
+    SearchArgs a{p.desc, p.sorted, p.node_a, p.node_b, 0, nullptr, 0, nq, -1, nullptr, 0, p.ctr};
+    hipLaunchKernelGGL(kd_distance_pick_kernel, dim3((unsigned)ntrees), dim3(256), (size_t)64 * K * 8, s, a, d_rnd, K, npts, d_used, d_out_q,
+                       reinterpret_cast<long long*>(d_out_idx));
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

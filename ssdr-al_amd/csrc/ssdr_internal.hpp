@@ -104,6 +104,9 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees, hipStream_t s);
 // out: int32 or int64 [ntrees][nq][K].
 int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, size_t q_stride, int nq, int K,
               int qorder_tree0, void* d_out, bool out_i64, size_t out_stride, hipStream_t s);
+// knn_.cxx:136-203 on a built forest of ntrees trees of npts points each: d_rnd holds ntrees*nq std::mt19937 draws
+int kd_distance_pick(const KdForest& f, int ntrees, int npts, const uint32_t* d_rnd, int nq, int K, int* d_used, float* d_out_q,
+                     int64_t* d_out_idx, hipStream_t s);
 // float64 distances / bounds (sklearn semantics, partition/graphs.py): ids by ascending distance + squared distances
 int kd_search_f64(const KdForest& f, int tree0, int ntrees, const float* d_queries, size_t q_stride, int nq, int K,
                   int qorder_tree0, int32_t* d_out, double* d_out_d2, size_t out_stride, hipStream_t s);

@@ -81,6 +81,7 @@ def lib():
         L.ssdr_rank_regions_dev.argtypes = [vp, sz, vp, vp]
         L.ssdr_segment_mean_features_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, sz, vp, vp]
         L.ssdr_widen_f32_f64_dev.argtypes = [vp, sz, vp, vp, vp]
+        L.ssdr_knn_batch_distance_pick.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp, C.c_uint32]
         L.ssdr_knn_graph_dev.argtypes = [vp, sz, sz, sz, vp, vp, vp, vp, vp]
         L.ssdr_geof_dev.argtypes = [vp, sz, vp, sz, vp, vp]
         L.ssdr_cloud_graph_dev.argtypes = [vp, vp, vp, vp, sz, sz, i32, vp, vp, vp, vp]

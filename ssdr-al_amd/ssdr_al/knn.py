@@ -29,6 +29,20 @@ def knn_batch(pts, queries, K, omp=False):
     return indices
 
 
+def knn_batch_distance_pick(pts, nqueries, K, omp=False, seed=None):
+    """knn.pyx:111-149 — pts [B,Np,3] -> (indices int64 [B,nqueries,K], queries float32 [B,nqueries,3]): query points picked
+    "least used first".  The reference seeds std::mt19937 with time(0); `seed=None` does the same, an int reproduces a run
+    (of the reference too, given the same clock value).  `omp` is accepted and ignored."""
+    import time
+    pts_c = np.ascontiguousarray(pts, dtype=np.float32)
+    indices = np.zeros((pts_c.shape[0], nqueries, K), dtype=np.int64)
+    queries = np.zeros((pts_c.shape[0], nqueries, pts_c.shape[2]), dtype=np.float32)
+    s = int(time.time()) if seed is None else int(seed)
+    _lib.check(_lib.lib().ssdr_knn_batch_distance_pick(_lib.ptr(pts_c), pts_c.shape[0], pts_c.shape[1], pts_c.shape[2], _lib.ptr(queries),
+                                                       int(nqueries), int(K), _lib.ptr(indices), s & 0xffffffff))
+    return indices, queries
+
+
 def knn_batch_i32(pts, queries, K):
     """Same search, int32 result (what DataProcessing.knn_search returns, helper_tool.py:182-183)."""
     pts_c = np.ascontiguousarray(pts, dtype=np.float32)

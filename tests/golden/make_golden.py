@@ -99,5 +99,21 @@ def main():
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
+def distance_pick_golden():
+    """knn_batch_distance_pick of the REAL reference with the clock its std::mt19937 is seeded from pinned (oracle/ref_shim.cpp)."""
+    import oracle
+    rng = np.random.default_rng(21)
+    pts = (rng.random((3, 700, 3)) * np.array([4, 3, 2])).astype(np.float32)
+    pts[1, 300:] = pts[1, :400]                               # duplicated points: equidistant neighbours
+    out = {"dp/pts": pts}
+    for seed, nq, K in ((1700000000, 120, 16), (7, 64, 1)):
+        idx, q = oracle.ref().knn_batch_distance_pick(pts, nq, K, seed)
+        out["dp/%d/idx" % seed], out["dp/%d/q" % seed] = idx, q
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "distance_pick_golden.npz"), **out)
+    print("distance_pick_golden.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("SSDR_GOLDEN_ONLY") != "distance_pick":       # the other files are byte-stable; regenerate them only on purpose
+        main()
+    distance_pick_golden()

@@ -1,5 +1,6 @@
 """KNN parity: the HIP kd-tree path through the C ABI against the golden vectors of the reference build and
 against the oracle on fresh inputs.  Bit-exact index equality, ties included."""
+import os
 import numpy as np
 import pytest
 
@@ -109,3 +110,26 @@ def test_pyramid_full_size_properties():
                 cur = s
     finally:
         _lib.use(None)
+
+
+def test_knn_batch_distance_pick_matches_reference(backend, orc):
+    """knn_batch_distance_pick (knn.pyx:111-149): golden vectors from the REAL reference with its mt19937 clock seed pinned
+    (tests/golden/make_golden.py: distance_pick_golden), the oracle, and the HIP path with the same seed."""
+    import nearest_neighbors.lib.python.nearest_neighbors as nn
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "distance_pick_golden.npz"))
+    pts = g["dp/pts"]
+    for seed, nq, K in ((1700000000, 120, 16), (7, 64, 1)):
+        oi, oq = orc.knn_batch_distance_pick(pts, nq, K, seed)
+        assert_bits_equal(oi, g["dp/%d/idx" % seed], "oracle idx"); assert_bits_equal(oq, g["dp/%d/q" % seed], "oracle queries")
+        idx, q = nn.knn_batch_distance_pick(pts, nq, K, omp=True, seed=seed)
+        assert idx.dtype == np.int64 and idx.shape == (3, nq, K) and q.dtype == np.float32 and q.shape == (3, nq, 3)
+        assert_bits_equal(idx, g["dp/%d/idx" % seed], "idx seed %d" % seed)
+        assert_bits_equal(q, g["dp/%d/q" % seed], "queries seed %d" % seed)
+    # enough queries to exhaust the zero-count points: the "continue from the minimum count" branch (knn_.cxx:160-162)
+    small = pts[:1, :40]
+    idx, q = nn.knn_batch_distance_pick(small, 60, 4, seed=3)
+    oi, oq = orc.knn_batch_distance_pick(small, 60, 4, 3)
+    assert_bits_equal(idx, oi); assert_bits_equal(q, oq)
+    # time-seeded like the reference when no seed is given: still a valid pick (every query is one of the points)
+    idx, q = nn.knn_batch_distance_pick(small, 5, 4)
+    assert all((small[0] == q[0, i]).all(1).any() for i in range(5))
