@@ -82,3 +82,29 @@ def test_overlapped_batches_give_the_same_selection(backend, depth):
     for k in ((depth + 1,) if backend == "emu" else (1, 2, 5)):       # the emulator is slow: one run that fills and drains the pipe
         sel, _ = pipe.run(k)
         assert np.array_equal(sel, one)
+
+
+def test_semantic3d_configuration_matches_oracle(backend):
+    """The other dataset flavour of the reference (helper_tool.py:77-117): 8 classes, 0.06 m grid, 65536-point tiles (a small
+    tile on the CPU logic build); every stage against the oracle like the S3DIS case."""
+    from oracle import pipeline_np, randla_np as R
+    from ssdr_al import pipeline, synthetic
+    from ssdr_al.helper_tool import ConfigSemantic3D
+
+    class Cfg(ConfigSemantic3D):
+        pass
+    Cfg.num_points = 1024 if backend == "emu" else 65536
+    W = R.init_weights(0, num_classes=Cfg.num_classes)
+    rooms = [synthetic.make_room(6100 + i, density=60.0 if backend == "emu" else 3000.0) for i in range(2)]
+    rooms = [(r[0], r[1], (r[2] % Cfg.num_classes).astype(r[2].dtype)) + tuple(r[3:]) for r in rooms]
+    hp = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms(rooms)
+    sel, unl = hp.step()
+    ref = pipeline_np.run(hp, rooms, W, threads=2)
+    assert_bits_equal(hp.xyz.to_host(), ref["xyz"], "tiles")
+    for l in range(Cfg.num_layers):
+        assert_bits_equal(hp.neigh[l].to_host(), ref["neigh"][l], "neigh level %d" % l)
+        assert_bits_equal(hp.interp[l].to_host(), ref["interp"][l], "interp level %d" % l)
+    gp, gf = hp.probs.to_host(), hp.f32.to_host()
+    assert gp.shape[1] == 8 and np.abs(gp - ref["probs"]).max() < 1e-3 and np.abs(gf - ref["f32"]).max() < 1e-3     # north_star tolerance (fp32)
+    ref2 = pipeline_np.run(hp, rooms, W, threads=2, net_outputs=(gp, gf))                # selection: exact given the same network outputs
+    assert np.array_equal(hp.sorted_inds.to_host(), ref2["sorted_inds"]) and unl == ref2["unl"] and np.array_equal(sel, ref2["selected"])
