@@ -346,6 +346,12 @@ struct SearchArgs {
     int tree0; const float* queries; size_t q_stride; int nq; int qorder_tree0; void* out; size_t out_stride; int* ctr;
 };
 
+#ifndef HIPEMU
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+#else
+static inline float med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+#endif
+
 template <int K>
 struct RegSet {   // KNNResultSet (:36-102) in registers
     float d[K]; int id[K];
@@ -355,12 +361,17 @@ struct RegSet {   // KNNResultSet (:36-102) in registers
     }
     __device__ __forceinline__ float worst() const { return d[K - 1]; }
     __device__ __forceinline__ void add(float dist, int index) {   // requires dist < worst()
+        // sorted insertion after the elements that are <= dist (KNNResultSet::addPoint :63-92): slot j takes the median of
+        // (d[j-1], dist, d[j]) — one v_med3_f32 — and the id follows from the comparisons c_j = d[j] > dist
+        bool c[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = d[j] > dist;
 #pragma unroll
         for (int j = K - 1; j > 0; --j) {
-            if (d[j - 1] > dist) { d[j] = d[j - 1]; id[j] = id[j - 1]; }
-            else if (d[j] > dist) { d[j] = dist; id[j] = index; }
+            id[j] = c[j - 1] ? id[j - 1] : (c[j] ? index : id[j]);
+            d[j] = med3(d[j - 1], dist, d[j]);
         }
-        if (d[0] > dist) { d[0] = dist; id[0] = index; }
+        if (c[0]) { d[0] = dist; id[0] = index; }
     }
     __device__ __forceinline__ int get(int j) const { return id[j]; }
 };
