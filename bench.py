@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the batches strictly one after the other")
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=(0, 2, 3, 4, 5),
-                    help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 3 with the exchanges of N > 1")
+                    help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 4 with the exchanges of N > 1")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
     args = ap.parse_args()
 
@@ -50,9 +50,10 @@ def main():
     dist = None
     use_dist = world > 1 or bool(os.environ.get("SSDR_BENCH_FORCE_DIST"))      # the latter: exercise the RCCL path on one GPU
     if args.pipeline_depth == 0:
-        # With the exchanges the host loop (selection + 3 host-synchronous collectives) is what bounds a step, and every extra
-        # stream in flight lengthens those waits: measured on one GPU through RCCL, 72 Mpoints/s at depth 3 vs 58 at depth 5.
-        args.pipeline_depth = 3 if use_dist else 5
+        # One GPU: every stage on its own stream (99 vs 86 Mpoints/s for the 4-stream grouping on the same box).  With the
+        # exchanges torch / RCCL bring their own streams into the process and the 4 hardware queues get shared: the grouping
+        # front end + KNN | network | scoring | selection then wins by far (one GPU through RCCL: 92 vs 63 Mpoints/s).
+        args.pipeline_depth = 4 if use_dist else 5
     if use_dist:
         import torch
         import torch.distributed as dist

@@ -282,16 +282,21 @@ class Pipelined:
     depth 2: selection of batch k (latency-bound: host decisions, one workgroup of FPS) on the main stream next to
              everything else of batch k+1 on a second stream;
     depth 3: front end (subsample + tiles) on its own stream, one batch further ahead;
-    depth 4: KNN pyramid on its own stream too;   depth 5: and scoring apart from the network.
+    depth 4: front end + KNN pyramid | network | scoring | selection — three created streams + the main one; the choice when a
+             framework's own streams (RCCL exchanges) share the process and its 4 hardware queues (92 vs 63 Mpoints/s);
+    depth 5 (default): every stage on its own stream (one GPU, no framework streams: 99 vs 86 Mpoints/s for depth 4).
     Every batch still goes through every stage; `run(K)` finishes K selections."""
     STAGES = ("front", "knn", "infer", "score")
-    GROUPS = {2: (0, 0, 0, 0), 3: (0, 1, 1, 1), 4: (0, 1, 2, 2), 5: (0, 1, 2, 3)}     # stage -> stream group
+    GROUPS = {2: (0, 0, 0, 0), 3: (0, 1, 1, 1), 4: (0, 0, 1, 2), 5: (0, 1, 2, 3)}     # stage -> stream group
 
-    def __init__(self, make_hot_path, depth=5):
-        assert depth in self.GROUPS
+    def __init__(self, make_hot_path, depth=5, groups=None):
+        """groups: optional stage -> stream-group tuple for (front, knn, infer, score), non-decreasing from 0; depth = last group + 2"""
+        if groups is not None:
+            depth = groups[-1] + 2
+        assert groups is not None or depth in self.GROUPS
         L = _lib.lib()
         self.depth = depth
-        self.group = dict(zip(self.STAGES, self.GROUPS[depth]))
+        self.group = dict(zip(self.STAGES, groups if groups is not None else self.GROUPS[depth]))
         # The first stream created after the library's own shares its hardware queue on this runtime (measured on
         # MI355X / ROCm 7.2: whatever stage sat on it serialised with the selection kernels of the main stream, 67 vs
         # 81 Mpoints/s at depth 4, for any GPU_MAX_HW_QUEUES): leave that one unused.
