@@ -158,6 +158,9 @@ def main():
         roofline = {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
                     "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2), "conditions": "sequential pass, one kernel at a time",
+                    "note": ("algorithmic FLOPs of the reference's formulation (attention dense d x d on every neighbour row); the kernel itself "
+                             "executes the position half on the matrix cores, the neighbour half runs once per point in dense_kernel and is "
+                             "gathered: frac is algorithmic work per second against the MFMA peak, not matrix-core utilisation") if name == "lfa_att_kernel" else None,
                     "others": {r[0]: {"ms_per_step": round(r[2] / NPROF, 3), "launches_per_step": r[1] // NPROF} for r in rows}}
         for r in timed_rows:
             if r[0] == name and pipe is not None:
