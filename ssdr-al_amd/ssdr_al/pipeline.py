@@ -203,6 +203,11 @@ class HotPath:
         return unl, lab, sampling_batch
 
     def _select(self, comm=None):
+        self._select_issue(comm)
+        return self._select_collect()
+
+    def _select_issue(self, comm=None):
+        """everything of the selection up to the enqueued FPS chain (the host decisions and uploads happen here)"""
         L = _lib.lib()
         sorted_inds = self.sorted_inds.to_host() if self.global_order is None else None   # small D2H: the host decides the candidate lists
         unl, lab, sampling_batch = self._candidates(sorted_inds)
@@ -253,8 +258,14 @@ class HotPath:
         d_out = DevArray((sampling_batch,), np.int32)
         start = 0                                            # np.random.randint(0, n) in the reference (:133); fixed here
         _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
+        self._keep = (blocks, d_v, d_tmp, d_mf, d_comb)
+        self._pending = (d_out, unl)
+
+    def _select_collect(self):
+        """wait for the FPS chain of _select_issue and read the selection back"""
+        d_out, unl = self._pending
+        self._pending = None
         _lib.sync()
-        self._keep = (blocks, d_v, d_tmp, d_mf)
         sel = d_out.to_host()
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
         return sel, unl
@@ -343,14 +354,16 @@ class Pipelined:
                         self.hp[b % self.depth]._score_finish(comm)
         for k in range(steps):
             _lib.check(L.ssdr_stream_wait(None, self.streams[self.group["score"]]))    # main stream: batch k's scores are ready
+            hk = self.hp[k % self.depth]
+            hk._select_issue(comm)                           # batch k: host decisions + the whole selection chain enqueued ...
             late = []
-            for b in range(k + 1, min(steps, k + first + 1)):
-                for name in self.STAGES:
+            for b in range(k + 1, min(steps, k + first + 1)):   # ... the other stages are issued while its FPS chain (one workgroup,
+                for name in self.STAGES:                        # ~1.6 ms) runs, instead of before it ...
                     if b == k + lead[name]:
                         self._stage(name, b)                 # the buffer set of batch b was last read by select(b - depth), done
                         if name == "score":
                             late.append(b)
-            out = self.hp[k % self.depth]._select(comm)      # batch k: selection (host-synchronous)
+            out = hk._select_collect()                       # ... and only then the host waits for the selection
             for b in late:                                   # with a communicator: exchanges 1 + 2 of batch k+1, host-synchronous, after the
                 self.hp[b % self.depth]._score_finish(comm)  # selection, by when that batch's scoring kernels have long finished
         self._drain()
