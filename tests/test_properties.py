@@ -1,0 +1,77 @@
+"""Size-independent properties at the sizes of BASELINE.json (the oracle finishes such inputs in minutes, not seconds, so the
+full-size runs are checked through invariants of the domain; the bit-exact comparisons live in the other test files).
+On the CPU logic build the same checks run on small inputs."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+
+def _d2(a, b):
+    d = a.astype(np.float32) - b.astype(np.float32)
+    s = d[..., 0] * d[..., 0]; s = s + d[..., 1] * d[..., 1]; s = s + d[..., 2] * d[..., 2]      # the metric's own fp32 order
+    return s
+
+
+def test_knn_batch_invariants_at_tile_size(backend):
+    from ssdr_al import knn
+    rng = np.random.default_rng(41)
+    B, N, K = (2, 2048, 16) if backend == "emu" else (16, 40960, 16)
+    pts = (rng.random((B, N, 3)) * np.array([6, 5, 3])).astype(np.float32)
+    idx = knn.knn_batch(pts, pts, K)
+    assert idx.shape == (B, N, K) and idx.min() >= 0 and idx.max() < N
+    nb = pts[np.arange(B)[:, None, None], idx]
+    d = _d2(pts[:, :, None, :], nb)
+    assert (np.diff(d, axis=2) >= 0).all()                                   # ascending distance
+    assert np.array_equal(idx[:, :, 0], np.broadcast_to(np.arange(N), (B, N)))      # distinct points: a point is its own nearest
+    assert all(len(np.unique(r)) == K for r in idx[0, :64])                  # no repeated neighbour
+    # exactness on a random sample of queries: nothing outside the list is closer than its last entry
+    for b, q in zip(rng.integers(0, B, 24), rng.integers(0, N, 24)):
+        allr = _d2(pts[b, q][None], pts[b])
+        assert np.sort(allr)[K - 1] == d[b, q, K - 1]
+
+
+def test_grid_subsample_invariants_at_room_size(backend):
+    from ssdr_al import subsampling
+    rng = np.random.default_rng(43)
+    n = 30000 if backend == "emu" else 1200000
+    pts = (rng.random((n, 3), dtype=np.float32) * np.array([9, 7, 3], np.float32)).astype(np.float32)
+    col = rng.integers(0, 256, (n, 3)).astype(np.float32)
+    lab = rng.integers(0, 13, n).astype(np.int32)
+    dl = np.float32(0.04 if backend != "emu" else 0.25)
+    sp, sc, sl = subsampling.compute(pts, features=col, classes=lab, sampleDl=float(dl), order="key")
+    org = np.floor(pts.min(0) * (np.float32(1) / dl)) * dl
+    key = lambda p: np.floor((p - org) / dl).astype(np.int64)
+    kin = key(pts); kout = key(sp)
+    nx, ny = kin[:, 0].max() + 2, kin[:, 1].max() + 2
+    flat = lambda k: k[:, 0] + nx * (k[:, 1] + ny * k[:, 2])
+    uin = np.unique(flat(kin))
+    assert len(sp) == len(uin)                                               # one output row per occupied voxel ...
+    assert np.array_equal(np.sort(flat(kout)), uin)                          # ... whose barycentre lies inside that voxel
+    assert (sc >= 0).all() and (sc <= 255).all() and set(np.unique(sl)) <= set(range(13))
+    # means of means: the count-weighted mean of the barycentres is the mean of the cloud
+    cnt = np.bincount(np.searchsorted(uin, flat(kin)), minlength=len(uin))
+    order = np.argsort(flat(kout))
+    assert np.allclose((sp[order].astype(np.float64) * cnt[:, None]).sum(0) / n, pts.astype(np.float64).mean(0), atol=1e-4)
+
+
+def test_ranking_and_fps_invariants(backend):
+    from ssdr_al import sampler
+    rng = np.random.default_rng(47)
+    S = 5000 if backend == "emu" else 800000
+    u = rng.normal(0, 1, S); u[rng.integers(0, S, S // 10)] = 0.25          # plenty of exact ties
+    order = sampler.rank_regions(u)
+    assert np.array_equal(np.sort(order), np.arange(S))                      # a permutation
+    su = u[order]
+    assert (np.diff(su) <= 0).all()                                          # descending uncertainty
+    tie = np.diff(su) == 0
+    assert (np.diff(order)[tie] > 0).all()                                   # equal values keep ascending index (argsort(-u), stable)
+    n, m = (600, 200) if backend == "emu" else (12000, 3000)
+    f = rng.normal(0, 1, (n, 32))
+    sel = sampler.farthest_features_sample(f, m, 5)
+    assert sel[0] == 5 and len(np.unique(sel)) == m                          # starts where told, never picks a point twice
+    # greedy property: every pick is (one of) the farthest from the picks before it
+    dmin = np.full(n, 1e10)
+    for j in range(min(m - 1, 40)):
+        dmin = np.minimum(dmin, ((f - f[sel[j]]) ** 2).sum(1))
+        assert dmin[sel[j + 1]] >= dmin.max() * (1 - 1e-12)
