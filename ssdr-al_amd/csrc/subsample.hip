@@ -406,7 +406,7 @@ __global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, con
 // Per-cloud tables of a batch, passed by value.  Cloud r: input rows [off[r], off[r+1]) of the concatenated arrays,
 // sort slots [toff[r], toff[r+1]) (tile-aligned), segment-start slots from toff[r] + r.
 struct CloudTab { int nr; int off[RADIX_MAX_SEG + 1]; int toff[RADIX_MAX_SEG + 1]; };
-constexpr int PB = 64;      // partial min/max blocks per cloud
+constexpr int PB = 256;     // partial min/max blocks per cloud
 
 __global__ __launch_bounds__(BS) void gs_minmax_partial_b(CloudTab t, const float* __restrict__ P, float* partial) {
     const int r = blockIdx.y;
