@@ -63,12 +63,11 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=not os.environ.get("SSDR_NCCL_NORMAL_PRIO"))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
-    from oracle import randla_np as R          # only the weight initialiser here; the oracle proper runs in cpu_baseline
     from ssdr_al import _lib, pipeline, synthetic
     from ssdr_al.helper_tool import ConfigS3DIS
     _lib.check(_lib.lib().ssdr_init(local_rank))
 
-    weights = R.init_weights(0)
+    weights = synthetic.init_weights(0)         # random-init weights of the reference architecture (helper_tf_util.py:43-48 rule)
     rooms = [synthetic.make_room(5000 + rank * TILES_PER_GPU + i, density=RAW_DENSITY) for i in range(TILES_PER_GPU)]
     hp = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
 

@@ -16,61 +16,14 @@ BN_EPS = 1e-6           # helper_tf_util.py:162 / RandLANet.py:145
 LRELU = 0.2             # helper_tf_util.py:165, tf.nn.leaky_relu default
 
 
-def layer_specs(d_out=(16, 64, 128, 256, 512), num_classes=13, in_dim=6):
-    """Ordered list of (name, in, out, bias, bn, act, transposed) — also the layer order of the C ABI."""
-    specs = [("fc0", in_dim, 8, True, True, True, False)]
-    d_in = 8
-    for i, d in enumerate(d_out):
-        h = d // 2
-        p = "Encoder_layer_%d" % i
-        specs += [(p + "mlp1", d_in, h, True, True, True, False),
-                  (p + "LFAmlp1", 10, h, True, True, True, False),
-                  (p + "LFAatt_pooling_1fc", d, d, False, False, False, False),
-                  (p + "LFAatt_pooling_1mlp", d, h, True, True, True, False),
-                  (p + "LFAmlp2", h, h, True, True, True, False),
-                  (p + "LFAatt_pooling_2fc", d, d, False, False, False, False),
-                  (p + "LFAatt_pooling_2mlp", d, d, True, True, True, False),
-                  (p + "mlp2", d, 2 * d, True, True, False, False),
-                  (p + "shortcut", d_in, 2 * d, True, True, False, False)]
-        d_in = 2 * d
-    specs.append(("decoder_0", d_in, d_in, True, True, True, False))
-    enc_ch = [2 * d_out[0]] + [2 * d for d in d_out]        # f_encoder_list channels (RandLANet.py:149-157)
-    feat = d_in
-    for j in range(len(d_out)):
-        skip = enc_ch[-j - 2]
-        specs.append(("Decoder_layer_%d" % j, skip + feat, skip, True, True, True, True))
-        feat = skip
-    specs += [("fc1", feat, 64, True, True, True, False), ("fc2", 64, 32, True, True, True, False),
-              ("fc", 32, num_classes, True, False, False, False)]
-    return specs
-
-
-def init_weights(seed=0, d_out=(16, 64, 128, 256, 512), num_classes=13, in_dim=6, trained_like=True):
-    """Random-init weights following helper_tf_util.py:43-48 (round(truncated_normal(std=sqrt(2/shape[-1]))*1000)/1000,
-    bias 0) and Glorot-uniform for tf.layers.dense.  trained_like=True also randomises the BN statistics and biases
-    (a fresh TF graph has gamma=1, beta=0, mean=0, var=1, which would leave the BN fold untested)."""
-    rng = np.random.default_rng(seed)
-    W = {}
-    for name, cin, cout, bias, bn, act, transposed in layer_specs(d_out, num_classes, in_dim):
-        shape = (cout, cin) if transposed else (cin, cout)
-        if name == "fc0" or name.endswith("fc") and "att_pooling" in name:
-            lim = np.sqrt(6.0 / (cin + cout))
-            w = rng.uniform(-lim, lim, shape)
-        else:
-            std = np.sqrt(2.0 / shape[-1])
-            w = np.clip(rng.normal(0, std, shape), -2 * std, 2 * std)
-            w = np.round(w * 1000) / 1000
-        ent = {"W": w.astype(np.float32), "b": None, "bn": None, "act": act, "transposed": transposed}
-        if bias:
-            ent["b"] = (rng.normal(0, 0.05, cout) if trained_like else np.zeros(cout)).astype(np.float32)
-        if bn:
-            if trained_like:
-                ent["bn"] = tuple(a.astype(np.float32) for a in (rng.uniform(0.7, 1.3, cout), rng.normal(0, 0.1, cout),
-                                                                  rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout)))
-            else:
-                ent["bn"] = (np.ones(cout, np.float32), np.zeros(cout, np.float32), np.zeros(cout, np.float32), np.ones(cout, np.float32))
-        W[name] = ent
-    return W
+# The layer table and the synthetic weight generator belong to the product's synthetic-data module (bench.py needs them
+# without touching the oracle); the oracle uses the same ones.
+import os as _os
+import sys as _sys
+_pkg = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "ssdr-al_amd")
+if _pkg not in _sys.path:
+    _sys.path.insert(0, _pkg)
+from ssdr_al.synthetic import init_weights, layer_specs  # noqa: E402,F401
 
 
 def fold_bn(ent, dtype=np.float32):
