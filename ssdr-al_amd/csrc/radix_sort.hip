@@ -29,6 +29,7 @@ struct SortPtrs {
     unsigned* hist;              // [256][nblocks_max]
     unsigned* tot;               // [nseg][256] digit totals of the current pass
     const int* d_cnt;            // optional device counts per segment
+    int home;                    // which of k[] / v[] is the caller's buffer (the sorted pairs end up there); the input is always in k[0] / v[0]
     int nblocks_max;
     SegTab seg;
 };
@@ -299,14 +300,14 @@ __global__ __launch_bounds__(1024) void rs_high_passes(SortPtrs s) {
     }
 }
 
-// after the last pass the result may sit in buffer 1: bring it home to buffer 0 (grid.y = segment)
+// after the last pass the result may sit in the other buffer: bring it home to the caller's (grid.y = segment)
 __global__ __launch_bounds__(RS_BS) void rs_finish(SortPtrs s) {
     const unsigned long long diff = union_diff(s);
     int par = 0;
     for (int q = 0; q < 8; ++q) par ^= ((diff >> (8 * q)) & 0xffull) != 0;
-    if (!par) return;
+    if (par == s.home) return;                            // already in the caller's buffer
     const int sg = blockIdx.y, n = seg_count(s, sg), so = s.seg.off[sg];
-    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { s.k[0][so + i] = s.k[1][so + i]; s.v[0][so + i] = s.v[1][so + i]; }
+    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { s.k[s.home][so + i] = s.k[par][so + i]; s.v[s.home][so + i] = s.v[par][so + i]; }
 }
 
 }  // namespace
@@ -318,13 +319,14 @@ int RadixSorter::reserve(size_t slots) {
     return SSDR_OK;
 }
 
-int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t st, int key_bits) {
+int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t st, int key_bits, bool input_in_alt) {
     if (nseg <= 0) return SSDR_OK;
     if (nseg > RADIX_MAX_SEG) { set_error("radix sort: more than %d segments", RADIX_MAX_SEG); return SSDR_ERR_INVALID; }
     const int slots = off[nseg];
     if (slots <= 0) return SSDR_OK;
     SSDR_TRY(reserve((size_t)slots));
-    SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>();
+    SortPtrs s; s.k[0] = keys; s.k[1] = k1.as<uint64_t>(); s.v[0] = vals; s.v[1] = v1.as<uint32_t>(); s.home = 0;
+    if (input_in_alt) { std::swap(s.k[0], s.k[1]); std::swap(s.v[0], s.v[1]); s.home = 1; }     // the producer wrote into alt_keys() / alt_vals()
     s.andor = andor.as<unsigned long long>(); s.andor_part = s.andor + 2 * RADIX_MAX_SEG; s.hist = hist.as<unsigned>(); s.tot = hist.as<unsigned>() + 256 * (size_t)nblocks_max;
     s.d_cnt = d_cnt; s.nblocks_max = nblocks_max; s.seg.nseg = nseg;
     int maxn = 0;
@@ -346,16 +348,16 @@ int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const i
         hipLaunchKernelGGL(rs_scatter, dim3(g), dim3(RS_BS), 0, st, s, p);
     }
     if (key_bits > 32) hipLaunchKernelGGL(rs_high_passes, dim3(1), dim3(1024), 0, st, s);   // ... one kernel for the rest
-    hipLaunchKernelGGL(rs_finish, dim3(gseg, nseg), dim3(RS_BS), 0, st, s);
+    hipLaunchKernelGGL(rs_finish, dim3(std::min(gseg, std::max(1, 2048 / nseg)), nseg), dim3(RS_BS), 0, st, s);     // usually nothing to copy: keep the (empty) launch small
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
 
-int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t st, int key_bits) {
+int RadixSorter::sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t st, int key_bits, bool input_in_alt) {
     if (n_host <= 0) return SSDR_OK;
     // one segment; the tail of its last tile is never touched, so a buffer of exactly n_host slots is enough
     const int off[2] = {0, (n_host + RS_TILE - 1) / RS_TILE * RS_TILE};
-    return sort_segments(keys, vals, 1, off, &n_host, d_n, st, key_bits);
+    return sort_segments(keys, vals, 1, off, &n_host, d_n, st, key_bits, input_in_alt);
 }
 
 }  // namespace ssdr

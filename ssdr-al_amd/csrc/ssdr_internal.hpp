@@ -73,10 +73,15 @@ struct RadixSorter {
     int nblocks_max = 0;
     int reserve(size_t slots);
     // key_bits: upper bound on the significant key bits when the caller knows one (skips launching higher passes)
-    int sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t s, int key_bits = 64);
+    // input_in_alt: the caller wrote the unsorted pairs into alt_keys() / alt_vals() (valid after reserve()) instead of keys / vals;
+    // with an odd number of executed digit passes the result then lands in keys / vals without the final copy
+    int sort(uint64_t* keys, uint32_t* vals, int n_host, const int* d_n, hipStream_t s, int key_bits = 64, bool input_in_alt = false);
+    uint64_t* alt_keys() { return k1.as<uint64_t>(); }
+    uint32_t* alt_vals() { return v1.as<uint32_t>(); }
     // nseg independent segments in the same launches: segment i lives in slots [off[i], off[i+1]) (tile-aligned), holds
     // n_host[i] pairs (d_cnt[i] when given, device side).  off has nseg + 1 entries.
-    int sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t s, int key_bits = 64);
+    int sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t s, int key_bits = 64,
+                      bool input_in_alt = false);
 };
 
 // ---- kd-tree forest (kdtree.hip) ----------------------------------------------------------------

@@ -536,8 +536,13 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
     const bool packed = 3 + fdim + ldim <= (size_t)REC_W;
     uint32_t* rec = nullptr;
     if (packed) { SSDR_TRY(S.rec.reserve(4 * (size_t)REC_W * (size_t)room_off[nr] + 16)); rec = S.rec.as<uint32_t>(); }
-    hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), d_f, (int)fdim, (const int*)d_c, (int)ldim, rec);
-    SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), (int)nr, t.toff, n_host.data(), nullptr, s));
+    // voxel keys of a room at this grid size span 17-24 bits: three digit passes.  The keys are written into the sorter's other
+    // buffer, so that after an odd number of passes the sorted pairs sit in S.keys / S.vals without a copy (any other count
+    // still ends there, through the sorter's final copy).
+    SSDR_TRY(S.sorter.reserve((size_t)toff));
+    uint64_t* const k_in = S.sorter.alt_keys(); uint32_t* const v_in = S.sorter.alt_vals();
+    hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, k_in, v_in, d_f, (int)fdim, (const int*)d_c, (int)ldim, rec);
+    SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), (int)nr, t.toff, n_host.data(), nullptr, s, 64, true));
     hipLaunchKernelGGL(gs_heads_count_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max);
     hipLaunchKernelGGL(gs_heads_scan_b, dim3(R), dim3(1024), 0, s, t, S.bsum.as<int>(), nb_max, prm, S.seg.as<int>());
     hipLaunchKernelGGL(gs_heads_write_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, S.seg.as<int>());
