@@ -234,7 +234,7 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const double dx = ax - tb[3 * (b + u)], dy = ay - tb[3 * (b + u) + 1], dz = az - tb[3 * (b + u) + 2];
-                            double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+                            const double d = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
                             m4[u] = d < m4[u] ? d : m4[u];
                         }
                     }
