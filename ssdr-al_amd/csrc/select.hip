@@ -359,6 +359,51 @@ struct Part { double v; int i; int pad; };
 
 __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }   // np.argmax: first maximum
 
+// Wavefront arg-max of (value, index) pairs, result in every lane.  The picks of FPS / k-center form a serial chain of
+// ~600 such reductions: inside a row of 16 lanes the partners come through DPP (quad permutes, half-row and row mirrors),
+// across rows through gfx950's v_permlane16_swap / v_permlane32_swap — no LDS crossbar round trips (ds_bpermute) at all.
+__device__ __forceinline__ void wave_argmax(double& v, int& i) {
+#ifndef HIPEMU
+    auto step = [&](auto partner) {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = partner((unsigned)b), hi = partner((unsigned)(b >> 32));
+        const int oi = (int)partner((unsigned)i);
+        const double ov = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        if (better(ov, oi, v, i)) { v = ov; i = oi; }
+    };
+    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, true); });     // quad_perm [1,0,3,2]
+    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, true); });     // quad_perm [2,3,0,1]
+    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, true); });    // row_half_mirror
+    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, true); });    // row_mirror
+    // rows 0<->1, 2<->3: after swap(a, a) the two results hold the even / odd row of each pair; every lane already equals its
+    // row's best, so "the other row's value" is whichever of the two differs from mine (or both are equal)
+    auto swap_step = [&](bool thirty_two) {
+        const long long b = __double_as_longlong(v);
+        unsigned r0[3], r1[3];
+        const unsigned w[3] = {(unsigned)b, (unsigned)(b >> 32), (unsigned)i};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (thirty_two) { auto r = __builtin_amdgcn_permlane32_swap(w[k], w[k], false, false); r0[k] = r[0]; r1[k] = r[1]; }
+            else { auto r = __builtin_amdgcn_permlane16_swap(w[k], w[k], false, false); r0[k] = r[0]; r1[k] = r[1]; }
+        }
+        const double v0 = __longlong_as_double((long long)(((unsigned long long)r0[1] << 32) | r0[0]));
+        const double v1 = __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r1[0]));
+        const int i0 = (int)r0[2], i1 = (int)r1[2];
+        if (better(v1, i1, v0, i0)) { v = v1; i = i1; } else { v = v0; i = i0; }
+    };
+    swap_step(false);
+    swap_step(true);
+#else
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
+        const double ov = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        const int oi = __shfl_xor(i, o);
+        if (better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+#endif
+}
+
 // One step: (1) every block reduces the previous step's partial maxima to learn the current centre,
 // (2) updates the running min-distance of its points, (3) publishes its own partial maximum.
 __global__ __launch_bounds__(256) void fps_step(const double* __restrict__ f, int n, int D, int from_partials, int start, int use_sqrt,
@@ -409,14 +454,7 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
     __shared__ double s_fc[DF > 0 ? DF : 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     auto block_argmax = [&](double v, int i) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const long long b = __double_as_longlong(v);
-            const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
-            const double ov = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-            const int oi = __shfl_xor(i, o);
-            if (better(ov, oi, v, i)) { v = ov; i = oi; }
-        }
+        wave_argmax(v, i);
         if (lane == 0) { s_v[wid] = v; s_i[wid] = i; }
         __syncthreads();
         if (tid == 0) {
@@ -498,14 +536,7 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
     }
     // publishes this thread's best into s_v/s_i[par]; after the barrier every thread reduces the 8 wave results itself
     auto block_argmax = [&](double v, int i, int par) -> int {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const long long b = __double_as_longlong(v);
-            const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
-            const double ov = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-            const int oi = __shfl_xor(i, o);
-            if (better(ov, oi, v, i)) { v = ov; i = oi; }
-        }
+        wave_argmax(v, i);
         if (lane == 0) { s_v[par][wid] = v; s_i[par][wid] = i; }
         __syncthreads();
         double bv = s_v[par][0]; int bi = s_i[par][0];
