@@ -9,6 +9,31 @@ constexpr int BS = 256;              // workgroup size of the build / scan style
 constexpr int U = 4;                 // positions per thread per sweep step
 constexpr int CHUNK = BS * U;
 
+// Wavefront reductions, result in every lane.  On gfx950 the partners come through DPP inside a row of 16 lanes (quad permutes,
+// half-row and row mirrors) and through v_permlane16_swap / v_permlane32_swap across rows: pure vector-ALU instructions instead
+// of six trips through the LDS crossbar (ds_bpermute) per reduction — the tree build does dozens of these per node.
+#ifndef HIPEMU
+template <class Op>
+__device__ __forceinline__ unsigned wave_reduce_u32(unsigned x, Op op) {
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, true));     // row_half_mirror
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, true));     // row_mirror
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);                                // rows 0<->1, 2<->3
+    x = op(r[0], r[1]);
+    r = __builtin_amdgcn_permlane32_swap(x, x, false, false);                                     // halves
+    return op(r[0], r[1]);
+}
+__device__ __forceinline__ float wave_min(float v) {
+    return __uint_as_float(wave_reduce_u32(__float_as_uint(v), [](unsigned a, unsigned b) { return __float_as_uint(fminf(__uint_as_float(a), __uint_as_float(b))); }));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    return __uint_as_float(wave_reduce_u32(__float_as_uint(v), [](unsigned a, unsigned b) { return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b))); }));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    return (int)wave_reduce_u32((unsigned)v, [](unsigned a, unsigned b) { return a + b; });
+}
+#else
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -24,6 +49,7 @@ __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+#endif
 
 // min/max of 3 coordinates over the workgroup; result broadcast to every thread.
 template <int NT = BS>
