@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=(0, 2, 3, 4, 5),
                     help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 4 with the exchanges of N > 1")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
+    ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3", "bf16"),
+                    help="arithmetic of the network's matrix products (activations / accumulation are fp32 in every mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,7 +71,7 @@ def main():
 
     weights = synthetic.init_weights(0)         # random-init weights of the reference architecture (helper_tf_util.py:43-48 rule)
     rooms = [synthetic.make_room(5000 + rank * TILES_PER_GPU + i, density=RAW_DENSITY) for i in range(TILES_PER_GPU)]
-    hp = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
+    hp = pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
 
     gather = None
     if use_dist:
@@ -90,7 +92,7 @@ def main():
     if not args.no_pipeline:
         ids = [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)]
         def mk():
-            return pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms, ids)
+            return pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision).load_rooms(rooms, ids)
         pipe = pipeline.Pipelined(mk, args.pipeline_depth)
     if pipe is not None:
         pipe.run(max(args.warmup, 1), gather)

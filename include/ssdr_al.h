@@ -149,7 +149,11 @@ int ssdr_tile_select_possibility_dev(const float* d_points, const float* d_color
 
 /* ---- RandLA-Net inference (replaces the TF1 graph of S3/RandLANet.py:140-180, 505-585 run by
  *      model.sess.run([prob_logits, last_second_features, ...]) in S3/sampler2.py:598 / :327) ----------
- * fp32 throughout (exact-f32 MFMA).  Weights are handed over per layer with batch-norm already folded
+ * Activations, accumulation and every non-matrix operation are fp32.  The matrix products run in one of three arithmetic
+ * modes (ssdr_randla_set_precision): SSDR_PREC_F32 (default) exact f32-input MFMA; SSDR_PREC_BF16X3 both operands carried as
+ * two bf16 pieces, hi*hi + lo*hi + hi*lo on the bf16 MFMA with fp32 accumulation (within the 1e-3 feature tolerance of
+ * the fp32 path); SSDR_PREC_BF16 operands rounded to bf16 once (BASELINE configuration 3; tolerance reported separately).
+ * Weights are handed over per layer with batch-norm already folded
  * (W [in,out] row-major, b [out]); the layer table is documented in csrc/randla_model.hip and built from the
  * reference's variable scopes by ssdr_al/randlanet.py.  Inputs are device pointers:
  *   d_features [B,N0,in_dim]   d_xyz [B,N0,3] (level i uses the first N_i points, tf_map's prefix sub-sampling)
@@ -160,6 +164,10 @@ int  ssdr_randla_create(int num_layers, const int32_t* d_out, int k_n, int num_c
 int  ssdr_randla_num_layers(void* handle);
 int  ssdr_randla_layer_shape(void* handle, int layer, int* in, int* out, int* has_bias);
 int  ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* b);   /* host pointers */
+#define SSDR_PREC_F32 0
+#define SSDR_PREC_BF16X3 1
+#define SSDR_PREC_BF16 2
+int  ssdr_randla_set_precision(void* handle, int mode);
 void ssdr_randla_destroy(void* handle);
 int  ssdr_randla_infer_dev(void* handle, size_t batch_size, size_t npts, const float* d_features, const float* d_xyz,
                            const int32_t* ratios, int32_t* const* d_neigh_idx, int32_t* const* d_interp_idx,

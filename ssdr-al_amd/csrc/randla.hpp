@@ -12,6 +12,8 @@ struct DenseArgs {        // y[M,N] = act( [x1 | x2(gathered)] [M,k1+k2] * W[k1+
     int x2_rows_per_batch;
     const float* W; const float* b;
     float* y; int M, N; int act;
+    // bf16 modes: the weights once more as bf16 pieces, transposed [N][kp] (k contiguous, kp = K rounded up to 64, zero padded)
+    const uint16_t* wt_hi; const uint16_t* wt_lo; int kp;
 };
 
 struct LfaArgs {
@@ -25,10 +27,21 @@ struct LfaArgs {
     const float* g;                              // optional [B][n][D]: fin * w_fc[0:D/2] per point (d >= 64): the kernel then only multiplies the position half
     float* out;                                  // [B][n][D]   sum_k f * softmax_k(f W)
     int n;
+    // bf16 modes: attention weights [col][k] (k over D, row stride D) and LFAmlp2 weights [col][k] (row stride kp2) as bf16 pieces
+    const uint16_t* fc_hi; const uint16_t* fc_lo;
+    const uint16_t* l2_hi; const uint16_t* l2_lo; int kp2;
 };
+
+// arithmetic of the matrix products (ssdr_randla_set_precision)
+constexpr int PREC_F32 = 0;       // exact f32-input MFMA (v_mfma_f32_16x16x4_f32)
+constexpr int PREC_BF16X3 = 1;    // split bf16: hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16, fp32 accumulate
+constexpr int PREC_BF16 = 2;      // plain bf16 operands, fp32 accumulate
 
 int launch_dense(const DenseArgs& a, hipStream_t s);
 int launch_lfa(int D, const LfaArgs& a, bool second, int B, hipStream_t s);
+// randla_bf16.hip: the same two operations on the bf16 matrix cores (prec = PREC_BF16X3 / PREC_BF16)
+int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s);
+int launch_lfa_bf16(int D, const LfaArgs& a, bool second, int B, int prec, hipStream_t s);
 int launch_gather_max(const float* f, const int* idx, int n_in, int n_out, int idx_rows, int C, float* out, int B, hipStream_t s);
 int launch_tail(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
                 int M, int C, float* feat32, float* probs, hipStream_t s);

@@ -1,0 +1,434 @@
+// RandLA-Net matrix products on the bf16 matrix cores of gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// Two arithmetic modes (randla.hpp): PREC_BF16X3 carries every fp32 operand as two bf16 pieces (hi, lo) and evaluates
+// hi*hi + lo*hi + hi*lo — products exact in fp32, operands good to 2^-16 — and PREC_BF16 rounds the operands to bf16 once
+// (BASELINE configuration 3).  The exact-f32 kernels of randla_kernels.hip stay the reference arithmetic (PREC_F32).
+//
+//   dense_bf16_kernel   per-point 1x1 convs (helper_tf_util.py:111-166 with BN folded; RandLANet.py:506-512, :159-172):
+//                       activations are split while they are staged into LDS, weights arrive pre-split and transposed.
+//   lfa_bf16_kernel     the K-expanded half of building_block (RandLANet.py:514-527, :572-585) for d >= 64: relative
+//                       position encoding and LocSE conv as in lfa_att_kernel (K = 10, exact f32 MFMA), the LFAmlp2 conv and
+//                       the position half of the attention product on the bf16 cores; the neighbour half arrives as gathered
+//                       rows of G = f W[0:h] (one dense launch per point instead of per neighbour row), softmax over the 16
+//                       neighbours and the weighted sum in the accumulator layout.
+#include "ssdr_internal.hpp"
+#include "randla.hpp"
+#include "randla_dev.hpp"
+
+namespace ssdr {
+
+// 16-byte LDS / global accesses of packed bf16 fragments
+__device__ __forceinline__ u32x4 ld128(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st128(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+template <int TERMS>
+__device__ __forceinline__ f32x4 mma_split(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x4 c) {
+    c = mfma_bf16(a[0], b[0], c);
+    if (TERMS == 2) { c = mfma_bf16(a[1], b[0], c); c = mfma_bf16(a[0], b[1], c); }
+    return c;
+}
+
+// ---- dense ------------------------------------------------------------------------------------------------------
+// TM x 64 output tile per workgroup of 4 waves, K in chunks of KC.  TM = 128: wave w owns rows [32w, 32w+32) x 64 columns
+// (2 x 4 MFMA tiles); TM = 32 (layers with few rows: 4x the workgroups): wave w owns columns [16w, 16w+16) of both row tiles.
+// LDS rows hold KC bf16 (+8 of padding: 16-byte aligned rows whose 16-byte slots rotate through the banks); the next chunk
+// is fetched into registers while the current one is multiplied.
+template <int TM, int KC, int TERMS, bool VEC>
+__global__ __launch_bounds__(256) void dense_bf16_kernel(DenseArgs a) {
+    constexpr int KS = KC + 8;                         // LDS row stride in bf16 elements
+    constexpr int TPR = KC / 8;                        // threads per staged row (8 k each)
+    constexpr int RPP = 256 / TPR;                     // rows staged per pass
+    constexpr int APASS = TM / RPP, BPASS = 64 / RPP;
+    static_assert(TM % RPP == 0 && 64 % RPP == 0, "staging passes");
+    constexpr int CT = TM == 128 ? 4 : 1;              // column tiles per wave (2 row tiles each)
+    __shared__ __attribute__((aligned(16))) uint16_t As[TERMS][TM * KS];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[TERMS][64 * KS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = blockIdx.x * TM, col0 = blockIdx.y * 64;
+    const int K = a.k1 + a.k2;
+    const int sr = tid / TPR, sk = (tid % TPR) * 8;
+    const float* x1r[APASS]; const float* x2r[APASS];
+#pragma unroll
+    for (int h = 0; h < APASS; ++h) {
+        const int grow = row0 + sr + RPP * h;
+        x1r[h] = nullptr; x2r[h] = nullptr;
+        if (grow < a.M) {
+            x1r[h] = a.x1 + (size_t)grow * a.k1;
+            if (a.k2) {
+                size_t r2 = (size_t)grow;
+                if (a.idx2) r2 = (size_t)(grow / a.m_per_batch) * a.x2_rows_per_batch + (size_t)a.idx2[grow];
+                x2r[h] = a.x2 + r2 * a.k2;
+            }
+        }
+    }
+    float ra[APASS][8]; u32x4 rb[BPASS][TERMS];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int h = 0; h < APASS; ++h) {
+            if (VEC) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int gk = kc + sk + 4 * q;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (x1r[h] && gk < K) v = (gk < a.k1) ? *reinterpret_cast<const float4*>(x1r[h] + gk) : *reinterpret_cast<const float4*>(x2r[h] + (gk - a.k1));
+                    ra[h][4 * q] = v.x; ra[h][4 * q + 1] = v.y; ra[h][4 * q + 2] = v.z; ra[h][4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int gk = kc + sk + j;
+                    float v = 0.f;
+                    if (x1r[h]) { if (gk < a.k1) v = x1r[h][gk]; else if (gk < K) v = x2r[h][gk - a.k1]; }
+                    ra[h][j] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < BPASS; ++h) {
+            const int gc = col0 + sr + RPP * h;
+#pragma unroll
+            for (int t = 0; t < TERMS; ++t) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (gc < a.N) v = ld128((t ? a.wt_lo : a.wt_hi) + (size_t)gc * a.kp + kc + sk);     // kp is padded: always in range
+                rb[h][t] = v;
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int h = 0; h < APASS; ++h) {
+            u32x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned hq, lq;
+                split_bf16(ra[h][2 * q], ra[h][2 * q + 1], hq, lq);
+                hi[q] = hq; lo[q] = lq;
+            }
+            st128(&As[0][(sr + RPP * h) * KS + sk], hi);
+            if (TERMS == 2) st128(&As[TERMS - 1][(sr + RPP * h) * KS + sk], lo);
+        }
+#pragma unroll
+        for (int h = 0; h < BPASS; ++h)
+#pragma unroll
+            for (int t = 0; t < TERMS; ++t) st128(&Bs[t][(sr + RPP * h) * KS + sk], rb[h][t]);
+    };
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rbase = TM == 128 ? w * 32 : 0, cbase = TM == 128 ? 0 : w * 16;
+    const int fr = lane & 15, fk = 8 * (lane >> 4);
+    fetch(0);
+    for (int kc = 0; kc < K; kc += KC) {
+        stash();
+        __syncthreads();
+        if (kc + KC < K) fetch(kc + KC);          // in flight while the MFMAs below run
+#pragma unroll
+        for (int ks = 0; ks < KC / 32; ++ks) {
+            u32x4 af[2][2], bf[CT][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) af[r][t] = ld128(&As[t][(rbase + r * 16 + fr) * KS + ks * 32 + fk]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128(&Bs[t][(cbase + c * 16 + fr) * KS + ks * 32 + fk]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[r][c] = mma_split<TERMS>(af[r], bf[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = col0 + cbase + c * 16 + (lane & 15);
+        if (col >= a.N) continue;
+        const float bias = a.b ? a.b[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row0 + rbase + r * 16 + (lane >> 4) * 4 + q;
+                if (row < a.M) { float v = acc[r][c][q] + bias; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
+            }
+    }
+}
+
+// ---- fused local-feature-aggregation attention half, d >= 64 -------------------------------------------------------------
+template <int D> struct LfaBf16Cfg {
+    static constexpr int H = D / 2;
+    static constexpr int NW = D >= 512 ? 8 : 4;                       // waves per workgroup
+    static constexpr int NT = NW * 64;
+    static constexpr int PTS = D == 64 ? 8 : (D == 128 ? 8 : 4);      // points per workgroup
+    static constexpr int ROWS = PTS * 16;
+    static constexpr int LDX = H + 8;                                 // bf16 elements per LDS row of a piece (16-byte aligned, rotating bank slots)
+    static constexpr int NCT = D / 16;                                // column tiles of the attention product
+    static constexpr int NC_W = NCT / NW;                             // ... per wave (every wave sees all PTS points)
+    static constexpr int NCT1 = H / 16;                               // column tiles of the LocSE / LFAmlp2 convs
+    static constexpr int CW2 = NCT1 / NW > 1 ? NCT1 / NW : 1;         // LFAmlp2: column tiles per wave
+    static constexpr int G2 = NCT1 / CW2;                             // ... column groups (<= NW)
+    static constexpr int PSTEP = NW / G2;                             // ... waves sharing a column group take every PSTEP-th point
+    static constexpr int PW2 = PTS / PSTEP;
+    static_assert(NCT % NW == 0 && NW % G2 == 0 && PTS % PSTEP == 0 && (PTS * NCT1) % NW == 0, "tile split");
+    static constexpr size_t lds_bytes(int terms) { return (size_t)ROWS * ((size_t)terms * LDX * 2 + 10 * 4 + 4); }
+};
+
+template <int D, bool SECOND, int TERMS>
+__global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) {
+    using C = LfaBf16Cfg<D>;
+    constexpr int H = C::H, PTS = C::PTS, ROWS = C::ROWS, LDX = C::LDX, NW = C::NW, NT = C::NT;
+    SSDR_DYN_SHARED(float, smem);
+    uint16_t* X[2];                                // f_xyz as bf16 pieces [ROWS][LDX]
+    X[0] = reinterpret_cast<uint16_t*>(smem);
+    X[1] = X[0] + (TERMS == 2 ? (size_t)ROWS * LDX : 0);
+    float* REL = reinterpret_cast<float*>(X[0] + (size_t)TERMS * ROWS * LDX);      // [ROWS][10]
+    int* NBR = reinterpret_cast<int*>(REL + (size_t)ROWS * 10);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lc = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.y, pt0 = blockIdx.x * PTS;
+    const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
+    const int* neigh = a.neigh + (size_t)b * a.n * 16;
+
+    // LocSE weights of this wave's tiles, requested first (see lfa_att_kernel)
+    constexpr int NCT1 = C::NCT1, T1W = PTS * NCT1 / NW;
+    constexpr int NB1 = T1W < NCT1 ? T1W : NCT1;
+    static_assert(T1W % NB1 == 0 && (T1W >= NCT1 ? T1W % NCT1 == 0 : NCT1 % T1W == 0), "slot rule");
+    float w1[NB1][3], b1[NB1];
+#pragma unroll
+    for (int t = 0; t < NB1; ++t) {
+        const int col = ((w * T1W + t) % NCT1) * 16 + lc;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int k = ks * 4 + lg;
+            const float v = a.w_l1[(k < 10 ? k : 9) * H + col];
+            w1[t][ks] = k < 10 ? v : 0.f;
+        }
+        b1[t] = a.b_l1[col];
+    }
+
+    // relative_pos_encoding (:529-535): [ |d|, d(3), p(3), p_nbr(3) ]
+    for (int row = tid; row < ROWS; row += NT) {
+        const int n = pt0 + (row >> 4);
+        float r[10]; int j = 0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) r[q] = 0.f;
+        if (n < a.n) {
+            j = neigh[(size_t)n * 16 + (row & 15)];
+            const float px = xyz[3 * (size_t)n], py = xyz[3 * (size_t)n + 1], pz = xyz[3 * (size_t)n + 2];
+            const float qx = xyz[3 * (size_t)j], qy = xyz[3 * (size_t)j + 1], qz = xyz[3 * (size_t)j + 2];
+            const float dx = px - qx, dy = py - qy, dz = pz - qz;
+            r[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+            r[1] = dx; r[2] = dy; r[3] = dz; r[4] = px; r[5] = py; r[6] = pz; r[7] = qx; r[8] = qy; r[9] = qz;
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) REL[row * 10 + q] = r[q];
+        NBR[row] = j;
+    }
+    __syncthreads();
+
+    // accumulator-layout store of one 16 x 16 tile (rows 4 lg + r, column lc) as bf16 pieces
+    auto store_tile = [&](int p, int col, const float (&v)[4]) {
+        unsigned h01, l01, h23, l23;
+        split_bf16(v[0], v[1], h01, l01); split_bf16(v[2], v[3], h23, l23);
+        const int r0 = (p * 16 + lg * 4) * LDX + col;
+        X[0][r0] = (uint16_t)h01; X[0][r0 + LDX] = (uint16_t)(h01 >> 16); X[0][r0 + 2 * LDX] = (uint16_t)h23; X[0][r0 + 3 * LDX] = (uint16_t)(h23 >> 16);
+        if (TERMS == 2) { X[1][r0] = (uint16_t)l01; X[1][r0 + LDX] = (uint16_t)(l01 >> 16); X[1][r0 + 2 * LDX] = (uint16_t)l23; X[1][r0 + 3 * LDX] = (uint16_t)(l23 >> 16); }
+    };
+
+    // LocSE conv 10 -> H (LFAmlp1, :518): K = 10 stays on the exact f32 MFMA (3 steps of 4)
+#pragma unroll
+    for (int t = 0; t < T1W; ++t) {
+        const int tile = w * T1W + t, p = tile / NCT1, ct = tile % NCT1;
+        f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int k = ks * 4 + lg;
+            const float av1 = (k < 10) ? REL[(p * 16 + lc) * 10 + k] : 0.f;
+            acc1 = mfma16(av1, w1[t % NB1][ks], acc1);
+        }
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = lrelu(acc1[r] + b1[t % NB1]);
+        store_tile(p, ct * 16 + lc, v);
+    }
+    __syncthreads();
+
+    if (SECOND) {
+        // f_xyz <- lrelu(f_xyz W2 + b2) (LFAmlp2, :523), in place: every product is finished before the first store
+        constexpr int CW2 = C::CW2, G2 = C::G2, PSTEP = C::PSTEP, PW2 = C::PW2;
+        const int cg = w % G2, pg = w / G2;
+        f32x4 acc2[PW2][CW2];
+#pragma unroll
+        for (int p = 0; p < PW2; ++p)
+#pragma unroll
+            for (int c = 0; c < CW2; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < H / 32; ++kb) {
+            u32x4 af[PW2][2], bf[CW2][2];
+#pragma unroll
+            for (int c = 0; c < CW2; ++c)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128((t ? a.l2_lo : a.l2_hi) + (size_t)((cg * CW2 + c) * 16 + lc) * a.kp2 + kb * 32 + 8 * lg);
+#pragma unroll
+            for (int p = 0; p < PW2; ++p)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) af[p][t] = ld128(&X[t][((pg + PSTEP * p) * 16 + lc) * LDX + kb * 32 + 8 * lg]);
+#pragma unroll
+            for (int p = 0; p < PW2; ++p)
+#pragma unroll
+                for (int c = 0; c < CW2; ++c) acc2[p][c] = mma_split<TERMS>(af[p], bf[c], acc2[p][c]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CW2; ++c) {
+            const int col = (cg * CW2 + c) * 16 + lc;
+            const float bv = a.b_l2[col];
+#pragma unroll
+            for (int p = 0; p < PW2; ++p) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = lrelu(acc2[p][c][r] + bv);
+                store_tile(pg + PSTEP * p, col, v);
+            }
+        }
+        __syncthreads();
+    }
+
+    // attention scores S = [f_nbr | f_xyz] Wfc (:578).  The neighbour half is the gathered row of G = f Wfc[0:H] (dense launch, one
+    // row per point); the position half is multiplied here: A = f_xyz pieces from LDS, B = rows H..D of Wfc, transposed pieces.
+    constexpr int NC_W = C::NC_W;
+    const int ct0 = w * NC_W;
+    f32x4 acc[PTS][NC_W];
+    int nb4[PTS][4];
+    {
+        const float* G = a.g + (size_t)b * a.n * D;
+#pragma unroll
+        for (int p = 0; p < PTS; ++p) {
+            const bool ok = pt0 + p < a.n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nb4[p][r] = NBR[p * 16 + lg * 4 + r];
+#pragma unroll
+            for (int c = 0; c < NC_W; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[p][c][r] = ok ? G[(size_t)nb4[p][r] * D + (ct0 + c) * 16 + lc] : 0.f;
+        }
+    }
+    for (int kb = 0; kb < H / 32; ++kb) {
+        u32x4 af[PTS][2], bf[NC_W][2];
+#pragma unroll
+        for (int c = 0; c < NC_W; ++c)
+#pragma unroll
+            for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128((t ? a.fc_lo : a.fc_hi) + (size_t)((ct0 + c) * 16 + lc) * D + H + kb * 32 + 8 * lg);
+#pragma unroll
+        for (int p = 0; p < PTS; ++p)
+#pragma unroll
+            for (int t = 0; t < TERMS; ++t) af[p][t] = ld128(&X[t][(p * 16 + lc) * LDX + kb * 32 + 8 * lg]);
+#pragma unroll
+        for (int p = 0; p < PTS; ++p)
+#pragma unroll
+            for (int c = 0; c < NC_W; ++c) acc[p][c] = mma_split<TERMS>(af[p], bf[c], acc[p][c]);
+    }
+
+    // softmax over the 16 neighbours (:579) and weighted sum (:580-581).  f in the accumulator layout: neighbour-feature columns
+    // straight from the feature rows (64 contiguous bytes per 16 lanes), position columns from the LDS pieces.
+    const float* fin = a.fin + (size_t)b * a.n * H;
+    float* out = a.out + (size_t)b * a.n * D;
+    const bool nbr_cols = ct0 * 16 < H;                 // wave-uniform: a wave's tiles lie in one half (NC_W divides NCT / 2)
+    static_assert((C::NCT / 2) % NC_W == 0, "a wave's column tiles stay inside one half");
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+        const int n = pt0 + p;
+        const bool ok = n < a.n;
+#pragma unroll
+        for (int c = 0; c < NC_W; ++c) {
+            const int col = (ct0 + c) * 16 + lc;
+            float f[4];
+            if (nbr_cols) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] = ok ? fin[(size_t)nb4[p][r] * H + col] : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = (p * 16 + lg * 4 + r) * LDX + col - H;
+                    f[r] = __uint_as_float((unsigned)X[0][e] << 16);
+                    if (TERMS == 2) f[r] += __uint_as_float((unsigned)X[1][e] << 16);
+                }
+            }
+            float m = fmaxf(fmaxf(acc[p][c][0], acc[p][c][1]), fmaxf(acc[p][c][2], acc[p][c][3]));
+            m = rows_max(m);
+            float s = 0.f, v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __expf(acc[p][c][r] - m); s += e; v += f[r] * e; }
+            s = rows_sum(s); v = rows_sum(v);
+            v = v * fast_rcp(s);
+            if (lg == 0 && ok) out[(size_t)n * D + col] = v;
+        }
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+template <int TM, int KC>
+static int launch_dense_bf16_t(const DenseArgs& a, int prec, bool vec, hipStream_t s) {
+    dim3 grid((unsigned)((a.M + TM - 1) / TM), (unsigned)((a.N + 63) / 64));
+    if (prec == PREC_BF16X3) {
+        if (vec) hipLaunchKernelGGL((dense_bf16_kernel<TM, KC, 2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dense_bf16_kernel<TM, KC, 2, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((dense_bf16_kernel<TM, KC, 1, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dense_bf16_kernel<TM, KC, 1, false>), grid, dim3(256), 0, s, a);
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return SSDR_OK;
+    if (a.N == 8 && a.k2 == 0 && a.k1 <= 16) return launch_dense(a, s);      // thin layers: HBM streams on fp32 FMAs in every mode
+    if (!a.wt_hi || (prec == PREC_BF16X3 && !a.wt_lo)) { set_error("dense (bf16): the layer has no bf16 weight pieces"); return SSDR_ERR_INVALID; }
+    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
+    const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0;
+    if (a.M <= 16384) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
+    return launch_dense_bf16_t<128, 32>(a, prec, vec, s);
+}
+
+template <int D> static int launch_lfa_bf16_d(const LfaArgs& a, bool second, int B, int prec, hipStream_t s) {
+    using C = LfaBf16Cfg<D>;
+    dim3 grid((unsigned)((a.n + C::PTS - 1) / C::PTS), (unsigned)B);
+    const int terms = prec == PREC_BF16X3 ? 2 : 1;
+    const size_t lds = C::lds_bytes(terms);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2)));
+        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2)));
+        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1)));
+        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1)));
+        attr_done = true;
+    }
+    const double rows = (double)B * (double)a.n * 16.0;       // algorithmic FLOPs of the reference's formulation (as lfa_att_kernel)
+    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D));
+    if (terms == 2) {
+        if (second) hipLaunchKernelGGL((lfa_bf16_kernel<D, true, 2>), grid, dim3(C::NT), lds, s, a);
+        else hipLaunchKernelGGL((lfa_bf16_kernel<D, false, 2>), grid, dim3(C::NT), lds, s, a);
+    } else {
+        if (second) hipLaunchKernelGGL((lfa_bf16_kernel<D, true, 1>), grid, dim3(C::NT), lds, s, a);
+        else hipLaunchKernelGGL((lfa_bf16_kernel<D, false, 1>), grid, dim3(C::NT), lds, s, a);
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int launch_lfa_bf16(int D, const LfaArgs& a, bool second, int B, int prec, hipStream_t s) {
+    if (a.n <= 0 || B <= 0) return SSDR_OK;
+    if (!a.g || !a.fc_hi || (second && !a.l2_hi)) { set_error("lfa (bf16): missing G rows or bf16 weight pieces"); return SSDR_ERR_INVALID; }
+    switch (D) {
+        case 64: return launch_lfa_bf16_d<64>(a, second, B, prec, s);
+        case 128: return launch_lfa_bf16_d<128>(a, second, B, prec, s);
+        case 256: return launch_lfa_bf16_d<256>(a, second, B, prec, s);
+        case 512: return launch_lfa_bf16_d<512>(a, second, B, prec, s);
+        default: set_error("d_out=%d has no bf16 LFA kernel (64, 128, 256, 512)", D); return SSDR_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace ssdr

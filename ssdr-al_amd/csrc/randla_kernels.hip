@@ -18,32 +18,9 @@
 //   head_kernel      fc (32 -> C, no BN / no act, :176) + softmax (:84).
 #include "ssdr_internal.hpp"
 #include "randla.hpp"
+#include "randla_dev.hpp"
 
 namespace ssdr {
-
-#ifndef HIPEMU
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-#else
-typedef hipemu_f32x4 f32x4;
-static inline f32x4 mfma16(float a, float b, f32x4 c) { return hipemu_mfma_f32_16x16x4f32(a, b, c); }
-#endif
-
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.2f); }     // = v > 0 ? v : 0.2 v, one instruction less
-
-#ifndef HIPEMU
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ulp
-#else
-static inline float fast_rcp(float x) { return 1.0f / x; }
-#endif
-
-// In the fully unrolled row-per-lane layers the scheduler would otherwise hoist every weight read of the layer to the top
-// (hundreds of live registers, spills): a fence per k keeps one k-slice of weights live at a time.
-#ifndef HIPEMU
-#define SSDR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define SSDR_SCHED_FENCE() ((void)0)
-#endif
 
 // ---- dense --------------------------------------------------------------------------------------------
 // 128 x 64 output tile per workgroup, K in chunks of 32; wave w owns rows [32w, 32w+32) x all 64 columns as 2 x 4

@@ -10,14 +10,19 @@
 //   then fc1 (->64), fc2 (64->32 = last_second_features), fc (32->C)                   (:174-178)
 #include "ssdr_internal.hpp"
 #include "randla.hpp"
+#include <cstring>
 
 namespace ssdr {
 namespace {
 
-struct Layer { int in = 0, out = 0; bool has_b = true; DevBuf W, b, Wt; bool set = false; };     // Wt: [out][in] copy for the attention layers
+struct Layer {
+    int in = 0, out = 0; bool has_b = true; DevBuf W, b, Wt; bool set = false;     // Wt: [out][in] copy for the attention layers
+    DevBuf Wh, Wl; int kp = 0;        // bf16 pieces of W, transposed [out][kp] (kp = in rounded up to 64, zero padded): hi = bf16(w), lo = bf16(w - hi)
+};
 
 struct Model {
     int L = 5, K = 16, C = 13, in_dim = 6;
+    int prec = PREC_F32;
     int d_out[8] = {16, 64, 128, 256, 512, 0, 0, 0};
     std::vector<Layer> layers;
     std::vector<DevBuf> ws;      // activation workspaces
@@ -47,8 +52,15 @@ void shapes(Model& m) {
 DenseArgs dense(const float* x1, int k1, const Layer& ly, float* y, int M, int act) {
     DenseArgs a{}; a.x1 = x1; a.k1 = k1; a.x2 = nullptr; a.k2 = 0; a.idx2 = nullptr; a.m_per_batch = 1; a.x2_rows_per_batch = 0;
     a.W = ly.W.as<float>(); a.b = ly.has_b ? ly.b.as<float>() : nullptr; a.y = y; a.M = M; a.N = ly.out; a.act = act;
+    a.wt_hi = ly.Wh.as<uint16_t>(); a.wt_lo = ly.Wl.as<uint16_t>(); a.kp = ly.kp;
     return a;
 }
+
+// round-to-nearest-even bf16 of a finite float
+uint16_t bf16_rn(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+float bf16_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int run_dense(const Model& m, const DenseArgs& a, hipStream_t s) { return m.prec == PREC_F32 ? launch_dense(a, s) : launch_dense_bf16(a, m.prec, s); }
 
 }  // namespace
 }  // namespace ssdr
@@ -97,14 +109,34 @@ int ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* 
         SSDR_TRY(ly.Wt.reserve(sizeof(float) * t.size()));
         SSDR_HIP(hipMemcpy(ly.Wt.p, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
     }
+    {   // bf16 pieces for the PREC_BF16X3 / PREC_BF16 modes
+        ly.kp = (ly.in + 63) / 64 * 64;
+        std::vector<uint16_t> hi((size_t)ly.out * ly.kp, 0), lo((size_t)ly.out * ly.kp, 0);
+        for (int k = 0; k < ly.in; ++k)
+            for (int c = 0; c < ly.out; ++c) {
+                const float v = W[(size_t)k * ly.out + c];
+                const uint16_t h = bf16_rn(v);
+                hi[(size_t)c * ly.kp + k] = h; lo[(size_t)c * ly.kp + k] = bf16_rn(v - bf16_f32(h));
+            }
+        SSDR_TRY(ly.Wh.reserve(2 * hi.size())); SSDR_TRY(ly.Wl.reserve(2 * lo.size()));
+        SSDR_HIP(hipMemcpy(ly.Wh.p, hi.data(), 2 * hi.size(), hipMemcpyHostToDevice));
+        SSDR_HIP(hipMemcpy(ly.Wl.p, lo.data(), 2 * lo.size(), hipMemcpyHostToDevice));
+    }
     ly.set = true;
+    return SSDR_OK;
+}
+
+int ssdr_randla_set_precision(void* handle, int mode) {
+    Model* m = static_cast<Model*>(handle);
+    if (!m || (mode != PREC_F32 && mode != PREC_BF16X3 && mode != PREC_BF16)) { set_error("randla_set_precision: mode must be 0 (f32), 1 (split bf16) or 2 (bf16)"); return SSDR_ERR_INVALID; }
+    m->prec = mode;
     return SSDR_OK;
 }
 
 void ssdr_randla_destroy(void* handle) {
     Model* m = static_cast<Model*>(handle);
     if (!m) return;
-    for (auto& l : m->layers) { l.W.release(); l.b.release(); l.Wt.release(); }
+    for (auto& l : m->layers) { l.W.release(); l.b.release(); l.Wt.release(); l.Wh.release(); l.Wl.release(); }
     for (auto& w : m->ws) w.release();
     delete m;
 }
@@ -130,7 +162,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
 
     // fc0
     float* f0 = buf(6 * L + 0, B * N[0] * 8); if (!f0) return SSDR_ERR_HIP;
-    SSDR_TRY(launch_dense(dense(d_features, m->in_dim, m->layers[0], f0, Bi * N[0], 1), s));
+    SSDR_TRY(run_dense(*m, dense(d_features, m->in_dim, m->layers[0], f0, Bi * N[0], 1), s));
     const float* f = f0; int d_in = 8;
     std::vector<const float*> enc; std::vector<int> enc_ch, enc_n;
     for (int i = 0; i < L; ++i) {
@@ -139,30 +171,36 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         float* f_pc = buf(idxs(i, 0), rows * h); float* agg = buf(idxs(i, 1), rows * d); float* aggm = buf(idxs(i, 2), rows * d);
         float* out = buf(idxs(i, 3), rows * 2 * d); float* samp = buf(idxs(i, 4), B * (size_t)N[i + 1] * 2 * d);
         if (!f_pc || !agg || !aggm || !out || !samp) return SSDR_ERR_HIP;
-        SSDR_TRY(launch_dense(dense(f, d_in, m->layers[base + 0], f_pc, (int)rows, 1), s));                 // mlp1
+        SSDR_TRY(run_dense(*m, dense(f, d_in, m->layers[base + 0], f_pc, (int)rows, 1), s));                 // mlp1
         LfaArgs la{}; la.xyz = d_xyz; la.xyz_batch_stride = n0 * 3; la.neigh = d_neigh_idx[i]; la.n = n;
         la.w_l1 = m->layers[base + 1].W.as<float>(); la.b_l1 = m->layers[base + 1].b.as<float>();
         la.w_l2 = m->layers[base + 4].W.as<float>(); la.b_l2 = m->layers[base + 4].b.as<float>();
         la.fin = f_pc; la.w_fc = m->layers[base + 2].W.as<float>(); la.w_fc_t = m->layers[base + 2].Wt.as<float>(); la.out = agg;
+        la.fc_hi = m->layers[base + 2].Wh.as<uint16_t>(); la.fc_lo = m->layers[base + 2].Wl.as<uint16_t>();
+        la.l2_hi = m->layers[base + 4].Wh.as<uint16_t>(); la.l2_lo = m->layers[base + 4].Wl.as<uint16_t>(); la.kp2 = m->layers[base + 4].kp;
+        const bool lfa16 = m->prec != PREC_F32 && d >= 64;      // d = 16: exact-f32 kernel in every mode
         float* gbuf = nullptr;
         if (d >= 64) {      // neighbour half of the attention product once per point: G = f_pc * W[0:h]  (rows 0..h-1 of the [d][d] weights)
             gbuf = buf(idxs(i, 5), rows * d); if (!gbuf) return SSDR_ERR_HIP;
             DenseArgs ga{}; ga.x1 = f_pc; ga.k1 = h; ga.W = la.w_fc; ga.b = nullptr; ga.y = gbuf; ga.M = (int)rows; ga.N = d; ga.act = 0; ga.m_per_batch = 1;
-            SSDR_TRY(launch_dense(ga, s));
+            ga.wt_hi = la.fc_hi; ga.wt_lo = la.fc_lo; ga.kp = m->layers[base + 2].kp;
+            SSDR_TRY(run_dense(*m, ga, s));
         }
         la.g = gbuf;
-        SSDR_TRY(launch_lfa(d, la, false, Bi, s));                                                          // LocSE + att pool 1
-        SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 3], aggm, (int)rows, 1), s));                   // att1 mlp d->h
+        SSDR_TRY(lfa16 ? launch_lfa_bf16(d, la, false, Bi, m->prec, s) : launch_lfa(d, la, false, Bi, s));                                                          // LocSE + att pool 1
+        SSDR_TRY(run_dense(*m, dense(agg, d, m->layers[base + 3], aggm, (int)rows, 1), s));                   // att1 mlp d->h
         la.fin = aggm; la.w_fc = m->layers[base + 5].W.as<float>(); la.w_fc_t = m->layers[base + 5].Wt.as<float>(); la.out = agg;
+        la.fc_hi = m->layers[base + 5].Wh.as<uint16_t>(); la.fc_lo = m->layers[base + 5].Wl.as<uint16_t>();
         if (gbuf) {
             DenseArgs ga{}; ga.x1 = aggm; ga.k1 = h; ga.W = la.w_fc; ga.b = nullptr; ga.y = gbuf; ga.M = (int)rows; ga.N = d; ga.act = 0; ga.m_per_batch = 1;
-            SSDR_TRY(launch_dense(ga, s));
+            ga.wt_hi = la.fc_hi; ga.wt_lo = la.fc_lo; ga.kp = m->layers[base + 5].kp;
+            SSDR_TRY(run_dense(*m, ga, s));
         }
-        SSDR_TRY(launch_lfa(d, la, true, Bi, s));                                                           // LocSE2 + att pool 2
-        SSDR_TRY(launch_dense(dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
+        SSDR_TRY(lfa16 ? launch_lfa_bf16(d, la, true, Bi, m->prec, s) : launch_lfa(d, la, true, Bi, s));                                                           // LocSE2 + att pool 2
+        SSDR_TRY(run_dense(*m, dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
         DenseArgs r = dense(aggm, d, m->layers[base + 7], out, (int)rows, 1);                               // lrelu(mlp2 + shortcut)
         r.x2 = f; r.k2 = d_in;
-        SSDR_TRY(launch_dense(r, s));
+        SSDR_TRY(run_dense(*m, r, s));
         SSDR_TRY(launch_gather_max(out, d_neigh_idx[i], n, N[i + 1], n, 2 * d, samp, Bi, s));               // random_sample
         if (i == 0) { enc.push_back(out); enc_ch.push_back(2 * d); enc_n.push_back(n); }
         enc.push_back(samp); enc_ch.push_back(2 * d); enc_n.push_back(N[i + 1]);
@@ -170,7 +208,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
     }
     int li = 1 + 8 * L;
     float* dec = buf(6 * L + 1, B * (size_t)N[L] * d_in); if (!dec) return SSDR_ERR_HIP;
-    SSDR_TRY(launch_dense(dense(enc.back(), d_in, m->layers[li++], dec, Bi * N[L], 1), s));                  // decoder_0
+    SSDR_TRY(run_dense(*m, dense(enc.back(), d_in, m->layers[li++], dec, Bi * N[L], 1), s));                  // decoder_0
     const float* feat = dec; int feat_c = d_in, feat_n = N[L];
     for (int j = 0; j < L; ++j) {
         const int e = (int)enc.size() - j - 2;
@@ -178,7 +216,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         float* y = buf(6 * L + 2 + (j & 1), B * (size_t)n * skip_c); if (!y) return SSDR_ERR_HIP;
         DenseArgs a = dense(enc[e], skip_c, m->layers[li++], y, Bi * n, 1);
         a.x2 = feat; a.k2 = feat_c; a.idx2 = d_interp_idx[L - 1 - j]; a.m_per_batch = n; a.x2_rows_per_batch = feat_n;
-        SSDR_TRY(launch_dense(a, s));
+        SSDR_TRY(run_dense(*m, a, s));
         feat = y; feat_c = skip_c; feat_n = n;
     }
     const Layer& l1 = m->layers[li]; const Layer& l2 = m->layers[li + 1]; const Layer& fc = m->layers[li + 2];
@@ -188,8 +226,8 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
                             Bi * N[0], m->C, d_feat32, d_probs, s);
     if (fused == SSDR_ERR_UNSUPPORTED) {
         float* f1 = buf(6 * L + 4, B * (size_t)N[0] * 64); if (!f1) return SSDR_ERR_HIP;
-        SSDR_TRY(launch_dense(dense(feat, feat_c, l1, f1, Bi * N[0], 1), s));                                 // fc1
-        SSDR_TRY(launch_dense(dense(f1, 64, l2, d_feat32, Bi * N[0], 1), s));                                 // fc2 = last_second_features
+        SSDR_TRY(run_dense(*m, dense(feat, feat_c, l1, f1, Bi * N[0], 1), s));                                 // fc1
+        SSDR_TRY(run_dense(*m, dense(f1, 64, l2, d_feat32, Bi * N[0], 1), s));                                 // fc2 = last_second_features
         SSDR_TRY(launch_head(d_feat32, fc.W.as<float>(), fc.b.as<float>(), Bi * N[0], m->C, d_probs, s));     // fc + softmax
     } else SSDR_TRY(fused);
     return SSDR_OK;

@@ -39,6 +39,7 @@ class Network:
         _lib.check(_lib.lib().ssdr_randla_create(config.num_layers, _lib.ptr(d), config.k_n, config.num_classes, in_dim,
                                                  C.byref(self._h)))
         self._lib = _lib.lib()
+        self.precision = "f32"
 
     def __del__(self):
         try:
@@ -47,6 +48,15 @@ class Network:
                 self._h = None
         except Exception:
             pass
+
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+    def set_precision(self, mode):
+        """Arithmetic of the matrix products: "f32" (exact, default), "bf16x3" (split bf16, fp32 accumulate; within the
+        1e-3 tolerance of the fp32 path) or "bf16" (BASELINE configuration 3)."""
+        _lib.check(_lib.lib().ssdr_randla_set_precision(self._h, self.PRECISIONS[mode]))
+        self.precision = mode
+        return self
 
     def layer_table(self, weights):
         """Reference-named weights -> the ABI's ordered (W, b) list (csrc/randla_model.hip header)."""

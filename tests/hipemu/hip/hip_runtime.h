@@ -217,6 +217,43 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f
     return d;
 }
 
+// bf16 helpers and the 16x16x32 bf16 MFMA (v_mfma_f32_16x16x32_bf16): lane l holds A[row l&15][k = 8(l>>4)+j] and
+// B[k = 8(l>>4)+j][col l&15], j = 0..7, two bf16 per dword (low half first); C/D as the f32 form.  Products of bf16 values are exact
+// in fp32; the hardware's internal summation order is not specified, so the stand-in sums in double and rounds once.
+typedef unsigned hipemu_u32x4 __attribute__((vector_size(16)));
+typedef unsigned hipemu_u32x2 __attribute__((vector_size(8)));
+static inline unsigned hipemu_bf16_rn(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x7fffffu)) return (u >> 16) | 0x40u;      // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x4 c) {
+    auto* f = hipemu::g_bs->cur; auto& w = hipemu::g_bs->waves[f->wave];
+    const int col = f->lane & 15, rg = f->lane >> 4;
+    unsigned A[4][4][4], Bv[4][4];          // A[r][g][dword], B[g][dword]
+    for (int half = 0; half < 4; ++half) {  // a.xy, a.zw, b.xy, b.zw as four 64-bit exchanges
+        const hipemu_u32x4& v = half < 2 ? a : b; const int d0 = (half & 1) * 2;
+        hipemu::wave_op((uint64_t)v[d0] | ((uint64_t)v[d0 + 1] << 32), 4 + half);
+        for (int g = 0; g < 4; ++g) {
+            if (half < 2) for (int r = 0; r < 4; ++r) { const uint64_t s = w.snap[rg * 4 + r + 16 * g]; A[r][g][d0] = (unsigned)s; A[r][g][d0 + 1] = (unsigned)(s >> 32); }
+            else { const uint64_t s = w.snap[col + 16 * g]; Bv[g][d0] = (unsigned)s; Bv[g][d0 + 1] = (unsigned)(s >> 32); }
+        }
+    }
+    hipemu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        double acc = c[r];
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j) {
+                const unsigned ad = A[r][g][j >> 1], bd = Bv[g][j >> 1];
+                const float av = __uint_as_float((j & 1) ? (ad & 0xffff0000u) : (ad << 16));
+                const float bv = __uint_as_float((j & 1) ? (bd & 0xffff0000u) : (bd << 16));
+                acc += (double)av * (double)bv;
+            }
+        d[r] = (float)acc;
+    }
+    return d;
+}
+
 // ---- runtime API (host memory stands in for device memory) --------------------------------------
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
