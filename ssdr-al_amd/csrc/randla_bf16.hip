@@ -158,28 +158,46 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseArgs a) {
 }
 
 // ---- fused local-feature-aggregation attention half, d >= 64 -------------------------------------------------------------
+// Work split: NW waves = NCG column groups x NPG point groups.  A wave owns NCH column tiles of the neighbour-feature half and
+// the NCH matching tiles of the position half, for PW of the workgroup's PTS points.
+//
+// Both MFMA operand fragments of a 16-wide tile have the same shape (lane = (index, k group)), so one pair of registers gives
+// the product in either orientation: mfma(A = x, B = w) has the neighbour row in the accumulator registers and the channel on the
+// lane (what softmax / weighted sum need), mfma(A = w, B = x) has four consecutive channels of one neighbour row per lane (what
+// the next product's A operand needs: one 8-byte LDS store per piece instead of eight 2-byte scatters).  The position
+// encoding chain is therefore computed in both orientations: the transposed one feeds LDS, the other stays in registers
+// until the weighted sum.
 template <int D> struct LfaBf16Cfg {
     static constexpr int H = D / 2;
-    static constexpr int NW = D >= 512 ? 8 : 4;                       // waves per workgroup
+    static constexpr int NW = D >= 256 ? 8 : 4;                       // waves per workgroup
     static constexpr int NT = NW * 64;
-    static constexpr int PTS = D == 64 ? 8 : (D == 128 ? 8 : 4);      // points per workgroup
+    static constexpr int NCG = D == 64 ? 2 : NW;                      // column groups
+    static constexpr int NPG = NW / NCG;                              // point groups
+    static constexpr int PTS = D == 64 ? 8 : 4;                            // points per workgroup (a wave keeps 4 x PW x 4 NCH accumulator / feature registers)
+    static constexpr int PW = PTS / NPG;                              // points per wave
     static constexpr int ROWS = PTS * 16;
     static constexpr int LDX = H + 8;                                 // bf16 elements per LDS row of a piece (16-byte aligned, rotating bank slots)
-    static constexpr int NCT = D / 16;                                // column tiles of the attention product
-    static constexpr int NC_W = NCT / NW;                             // ... per wave (every wave sees all PTS points)
-    static constexpr int NCT1 = H / 16;                               // column tiles of the LocSE / LFAmlp2 convs
-    static constexpr int CW2 = NCT1 / NW > 1 ? NCT1 / NW : 1;         // LFAmlp2: column tiles per wave
-    static constexpr int G2 = NCT1 / CW2;                             // ... column groups (<= NW)
-    static constexpr int PSTEP = NW / G2;                             // ... waves sharing a column group take every PSTEP-th point
-    static constexpr int PW2 = PTS / PSTEP;
-    static_assert(NCT % NW == 0 && NW % G2 == 0 && PTS % PSTEP == 0 && (PTS * NCT1) % NW == 0, "tile split");
+    static constexpr int NCT1 = H / 16;                               // column tiles per half
+    static constexpr int NCH = NCT1 / NCG;                            // ... per wave and half
+    static_assert(NCT1 % NCG == 0 && PTS % NPG == 0, "tile split");
     static constexpr size_t lds_bytes(int terms) { return (size_t)ROWS * ((size_t)terms * LDX * 2 + 10 * 4 + 4); }
 };
+
+#ifndef HIPEMU
+// raw buffer loads: 32-bit per-lane byte offset + immediate, one VALU op of address arithmetic per gathered row
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); }
+template <int IMM> __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff + IMM, 0, 0)); }
+#else
+struct rsrc_t { const char* p; };
+static inline rsrc_t make_rsrc(const void* p, unsigned) { return rsrc_t{reinterpret_cast<const char*>(p)}; }
+template <int IMM> static inline float buf_load(rsrc_t r, unsigned voff) { return *reinterpret_cast<const float*>(r.p + voff + IMM); }
+#endif
 
 template <int D, bool SECOND, int TERMS>
 __global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) {
     using C = LfaBf16Cfg<D>;
-    constexpr int H = C::H, PTS = C::PTS, ROWS = C::ROWS, LDX = C::LDX, NW = C::NW, NT = C::NT;
+    constexpr int H = C::H, PTS = C::PTS, ROWS = C::ROWS, LDX = C::LDX, NT = C::NT, NCG = C::NCG, PW = C::PW, NCH = C::NCH, NCT1 = C::NCT1;
     SSDR_DYN_SHARED(float, smem);
     uint16_t* X[2];                                // f_xyz as bf16 pieces [ROWS][LDX]
     X[0] = reinterpret_cast<uint16_t*>(smem);
@@ -188,25 +206,24 @@ __global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) 
     int* NBR = reinterpret_cast<int*>(REL + (size_t)ROWS * 10);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lc = lane & 15, lg = lane >> 4;
+    const int cg = w % NCG, p0 = (w / NCG) * PW;   // this wave's column group and first point
     const int b = blockIdx.y, pt0 = blockIdx.x * PTS;
     const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
     const int* neigh = a.neigh + (size_t)b * a.n * 16;
 
-    // LocSE weights of this wave's tiles, requested first (see lfa_att_kernel)
-    constexpr int NCT1 = C::NCT1, T1W = PTS * NCT1 / NW;
-    constexpr int NB1 = T1W < NCT1 ? T1W : NCT1;
-    static_assert(T1W % NB1 == 0 && (T1W >= NCT1 ? T1W % NCT1 == 0 : NCT1 % T1W == 0), "slot rule");
-    float w1[NB1][3], b1[NB1];
+    // LocSE weights of this wave's column tiles: one fragment register per k step serves both orientations
+    float w1[NCH][3], b1c[NCH]; float4 b1r[NCH];
 #pragma unroll
-    for (int t = 0; t < NB1; ++t) {
-        const int col = ((w * T1W + t) % NCT1) * 16 + lc;
+    for (int j = 0; j < NCH; ++j) {
+        const int ct = cg * NCH + j;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const int k = ks * 4 + lg;
-            const float v = a.w_l1[(k < 10 ? k : 9) * H + col];
-            w1[t][ks] = k < 10 ? v : 0.f;
+            const float v = a.w_l1[(k < 10 ? k : 9) * H + ct * 16 + lc];
+            w1[j][ks] = k < 10 ? v : 0.f;
         }
-        b1[t] = a.b_l1[col];
+        b1c[j] = a.b_l1[ct * 16 + lc];                                           // channel on the lane
+        b1r[j] = *reinterpret_cast<const float4*>(a.b_l1 + ct * 16 + 4 * lg);    // channels in the registers
     }
 
     // relative_pos_encoding (:529-535): [ |d|, d(3), p(3), p_nbr(3) ]
@@ -229,141 +246,143 @@ __global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) 
     }
     __syncthreads();
 
-    // accumulator-layout store of one 16 x 16 tile (rows 4 lg + r, column lc) as bf16 pieces
-    auto store_tile = [&](int p, int col, const float (&v)[4]) {
-        unsigned h01, l01, h23, l23;
-        split_bf16(v[0], v[1], h01, l01); split_bf16(v[2], v[3], h23, l23);
-        const int r0 = (p * 16 + lg * 4) * LDX + col;
-        X[0][r0] = (uint16_t)h01; X[0][r0 + LDX] = (uint16_t)(h01 >> 16); X[0][r0 + 2 * LDX] = (uint16_t)h23; X[0][r0 + 3 * LDX] = (uint16_t)(h23 >> 16);
-        if (TERMS == 2) { X[1][r0] = (uint16_t)l01; X[1][r0 + LDX] = (uint16_t)(l01 >> 16); X[1][r0 + 2 * LDX] = (uint16_t)l23; X[1][r0 + 3 * LDX] = (uint16_t)(l23 >> 16); }
+    // four consecutive channels (ct*16 + 4 lg ..) of neighbour row lc of point p as bf16 pieces: one 8-byte store per piece
+    auto store_row4 = [&](int p, int ct, const float (&v)[4]) {
+        u32x2 hi, lo; unsigned h, l;
+        split_bf16(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
+        split_bf16(v[2], v[3], h, l); hi[1] = h; lo[1] = l;
+        const int e = (p * 16 + lc) * LDX + ct * 16 + 4 * lg;
+        *reinterpret_cast<u32x2*>(&X[0][e]) = hi;
+        if (TERMS == 2) *reinterpret_cast<u32x2*>(&X[1][e]) = lo;
     };
 
-    // LocSE conv 10 -> H (LFAmlp1, :518): K = 10 stays on the exact f32 MFMA (3 steps of 4)
+    // f_xyz of this wave's (point, position-column tile) pairs in the accumulator layout, kept for the weighted sum
+    float fx[PW][NCH][4];
+
+    // LocSE conv 10 -> H (LFAmlp1, :518): K = 10 stays on the exact f32 MFMA (3 steps of 4), bias in the accumulator
 #pragma unroll
-    for (int t = 0; t < T1W; ++t) {
-        const int tile = w * T1W + t, p = tile / NCT1, ct = tile % NCT1;
-        f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < PW; ++p) {
+        float rf[3];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const int k = ks * 4 + lg;
-            const float av1 = (k < 10) ? REL[(p * 16 + lc) * 10 + k] : 0.f;
-            acc1 = mfma16(av1, w1[t % NB1][ks], acc1);
+        for (int ks = 0; ks < 3; ++ks) { const int k = ks * 4 + lg; rf[ks] = (k < 10) ? REL[((p0 + p) * 16 + lc) * 10 + k] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            f32x4 at = f32x4{b1r[j].x, b1r[j].y, b1r[j].z, b1r[j].w};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) at = mfma16(w1[j][ks], rf[ks], at);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = lrelu(at[r]);
+            store_row4(p0 + p, cg * NCH + j, v);
+            if (!SECOND) {
+                f32x4 ac = f32x4{b1c[j], b1c[j], b1c[j], b1c[j]};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) ac = mfma16(rf[ks], w1[j][ks], ac);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fx[p][j][r] = lrelu(ac[r]);
+            }
         }
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = lrelu(acc1[r] + b1[t % NB1]);
-        store_tile(p, ct * 16 + lc, v);
     }
     __syncthreads();
 
     if (SECOND) {
-        // f_xyz <- lrelu(f_xyz W2 + b2) (LFAmlp2, :523), in place: every product is finished before the first store
-        constexpr int CW2 = C::CW2, G2 = C::G2, PSTEP = C::PSTEP, PW2 = C::PW2;
-        const int cg = w % G2, pg = w / G2;
-        f32x4 acc2[PW2][CW2];
+        // f_xyz <- lrelu(f_xyz W2 + b2) (LFAmlp2, :523), both orientations from the same fragments; in place in LDS: every
+        // product is finished before the first store
+        f32x4 accT[PW][NCH], acc2[PW][NCH];
 #pragma unroll
-        for (int p = 0; p < PW2; ++p)
+        for (int j = 0; j < NCH; ++j) {
+            const int ct = cg * NCH + j;
+            const float4 br = *reinterpret_cast<const float4*>(a.b_l2 + ct * 16 + 4 * lg);
+            const float bc = a.b_l2[ct * 16 + lc];
 #pragma unroll
-            for (int c = 0; c < CW2; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < PW; ++p) { accT[p][j] = f32x4{br.x, br.y, br.z, br.w}; acc2[p][j] = f32x4{bc, bc, bc, bc}; }
+        }
         for (int kb = 0; kb < H / 32; ++kb) {
-            u32x4 af[PW2][2], bf[CW2][2];
+            u32x4 xf[PW][2], wf[NCH][2];
 #pragma unroll
-            for (int c = 0; c < CW2; ++c)
+            for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128((t ? a.l2_lo : a.l2_hi) + (size_t)((cg * CW2 + c) * 16 + lc) * a.kp2 + kb * 32 + 8 * lg);
+                for (int t = 0; t < TERMS; ++t) wf[j][t] = ld128((t ? a.l2_lo : a.l2_hi) + (size_t)((cg * NCH + j) * 16 + lc) * a.kp2 + kb * 32 + 8 * lg);
 #pragma unroll
-            for (int p = 0; p < PW2; ++p)
+            for (int p = 0; p < PW; ++p)
 #pragma unroll
-                for (int t = 0; t < TERMS; ++t) af[p][t] = ld128(&X[t][((pg + PSTEP * p) * 16 + lc) * LDX + kb * 32 + 8 * lg]);
+                for (int t = 0; t < TERMS; ++t) xf[p][t] = ld128(&X[t][((p0 + p) * 16 + lc) * LDX + kb * 32 + 8 * lg]);
 #pragma unroll
-            for (int p = 0; p < PW2; ++p)
+            for (int p = 0; p < PW; ++p)
 #pragma unroll
-                for (int c = 0; c < CW2; ++c) acc2[p][c] = mma_split<TERMS>(af[p], bf[c], acc2[p][c]);
+                for (int j = 0; j < NCH; ++j) { accT[p][j] = mma_split<TERMS>(wf[j], xf[p], accT[p][j]); acc2[p][j] = mma_split<TERMS>(xf[p], wf[j], acc2[p][j]); }
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < CW2; ++c) {
-            const int col = (cg * CW2 + c) * 16 + lc;
-            const float bv = a.b_l2[col];
+        for (int p = 0; p < PW; ++p)
 #pragma unroll
-            for (int p = 0; p < PW2; ++p) {
+            for (int j = 0; j < NCH; ++j) {
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = lrelu(acc2[p][c][r] + bv);
-                store_tile(pg + PSTEP * p, col, v);
+                for (int r = 0; r < 4; ++r) { v[r] = lrelu(accT[p][j][r]); fx[p][j][r] = lrelu(acc2[p][j][r]); }
+                store_row4(p0 + p, cg * NCH + j, v);
             }
-        }
         __syncthreads();
     }
 
-    // attention scores S = [f_nbr | f_xyz] Wfc (:578).  The neighbour half is the gathered row of G = f Wfc[0:H] (dense launch, one
-    // row per point); the position half is multiplied here: A = f_xyz pieces from LDS, B = rows H..D of Wfc, transposed pieces.
-    constexpr int NC_W = C::NC_W;
-    const int ct0 = w * NC_W;
-    f32x4 acc[PTS][NC_W];
-    int nb4[PTS][4];
-    {
-        const float* G = a.g + (size_t)b * a.n * D;
+    // attention scores S = [f_nbr | f_xyz] Wfc (:578), pre-scaled by log2(e) through the weight pieces.  The neighbour half is
+    // the gathered row of G = f Wfc[0:H] (dense launch, one row per point); the position half is multiplied here: A = f_xyz
+    // pieces from LDS, B = rows H..D of Wfc (transposed pieces).  Column tile c < NCH: neighbour-feature columns, else position columns.
+    const rsrc_t rG = make_rsrc(a.g + (size_t)b * a.n * D, (unsigned)a.n * D * 4u);
+    const rsrc_t rF = make_rsrc(a.fin + (size_t)b * a.n * H, (unsigned)a.n * H * 4u);
+    f32x4 acc[PW][2 * NCH];
+    float fn[PW][NCH][4];
 #pragma unroll
-        for (int p = 0; p < PTS; ++p) {
-            const bool ok = pt0 + p < a.n;
+    for (int p = 0; p < PW; ++p) {
+        int nb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) nb4[p][r] = NBR[p * 16 + lg * 4 + r];
+        for (int r = 0; r < 4; ++r) nb[r] = NBR[(p0 + p) * 16 + lg * 4 + r];
 #pragma unroll
-            for (int c = 0; c < NC_W; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[p][c][r] = ok ? G[(size_t)nb4[p][r] * D + (ct0 + c) * 16 + lc] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const unsigned og = (unsigned)nb[r] * (D * 4u) + lc * 4u + cg * NCH * 64u, of = (unsigned)nb[r] * (H * 4u) + lc * 4u + cg * NCH * 64u;
+            acc[p][0][r] = buf_load<0>(rG, og); acc[p][NCH][r] = buf_load<H * 4>(rG, og); fn[p][0][r] = buf_load<0>(rF, of);
+            if constexpr (NCH == 2) { acc[p][1][r] = buf_load<64>(rG, og); acc[p][NCH + 1][r] = buf_load<H * 4 + 64>(rG, og); fn[p][1][r] = buf_load<64>(rF, of); }
         }
     }
+    static_assert(NCH <= 2, "gather immediates are written out for one or two tiles per half");
     for (int kb = 0; kb < H / 32; ++kb) {
-        u32x4 af[PTS][2], bf[NC_W][2];
+        u32x4 af[PW][2], bf[2 * NCH][2];
 #pragma unroll
-        for (int c = 0; c < NC_W; ++c)
+        for (int c = 0; c < 2 * NCH; ++c) {
+            const int col = (c < NCH ? cg * NCH + c : NCT1 + cg * NCH + (c - NCH)) * 16 + lc;
 #pragma unroll
-            for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128((t ? a.fc_lo : a.fc_hi) + (size_t)((ct0 + c) * 16 + lc) * D + H + kb * 32 + 8 * lg);
+            for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128((t ? a.fc_lo : a.fc_hi) + (size_t)col * D + H + kb * 32 + 8 * lg);
+        }
 #pragma unroll
-        for (int p = 0; p < PTS; ++p)
+        for (int p = 0; p < PW; ++p)
 #pragma unroll
-            for (int t = 0; t < TERMS; ++t) af[p][t] = ld128(&X[t][(p * 16 + lc) * LDX + kb * 32 + 8 * lg]);
+            for (int t = 0; t < TERMS; ++t) af[p][t] = ld128(&X[t][((p0 + p) * 16 + lc) * LDX + kb * 32 + 8 * lg]);
 #pragma unroll
-        for (int p = 0; p < PTS; ++p)
+        for (int p = 0; p < PW; ++p)
 #pragma unroll
-            for (int c = 0; c < NC_W; ++c) acc[p][c] = mma_split<TERMS>(af[p], bf[c], acc[p][c]);
+            for (int c = 0; c < 2 * NCH; ++c) acc[p][c] = mma_split<TERMS>(af[p], bf[c], acc[p][c]);
     }
 
-    // softmax over the 16 neighbours (:579) and weighted sum (:580-581).  f in the accumulator layout: neighbour-feature columns
-    // straight from the feature rows (64 contiguous bytes per 16 lanes), position columns from the LDS pieces.
-    const float* fin = a.fin + (size_t)b * a.n * H;
+    // softmax over the 16 neighbours (:579) and weighted sum (:580-581): out = sum_k f_k 2^(s_k - m) / sum_k 2^(s_k - m)
     float* out = a.out + (size_t)b * a.n * D;
-    const bool nbr_cols = ct0 * 16 < H;                 // wave-uniform: a wave's tiles lie in one half (NC_W divides NCT / 2)
-    static_assert((C::NCT / 2) % NC_W == 0, "a wave's column tiles stay inside one half");
 #pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        const int n = pt0 + p;
-        const bool ok = n < a.n;
+    for (int p = 0; p < PW; ++p) {
+        const int n = pt0 + p0 + p;
 #pragma unroll
-        for (int c = 0; c < NC_W; ++c) {
-            const int col = (ct0 + c) * 16 + lc;
-            float f[4];
-            if (nbr_cols) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) f[r] = ok ? fin[(size_t)nb4[p][r] * H + col] : 0.f;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int e = (p * 16 + lg * 4 + r) * LDX + col - H;
-                    f[r] = __uint_as_float((unsigned)X[0][e] << 16);
-                    if (TERMS == 2) f[r] += __uint_as_float((unsigned)X[1][e] << 16);
-                }
-            }
+        for (int c = 0; c < 2 * NCH; ++c) {
+            const int col = (c < NCH ? cg * NCH + c : NCT1 + cg * NCH + (c - NCH)) * 16 + lc;
             float m = fmaxf(fmaxf(acc[p][c][0], acc[p][c][1]), fmaxf(acc[p][c][2], acc[p][c][3]));
             m = rows_max(m);
             float s = 0.f, v = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = __expf(acc[p][c][r] - m); s += e; v += f[r] * e; }
+            for (int r = 0; r < 4; ++r) {
+                const float e = fast_exp2(acc[p][c][r] - m);
+                const float f = c < NCH ? fn[p][c][r] : fx[p][c - NCH][r];
+                s += e; v = fmaf(f, e, v);
+            }
             s = rows_sum(s); v = rows_sum(v);
             v = v * fast_rcp(s);
-            if (lg == 0 && ok) out[(size_t)n * D + col] = v;
+            if (lg == 0 && n < a.n) out[(size_t)n * D + col] = v;
         }
     }
 }

@@ -25,6 +25,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 // (bf16_rn(b) << 16) | bf16_rn(a): one v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t)); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 // combine a value with the one held by lane ^ 16 / lane ^ 32 (op commutative): v_permlane16_swap / v_permlane32_swap hand every
 // lane its own value and its partner's in the two results, no trip through the LDS crossbar
 template <class Op> __device__ __forceinline__ float combine_xor16(float v, Op op) {
@@ -44,6 +45,7 @@ static inline f32x4 mfma16(float a, float b, f32x4 c) { return hipemu_mfma_f32_1
 static inline f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) { return hipemu_mfma_f32_16x16x32_bf16(a, b, c); }
 static inline unsigned pack_bf16(float a, float b) { return hipemu_bf16_rn(a) | (hipemu_bf16_rn(b) << 16); }
 static inline float fast_rcp(float x) { return 1.0f / x; }
+static inline float fast_exp2(float x) { return exp2f(x); }
 template <class Op> static inline float combine_xor16(float v, Op op) { return op(v, __shfl_xor(v, 16)); }
 template <class Op> static inline float combine_xor32(float v, Op op) { return op(v, __shfl_xor(v, 32)); }
 #define SSDR_SCHED_FENCE() ((void)0)

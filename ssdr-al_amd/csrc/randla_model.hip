@@ -112,9 +112,12 @@ int ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* 
     {   // bf16 pieces for the PREC_BF16X3 / PREC_BF16 modes
         ly.kp = (ly.in + 63) / 64 * 64;
         std::vector<uint16_t> hi((size_t)ly.out * ly.kp, 0), lo((size_t)ly.out * ly.kp, 0);
+        // attention dense (no bias, square): the pieces carry W * log2(e), so the bf16 kernels' scores (and G = f W[0:h], computed from
+        // the same pieces) come out in base-2 units and the softmax is a bare v_exp_f32
+        const double scale = (!ly.has_b && ly.in == ly.out) ? 1.4426950408889634 : 1.0;
         for (int k = 0; k < ly.in; ++k)
             for (int c = 0; c < ly.out; ++c) {
-                const float v = W[(size_t)k * ly.out + c];
+                const float v = (float)((double)W[(size_t)k * ly.out + c] * scale);
                 const uint16_t h = bf16_rn(v);
                 hi[(size_t)c * ly.kp + k] = h; lo[(size_t)c * ly.kp + k] = bf16_rn(v - bf16_f32(h));
             }
