@@ -73,6 +73,12 @@ int ssdr_knn_batch_i32(const float* batch_data, size_t batch_size, size_t npts, 
 /* Device flavour: d_* are device pointers; out is int32 [B,nq,K]. */
 int ssdr_knn_batch_dev(const float* d_batch_data, size_t batch_size, size_t npts, size_t dim,
                        const float* d_queries, size_t nqueries, size_t K, int32_t* d_indices, void* stream);
+/* The device flavours (ssdr_knn_batch_dev, ssdr_knn_pyramid_dev) only enqueue work, so they cannot report what the kernels
+ * found.  ssdr_knn_status waits for `stream` and returns SSDR_ERR_INTERNAL if the last KNN call issued on it overflowed one of
+ * its device-side capacities (kd queue / node table / level limit, hand-over list); the host flavours check this themselves.
+ * out4 (optional, host): rows handed from the grid search to the exact tree walk for K = 16 and K = 1 (tie rows, see
+ * csrc/knn_grid.hip), the status bits, and the depth of the deepest tree built. */
+int ssdr_knn_status(void* stream, int32_t* out4);
 
 /* ---- KNN pyramid (replaces the loop of tf_map, S3/s3dis_dataset.py:156-183) ------------------
  * For level i in [0,num_layers): N_0 = npts, N_{i+1} = N_i / ratio[i] (integer division);

@@ -1,15 +1,52 @@
 // C-ABI entry points of the KNN ops (include/ssdr_al.h), host and device flavours.
 #include "ssdr_internal.hpp"
 #include <random>
+#include <map>
 
 namespace ssdr {
 namespace {
 
+// One state per stream: calls on different streams own different forests / grids / scratch and may run concurrently.
 struct KnnState {
     KdForest forest;
+    GridForest grid;
     DevBuf pts, qry, out;
 };
-KnnState& st() { static KnnState s; return s; }
+KnnState& st(hipStream_t s = nullptr) { static std::map<hipStream_t, KnnState> m; return m[s ? s : ctx().stream]; }
+
+constexpr int GRID_TARGET_PTS = 26;      // the measured cell radius holds about this many points (K + 1 = 17 and a margin)
+
+// grid search of a job table split as [jobs16 | jobs1], then the tree walk for the rows the grid handed over
+int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<GridJob>& jobs16, const std::vector<GridJob>& jobs1, bool i64, hipStream_t s) {
+    SSDR_TRY(grid_build(S.grid, sets, GRID_TARGET_PTS, s));
+    std::vector<GridJob> jobs(jobs16); jobs.insert(jobs.end(), jobs1.begin(), jobs1.end());
+    SSDR_TRY(grid_set_jobs(S.grid, jobs, s));
+    int mq16 = 0, mq1 = 0;
+    for (auto& j : jobs16) mq16 = std::max(mq16, j.nq);
+    for (auto& j : jobs1) mq1 = std::max(mq1, j.nq);
+    {
+        double bytes = 0;      // algorithmic bytes: support + query coordinates read once, indices written once
+        for (auto& j : jobs16) bytes += 24.0 * j.nq + (i64 ? 8.0 : 4.0) * 16 * j.nq;
+        ProfScope prof("knn_grid_search<16>", s, bytes);
+        SSDR_TRY(grid_search(S.grid, 0, (int)jobs16.size(), mq16, 16, i64, s));
+    }
+    {
+        double bytes = 0;
+        for (auto& j : jobs1) bytes += 24.0 * j.nq + (i64 ? 8.0 : 4.0) * j.nq;
+        ProfScope prof("knn_grid_search<1>", s, bytes);
+        bool fused = !jobs16.empty() && !jobs1.empty();       // every K = 1 job rides on a K = 16 scan: only the second pass runs for them
+        for (auto& j : jobs16) fused = fused && j.job1 >= 0;
+        SSDR_TRY(grid_search(S.grid, (int)jobs16.size(), (int)jobs1.size(), fused ? 0 : mq1, 1, i64, s));
+    }
+    // exact nanoflann trees only for the support sets that own handed-over rows (flags set by the searches above)
+    std::vector<KdTreeDesc> trees(sets.size());
+    for (size_t i = 0; i < sets.size(); ++i) { trees[i].pts = sets[i].pts; trees[i].n = sets[i].n; }
+    ProfScope prof("knn_tree_handover", s, 0.0);
+    SSDR_TRY(kd_build(S.forest, trees, s, S.grid.need.as<int>()));
+    if (!jobs16.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(0), S.grid.counters() + 0, S.grid.work_cap, 16, i64, s));
+    if (!jobs1.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(1), S.grid.counters() + 1, S.grid.work_cap, 1, i64, s));
+    return SSDR_OK;
+}
 
 int check_knn_args(const void* p, size_t npts, size_t dim, const void* q, size_t nq, size_t K, const void* out) {
     if (dim != 3) { set_error("dim=%zu: only dim == 3 is implemented", dim); return SSDR_ERR_UNSUPPORTED; }
@@ -21,7 +58,16 @@ int check_knn_args(const void* p, size_t npts, size_t dim, const void* q, size_t
 // device-resident batch: B trees of npts points, nq queries each
 int knn_batch_device(const float* d_pts, size_t B, size_t npts, const float* d_q, size_t nq, size_t K,
                      void* d_out, bool i64, bool self_order, hipStream_t s) {
-    KnnState& S = st();
+    KnnState& S = st(s);
+    if ((K == 16 || K == 1) && !getenv("SSDR_KNN_TREE_ONLY")) {
+        std::vector<GridDesc> sets(B); std::vector<GridJob> jobs(B);
+        const size_t esz = i64 ? 8 : 4;
+        for (size_t b = 0; b < B; ++b) {
+            sets[b] = GridDesc{}; sets[b].pts = d_pts + b * npts * 3; sets[b].n = (int)npts;
+            jobs[b] = GridJob{(int)b, self_order ? (int)b : -1, (int)nq, -1, d_q + b * nq * 3, reinterpret_cast<char*>(d_out) + b * nq * K * esz, 0, 0};
+        }
+        return K == 16 ? grid_knn(S, sets, jobs, {}, i64, s) : grid_knn(S, sets, {}, jobs, i64, s);
+    }
     std::vector<KdTreeDesc> trees(B);
     for (size_t b = 0; b < B; ++b) { trees[b].pts = d_pts + b * npts * 3; trees[b].n = (int)npts; }
     SSDR_TRY(kd_build(S.forest, trees, s));
@@ -34,7 +80,7 @@ int knn_batch_host(const float* pts, size_t B, size_t npts, size_t dim, const fl
     SSDR_TRY(check_knn_args(pts, npts, dim, q, nq, K, out));
     SSDR_TRY(ensure_init());
     if (B == 0 || nq == 0 || K == 0) return SSDR_OK;
-    KnnState& S = st(); Context& c = ctx(); hipStream_t s = c.stream;
+    Context& c = ctx(); hipStream_t s = c.stream; KnnState& S = st(s);
     const size_t esz = i64 ? 8 : 4;
     SSDR_TRY(S.pts.reserve(B * npts * 12 + 16)); SSDR_TRY(S.qry.reserve(B * nq * 12 + 16)); SSDR_TRY(S.out.reserve(B * nq * K * esz + 16));
     const bool same = (pts == q && npts == nq);
@@ -77,13 +123,47 @@ int ssdr_knn_batch_dev(const float* d_batch_data, size_t batch_size, size_t npts
                             d_batch_data == d_queries && npts == nqueries, pick_stream(stream));
 }
 
+int ssdr_knn_status(void* stream, int32_t* out4) {
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream);
+    KnnState& S = st(s);
+    int32_t h[4] = {0, 0, 0, 0};
+    SSDR_HIP(hipStreamSynchronize(s));
+    if (S.grid.need.p && S.grid.nsets > 0) {
+        int g[6] = {0, 0, 0, 0, 0, 0};
+        SSDR_HIP(hipMemcpy(g, S.grid.counters(), sizeof(g), hipMemcpyDeviceToHost));
+        h[0] = g[0]; h[1] = g[1]; h[2] |= g[2];
+        if (getenv("SSDR_KNN_DEBUG")) {
+            fprintf(stderr, "knn grid: second pass for %d (K=16) + %d (K=1) rows; handed over to the tree %d + %d rows, %d of them unsettled\n", g[4], g[5], g[0], g[1], g[3]);
+            std::vector<GridDesc> d(S.grid.nsets); std::vector<int> need(S.grid.nsets);
+            SSDR_HIP(hipMemcpy(d.data(), S.grid.desc.p, sizeof(GridDesc) * d.size(), hipMemcpyDeviceToHost));
+            SSDR_HIP(hipMemcpy(need.data(), S.grid.need.p, 4 * need.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < d.size(); i += std::max<size_t>(1, d.size() / 12))
+                fprintf(stderr, "  set %zu: n=%d c=%.4f dims=%dx%dx%d cells=%d (%.1f pts/cell) need_tree=%d\n", i, d[i].n, d[i].c, d[i].nx, d[i].ny, d[i].nz, d[i].ncell,
+                        (double)d[i].n / d[i].ncell, need[i]);
+        }
+    }
+    if (S.forest.counters.p) {
+        int k[3] = {0, 0, 0};
+        SSDR_HIP(hipMemcpy(k, S.forest.counters.p, sizeof(k), hipMemcpyDeviceToHost));
+        h[2] |= k[1]; h[3] = k[2];
+    }
+    if (out4) for (int i = 0; i < 4; ++i) out4[i] = h[i];
+    if (h[2]) {
+        set_error("KNN device status 0x%x (1 = kd queue overflow, 2 = kd node overflow, 4 = kd tree deeper than its level limit, 8 = hand-over list overflow): "
+                  "the neighbour lists of the last call on this stream are not trustworthy", h[2]);
+        return SSDR_ERR_INTERNAL;
+    }
+    return SSDR_OK;
+}
+
 int ssdr_knn_batch_distance_pick(const float* batch_data, size_t batch_size, size_t npts, size_t dim, float* batch_queries, size_t nqueries,
                                  size_t K, int64_t* batch_indices, uint32_t seed) {
     if (dim != 3) { set_error("dim=%zu: only dim == 3 is implemented", dim); return SSDR_ERR_UNSUPPORTED; }
     if (!batch_data || !batch_queries || !batch_indices || npts == 0 || npts > 0x3fffffff) { set_error("knn_batch_distance_pick: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (batch_size == 0 || nqueries == 0 || K == 0) return SSDR_OK;
-    KnnState& S = st(); Context& c = ctx(); hipStream_t s = c.stream;
+    Context& c = ctx(); hipStream_t s = c.stream; KnnState& S = st(s);
     std::mt19937 gen(seed);                                   // the reference: mt19937 mt_rand(time(0)), one draw per query (:141, :168)
     std::vector<uint32_t> rnd(batch_size * nqueries);
     for (auto& r : rnd) r = (uint32_t)gen();
@@ -115,8 +195,27 @@ int ssdr_knn_pyramid_dev(const float* d_xyz, size_t B, size_t npts, size_t num_l
         if (ratios[l] <= 0) { set_error("ratio must be positive"); return SSDR_ERR_INVALID; }
         N[l + 1] = N[l] / (size_t)ratios[l];
     }
-    // tree (l, b) = prefix N_l of tile b; stored level-major so one level's trees are contiguous
-    KnnState& S = st();
+    // set (l, b) = prefix N_l of tile b; stored level-major so one level's sets are contiguous
+    KnnState& S = st(s);
+    if (K == 16 && !getenv("SSDR_KNN_TREE_ONLY")) {
+        std::vector<GridDesc> sets((num_layers + 1) * B);
+        for (size_t l = 0; l <= num_layers; ++l)
+            for (size_t b = 0; b < B; ++b) { GridDesc& d = sets[l * B + b]; d = GridDesc{}; d.pts = d_xyz + b * npts * 3; d.n = (int)N[l]; }
+        std::vector<GridJob> j16, j1;
+        for (size_t l = 0; l < num_layers; ++l)
+            for (size_t b = 0; b < B; ++b) {
+                // neigh_idx[l] = knn(xyz_l, xyz_l, K) (s3dis_dataset.py:165); interp_idx[l] = knn(xyz_{l+1}, xyz_l, 1) (:170)
+                // the K = 1 job (table position num_layers * B + its own index) is answered inside the K = 16 scan where that is final
+                j16.push_back(GridJob{(int)(l * B + b), (int)(l * B + b), (int)N[l], (int)(num_layers * B + j1.size()), d_xyz + b * npts * 3,
+                                      d_neigh_idx[l] + b * N[l] * K, (int)N[l + 1], 0});
+                j1.push_back(GridJob{(int)((l + 1) * B + b), (int)(l * B + b), (int)N[l], -1, d_xyz + b * npts * 3, d_interp_idx[l] + b * N[l], 0, 0});
+            }
+        SSDR_TRY(grid_knn(S, sets, j16, j1, false, s));
+        for (size_t l = 0; l < num_layers; ++l)      // sub_idx[l] = neigh_idx[l][:, :N_{l+1}] (s3dis_dataset.py:168)
+            if (d_sub_idx && d_sub_idx[l] && N[l + 1] > 0)
+                SSDR_HIP(hipMemcpy2DAsync(d_sub_idx[l], N[l + 1] * K * 4, d_neigh_idx[l], N[l] * K * 4, N[l + 1] * K * 4, B, hipMemcpyDeviceToDevice, s));
+        return SSDR_OK;
+    }
     std::vector<KdTreeDesc> trees((num_layers + 1) * B);
     for (size_t l = 0; l <= num_layers; ++l)
         for (size_t b = 0; b < B; ++b) { trees[l * B + b].pts = d_xyz + b * npts * 3; trees[l * B + b].n = (int)N[l]; }
@@ -140,7 +239,7 @@ int ssdr_knn_pyramid(const float* xyz, size_t B, size_t npts, size_t num_layers,
                      int32_t* const* neigh_idx, int32_t* const* sub_idx, int32_t* const* interp_idx) {
     if (!xyz || !ratios || !neigh_idx || !interp_idx || num_layers == 0 || num_layers > 16) { set_error("bad pyramid arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
-    Context& c = ctx(); hipStream_t s = c.stream; KnnState& S = st();
+    Context& c = ctx(); hipStream_t s = c.stream; KnnState& S = st(s);
     std::vector<size_t> N(num_layers + 1); N[0] = npts;
     for (size_t l = 0; l < num_layers; ++l) { if (ratios[l] <= 0) { set_error("ratio must be positive"); return SSDR_ERR_INVALID; } N[l + 1] = N[l] / (size_t)ratios[l]; }
     size_t tot = 0; std::vector<size_t> off_n(num_layers), off_i(num_layers);

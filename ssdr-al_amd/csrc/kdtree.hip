@@ -22,6 +22,7 @@
 // with -ffp-contract=off), the arithmetic of L2_Adaptor::evalMetric (:280-304) for dim == 3.
 #include "ssdr_internal.hpp"
 #include "block_prims.hpp"
+#include "knn_regset.hpp"
 #include <cfloat>
 #include <cstring>
 #include <algorithm>
@@ -59,11 +60,13 @@ struct ForestPtrs {
     int* queue; int* ctr; int* tmp; int node_cap; int queue_cap;
     int* squeue;     // open nodes with <= SMALL_MAX points, [2][queue_cap]
     int ntrees;
+    const int* need; // optional: build tree t only if need[t] != 0
 };
 
 __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
     __shared__ float s_mm[(BS / 64) * 6];
     const int t = blockIdx.x, tid = threadIdx.x;
+    if (f.need && !f.need[t]) return;          // nobody will walk this tree
     const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = tid; i < n; i += BS) {
@@ -346,36 +349,6 @@ struct SearchArgs {
     int tree0; const float* queries; size_t q_stride; int nq; int qorder_tree0; void* out; size_t out_stride; int* ctr;
 };
 
-#ifndef HIPEMU
-__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
-#else
-static inline float med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
-#endif
-
-template <int K>
-struct RegSet {   // KNNResultSet (:36-102) in registers
-    float d[K]; int id[K];
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int j = 0; j < K; ++j) { d[j] = FLT_MAX; id[j] = 0; }
-    }
-    __device__ __forceinline__ float worst() const { return d[K - 1]; }
-    __device__ __forceinline__ void add(float dist, int index) {   // requires dist < worst()
-        // sorted insertion after the elements that are <= dist (KNNResultSet::addPoint :63-92): slot j takes the median of
-        // (d[j-1], dist, d[j]) — one v_med3_f32 — and the id follows from the comparisons c_j = d[j] > dist
-        bool c[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) c[j] = d[j] > dist;
-#pragma unroll
-        for (int j = K - 1; j > 0; --j) {
-            id[j] = c[j - 1] ? id[j - 1] : (c[j] ? index : id[j]);
-            d[j] = med3(d[j - 1], dist, d[j]);
-        }
-        if (c[0]) { d[0] = dist; id[0] = index; }
-    }
-    __device__ __forceinline__ int get(int j) const { return id[j]; }
-};
-
 struct LdsSet {   // same rule, slots in LDS ([slot][lane]) for arbitrary K
     float* d; int* id; int K;
     __device__ __forceinline__ void init() { for (int j = 0; j < K; ++j) { d[j * 64] = FLT_MAX; id[j * 64] = 0; } }
@@ -488,6 +461,24 @@ __global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) 
     if (td.n > 0) kd_walk(a, td, Q[0], Q[1], Q[2], rs);
     OutT* o = reinterpret_cast<OutT*>(a.out) + (size_t)t * a.out_stride + (size_t)q * K;
     for (int j = 0; j < K; ++j) o[j] = (OutT)rs.get(j);
+}
+
+// Rows handed over by the grid search (knn_grid.hip): pairs (job, query); one lane per row.
+template <int K, typename OutT>
+__global__ __launch_bounds__(64) void kd_search_worklist_kernel(SearchArgs a, const GridJob* __restrict__ jobs, const int* __restrict__ work,
+                                                                const int* __restrict__ count, int cap) {
+    const int n = min(*count, cap);
+    for (int e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
+        const GridJob job = jobs[work[2 * (size_t)e]];
+        const int q = work[2 * (size_t)e + 1];
+        const KdTreeDesc td = a.desc[job.sup];
+        const float qx = job.qpts[3 * (size_t)q], qy = job.qpts[3 * (size_t)q + 1], qz = job.qpts[3 * (size_t)q + 2];
+        RegSet<K> rs; rs.init();
+        if (td.n > 0) kd_walk(a, td, qx, qy, qz, rs);
+        OutT* o = reinterpret_cast<OutT*>(job.out) + (size_t)q * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) o[j] = (OutT)rs.get(j);
+    }
 }
 
 // ---- knn_batch_distance_pick (knn_.cxx:136-203) --------------------------------------------------------------------
@@ -643,13 +634,13 @@ ForestPtrs ptrs(const KdForest& f) {
     p.node_box = f.node_box.as<float>();
     p.node_tree = f.node_tree.as<int>(); p.queue = f.queue.as<int>(); p.ctr = f.counters.as<int>();
     p.tmp = f.tmp.as<int>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
-    p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap; p.ntrees = f.ntrees;
+    p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap; p.ntrees = f.ntrees; p.need = nullptr;
     return p;
 }
 
 }  // namespace
 
-int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s) {
+int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s, const int* d_need) {
     std::vector<KdTreeDesc> trees = trees_in;
     long total = 0;
     for (auto& t : trees) { t.voff = (int)total; t.root = 0; total += t.n; if (total > 0x3fffffffL) { set_error("kd_build: too many points"); return SSDR_ERR_INVALID; } }
@@ -675,7 +666,7 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     SSDR_HIP(hipMemcpyAsync(f.desc.p, f.staging, sizeof(KdTreeDesc) * trees.size(), hipMemcpyHostToDevice, s));
     SSDR_HIP(hipEventRecord(f.staging_ev, s));
     SSDR_HIP(hipMemsetAsync(f.counters.p, 0, 4 * CTR_TOTAL, s));
-    ForestPtrs p = ptrs(f);
+    ForestPtrs p = ptrs(f); p.need = d_need;
     hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(BS), 0, s, p);
     const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
     // nodes above 64 points: one workgroup each, level by level; deeper than BIG_LEVELS a node that large means a
@@ -714,6 +705,23 @@ int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, 
         size_t lds = (size_t)64 * K * 8;
         if (out_i64) hipLaunchKernelGGL((kd_search_any_kernel<int64_t>), g2, dim3(64), lds, s, a, K);
         else hipLaunchKernelGGL((kd_search_any_kernel<int32_t>), g2, dim3(64), lds, s, a, K);
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int kd_search_worklist(const KdForest& f, const GridJob* d_jobs, const int* d_work, const int* d_count, int work_cap, int K, bool out_i64, hipStream_t s) {
+    if (K != 16 && K != 1) { set_error("work-list search: K=%d has no instantiation (1, 16)", K); return SSDR_ERR_UNSUPPORTED; }
+    ForestPtrs p = ptrs(f);
+    SearchArgs a{p.desc, p.sorted, p.node_a, p.node_b, 0, nullptr, 0, 0, -1, nullptr, 0, p.ctr};
+    // the list is usually empty or short (tie rows of padded tiles): a modest grid-stride launch, one wave per workgroup
+    const dim3 grid((unsigned)std::max(1, std::min(work_cap / 64 + 1, ctx().num_cu * 8)));
+    if (K == 16) {
+        if (out_i64) hipLaunchKernelGGL((kd_search_worklist_kernel<16, int64_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
+        else hipLaunchKernelGGL((kd_search_worklist_kernel<16, int32_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
+    } else {
+        if (out_i64) hipLaunchKernelGGL((kd_search_worklist_kernel<1, int64_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
+        else hipLaunchKernelGGL((kd_search_worklist_kernel<1, int32_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
     }
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;

@@ -1,0 +1,473 @@
+// Uniform-grid K-nearest-neighbour search with an exact tie-aware hand-over to the kd-tree walk (gfx950).
+//
+// The reference op (S3/utils/nearest_neighbors/knn_.cxx:22-135 over nanoflann.hpp) returns, per query, the K support
+// indices by ascending fp32 distance ((dx*dx + dy*dy) + dz*dz, no FMA); among equal distances the order is the order in
+// which nanoflann's tree walk met them (KNNResultSet::addPoint :63-92, searchLevel :1271-1329).  Whenever the K + 1 smallest
+// distances of a query are pairwise distinct that answer does not depend on the tree at all, so:
+//
+//   fast path  points are binned into a dense uniform grid per support set (cell size measured per set: the radius that
+//              holds ~20 points around sampled points), cell-sorted 16-byte records (x, y, z, index); one lane per query, in
+//              cell order, scans the 3 x 3 rows of cells around its own cell (x is the fastest cell dimension: each row is one
+//              contiguous range), keeps the K + 1 best in registers, and accepts when the (K+1)-th distance lies inside the
+//              radius the scanned block guarantees; otherwise the block grows (5^3, 7^3).
+//   hand-over  a row with two equal distances among its K + 1 best, with the K-th and (K+1)-th closer than 2^-19 relative
+//              (a tree bound rounded the other way could have pruned one of them), with fewer than K + 1 support points, or
+//              not settled inside the 7^3 block goes to a work list and is answered by kd_walk on the exact nanoflann
+//              tree (kdtree.hip); only support sets that own such rows get their tree built (device-side flags).
+//
+// Same arithmetic as kdtree.hip: this TU is compiled with -ffp-contract=off.
+#include "ssdr_internal.hpp"
+#include "block_prims.hpp"
+#include "knn_regset.hpp"
+#include <cfloat>
+#include <cstring>
+
+namespace ssdr {
+
+namespace {
+
+constexpr int GS_SAMPLES = 8;            // sampled points per set for the cell-size measurement
+constexpr int GS_BINS = 192;             // log-scale histogram of squared distances, four bins per octave
+constexpr int GS_BIN0 = (87 << 2);       // first bin: d^2 = 2^-40
+constexpr int GS_RMAX = 3;               // largest block: (2*3+1)^3 cells
+constexpr int SCAN_BLK = 4096;           // cells per scan block
+
+__device__ __forceinline__ int cell_of(float v, float o, float inv_c, int n) {
+    const float f = (v - o) * inv_c;
+    int c = f > 0.f ? (int)fminf(f, 1.0e9f) : 0;
+    return c < n ? c : n - 1;
+}
+
+// bounding box, cell size, grid dimensions; zeroes the set's cell counters
+__global__ __launch_bounds__(256) void grid_prepare_kernel(GridDesc* desc, int* cell, int target_pts) {
+    __shared__ float s_mm[(256 / 64) * 6];
+    __shared__ float s_smp[GS_SAMPLES][3];
+    __shared__ int s_hist[GS_BINS];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    GridDesc d = desc[t];
+    const float* P = d.pts; const int n = d.n;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = tid; i < n; i += 256) {
+        const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x); mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y); mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+    }
+    block_minmax3(mn, mx, s_mm);
+    for (int i = tid; i < GS_BINS; i += 256) s_hist[i] = 0;
+    if (tid < GS_SAMPLES && n > 0) {
+        const int i = (int)(((long long)tid * n) / GS_SAMPLES + n / (2 * GS_SAMPLES));
+        s_smp[tid][0] = P[3 * (size_t)i]; s_smp[tid][1] = P[3 * (size_t)i + 1]; s_smp[tid][2] = P[3 * (size_t)i + 2];
+    }
+    __syncthreads();
+    // distances of every stride-th point to the samples -> histogram over log2(d^2) (LDS atomics)
+    const int stride = n > 8192 ? n / 8192 : 1;
+    for (int i = tid * stride; i < n; i += 256 * stride) {
+        const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+#pragma unroll
+        for (int j = 0; j < GS_SAMPLES; ++j) {
+            const float dx = x - s_smp[j][0], dy = y - s_smp[j][1], dz = z - s_smp[j][2];
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            int b = (int)(__float_as_uint(d2) >> 21) - GS_BIN0;
+            b = b < 0 ? 0 : (b >= GS_BINS ? GS_BINS - 1 : b);
+            atomicAdd(&s_hist[b], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+        const float emax = fmaxf(ex, fmaxf(ey, ez));
+        float c = emax > 0.f ? emax : 1.f;
+        if (n > 4 * target_pts) {
+            // smallest radius holding `target_pts` points around a sample, on average
+            const long long want = ((long long)GS_SAMPLES * target_pts + stride - 1) / stride;
+            long long cum = 0; int b = 0;
+            for (; b < GS_BINS; ++b) { cum += s_hist[b]; if (cum >= want) break; }
+            if (b < GS_BINS) {
+                const float r2 = __uint_as_float((unsigned)(b + 1 + GS_BIN0) << 21);      // upper edge of the bin
+                const float r = sqrtf(r2) * 1.1f;
+                if (r > 0.f && r < c) c = r;
+            }
+        }
+        // dense table: at most d.cell_cap cells
+        for (int it = 0; it < 64; ++it) {
+            const double cells = ((double)floorf(ex / c) + 1.0) * ((double)floorf(ey / c) + 1.0) * ((double)floorf(ez / c) + 1.0);
+            if (cells <= (double)d.cell_cap) break;
+            c *= 1.26f;
+        }
+        d.c = c; d.inv_c = 1.0f / c;
+        d.nx = (int)floorf(ex / c) + 1; d.ny = (int)floorf(ey / c) + 1; d.nz = (int)floorf(ez / c) + 1;
+        if ((long long)d.nx * d.ny * d.nz > d.cell_cap) { d.nx = d.ny = d.nz = 1; d.c = emax * 2.f + 1.f; d.inv_c = 1.0f / d.c; }      // unreachable safety net
+        d.ncell = d.nx * d.ny * d.nz;
+        for (int k = 0; k < 3; ++k) { d.lo[k] = mn[k]; d.hi[k] = mx[k]; }
+        if (n == 0) { d.nx = d.ny = d.nz = 1; d.ncell = 1; d.lo[0] = d.lo[1] = d.lo[2] = 0.f; d.c = 1.f; d.inv_c = 1.f; }
+        desc[t] = d;
+        s_mm[0] = __int_as_float(d.ncell);
+    }
+    __syncthreads();
+    const int ncell = __float_as_int(s_mm[0]);
+    for (int i = tid; i <= ncell; i += 256) cell[d.cell_off + i] = 0;
+}
+
+// per point: its rank inside its cell (returning atomic on the cell counter)
+__global__ __launch_bounds__(256) void grid_count_kernel(const GridDesc* __restrict__ desc, int* cell, int* __restrict__ rank) {
+    const GridDesc d = desc[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n) return;
+    const float x = d.pts[3 * (size_t)i], y = d.pts[3 * (size_t)i + 1], z = d.pts[3 * (size_t)i + 2];
+    const int cid = (cell_of(z, d.lo[2], d.inv_c, d.nz) * d.ny + cell_of(y, d.lo[1], d.inv_c, d.ny)) * d.nx + cell_of(x, d.lo[0], d.inv_c, d.nx);
+    rank[d.pt_off + i] = atomicAdd(&cell[d.cell_off + cid], 1);
+}
+
+// exclusive scan of the cell counters, two launches: block sums, then offsets + local scan (in place; cell[ncell] = n)
+__global__ __launch_bounds__(256) void grid_scan_sums_kernel(const GridDesc* __restrict__ desc, const int* __restrict__ cell, int* __restrict__ bsum, int max_blk) {
+    __shared__ int s_part[4][2];
+    const GridDesc d = desc[blockIdx.y];
+    const int blk = blockIdx.x;
+    if (blk * SCAN_BLK >= d.ncell) return;
+    const int lo = blk * SCAN_BLK, hi = min(lo + SCAN_BLK, d.ncell);
+    int s = 0, dummy = 0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += cell[d.cell_off + i];
+    block_sum2(s, dummy, &s_part[0][0]);
+    if (threadIdx.x == 0) bsum[(size_t)blockIdx.y * max_blk + blk] = s;
+}
+
+__global__ __launch_bounds__(256) void grid_scan_apply_kernel(const GridDesc* __restrict__ desc, int* cell, const int* __restrict__ bsum, int max_blk) {
+    __shared__ int s_wave[4];
+    const GridDesc d = desc[blockIdx.y];
+    const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (blk * SCAN_BLK >= d.ncell) return;
+    int base = 0;
+    for (int b = 0; b < blk; ++b) base += bsum[(size_t)blockIdx.y * max_blk + b];
+    // thread tid owns cells lo + tid*16 .. +16
+    const int lo = blk * SCAN_BLK + tid * (SCAN_BLK / 256);
+    int v[SCAN_BLK / 256]; int s = 0;
+#pragma unroll
+    for (int u = 0; u < SCAN_BLK / 256; ++u) { const int i = lo + u; v[u] = i < d.ncell ? cell[d.cell_off + i] : 0; s += v[u]; }
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+    if (lane == 63) s_wave[wid] = incl;
+    __syncthreads();
+    int run = base + incl - s;
+    for (int w2 = 0; w2 < wid; ++w2) run += s_wave[w2];
+#pragma unroll
+    for (int u = 0; u < SCAN_BLK / 256; ++u) { const int i = lo + u; if (i < d.ncell) cell[d.cell_off + i] = run; run += v[u]; }
+    if (blk == (d.ncell - 1) / SCAN_BLK && tid == 0) cell[d.cell_off + d.ncell] = d.n;
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const GridDesc* __restrict__ desc, const int* __restrict__ cell, const int* __restrict__ rank,
+                                                           float4* __restrict__ sorted) {
+    const GridDesc d = desc[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n) return;
+    const float x = d.pts[3 * (size_t)i], y = d.pts[3 * (size_t)i + 1], z = d.pts[3 * (size_t)i + 2];
+    const int cid = (cell_of(z, d.lo[2], d.inv_c, d.nz) * d.ny + cell_of(y, d.lo[1], d.inv_c, d.ny)) * d.nx + cell_of(x, d.lo[0], d.inv_c, d.nx);
+    sorted[d.pt_off + cell[d.cell_off + cid] + rank[d.pt_off + i]] = make_float4(x, y, z, __int_as_float(i));
+}
+
+struct GridSearchArgs {
+    const GridDesc* desc; const int* cell; const float4* sorted; const GridJob* jobs; int job0;
+    int* retry; int* retry_count;       // rows whose 3^3 block did not settle: answered by the second pass (compacted: a lane that needs a
+                                        // larger block would otherwise hold its whole wave in the loop)
+    int* work; int* work_count; int work_cap; int* need; int* status;
+};
+
+// One query against the block of (2R+1)^3 cells around its cell.  Returns true when the K + 1 best found are final: every point
+// outside the block is farther than the (K+1)-th.
+template <int K>
+__device__ __forceinline__ bool grid_scan(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
+                                          int cx, int cy, int cz, int R, RegSet<K + 1>& rs) {
+    rs.init();
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1), y0 = max(cy - R, 0), y1 = min(cy + R, d.ny - 1), z0 = max(cz - R, 0), z1 = min(cz + R, d.nz - 1);
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+            const int row = (z * d.ny + y) * d.nx;      // x is the fastest cell dimension: the cells x0..x1 of a row are one contiguous range
+            const int s = cell[row + x0], e = cell[row + x1 + 1];
+            for (int i = s; i < e; ++i) {
+                const float4 p = S[i];
+                const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+                if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
+            }
+        }
+    // every point outside the scanned block is at least g away (faces on the grid boundary have nothing beyond them)
+    float g = FLT_MAX;
+    if (x0 > 0) g = fminf(g, qx - (d.lo[0] + (float)x0 * d.c));
+    if (x1 < d.nx - 1) g = fminf(g, (d.lo[0] + (float)(x1 + 1) * d.c) - qx);
+    if (y0 > 0) g = fminf(g, qy - (d.lo[1] + (float)y0 * d.c));
+    if (y1 < d.ny - 1) g = fminf(g, (d.lo[1] + (float)(y1 + 1) * d.c) - qy);
+    if (z0 > 0) g = fminf(g, qz - (d.lo[2] + (float)z0 * d.c));
+    if (z1 < d.nz - 1) g = fminf(g, (d.lo[2] + (float)(z1 + 1) * d.c) - qz);
+    if (g == FLT_MAX) return true;                          // the block is the whole grid
+    if (!(g > 0.f)) return false;
+    const float gs = g * 0.99998f;                          // cell boundaries are rounded fp32 products: stay inside
+    return rs.worst() <= gs * gs;
+}
+
+// rows whose answer depends on the tree (ties, a near-tie at the K-th boundary, too few support points, no settled block) go to the
+// work list; the others are written
+template <int K, typename OutT>
+__device__ __forceinline__ void grid_finish(const GridSearchArgs& a, const GridJob& job, int jid, int q, bool settled, const RegSet<K + 1>& rs) {
+    bool hard = !settled || rs.d[K] == FLT_MAX;
+    const bool unsettled = hard;
+#pragma unroll
+    for (int j = 0; j < K; ++j) hard |= rs.d[j] == rs.d[j + 1];
+    hard |= rs.d[K] <= rs.d[K - 1] * 1.0000019073486328f;       // 1 + 2^-19
+    if (hard) {
+        if (unsettled) atomicAdd(a.status + 1, 1);                // diagnostics: rows that left the grid for lack of a settled block
+        const int w = atomicAdd(a.work_count, 1);
+        if (w < a.work_cap) { a.work[2 * (size_t)w] = jid; a.work[2 * (size_t)w + 1] = q; a.need[job.sup] = 1; }
+        else atomicOr(a.status, 8);
+        return;
+    }
+    OutT* o = reinterpret_cast<OutT*>(job.out) + (size_t)q * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) o[j] = (OutT)rs.id[j];
+}
+
+// first pass: grid.y = job (one support set x one query set x one output block), grid.x = blocks of 256 queries.
+// A lane whose candidate passes `dist < worst` makes its whole wave execute the ~70-instruction sorted insertion, and with 64
+// queries of the same cells in a wave that is nearly every candidate.  So the scan of the 3 x 3 rows of cells only MARKS the
+// candidates inside the radius the block guarantees (distance from the query to the nearest block face that has cells beyond it)
+// in one 64-bit mask per row — registers only, four loads in flight — and the sorted insertion then runs over the marked
+// candidates alone.  Fewer than K + 1 marked, a row of more than 64 candidates, or a query outside the support box: second pass.
+//
+// LDS-staged cell buckets: when the queries are the support points themselves (taken in cell order), the 256 queries of a
+// workgroup own one interval of cell ids, so each of the nine (dy, dz) row offsets needs ONE contiguous slice of the cell-sorted
+// records: the workgroup copies the nine slices into LDS with coalesced loads and every lane reads its candidates from there
+// (per-lane 16-byte gathers through the vector L1 were the limit: ~60 M line look-ups per launch).
+//
+// job.job1 >= 0 (pyramid): interp_idx = the nearest of the first n1 support points (tf_map's prefix sub-sampling) falls out of the
+// same scan: the two nearest candidates with index < n1 are tracked, and the answer is final when the nearest lies inside the
+// guaranteed radius and clear of the second.
+constexpr int GS_STAGE = 2816;           // records staged per workgroup (44 KiB)
+template <int K, typename OutT>
+__global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
+    __shared__ float4 s_rec[GS_STAGE];
+    __shared__ int s_seg[9][2];          // per row offset: first record of the slice, its position in s_rec
+    __shared__ int s_ok;
+    const int jid = a.job0 + blockIdx.y;
+    const GridJob job = a.jobs[jid];
+    const int q0 = (int)blockIdx.x * 256;
+    if (q0 >= job.nq) return;
+    const int qi = min(q0 + (int)threadIdx.x, job.nq - 1);
+    const bool live = q0 + (int)threadIdx.x < job.nq;
+    const GridDesc d = a.desc[job.sup];
+    int q = qi; float qx, qy, qz;
+    if (job.ord >= 0) {       // the queries are the points of set `ord`: take them in its cell order (lanes of a wave scan the same cells)
+        const float4 r = a.sorted[a.desc[job.ord].pt_off + qi];
+        q = __float_as_int(r.w); qx = r.x; qy = r.y; qz = r.z;
+    } else {
+        qx = job.qpts[3 * (size_t)q]; qy = job.qpts[3 * (size_t)q + 1]; qz = job.qpts[3 * (size_t)q + 2];
+    }
+    const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
+    const int* cell = a.cell + d.cell_off;
+    const float4* S = a.sorted + d.pt_off;
+
+    // stage the nine slices (self-search only: the workgroup's queries are records [w0, w0 + 256) of the same cell-sorted array)
+    bool staged = false;
+    if (job.ord == job.sup) {
+        if (threadIdx.x == 0) {
+            const int w0 = q0, w1 = min(w0 + 256, job.nq) - 1;
+            const float4 f = S[w0], l = S[w1];
+            const int c_lo = (cell_of(f.z, d.lo[2], d.inv_c, d.nz) * d.ny + cell_of(f.y, d.lo[1], d.inv_c, d.ny)) * d.nx + cell_of(f.x, d.lo[0], d.inv_c, d.nx);
+            const int c_hi = (cell_of(l.z, d.lo[2], d.inv_c, d.nz) * d.ny + cell_of(l.y, d.lo[1], d.inv_c, d.ny)) * d.nx + cell_of(l.x, d.lo[0], d.inv_c, d.nx);
+            int tot = 0;
+            for (int o = 0; o < 9; ++o) {
+                const int off = ((o / 3 - 1) * d.ny + (o % 3 - 1)) * d.nx;
+                const int lo = max(c_lo - 1 + off, 0), hi = min(c_hi + 1 + off, d.ncell - 1);
+                int s0 = 0, e0 = 0;
+                if (lo <= hi) { s0 = cell[lo]; e0 = cell[hi + 1]; }
+                s_seg[o][0] = s0; s_seg[o][1] = tot;              // LDS position of record i of this slice: s_seg[o][1] + (i - s_seg[o][0])
+                tot += e0 - s0;
+            }
+            s_ok = tot <= GS_STAGE ? tot : -1;
+        }
+        __syncthreads();
+        staged = s_ok >= 0;
+        if (staged) {
+#pragma unroll 1
+            for (int o = 0; o < 9; ++o) {
+                const int s0 = s_seg[o][0], pos = s_seg[o][1], len = (o < 8 ? s_seg[o + 1][1] : s_ok) - pos;
+                for (int i = (int)threadIdx.x; i < len; i += 256) s_rec[pos + i] = S[s0 + i];
+            }
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, d.nx - 1);
+    // every point outside the block is at least g away (faces on the grid boundary have nothing beyond them)
+    float g = FLT_MAX;
+    if (x0 > 0) g = fminf(g, qx - (d.lo[0] + (float)x0 * d.c));
+    if (x1 < d.nx - 1) g = fminf(g, (d.lo[0] + (float)(x1 + 1) * d.c) - qx);
+    if (cy > 1) g = fminf(g, qy - (d.lo[1] + (float)(cy - 1) * d.c));
+    if (cy + 1 < d.ny - 1) g = fminf(g, (d.lo[1] + (float)(cy + 2) * d.c) - qy);
+    if (cz > 1) g = fminf(g, qz - (d.lo[2] + (float)(cz - 1) * d.c));
+    if (cz + 1 < d.nz - 1) g = fminf(g, (d.lo[2] + (float)(cz + 2) * d.c) - qz);
+    bool again = !(g > 0.f);
+    float tau = FLT_MAX;
+    if (g < FLT_MAX) { const float gs = g * 0.99998f; tau = gs * gs; }      // cell boundaries are rounded fp32 products: stay inside
+    unsigned long long m[9]; int rs0[9];
+    int cnt = 0;
+    float b0 = FLT_MAX, b1 = FLT_MAX; int i0 = 0;                            // two nearest among the first n1 support points
+    const int n1 = job.job1 >= 0 ? job.n1 : 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        m[r] = 0ull; rs0[r] = 0;
+        if (z < 0 || z >= d.nz || y < 0 || y >= d.ny) continue;
+        const int row = (z * d.ny + y) * d.nx;      // x is the fastest cell dimension: the cells x0..x1 of a row are one contiguous range
+        const int s = cell[row + x0], e = cell[row + x1 + 1];
+        rs0[r] = s;
+        if (e - s > 64) { again = true; continue; }
+        const int lpos = staged ? s_seg[r][1] - s_seg[r][0] + s : 0;      // LDS position of record s (kept as an index: no pointer below the array)
+        for (int i = s; i < e; i += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int k = min(i + u, e - 1); p[u] = staged ? s_rec[lpos + (k - s)] : S[k]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+                if (i + u < e) {
+                    if (dist < tau) { m[r] |= 1ull << (i + u - s); ++cnt; }
+                    if (K == 16 && __float_as_int(p[u].w) < n1 && dist < b1) {
+                        if (dist < b0) { b1 = b0; b0 = dist; i0 = __float_as_int(p[u].w); } else b1 = dist;
+                    }
+                }
+            }
+        }
+    }
+    if (K == 16 && job.job1 >= 0) {
+        // final iff the nearest prefix point lies inside the guaranteed radius and the runner-up (seen, or anything beyond the radius) is
+        // clear of it by more than the near-tie margin; otherwise the K = 1 job answers the row itself
+        const float second = fminf(b1, tau);
+        if (!again && b0 < tau && b0 * 1.0000019073486328f < second) {
+            const GridJob j1 = a.jobs[job.job1];
+            reinterpret_cast<OutT*>(j1.out)[q] = (OutT)i0;
+        } else {
+            const int w = atomicAdd(a.retry_count + 1, 1);
+            int* r1 = a.retry + 2 * (size_t)a.work_cap;          // retry list of K = 1 follows the one of K = 16
+            r1[2 * (size_t)w] = job.job1; r1[2 * (size_t)w + 1] = q;
+        }
+    }
+    if (again || cnt < K + 1) {
+        const int w = atomicAdd(a.retry_count, 1);             // < work_cap by construction (one entry per query at most)
+        a.retry[2 * (size_t)w] = jid; a.retry[2 * (size_t)w + 1] = q;
+        return;
+    }
+    RegSet<K + 1> rs; rs.init();
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        unsigned long long mm = m[r];
+        const int lpos = staged ? s_seg[r][1] - s_seg[r][0] + rs0[r] : 0;
+        while (mm) {
+            const int bpos = __ffsll((unsigned long long)mm) - 1;
+            mm &= mm - 1ull;
+            const float4 p = staged ? s_rec[lpos + bpos] : S[rs0[r] + bpos];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+            if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
+        }
+    }
+    grid_finish<K, OutT>(a, job, jid, q, true, rs);
+}
+
+// second pass over the rows the first one left: 5^3, then 7^3 cells
+template <int K, typename OutT>
+__global__ __launch_bounds__(64) void grid_retry_kernel(GridSearchArgs a) {
+    const int n = min(*a.retry_count, a.work_cap);
+    for (int e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
+        const int jid = a.retry[2 * (size_t)e], q = a.retry[2 * (size_t)e + 1];
+        const GridJob job = a.jobs[jid];
+        const GridDesc d = a.desc[job.sup];
+        const float qx = job.qpts[3 * (size_t)q], qy = job.qpts[3 * (size_t)q + 1], qz = job.qpts[3 * (size_t)q + 2];
+        const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
+        RegSet<K + 1> rs;
+        bool settled = false;
+        for (int R = 2; R <= GS_RMAX && !settled; ++R) settled = grid_scan<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, R, rs);
+        grid_finish<K, OutT>(a, job, jid, q, settled, rs);
+    }
+}
+
+}  // namespace
+
+int grid_build(GridForest& g, const std::vector<GridDesc>& sets_in, int target_pts, hipStream_t s) {
+    std::vector<GridDesc> sets = sets_in;
+    long pt = 0, cl = 0; int maxn = 0; long maxcap = 0;
+    for (auto& d : sets) {
+        d.pt_off = (int)pt; d.cell_off = (int)cl; d.cell_cap = 8 * d.n + 64;
+        pt += d.n; cl += (long)d.cell_cap + 1; maxn = std::max(maxn, d.n); maxcap = std::max(maxcap, (long)d.cell_cap);
+        if (pt > 0x3fffffffL || cl > 0x7ffffff0L) { set_error("grid_build: too many points"); return SSDR_ERR_INVALID; }
+    }
+    g.nsets = (int)sets.size(); g.total_pts = (int)pt; g.max_n = maxn;
+    g.max_blk = (int)((maxcap + SCAN_BLK - 1) / SCAN_BLK);
+    if (g.nsets == 0) return SSDR_OK;
+    SSDR_TRY(g.desc.reserve(sizeof(GridDesc) * sets.size()));
+    SSDR_TRY(g.cell.reserve(4 * (size_t)cl + 16)); SSDR_TRY(g.rank.reserve(4 * (size_t)std::max(pt, 1L))); SSDR_TRY(g.sorted.reserve(16 * (size_t)std::max(pt, 1L)));
+    SSDR_TRY(g.bsum.reserve(4 * (size_t)g.nsets * g.max_blk));
+    SSDR_TRY(g.need.reserve(4 * (size_t)g.nsets + 32));
+    // descriptors travel through a pinned staging buffer; the event guards its reuse by the next build
+    if (g.staging_cap < sets.size()) {
+        if (g.staging) (void)hipHostFree(g.staging);
+        g.staging_cap = sets.size() * 2;
+        SSDR_HIP(hipHostMalloc(&g.staging, sizeof(GridDesc) * g.staging_cap));
+    }
+    if (!g.staging_ev) SSDR_HIP(hipEventCreate(&g.staging_ev)); else SSDR_HIP(hipEventSynchronize(g.staging_ev));
+    memcpy(g.staging, sets.data(), sizeof(GridDesc) * sets.size());
+    SSDR_HIP(hipMemcpyAsync(g.desc.p, g.staging, sizeof(GridDesc) * sets.size(), hipMemcpyHostToDevice, s));
+    SSDR_HIP(hipEventRecord(g.staging_ev, s));
+    SSDR_HIP(hipMemsetAsync(g.need.p, 0, 4 * (size_t)g.nsets + 32, s));      // need[nsets], [nsets + 1]: work counts, [nsets + 2]: status
+    GridDesc* dd = g.desc.as<GridDesc>();
+    const dim3 gp((unsigned)((maxn + 255) / 256), (unsigned)g.nsets), gb((unsigned)g.max_blk, (unsigned)g.nsets);
+    ProfScope prof("knn_grid_build", s, 28.0 * (double)pt);
+    hipLaunchKernelGGL(grid_prepare_kernel, dim3(g.nsets), dim3(256), 0, s, dd, g.cell.as<int>(), target_pts);
+    hipLaunchKernelGGL(grid_count_kernel, gp, dim3(256), 0, s, dd, g.cell.as<int>(), g.rank.as<int>());
+    hipLaunchKernelGGL(grid_scan_sums_kernel, gb, dim3(256), 0, s, dd, g.cell.as<int>(), g.bsum.as<int>(), g.max_blk);
+    hipLaunchKernelGGL(grid_scan_apply_kernel, gb, dim3(256), 0, s, dd, g.cell.as<int>(), g.bsum.as<int>(), g.max_blk);
+    hipLaunchKernelGGL(grid_scatter_kernel, gp, dim3(256), 0, s, dd, g.cell.as<int>(), g.rank.as<int>(), g.sorted.as<float4>());
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+// jobs [job0, job0 + njobs) of the table uploaded by grid_set_jobs, all with the same K; rows that need the tree go to the K's work list
+int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, bool out_i64, hipStream_t s) {
+    if (njobs <= 0) return SSDR_OK;
+    if (K != 16 && K != 1) { set_error("grid search: K=%d has no instantiation (1, 16)", K); return SSDR_ERR_UNSUPPORTED; }
+    const int wl = K == 16 ? 0 : 1;
+    int* ctr = g.counters();            // [0], [1]: work counts of the two lists, [2]: status, [3]: unsettled rows, [4], [5]: retry counts
+    GridSearchArgs a{g.desc.as<GridDesc>(), g.cell.as<int>(), g.sorted.as<float4>(), g.jobs.as<GridJob>(), job0,
+                     g.work_list(2 + wl), ctr + 4 + wl, g.work_list(wl), ctr + wl, g.work_cap, g.need.as<int>(), ctr + 2};      // K = 16: the retry list / counter of K = 1 lie right behind its own
+    const dim3 grid((unsigned)((max_nq + 255) / 256), (unsigned)njobs);
+    const dim3 rgrid((unsigned)std::max(1, std::min(g.work_cap / 64 + 1, ctx().num_cu * 16)));
+    const bool first = max_nq > 0;      // max_nq == 0: the jobs were answered inside another scan, only their left-over rows remain
+    if (K == 16) {
+        if (out_i64) { if (first) hipLaunchKernelGGL((grid_search_kernel<16, int64_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<16, int64_t>), rgrid, dim3(64), 0, s, a); }
+        else { if (first) hipLaunchKernelGGL((grid_search_kernel<16, int32_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<16, int32_t>), rgrid, dim3(64), 0, s, a); }
+    } else {
+        if (out_i64) { if (first) hipLaunchKernelGGL((grid_search_kernel<1, int64_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<1, int64_t>), rgrid, dim3(64), 0, s, a); }
+        else { if (first) hipLaunchKernelGGL((grid_search_kernel<1, int32_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<1, int32_t>), rgrid, dim3(64), 0, s, a); }
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int grid_set_jobs(GridForest& g, const std::vector<GridJob>& jobs, hipStream_t s) {
+    if (jobs.empty()) return SSDR_OK;
+    long tq = 0; for (auto& j : jobs) tq += j.nq;
+    g.work_cap = (int)std::min(std::max(tq, 1024L), 0x3fffffffL);      // per list: every query of every job can go to the tree
+    SSDR_TRY(g.work.reserve(4 * 8 * (size_t)g.work_cap));      // hand-over lists (K = 16, K = 1) and retry lists
+    SSDR_TRY(g.jobs.reserve(sizeof(GridJob) * jobs.size()));
+    if (g.jstaging_cap < jobs.size()) {
+        if (g.jstaging) (void)hipHostFree(g.jstaging);
+        g.jstaging_cap = jobs.size() * 2;
+        SSDR_HIP(hipHostMalloc(&g.jstaging, sizeof(GridJob) * g.jstaging_cap));
+    }
+    if (!g.jstaging_ev) SSDR_HIP(hipEventCreate(&g.jstaging_ev)); else SSDR_HIP(hipEventSynchronize(g.jstaging_ev));
+    memcpy(g.jstaging, jobs.data(), sizeof(GridJob) * jobs.size());
+    SSDR_HIP(hipMemcpyAsync(g.jobs.p, g.jstaging, sizeof(GridJob) * jobs.size(), hipMemcpyHostToDevice, s));
+    SSDR_HIP(hipEventRecord(g.jstaging_ev, s));
+    return SSDR_OK;
+}
+
+}  // namespace ssdr

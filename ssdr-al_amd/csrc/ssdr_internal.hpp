@@ -103,7 +103,8 @@ struct KdForest {
 };
 
 // Builds `ntrees` trees described by host descriptors (pts/n filled in; voff/root/lo/hi are computed).
-int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees, hipStream_t s);
+// d_need (optional, device int[ntrees]): only trees whose flag is non-zero when the build runs are built.
+int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees, hipStream_t s, const int* d_need = nullptr);
 // For every tree t in [tree0, tree0+ntrees): queries q = d_queries + (t-tree0)*q_stride floats, nq each.
 // qorder_tree >= 0: visit queries in the vind order of forest tree (qorder_tree0 + (t-tree0)) (must have n == nq).
 // out: int32 or int64 [ntrees][nq][K].
@@ -117,5 +118,43 @@ int kd_search_f64(const KdForest& f, int tree0, int ntrees, const float* d_queri
                   int qorder_tree0, int32_t* d_out, double* d_out_d2, size_t out_stride, hipStream_t s);
 // Reads back the device status flags of the forest (synchronises the stream).
 int kd_check(const KdForest& f, hipStream_t s);
+
+// ---- uniform-grid search with hand-over to the kd walk (knn_grid.hip) -----------------------------------------------
+struct GridDesc {        // one support set
+    const float* pts;    // device pointer, n x 3 row-major
+    int n;
+    int pt_off;          // offset of this set's slice in `sorted` / `rank`
+    int cell_off;        // offset of its cell table (ncell + 1 ints)
+    int cell_cap;        // most cells the table may hold
+    float c, inv_c;      // cell size (measured on the device)
+    int nx, ny, nz, ncell;
+    float lo[3], hi[3];  // bounding box; lo is the grid origin
+};
+struct GridJob {         // one search: queries of one batch element against one support set, one output block [nq][K]
+    int sup;             // support set
+    int ord;             // >= 0: the queries are the points of this set and are taken in its cell order; < 0: natural order
+    int nq;
+    int job1;            // K = 16 self-searches of a pyramid: the K = 1 job answered in the same scan (-1: none).  That job's support set
+                         // must be the first n1 points of this job's support set (tf_map's prefix sub-sampling) and its queries the same
+    const float* qpts;   // query coordinates [nq][3]
+    void* out;           // [nq][K] int32 / int64
+    int n1; int pad;
+};
+struct GridForest {
+    DevBuf desc, cell, rank, sorted, bsum, work, need, jobs;
+    GridDesc* staging = nullptr; size_t staging_cap = 0; hipEvent_t staging_ev = nullptr;
+    GridJob* jstaging = nullptr; size_t jstaging_cap = 0; hipEvent_t jstaging_ev = nullptr;
+    int nsets = 0, total_pts = 0, max_n = 0, max_blk = 0, work_cap = 0;
+    // device ints behind the per-set `need` flags: [0], [1] hand-over list lengths (K = 16, K = 1), [2] status, [3] unsettled rows,
+    // [4], [5] retry list lengths; work_list(0..1): hand-over lists, work_list(2..3): retry lists
+    int* counters() const { return need.as<int>() + nsets; }
+    int* work_list(int which) const { return work.as<int>() + (size_t)which * 2 * work_cap; }
+};
+// Bins every set (pts / n filled in by the caller).  target_pts: number of points the measured cell radius should hold.
+int grid_build(GridForest& g, const std::vector<GridDesc>& sets, int target_pts, hipStream_t s);
+int grid_set_jobs(GridForest& g, const std::vector<GridJob>& jobs, hipStream_t s);
+int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, bool out_i64, hipStream_t s);
+// Answers the rows of a work list (pairs job id, query) by the exact tree walk; tree ids == set ids.
+int kd_search_worklist(const KdForest& f, const GridJob* d_jobs, const int* d_work, const int* d_count, int work_cap, int K, bool out_i64, hipStream_t s);
 
 }  // namespace ssdr

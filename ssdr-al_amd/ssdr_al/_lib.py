@@ -59,6 +59,7 @@ def lib():
         L.ssdr_knn_batch.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
         L.ssdr_knn_batch_i32.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
         L.ssdr_knn_batch_dev.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp, vp]
+        L.ssdr_knn_status.argtypes = [vp, vp]
         L.ssdr_knn_pyramid.argtypes = [vp, sz, sz, sz, vp, sz, vp, vp, vp]
         L.ssdr_knn_pyramid_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, vp, vp, vp]
         L.ssdr_grid_subsample.argtypes = [vp, sz, vp, sz, vp, sz, f32, i32, C.POINTER(sz)]
