@@ -14,7 +14,7 @@ struct KnnState {
 };
 KnnState& st(hipStream_t s = nullptr) { static std::map<hipStream_t, KnnState> m; return m[s ? s : ctx().stream]; }
 
-constexpr int GRID_TARGET_PTS = 26;      // the measured cell radius holds about this many points (K + 1 = 17 and a margin)
+constexpr int GRID_TARGET_PTS = 22;      // the measured cell radius holds about this many points (K + 1 = 17 and a margin)
 
 // grid search of a job table split as [jobs16 | jobs1], then the tree walk for the rows the grid handed over
 int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<GridJob>& jobs16, const std::vector<GridJob>& jobs1, bool i64, hipStream_t s) {

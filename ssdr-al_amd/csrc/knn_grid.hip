@@ -31,6 +31,7 @@ constexpr int GS_BINS = 192;             // log-scale histogram of squared dista
 constexpr int GS_BIN0 = (87 << 2);       // first bin: d^2 = 2^-40
 constexpr int GS_RMAX = 3;               // largest block: (2*3+1)^3 cells
 constexpr int SCAN_BLK = 4096;           // cells per scan block
+constexpr int RETRY_FROM_R1 = 1 << 30;   // tag on a retry entry's job id: the 3^3 block of that job's grid has not been searched yet
 
 __device__ __forceinline__ int cell_of(float v, float o, float inv_c, int n) {
     const float f = (v - o) * inv_c;
@@ -231,26 +232,15 @@ __device__ __forceinline__ void grid_finish(const GridSearchArgs& a, const GridJ
 // in one 64-bit mask per row — registers only, four loads in flight — and the sorted insertion then runs over the marked
 // candidates alone.  Fewer than K + 1 marked, a row of more than 64 candidates, or a query outside the support box: second pass.
 //
-// LDS-staged cell buckets: when the queries are the support points themselves (taken in cell order), the 256 queries of a
-// workgroup own one interval of cell ids, so each of the nine (dy, dz) row offsets needs ONE contiguous slice of the cell-sorted
-// records: the workgroup copies the nine slices into LDS with coalesced loads and every lane reads its candidates from there
-// (per-lane 16-byte gathers through the vector L1 were the limit: ~60 M line look-ups per launch).
-//
 // job.job1 >= 0 (pyramid): interp_idx = the nearest of the first n1 support points (tf_map's prefix sub-sampling) falls out of the
 // same scan: the two nearest candidates with index < n1 are tracked, and the answer is final when the nearest lies inside the
 // guaranteed radius and clear of the second.
-constexpr int GS_STAGE = 2816;           // records staged per workgroup (44 KiB)
 template <int K, typename OutT>
 __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
-    __shared__ float4 s_rec[GS_STAGE];
-    __shared__ int s_seg[9][2];          // per row offset: first record of the slice, its position in s_rec
-    __shared__ int s_ok;
     const int jid = a.job0 + blockIdx.y;
     const GridJob job = a.jobs[jid];
-    const int q0 = (int)blockIdx.x * 256;
-    if (q0 >= job.nq) return;
-    const int qi = min(q0 + (int)threadIdx.x, job.nq - 1);
-    const bool live = q0 + (int)threadIdx.x < job.nq;
+    const int qi = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (qi >= job.nq) return;
     const GridDesc d = a.desc[job.sup];
     int q = qi; float qx, qy, qz;
     if (job.ord >= 0) {       // the queries are the points of set `ord`: take them in its cell order (lanes of a wave scan the same cells)
@@ -263,37 +253,6 @@ __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
     const int* cell = a.cell + d.cell_off;
     const float4* S = a.sorted + d.pt_off;
 
-    // stage the nine slices (self-search only: the workgroup's queries are records [w0, w0 + 256) of the same cell-sorted array)
-    bool staged = false;
-    if (job.ord == job.sup) {
-        if (threadIdx.x == 0) {
-            const int w0 = q0, w1 = min(w0 + 256, job.nq) - 1;
-            const float4 f = S[w0], l = S[w1];
-            const int c_lo = (cell_of(f.z, d.lo[2], d.inv_c, d.nz) * d.ny + cell_of(f.y, d.lo[1], d.inv_c, d.ny)) * d.nx + cell_of(f.x, d.lo[0], d.inv_c, d.nx);
-            const int c_hi = (cell_of(l.z, d.lo[2], d.inv_c, d.nz) * d.ny + cell_of(l.y, d.lo[1], d.inv_c, d.ny)) * d.nx + cell_of(l.x, d.lo[0], d.inv_c, d.nx);
-            int tot = 0;
-            for (int o = 0; o < 9; ++o) {
-                const int off = ((o / 3 - 1) * d.ny + (o % 3 - 1)) * d.nx;
-                const int lo = max(c_lo - 1 + off, 0), hi = min(c_hi + 1 + off, d.ncell - 1);
-                int s0 = 0, e0 = 0;
-                if (lo <= hi) { s0 = cell[lo]; e0 = cell[hi + 1]; }
-                s_seg[o][0] = s0; s_seg[o][1] = tot;              // LDS position of record i of this slice: s_seg[o][1] + (i - s_seg[o][0])
-                tot += e0 - s0;
-            }
-            s_ok = tot <= GS_STAGE ? tot : -1;
-        }
-        __syncthreads();
-        staged = s_ok >= 0;
-        if (staged) {
-#pragma unroll 1
-            for (int o = 0; o < 9; ++o) {
-                const int s0 = s_seg[o][0], pos = s_seg[o][1], len = (o < 8 ? s_seg[o + 1][1] : s_ok) - pos;
-                for (int i = (int)threadIdx.x; i < len; i += 256) s_rec[pos + i] = S[s0 + i];
-            }
-        }
-        __syncthreads();
-    }
-    if (!live) return;
 
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, d.nx - 1);
     // every point outside the block is at least g away (faces on the grid boundary have nothing beyond them)
@@ -320,11 +279,10 @@ __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
         const int s = cell[row + x0], e = cell[row + x1 + 1];
         rs0[r] = s;
         if (e - s > 64) { again = true; continue; }
-        const int lpos = staged ? s_seg[r][1] - s_seg[r][0] + s : 0;      // LDS position of record s (kept as an index: no pointer below the array)
         for (int i = s; i < e; i += 4) {
             float4 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int k = min(i + u, e - 1); p[u] = staged ? s_rec[lpos + (k - s)] : S[k]; }
+            for (int u = 0; u < 4; ++u) p[u] = S[min(i + u, e - 1)];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
@@ -348,23 +306,22 @@ __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
         } else {
             const int w = atomicAdd(a.retry_count + 1, 1);
             int* r1 = a.retry + 2 * (size_t)a.work_cap;          // retry list of K = 1 follows the one of K = 16
-            r1[2 * (size_t)w] = job.job1; r1[2 * (size_t)w + 1] = q;
+            r1[2 * (size_t)w] = job.job1 | RETRY_FROM_R1; r1[2 * (size_t)w + 1] = q;      // its own (coarser) grid has not been tried yet
         }
     }
     if (again || cnt < K + 1) {
         const int w = atomicAdd(a.retry_count, 1);             // < work_cap by construction (one entry per query at most)
-        a.retry[2 * (size_t)w] = jid; a.retry[2 * (size_t)w + 1] = q;
+        a.retry[2 * (size_t)w] = again ? (jid | RETRY_FROM_R1) : jid; a.retry[2 * (size_t)w + 1] = q;      // a row too long for the masks can still settle at 3^3
         return;
     }
     RegSet<K + 1> rs; rs.init();
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
         unsigned long long mm = m[r];
-        const int lpos = staged ? s_seg[r][1] - s_seg[r][0] + rs0[r] : 0;
         while (mm) {
             const int bpos = __ffsll((unsigned long long)mm) - 1;
             mm &= mm - 1ull;
-            const float4 p = staged ? s_rec[lpos + bpos] : S[rs0[r] + bpos];
+            const float4 p = S[rs0[r] + bpos];
             const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
             float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
             if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
@@ -378,14 +335,15 @@ template <int K, typename OutT>
 __global__ __launch_bounds__(64) void grid_retry_kernel(GridSearchArgs a) {
     const int n = min(*a.retry_count, a.work_cap);
     for (int e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
-        const int jid = a.retry[2 * (size_t)e], q = a.retry[2 * (size_t)e + 1];
+        const int tag = a.retry[2 * (size_t)e], q = a.retry[2 * (size_t)e + 1];
+        const int jid = tag & ~RETRY_FROM_R1;
         const GridJob job = a.jobs[jid];
         const GridDesc d = a.desc[job.sup];
         const float qx = job.qpts[3 * (size_t)q], qy = job.qpts[3 * (size_t)q + 1], qz = job.qpts[3 * (size_t)q + 2];
         const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
         RegSet<K + 1> rs;
         bool settled = false;
-        for (int R = 2; R <= GS_RMAX && !settled; ++R) settled = grid_scan<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, R, rs);
+        for (int R = (tag & RETRY_FROM_R1) ? 1 : 2; R <= GS_RMAX && !settled; ++R) settled = grid_scan<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, R, rs);
         grid_finish<K, OutT>(a, job, jid, q, settled, rs);
     }
 }
