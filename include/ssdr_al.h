@@ -46,6 +46,7 @@ int  ssdr_stream_sync(void* stream);     /* NULL = library stream */
  * keeps its workspaces per stream, so calls on different streams may run concurrently. */
 int  ssdr_stream_create(void** out_stream);
 int  ssdr_stream_destroy(void* stream);
+int  ssdr_main_stream(void** out_stream);            /* the library's own stream (what stream == NULL means) */
 int  ssdr_stream_wait(void* waiter, void* waited);   /* waiter continues after what is enqueued on waited so far */
 /* Optional per-launch timing (HIP events on the launch stream) of the instrumented kernels; used by bench.py for
  * the roofline line.  ssdr_prof_report() synchronises and returns "name calls total_ms total_work\n" lines, where
@@ -212,6 +213,13 @@ int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorte
 int ssdr_segment_mean_features_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom,
                                    const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel, size_t nsel,
                                    float* d_out, void* stream);
+/* Device-side pieces of the sharded selection's exchanges (ssdr_al/distributed.py runs the RCCL collectives
+ * directly on these buffers, on the caller's stream):
+ * ssdr_mask_regions_dev: out[i] = labelled[i] ? -inf : region_unc[i] for i < S, -inf for S <= i < S_padded (what every rank
+ * contributes to the all-gather before the global ranking; labelled regions and padding sort last);
+ * ssdr_gather_rows_dev: out[r] = in[idx[r]] for rows of row_bytes bytes (compacts the padded all-gather of candidate features). */
+int ssdr_mask_regions_dev(const double* d_region_unc, const uint8_t* d_labelled, size_t S, size_t S_padded, double* d_out, void* stream);
+int ssdr_gather_rows_dev(const void* d_in, const int32_t* d_idx, size_t n, size_t row_bytes, void* d_out, void* stream);
 /* y0[i] = (y1[i] =) (double)x[i]: what np.concatenate / np.matmul do to the float32 features when they meet the float64
  * adjacency (sampler2.py:760-770, fps_gcn_cpu.py:162-166); y1 may be NULL. */
 int ssdr_widen_f32_f64_dev(const float* d_x, size_t n, double* d_y0, double* d_y1, void* stream);

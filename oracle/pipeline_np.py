@@ -33,6 +33,28 @@ def front_end(room, center, perm, dup, num_points, dl):
     return txyz.astype(np.float32), feat.astype(np.float32), len(sp)
 
 
+def candidates(sorted_inds, labeled, sp_cloud, batch_size, num_clouds):
+    """The candidate rule of sampling(), restated with plain loops (sampler2.py:533-552 create_file_top_and_all, :745-753):
+    walk the regions by descending uncertainty, skip labelled ones; the first `batch_size` survivors are the "top" regions and
+    fix selected_num per cloud; every cloud keeps its first 2 x selected_num survivors as candidates.  Candidate order: cloud
+    ascending, descending uncertainty inside a cloud; labelled list: cloud ascending, superpoint ascending."""
+    per_cloud = {b: [] for b in range(num_clouds)}
+    ntop = {b: 0 for b in range(num_clouds)}
+    seen = 0
+    batch_size = min(batch_size, len(sorted_inds))
+    for s in sorted_inds:
+        b = int(sp_cloud[s])
+        if int(s) in labeled.get(b, ()):
+            continue
+        per_cloud[b].append(int(s))
+        if seen < batch_size:
+            ntop[b] += 1
+        seen += 1
+    unl = [(b, s) for b in range(num_clouds) for s in per_cloud[b][: 2 * ntop[b]]]
+    lab = [(b, s) for b in sorted(labeled) for s in sorted(labeled[b])]
+    return unl, lab, sum(ntop.values())
+
+
 def run(hp, rooms, weights, threads=1, net_outputs=None, stop_after=None):
     """hp: the set-up ssdr_al.pipeline.HotPath (supplies centres, permutations, superpoints, labelled sets)."""
     cfg = hp.cfg
@@ -63,7 +85,7 @@ def run(hp, rooms, weights, threads=1, net_outputs=None, stop_after=None):
     sorted_inds = S.rank_regions(ru)
     out.update(unc=unc, cls=cls, region_unc=ru, dom=dom, sorted_inds=sorted_inds)
     t.append(time.perf_counter())
-    unl, lab, sampling_batch = hp._candidates(sorted_inds)
+    unl, lab, sampling_batch = candidates(sorted_inds, hp.labeled, hp.sp_cloud_h, hp.select_per_tile * hp.B, hp.B)
     refs = unl + lab
     sel = np.array([s for _, s in refs], np.int32)
     sub_off = np.concatenate([[0], np.cumsum(hp.sp_off_h[sel + 1] - hp.sp_off_h[sel])]).astype(np.int32)

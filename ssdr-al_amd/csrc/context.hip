@@ -112,6 +112,13 @@ int ssdr_stream_create(void** out_stream) {
     *out_stream = s;
     return SSDR_OK;
 }
+/* the library's own stream (what stream == NULL means everywhere), e.g. to wrap it as a framework's external stream */
+int ssdr_main_stream(void** out_stream) {
+    if (!out_stream) { ssdr::set_error("main_stream: NULL"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ssdr::ensure_init());
+    *out_stream = ssdr::ctx().stream;
+    return SSDR_OK;
+}
 int ssdr_stream_destroy(void* stream) { if (stream) SSDR_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream))); return SSDR_OK; }
 /* work enqueued on `waiter` after this call starts only after everything enqueued on `waited` so far has finished */
 int ssdr_stream_wait(void* waiter, void* waited) {

@@ -735,6 +735,38 @@ int ssdr_segment_mean_features_dev(const float* d_feat, int feat_dim, const int3
     return SSDR_OK;
 }
 
+// ---- sharded selection: device-side pieces of the exchanges (ssdr_al/distributed.py) -----------------------------------
+__global__ __launch_bounds__(256) void sel_mask_regions(const double* __restrict__ u, const unsigned char* __restrict__ labelled, int S, int Spad, double* out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Spad; i += gridDim.x * 256)
+        out[i] = (i < S && !labelled[i]) ? u[i] : __longlong_as_double((long long)0xfff0000000000000ULL);      // -inf: labelled regions and padding sort last
+}
+__global__ __launch_bounds__(256) void sel_gather_rows(const uint32_t* __restrict__ in, const int* __restrict__ idx, int n, int row_words, uint32_t* __restrict__ out) {
+    const long total = (long)n * row_words;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int r = (int)(e / row_words), c = (int)(e % row_words);
+        out[e] = in[(size_t)idx[r] * row_words + c];
+    }
+}
+
+int ssdr_mask_regions_dev(const double* d_region_unc, const uint8_t* d_labelled, size_t S, size_t S_padded, double* d_out, void* stream) {
+    if (!d_region_unc || !d_labelled || !d_out || S_padded < S) { set_error("mask_regions: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (S_padded == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_mask_regions, dim3(grid_for((long)S_padded)), dim3(256), 0, pick_stream(stream), d_region_unc, d_labelled, (int)S, (int)S_padded, d_out);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_gather_rows_dev(const void* d_in, const int32_t* d_idx, size_t n, size_t row_bytes, void* d_out, void* stream) {
+    if (!d_in || !d_idx || !d_out || row_bytes % 4) { set_error("gather_rows: bad arguments (row_bytes must be a multiple of 4)"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (n == 0) return SSDR_OK;
+    hipLaunchKernelGGL(sel_gather_rows, dim3(grid_for((long)n * (long)(row_bytes / 4))), dim3(256), 0, pick_stream(stream), (const uint32_t*)d_in, d_idx, (int)n,
+                       (int)(row_bytes / 4), (uint32_t*)d_out);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
 int ssdr_widen_f32_f64_dev(const float* d_x, size_t n, double* d_y0, double* d_y1, void* stream) {
     if (!d_x || !d_y0) { set_error("widen_f32_f64: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());

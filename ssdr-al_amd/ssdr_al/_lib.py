@@ -100,6 +100,9 @@ def lib():
         L.ssdr_chamfer3d_forward_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
         L.ssdr_vote_smooth_dev.argtypes = [vp, vp, vp, sz, i32, f64, vp, vp]
         L.ssdr_confusion_dev.argtypes = [vp, i32, vp, vp, sz, vp, vp, vp, vp]
+        L.ssdr_main_stream.argtypes = [C.POINTER(vp)]
+        L.ssdr_mask_regions_dev.argtypes = [vp, vp, sz, sz, vp, vp]
+        L.ssdr_gather_rows_dev.argtypes = [vp, vp, sz, sz, vp, vp]
         L.ssdr_prof_enable.argtypes = [i32]
         L.ssdr_prof_report.restype = C.c_char_p
         L.ssdr_dev_alloc.argtypes = [sz, C.POINTER(vp)]
@@ -158,6 +161,16 @@ class DevArray:
         d = cls(a.shape, a.dtype)
         check(lib().ssdr_memcpy_h2d(d.ptr, ptr(a), d.nbytes))
         return d
+
+    @property
+    def __cuda_array_interface__(self):
+        """Zero-copy view for frameworks (torch.as_tensor(arr, device="cuda")): the RCCL exchanges run on these buffers."""
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr), False), "version": 2, "strides": None}
+
+    def host_view(self):
+        """CPU logic build only (device memory == host memory there): a NumPy view of the buffer."""
+        buf = (C.c_char * self.nbytes).from_address(int(self.ptr))
+        return np.frombuffer(buf, self.dtype).reshape(self.shape)
 
     def to_host(self):
         out = np.empty(self.shape, self.dtype)

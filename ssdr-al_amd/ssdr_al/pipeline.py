@@ -127,8 +127,33 @@ class HotPath:
         self._score_async(comm)
         self._score_finish(comm)
 
+    def _dist_setup(self, comm):
+        """Static tables of the sharded run, exchanged once (untimed): every rank's superpoint count, labelled mask, cloud and room ids.
+        Global superpoint id = rank * Smax + local id (the all-gather of exchange 2 is padded to Smax rows per rank)."""
+        if getattr(self, "_dist", None) is not None and self._dist["comm"] is comm:
+            return self._dist
+        W = comm.world
+        S_all = comm.allgather_host(np.array([self.S, self.B], np.int64))
+        Smax = int(S_all[:, 0].max())
+        def padded(a, fill):
+            out = np.full(Smax, fill, np.int64); out[: self.S] = a; return out
+        lab = comm.allgather_host(padded(self.labeled_mask.astype(np.int64), 1)).reshape(-1)          # padding counts as labelled: never a candidate
+        cloud = comm.allgather_host(padded(self.sp_cloud_h, -1))                                      # local cloud index
+        room = comm.allgather_host(padded(np.asarray(self.room_ids, np.int64)[self.sp_cloud_h], -1)).reshape(-1)
+        spin = comm.allgather_host(padded(np.arange(self.S) - np.asarray(self.sp_base, np.int64)[self.sp_cloud_h], -1)).reshape(-1)
+        Bmax = int(S_all[:, 1].max())
+        gcloud = (cloud + (np.arange(W)[:, None] * Bmax)).reshape(-1)                                 # global cloud index, rank-major
+        gcloud[cloud.reshape(-1) < 0] = -1
+        batch = self.select_per_tile * int(S_all[:, 1].sum())
+        self._dist = dict(comm=comm, Smax=Smax, Bmax=Bmax, valid=lab == 0, gcloud=gcloud, room=room, spin=spin, batch=batch,
+                          S_total=int(S_all[:, 0].sum()), nu_max=int(min(2 * batch, Smax)),
+                          d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)),
+                          d_masked=DevArray((Smax,), np.float64), d_all=DevArray((W * Smax,), np.float64), d_ord=DevArray((W * Smax,), np.int32))
+        return self._dist
+
     def _score_async(self, comm=None):
-        """device part of the scoring: enqueued, never waits (with a communicator: up to the local class histogram)"""
+        """The scoring stage, enqueued, never waits.  With a communicator the two exchanges run on the same stream, on device buffers:
+        all-reduce of the class histogram, all-gather of the (masked, padded) region uncertainties, then the global ranking."""
         cfg, L = self.cfg, _lib.lib()
         n = self.B * cfg.num_points
         um = {"lc": 0, "entropy": 1, "sb": 2}[[a for a in self.sampler_args if a in ("lc", "entropy", "sb")][0]]
@@ -138,69 +163,44 @@ class HotPath:
         _lib.check(L.ssdr_region_stats_dev(self.unc.ptr, self.cls.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, cfg.num_classes, rm,
                                            self.region_unc.ptr, self.dom.ptr, self.dom_cnt.ptr, st))
         nsel = self.selected_class_list.shape[0]
-        if "clsbal" in self.sampler_args:
-            if comm is None:
-                _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, st))
-            else:       # the already-selected list is counted once, on rank 0
-                _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, st))
         if comm is None:
+            if "clsbal" in self.sampler_args:
+                _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, st))
             _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, st))
             self.global_order = None
+            return
+        D = self._dist_setup(comm)
+        if "clsbal" in self.sampler_args:       # exchange 1: the class histogram is global (the already-selected list is counted once, on rank 0)
+            _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, st))
+            comm.allreduce_sum_(self.hist, st)
+            _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, D["S_total"] + nsel, self.region_unc.ptr, st))
+        # exchange 2: rank the regions of ALL ranks; labelled regions (and the padding) are -inf and sort last
+        _lib.check(L.ssdr_mask_regions_dev(self.region_unc.ptr, D["d_lab"].ptr, self.S, D["Smax"], D["d_masked"].ptr, st))
+        comm.allgather_(D["d_masked"], D["d_all"], st)
+        _lib.check(L.ssdr_rank_regions_dev(D["d_all"].ptr, comm.world * D["Smax"], D["d_ord"].ptr, st))
+        self.global_order = D
 
     def _score_finish(self, comm=None):
-        """host-synchronous part (communicator only): exchanges 1 and 2, then the global ranking"""
-        if comm is None:
-            return
-        L = _lib.lib()
-        st = self.score_stream if self.score_stream is not None else self.stream
-        nsel = self.selected_class_list.shape[0]
-        if "clsbal" in self.sampler_args:       # exchange 1: the class histogram is global
-            _lib.sync(st)
-            h = comm.allreduce_sum(np.concatenate([self.hist.to_host().astype(np.int64), [self.S]]))
-            self.hist = DevArray.from_host(h[:64].astype(np.int32))
-            _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, int(h[64]) + nsel, self.region_unc.ptr, st))
-        # exchange 2: rank the regions of ALL ranks; labelled regions are taken out before the cut
-        _lib.sync(st)
-        u = self.region_unc.to_host()
-        lab = np.zeros(self.S, bool)
-        for b in self.labeled:
-            lab[list(self.labeled[b])] = True
-        allu, counts = comm.allgather_var(np.where(lab, -np.inf, u))
-        d_all = DevArray.from_host(allu); d_ord = DevArray((len(allu),), np.int32)
-        _lib.check(L.ssdr_rank_regions_dev(d_all.ptr, len(allu), d_ord.ptr, st))
-        _lib.sync(st)
-        base = int(sum(counts[: comm.rank]))
-        self.global_order = (d_ord.to_host(), allu, base, self.select_per_tile * self.B * comm.world)
+        """kept for callers of the two-step form: the exchanges are enqueued by _score_async and nothing waits on the host any more"""
+        return
 
-    def _candidates(self, sorted_inds):
-        """create_file_top_and_all + the candidate rule of sampling() (sampler2.py:533-552, :745-753) on index lists.
-        Candidate order is canonical (cloud ascending, then descending uncertainty): the reference's own order depends
-        on a shuffled DataLoader (sampler2.py:323) and carries no meaning."""
-        if self.global_order is None:
-            order = np.asarray(sorted_inds, np.int64)
-            keep = ~self.labeled_mask[order]                 # labelled regions never compete
-            cand = order[keep]
-            batch_size = min(self.select_per_tile * self.B, len(order))
-            local = cand                                      # all candidates are local
-            in_top = np.arange(len(cand)) < batch_size
-        else:
-            order, allu, base, batch_size = self.global_order
-            order = np.asarray(order, np.int64)
-            cand_g = order[allu[order] != -np.inf]           # labelled regions were masked to -inf and sort last
-            in_top_g = np.arange(len(cand_g)) < batch_size
-            mine = (cand_g >= base) & (cand_g < base + self.S)
-            local, in_top = cand_g[mine] - base, in_top_g[mine]
-        cloud = self.sp_cloud_h[local]
-        grp = np.argsort(cloud, kind="stable")               # cloud ascending, descending uncertainty inside a cloud
-        local, in_top, cloud = local[grp], in_top[grp], cloud[grp]
-        ntop = np.bincount(cloud[in_top], minlength=self.B)  # selected_num per cloud (len(file_list_top[cloud]))
-        first = np.searchsorted(cloud, np.arange(self.B))
-        pos = np.arange(len(local)) - first[cloud]
-        take = pos < 2 * ntop[cloud]                          # candidates = first 2 x selected_num of the cloud (:748)
-        unl = [(int(b), int(s)) for b, s in zip(cloud[take], local[take])]
-        sampling_batch = int(ntop.sum())
-        lab = [(b, s) for b in sorted(self.labeled) for s in sorted(self.labeled[b])]
-        return unl, lab, sampling_batch
+    def _candidates(self, order, valid, cloud, batch_size):
+        """create_file_top_and_all + the candidate rule of sampling() (sampler2.py:533-552, :745-753) on index lists: `order` ranks
+        the regions by descending uncertainty, valid[i] = region i may compete (not labelled), cloud[i] = its cloud.  Returns the
+        candidates (cloud ascending, descending uncertainty inside a cloud) and their clouds, and the number to select.
+        The order is canonical: the reference's own depends on a shuffled DataLoader (sampler2.py:323) and carries no meaning."""
+        order = np.asarray(order, np.int64)
+        cand = order[valid[order]]                            # labelled regions never compete
+        in_top = np.arange(len(cand)) < min(batch_size, len(order))
+        c = cloud[cand]
+        grp = np.argsort(c, kind="stable")                    # cloud ascending, descending uncertainty inside a cloud
+        cand, in_top, c = cand[grp], in_top[grp], c[grp]
+        nc = int(cloud.max()) + 1 if len(cloud) else 0
+        ntop = np.bincount(c[in_top], minlength=nc)           # selected_num per cloud (len(file_list_top[cloud]))
+        first = np.searchsorted(c, np.arange(nc))
+        pos = np.arange(len(cand)) - first[c]
+        take = pos < 2 * ntop[c]                              # candidates = first 2 x selected_num of the cloud (:748)
+        return cand[take], c[take], int(ntop.sum())
 
     def _select(self, comm=None):
         self._select_issue(comm)
@@ -209,8 +209,20 @@ class HotPath:
     def _select_issue(self, comm=None):
         """everything of the selection up to the enqueued FPS chain (the host decisions and uploads happen here)"""
         L = _lib.lib()
-        sorted_inds = self.sorted_inds.to_host() if self.global_order is None else None   # small D2H: the host decides the candidate lists
-        unl, lab, sampling_batch = self._candidates(sorted_inds)
+        if self.global_order is None:          # (the D2H below runs on the main stream, which already waits for the scoring stream's work)
+            cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(), ~self.labeled_mask, self.sp_cloud_h, self.select_per_tile * self.B)
+            unl = [(int(b), int(s)) for b, s in zip(ccloud, cand)]
+            gl_room = np.asarray(self.room_ids, np.int64)[ccloud]; gl_sp = cand - np.asarray(self.sp_base, np.int64)[ccloud]
+            counts_r = None
+        else:       # every rank derives the global candidate list from the global ranking, then keeps its own rows
+            D = self.global_order
+            gcand, gcloud, sampling_batch = self._candidates(D["d_ord"].to_host(), D["valid"], D["gcloud"], D["batch"])
+            r_of = gcand // D["Smax"]
+            counts_r = np.bincount(r_of, minlength=comm.world)
+            mine = r_of == comm.rank
+            unl = [(int(b), int(s)) for b, s in zip(gcloud[mine] - comm.rank * D["Bmax"], gcand[mine] - comm.rank * D["Smax"])]
+            gl_room, gl_sp = D["room"][gcand], D["spin"][gcand]
+        lab = [(b, s) for b in sorted(self.labeled) for s in sorted(self.labeled[b])]
         refs = unl + lab
         sel = np.array([s for _, s in refs], np.int32)
         # every cloud's chamfer graph and propagation hop in one batched call (rows grouped cloud by cloud)
@@ -221,16 +233,21 @@ class HotPath:
         coff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         boff = np.concatenate([[0], np.cumsum(counts * counts)]).astype(np.int64)
         ntot, nmax, nsq = int(coff[-1]), int(counts.max()), int(boff[-1])
+        n_unl = len(unl)
+        src = np.zeros(0, np.int32)
+        if counts_r is not None:     # exchange 3 is padded to nu_max rows per rank: positions of the real rows in the gathered array
+            src = np.concatenate([r * self.global_order["nu_max"] + np.arange(c) for r, c in enumerate(counts_r)]).astype(np.int32)
         # ONE upload for all the small index tables (each separate copy is a host round trip behind the kernels in flight)
-        parts = [sel, sel[order], order, coff, boff.view(np.int32)]
+        parts = [sel, sel[order], order, coff, boff.view(np.int32), src]
         offs = np.cumsum([0] + [(len(p) + 3) // 4 * 4 for p in parts])           # 16-byte aligned pieces
         pack = np.zeros(offs[-1], np.int32)
         for p, o in zip(parts, offs):
             pack[o:o + len(p)] = p
         d_pack = DevArray.from_host(pack)
-        d_sel, d_gsel, d_rows, d_coff, d_boff = (d_pack.ptr + 4 * int(o) for o in offs[:-1])
+        d_sel, d_gsel, d_rows, d_coff, d_boff, d_src = (d_pack.ptr + 4 * int(o) for o in offs[:-1])
+        rows = max(len(sel), self.global_order["nu_max"] if counts_r is not None else 0)
         d_mf = DevArray((len(sel), 32), np.float32)
-        d_v = DevArray((len(sel), 32), np.float64); d_comb = DevArray((len(sel), 32), np.float64)
+        d_v = DevArray((len(sel), 32), np.float64); d_comb = DevArray((rows, 32), np.float64)
         d_tmp = [DevArray(d_v.shape, np.float64), DevArray(d_v.shape, np.float64)]
         _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel, len(sel), d_mf.ptr, None))
         # float32 -> float64 as np.concatenate / np.matmul promote it (V and the running sum comb start as the same values)
@@ -238,28 +255,34 @@ class HotPath:
         d_cen = DevArray((ntot, 3), np.float64); d_dir = DevArray((nsq,), np.float64); d_adj = DevArray((nsq,), np.float64)
         _lib.check(L.ssdr_cloud_graph_batch_dev(self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_gsel, d_coff, d_boff, len(clouds), ntot, nmax,
                                                 int(self.gcn_top), d_cen.ptr, d_dir.ptr, d_adj.ptr, None))
-        src = d_v
+        src_v = d_v
         for hop in range(int(self.gcn_number)):
             dst = d_tmp[hop & 1]
-            _lib.check(L.ssdr_propagate_batch_dev(d_adj.ptr, d_coff, d_boff, len(clouds), nmax, d_rows, src.ptr, 32, dst.ptr, d_comb.ptr, None))
-            src = dst
-        blocks = (d_pack, d_cen, d_dir, d_adj)
-        n_unl = len(unl)
-        self.unl_cloud_ids = np.array([self.room_ids[b] for b, _ in unl], np.int64)
-        self.unl_sp = np.array([s - self.sp_base[b] for b, s in unl], np.int64)       # superpoint index inside its room
-        if comm is not None:                                 # exchange 3: the candidates' propagated features (+ their ids)
-            _lib.sync()
-            comb_all, _ = comm.allgather_var(d_comb.to_host()[:n_unl])
-            ids_all, _ = comm.allgather_var(np.stack([self.unl_cloud_ids, self.unl_sp], 1))
-            sampling_batch = int(comm.allreduce_sum(np.array([sampling_batch], np.int64))[0])
-            d_comb = DevArray.from_host(comb_all); n_unl = len(comb_all)
-            self.unl_cloud_ids, self.unl_sp = ids_all[:, 0], ids_all[:, 1]
-            self.comb_all = comb_all
+            _lib.check(L.ssdr_propagate_batch_dev(d_adj.ptr, d_coff, d_boff, len(clouds), nmax, d_rows, src_v.ptr, 32, dst.ptr, d_comb.ptr, None))
+            src_v = dst
+        keep = [d_pack, d_cen, d_dir, d_adj, d_v, d_tmp, d_mf, d_comb]
+        self.unl_cloud_ids, self.unl_sp = gl_room, gl_sp          # (room id, superpoint inside its room) of every candidate, global order
+        if comm is not None:                                 # exchange 3: the candidates' propagated features, on the selection stream
+            D = self.global_order
+            d_gath = DevArray((comm.world, D["nu_max"], 32), np.float64)
+            comm.allgather_(_Prefix(d_comb, D["nu_max"] * 32), d_gath, None)
+            n_unl = int(counts_r.sum())
+            d_glob = DevArray((max(n_unl, 1), 32), np.float64)
+            _lib.check(L.ssdr_gather_rows_dev(d_gath.ptr, d_src, n_unl, 32 * 8, d_glob.ptr, None))
+            keep += [d_gath, d_glob]
+            d_comb = d_glob
+            self._comb_dev, self._comb_n = d_glob, n_unl
         d_out = DevArray((sampling_batch,), np.int32)
         start = 0                                            # np.random.randint(0, n) in the reference (:133); fixed here
         _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
-        self._keep = (blocks, d_v, d_tmp, d_mf, d_comb)
+        self._keep = keep
         self._pending = (d_out, unl)
+
+    @property
+    def comb_all(self):
+        """the gathered candidate features of the last sharded step (tests)"""
+        _lib.sync()
+        return self._comb_dev.to_host()[: self._comb_n]
 
     def _select_collect(self):
         """wait for the FPS chain of _select_issue and read the selection back"""
@@ -285,6 +308,17 @@ class HotPath:
         if timed_stages:
             self.timing = dict(zip(("subsample+tile", "knn_pyramid", "randla_infer", "score", "select"), np.diff(t) * 1e3))
         return out
+
+
+class _Prefix:
+    """the first `count` elements of a DevArray as a flat array of its own (exchange buffers)"""
+    def __init__(self, arr, count):
+        self.ptr, self.dtype, self.shape, self.nbytes = arr.ptr, arr.dtype, (int(count),), int(count) * arr.dtype.itemsize
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr), False), "version": 2, "strides": None}
+
+    def host_view(self):
+        import ctypes as C
+        return np.frombuffer((C.c_char * self.nbytes).from_address(int(self.ptr)), self.dtype)
 
 
 class Pipelined:

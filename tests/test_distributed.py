@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -21,3 +23,18 @@ def test_two_rank_sharded_selection_equals_single_process(tmp_path, emu_lib):
     assert {c for c, _ in r[0]["selected"]} <= {0, 1, 2, 3}
     assert r[0]["selected"] == r[0]["single"]          # sharded == single process, index for index
     assert all(x["pipelined_equal"] and x["pipelined_selected"] == x["selected"] for x in r)    # batches in flight: same result
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_path_on_one_gpu_equals_plain_path(tmp_path):
+    """bench.py's N > 1 code path (device-resident exchanges through RCCL, ordered on the library's streams) on one GPU."""
+    from conftest import _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    out = tmp_path / "res.json"
+    env = dict(os.environ, SSDR_TEST_OUT=str(out), MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_worker.py")], check=True, env=env, timeout=600, cwd=ROOT)
+    r = json.load(open(out))
+    assert len(r["plain"]) == 36 and r["plain"] == r["dist"] == r["dist_pipelined"]
+    assert r["selected_plain"] == r["selected_dist"]
+    assert r["lib"].endswith("libssdr_al.so")
