@@ -98,7 +98,7 @@ def run(hp, rooms, weights, threads=1, net_outputs=None, stop_after=None):
         so = np.concatenate([[0], np.cumsum(sub_off[rows + 1] - sub_off[rows])]).astype(np.int32)
         spts = np.concatenate([sub_pts[sub_off[i]:sub_off[i + 1]] for i in rows])
         cen = S.bbox_centres(flat, so, spts)
-        blocks.append(S.block_adjacency(cen, S.create_cd(flat, so, spts, cen))); rows_l.append(rows)
+        blocks.append(S.keep_top(S.block_adjacency(cen, S.create_cd(flat, so, spts, cen)), hp.gcn_top)); rows_l.append(rows)
     comb = S.propagate(blocks, rows_l, V, hp.gcn_number)
     seq = S.farthest_features_sample(comb[:len(unl)], sampling_batch, 0)
     t.append(time.perf_counter())

@@ -16,14 +16,71 @@ BN_EPS = 1e-6           # helper_tf_util.py:162 / RandLANet.py:145
 LRELU = 0.2             # helper_tf_util.py:165, tf.nn.leaky_relu default
 
 
-# The layer table and the synthetic weight generator belong to the product's synthetic-data module (bench.py needs them
-# without touching the oracle); the oracle uses the same ones.
-import os as _os
-import sys as _sys
-_pkg = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "ssdr-al_amd")
-if _pkg not in _sys.path:
-    _sys.path.insert(0, _pkg)
-from ssdr_al.synthetic import init_weights, layer_specs  # noqa: E402,F401
+# The oracle's OWN layer table (written from RandLANet.py:140-180, 505-585 / SURVEY appendix B, independently of the product's
+# ssdr_al/synthetic.py, which bench.py uses): a wrong BN / activation flag in one of the two tables shows up as a parity failure
+# (tests/test_randla.py::test_layer_tables_agree compares them field by field).
+def layer_specs(d_out=(16, 64, 128, 256, 512), num_classes=13, in_dim=6):
+    """[(scope, in, out, has_bias, has_bn, has_act, transposed_kernel)] in graph order."""
+    rows = []
+
+    def conv(scope, cin, cout, bn=True, act=True, bias=True, transposed=False):
+        rows.append((scope, cin, cout, bias, bn, act, transposed))
+
+    conv("fc0", in_dim, 8)                                              # tf.layers.dense + BN + lrelu (:144-146)
+    width = 8
+    skips = []
+    for level, d in enumerate(d_out):
+        scope = "Encoder_layer_%d" % level
+        conv(scope + "mlp1", width, d // 2)                            # dilated_res_block :506
+        conv(scope + "LFAmlp1", 10, d // 2)                            # building_block :518
+        conv(scope + "LFAatt_pooling_1fc", d, d, bn=False, act=False, bias=False)     # att_pooling :578 (tf.layers.dense, use_bias=False)
+        conv(scope + "LFAatt_pooling_1mlp", d, d // 2)                 # :583
+        conv(scope + "LFAmlp2", d // 2, d // 2)                        # :523
+        conv(scope + "LFAatt_pooling_2fc", d, d, bn=False, act=False, bias=False)
+        conv(scope + "LFAatt_pooling_2mlp", d, d)
+        conv(scope + "mlp2", d, 2 * d, act=False)                      # :509, activation_fn=None
+        conv(scope + "shortcut", width, 2 * d, act=False)              # :510-511
+        if level == 0:
+            skips.append(2 * d)                                        # f_encoder_list starts with the un-sampled level-0 output (:152-153)
+        width = 2 * d
+        skips.append(width)
+    conv("decoder_0", width, width)                                    # :159-161
+    for j in range(len(d_out)):
+        skip = skips[-j - 2]
+        conv("Decoder_layer_%d" % j, skip + width, skip, transposed=True)      # conv2d_transpose over concat[skip, interpolated] (:165-172)
+        width = skip
+    conv("fc1", width, 64)
+    conv("fc2", 64, 32)
+    conv("fc", 32, num_classes, bn=False, act=False)                   # :176-178, activation_fn=None
+    return rows
+
+
+def init_weights(seed=0, d_out=(16, 64, 128, 256, 512), num_classes=13, in_dim=6, trained_like=True):
+    """Random weights by the reference's initialisers: conv kernels round(truncated_normal(std = sqrt(2 / shape[-1])) * 1000) / 1000 with
+    zero bias (helper_tf_util.py:43-48, :158-159), tf.layers.dense Glorot-uniform.  trained_like=True also draws non-trivial biases and
+    BN statistics (a fresh graph has gamma 1, beta 0, mean 0, var 1, which would leave the BN fold untested).  Draw order == the
+    product generator's, so the same seed gives the same network in both."""
+    rng = np.random.default_rng(seed)
+    W = {}
+    for scope, cin, cout, has_bias, has_bn, has_act, transposed in layer_specs(d_out, num_classes, in_dim):
+        shape = (cout, cin) if transposed else (cin, cout)
+        if scope == "fc0" or scope.endswith("fc") and "att_pooling" in scope:
+            lim = np.sqrt(6.0 / (cin + cout))
+            w = rng.uniform(-lim, lim, shape)
+        else:
+            std = np.sqrt(2.0 / shape[-1])
+            w = np.round(np.clip(rng.normal(0, std, shape), -2 * std, 2 * std) * 1000) / 1000
+        ent = {"W": w.astype(np.float32), "b": None, "bn": None, "act": has_act, "transposed": transposed}
+        if has_bias:
+            ent["b"] = (rng.normal(0, 0.05, cout) if trained_like else np.zeros(cout)).astype(np.float32)
+        if has_bn:
+            if trained_like:
+                ent["bn"] = tuple(a.astype(np.float32) for a in (rng.uniform(0.7, 1.3, cout), rng.normal(0, 0.1, cout),
+                                                                  rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout)))
+            else:
+                ent["bn"] = (np.ones(cout, np.float32), np.zeros(cout, np.float32), np.zeros(cout, np.float32), np.ones(cout, np.float32))
+        W[scope] = ent
+    return W
 
 
 def fold_bn(ent, dtype=np.float32):

@@ -125,6 +125,20 @@ def block_adjacency(centres, cd):
     return adj * dinv[None, :] + np.eye(len(adj))
 
 
+def keep_top(adj, gcn_top):
+    """The keep-top mask of GCN_FPS_sampling (fps_gcn_cpu.py:153-160) on one cloud's block: every row keeps its gcn_top largest
+    entries.  The reference sorts whole rows of the global matrix; entries outside the block are exactly 0 and block entries are
+    positive, so the row's top entries are the block's (and a mask on zeros changes nothing)."""
+    gcn_top = int(gcn_top)
+    if gcn_top <= 0 or gcn_top >= adj.shape[1]:
+        return adj
+    out = np.zeros_like(adj)
+    for i in range(adj.shape[0]):
+        keep = np.argsort(adj[i], kind="stable")[-gcn_top:]
+        out[i, keep] = adj[i, keep]
+    return out
+
+
 def propagate(adj_blocks, block_rows, V, gcn_number):
     """sum_{i=0..gcn_number} A^i V (fps_gcn_cpu.py:162-167), A block-diagonal."""
     V = np.asarray(V, np.float64)

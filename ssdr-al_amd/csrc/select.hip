@@ -318,24 +318,53 @@ __global__ __launch_bounds__(256) void sel_adj_norm_batch(const double* __restri
     const int c = blockIdx.z, lo = coff[c];
     adj_norm_body(rowsum + lo, coff[c + 1] - lo, adj + boff[c]);
 }
-// keep the gcn_top largest entries of every row (fps_gcn_cpu.py:153-160); ties keep the higher column index
-__device__ void adj_topk_body(double* adj, int n, int top) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        double* row = adj + (size_t)i * n;
-        for (int j = 0; j < n; ++j) {
-            int larger = 0;
-            for (int k = 0; k < n; ++k) larger += (row[k] > row[j]) || (row[k] == row[j] && k > j);
-            if (larger >= top) row[j] = -row[j] - 4.0;      // mark (entries are in [0,2])
+// keep the gcn_top largest entries of every row (fps_gcn_cpu.py:153-160: mask[row, argsort(row)[-top:]] = 1); among equal entries the
+// higher column index is kept (NumPy's quicksort leaves such ties unspecified).  One wave per row: the row is copied to LDS, every
+// lane ranks its columns against the whole row (n^2 / 64 comparisons per lane) and zeroes the ones ranked >= top.
+constexpr int TOPK_ROW = 2048;       // columns a wave keeps in LDS (4 waves x 16 KiB); longer rows rank against global memory
+__device__ void adj_topk_body(double* adj, int n, int top, double* s_row /* [4][TOPK_ROW] */) {
+    if (top <= 0 || top >= n) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double* mine = s_row + (size_t)wid * TOPK_ROW;
+    const bool in_lds = n <= TOPK_ROW;
+    for (int i0 = blockIdx.x * 4; i0 < n; i0 += gridDim.x * 4) {          // uniform over the workgroup: barriers inside
+        const int i = i0 + wid;
+        const bool live = i < n;
+        double* row = adj + (size_t)(live ? i : 0) * n;
+        if (live && in_lds) for (int k = lane; k < n; k += 64) mine[k] = row[k];
+        __syncthreads();
+        for (int base = 0; base < n; base += 64 * 64) {
+            unsigned long long zero = 0ull;   // this lane's columns j = base + lane + 64 u to clear
+            if (live)
+                for (int u = 0; u < 64; ++u) {
+                    const int j = base + lane + 64 * u;
+                    if (j >= n) break;
+                    // rows longer than the LDS copy are ranked in place: a column already decided is stored as -v - 4 (entries lie in
+                    // [0, 2]) and decoded here, and is cleared after the whole row has been ranked
+                    auto val = [&](int k) { const double v = in_lds ? mine[k] : row[k]; return v < -1.0 ? -(v + 4.0) : v; };
+                    const double vj = val(j);
+                    int larger = 0;
+                    for (int k = 0; k < n; ++k) { const double vk = val(k); larger += (vk > vj) || (vk == vj && k > j); }
+                    if (larger >= top) zero |= 1ull << u;
+                }
+            if (!in_lds) __syncthreads();     // every lane has read this pass's columns before anyone marks one
+            for (int u = 0; u < 64; ++u) if ((zero >> u) & 1ull) row[base + lane + 64 * u] = in_lds ? 0.0 : -row[base + lane + 64 * u] - 4.0;
+            if (!in_lds) __syncthreads();
         }
-        for (int j = 0; j < n; ++j) if (row[j] < -1.0) row[j] = 0.0;
+        if (live && !in_lds) for (int k = lane; k < n; k += 64) if (row[k] < -1.0) row[k] = 0.0;
+        __syncthreads();
     }
 }
-// Vout[rows[i]] = sum_j adj[i][j] * Vin[rows[j]]  (one hop of fps_gcn_cpu.py:164-165), comb[rows[i]] += Vout
-__global__ __launch_bounds__(256) void sel_adj_topk(double* adj, int n, int top) { adj_topk_body(adj, n, top); }
-__global__ __launch_bounds__(256) void sel_adj_topk_batch(double* adj, const int* __restrict__ coff, const long long* __restrict__ boff, int top) {
-    const int c = blockIdx.z;
-    adj_topk_body(adj + boff[c], coff[c + 1] - coff[c], top);
+__global__ __launch_bounds__(256) void sel_adj_topk(double* adj, int n, int top) {
+    __shared__ double s_row[4 * TOPK_ROW];
+    adj_topk_body(adj, n, top, s_row);
 }
+__global__ __launch_bounds__(256) void sel_adj_topk_batch(double* adj, const int* __restrict__ coff, const long long* __restrict__ boff, int top) {
+    __shared__ double s_row[4 * TOPK_ROW];
+    const int c = blockIdx.z;
+    adj_topk_body(adj + boff[c], coff[c + 1] - coff[c], top, s_row);
+}
+// Vout[rows[i]] = sum_j adj[i][j] * Vin[rows[j]]  (one hop of fps_gcn_cpu.py:164-165), comb[rows[i]] += Vout
 __device__ void propagate_body(const double* __restrict__ adj, int n, const int* __restrict__ rows, const double* __restrict__ vin, int D,
                                double* vout, double* comb) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n * D; e += gridDim.x * 256) {
@@ -788,7 +817,7 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     hipLaunchKernelGGL(sel_chamfer_dir, dim3(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir);
     hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
-    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(grid_for(n)), dim3(256), 0, s, d_adj, n, gcn_top);
+    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_adj, n, gcn_top);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
@@ -807,7 +836,7 @@ int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, cons
                        d_coff, (const long long*)d_boff, d_centres, d_cd_dir);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, d_centres, d_cd_dir, d_coff, (const long long*)d_boff, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), d_coff, (const long long*)d_boff, d_adj);
-    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(grid_for(nm), 1, nc), dim3(256), 0, s, d_adj, d_coff, (const long long*)d_boff, gcn_top);
+    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(std::max(1, std::min((nm + 3) / 4, 1024)), 1, nc), dim3(256), 0, s, d_adj, d_coff, (const long long*)d_boff, gcn_top);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

@@ -166,6 +166,8 @@ def GCN_FPS_sampling(labeled_select_features, labeled_select_ref, unlabeled_cand
     Returns {cloud_name: [sp_idx, ...]} in selection order."""
     n_unl, n_lab = len(unlabeled_candidate_ref), len(labeled_select_ref)
     N, D = n_unl + n_lab, np.asarray(unlabeled_candidate_features).shape[1]
+    if int(gcn_top) > N:       # the reference's mask[source_idx, arg_idx] = 1.0 cannot broadcast (N, gcn_top) against (N, N) (:155-159)
+        raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes (%d,%d) (%d,%d)" % (N, int(gcn_top), N, N))
     V = np.concatenate([np.asarray(unlabeled_candidate_features, np.float64).reshape(n_unl, D),
                         np.asarray(labeled_select_features, np.float64).reshape(n_lab, D)])
     total_cloud, order = {}, []                 # fps_adj_all :47-62

@@ -68,6 +68,16 @@ def main():
     dom = [sampler2._dominant_label(cls[pts[offs[s]:offs[s + 1]]]) for s in range(80)]
     g["u/dom"] = np.array([d[0] for d in dom], np.int32)
     g["u/purity"] = np.array([d[1] for d in dom], np.float64)
+    # compute_features' per-superpoint mean (sampler2.py:333, :339): np.mean(last_second_features[dominant_point_ids], axis=0) with the
+    # dominant_point_ids the reference derives by _dominant_2 over the predicted classes (:625-626, ids are positions in the list)
+    feat = rng.normal(0, 1, (n, 32)).astype(np.float32)
+    g["u/feat32"] = feat
+    means = []
+    for s in range(80):
+        ids = pts[offs[s]:offs[s + 1]]
+        _, local = sampler2._dominant_2(cls[ids])
+        means.append(np.mean(feat[ids[local[0]]], axis=0))
+    g["u/segmean"] = np.stack(means).astype(np.float32)
     sel = rng.integers(0, C, 40)
     g["u/selected_class_list"] = sel
     g["u/clsbal"] = sampler2.add_clsbal(C, g["u/dom"], g["u/ru_WetSU"], {"selected_class_list": list(sel)})
@@ -113,6 +123,18 @@ def main():
         g["f/gcnfps_start_%d" % gn] = np.int32(start)
         g["f/gcnfps_A_%d" % gn] = np.array(fl.get("cloudA", []), np.int32)
         g["f/gcnfps_B_%d" % gn] = np.array(fl.get("cloudB", []), np.int32)
+    # gcn_top > 0 (the reference's scripts run --gcn_top 100, S3/run_graph_reasoning_analysis.sh:9-11): keep-top mask of :153-160.
+    # 2 and 3 cut inside the 7- and 6-row cloud blocks, 5 cuts them less, 13 (= N) keeps everything; gcn_top > N raises in the reference (:159).
+    for gt in (2, 3, 5, 13):
+        # the masked adjacency GCN_FPS_sampling builds internally (:155-160, the same NumPy statements applied to the reference's adj)
+        mask = np.zeros(adj.shape)
+        mask[np.repeat(np.expand_dims(np.arange(adj.shape[0]), axis=1), repeats=gt, axis=1), np.argsort(adj, axis=1)[:, -gt:]] = 1.0
+        g["f/adj_top%d" % gt] = np.multiply(adj, mask)
+        for gn in (1, 2):
+            np.random.seed(5)
+            fl = fps_gcn_cpu.GCN_FPS_sampling(list(lf), lab, list(uf), unl, os.path.join(tmp, "input"), os.path.join(tmp, "data"), 5, gn, gt)
+            g["f/gcnfps_top%d_A_%d" % (gt, gn)] = np.array(fl.get("cloudA", []), np.int32)
+            g["f/gcnfps_top%d_B_%d" % (gt, gn)] = np.array(fl.get("cloudB", []), np.int32)
 
     # FPS / k-center sequences on generic features
     feats = rng.normal(0, 1, (300, 32)).astype(np.float32).astype(np.float64)
@@ -127,6 +149,11 @@ def main():
     # F6: the "edcd" branch's farthest_superpoint_sample (sampler2.py:49-80) on cloudA's superpoints
     xyzA, compsA = clouds["cloudA"]
     cenA = np.stack([(xyzA[c].min(0) + xyzA[c].max(0)).astype(np.float64) / 2.0 for c in compsA])
+    kf2 = rng.normal(0, 1, (1000, 129)).astype(np.float32).astype(np.float64)
+    kc2 = kcenterGreedy.kCenterGreedy(kf2)
+    g["kc2/feat"] = kf2.astype(np.float32)
+    g["kc2/already"] = np.arange(900, 1000, dtype=np.int64)
+    g["kc2/seq"] = np.array(kc2.select_batch_(g["kc2/already"], 80), np.int32)
     g["f6/seq"] = sampler2.farthest_superpoint_sample([xyzA[c] for c in compsA], cenA, 5, 0)
     np.savez_compressed(os.path.join(HERE, "select_golden.npz"), **g)
     print("select_golden.npz", os.path.getsize(os.path.join(HERE, "select_golden.npz")) // 1024, "KiB")

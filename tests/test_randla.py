@@ -100,6 +100,23 @@ def test_layer_table_shapes_and_bn_fold():
     assert np.allclose(R._lrelu(x @ w + b), R._conv(x, e), atol=1e-6)
 
 
+def test_layer_tables_agree():
+    """The oracle and the product each carry their own layer table / weight generator (oracle/randla_np.py, ssdr_al/synthetic.py):
+    same scopes, shapes and flags, and the same seed gives bit-identical weights."""
+    from oracle import randla_np as R
+    from ssdr_al import synthetic
+    assert R.layer_specs is not synthetic.layer_specs and R.init_weights is not synthetic.init_weights
+    for args in ((), ((16, 64, 128, 256), 8, 6)):
+        assert R.layer_specs(*args) == synthetic.layer_specs(*args)
+    a, b = R.init_weights(4), synthetic.init_weights(4)
+    assert list(a) == list(b)
+    for k in a:
+        assert a[k]["act"] == b[k]["act"] and a[k]["transposed"] == b[k]["transposed"]
+        for f in ("W", "b"):
+            assert (a[k][f] is None) == (b[k][f] is None) and (a[k][f] is None or np.array_equal(a[k][f], b[k][f]))
+        assert (a[k]["bn"] is None) == (b[k]["bn"] is None) and (a[k]["bn"] is None or all(np.array_equal(x, y) for x, y in zip(a[k]["bn"], b[k]["bn"])))
+
+
 def test_randla_matches_oracle(backend):
     from oracle import randla_np as R
     from ssdr_al import randlanet

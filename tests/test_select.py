@@ -58,6 +58,17 @@ def test_chamfer_adjacency_gcnfps_golden(backend, golden):
     for gn in (1, 2, 3):
         fl = sampler.GCN_FPS_sampling(list(g["f/lab_feat"]), lab, list(g["f/unl_feat"]), unl, clouds, 5, gn, 0, int(g["f/gcnfps_start_%d" % gn]))
         assert fl.get("cloudA", []) == list(g["f/gcnfps_A_%d" % gn]) and fl.get("cloudB", []) == list(g["f/gcnfps_B_%d" % gn])
+    # gcn_top > 0 (fps_gcn_cpu.py:153-160; the reference's scripts run --gcn_top 100): masked adjacency and selections
+    for gt in (2, 3, 5, 13):
+        for c, name in enumerate(names):
+            rows = [i for i, r in enumerate(refs) if r["cloud_name"] == name]
+            _, _, adj = sampler.cloud_graph(*clouds[name], [refs[i]["sp_idx"] for i in rows], gcn_top=gt)
+            assert np.allclose(adj, g["f/adj_top%d" % gt][np.ix_(rows, rows)], rtol=1e-12, atol=1e-15), (gt, name)
+        for gn in (1, 2):
+            fl = sampler.GCN_FPS_sampling(list(g["f/lab_feat"]), lab, list(g["f/unl_feat"]), unl, clouds, 5, gn, gt, int(g["f/gcnfps_start_%d" % gn]))
+            assert fl.get("cloudA", []) == list(g["f/gcnfps_top%d_A_%d" % (gt, gn)]) and fl.get("cloudB", []) == list(g["f/gcnfps_top%d_B_%d" % (gt, gn)]), (gt, gn)
+    with pytest.raises(IndexError):          # the reference's mask assignment cannot broadcast when gcn_top exceeds the matrix size (:159)
+        sampler.GCN_FPS_sampling(list(g["f/lab_feat"]), lab, list(g["f/unl_feat"]), unl, clouds, 5, 1, 14, 0)
 
 
 def test_fps_and_kcenter_golden(backend, golden):
@@ -66,6 +77,33 @@ def test_fps_and_kcenter_golden(backend, golden):
     assert np.array_equal(sampler.farthest_features_sample(g["fps/feat"], 50, int(g["fps/start"])), g["fps/seq"])
     kc = sampler.kCenterGreedy(g["kc/feat"])
     assert kc.select_batch_(g["kc/already"], 30) == list(g["kc/seq"])
+
+
+def test_compute_features_mean_golden(backend, golden):
+    """np.mean(last_second_features[dominant_point_ids], axis=0) (sampler2.py:333, :339) with the reference's own _dominant_2 ids."""
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    cls = np.argmax(g["u/prob"], -1).astype(np.int32)
+    mf = sampler.segment_mean_features(g["u/feat32"], cls, g["u/dom"], g["u/offsets"], g["u/points"])
+    assert np.array_equal(mf, g["u/segmean"])                           # bit-exact float32 (row-sequential sums, one division)
+    assert np.array_equal(O.segment_mean_features(g["u/feat32"], g["u/offsets"], g["u/points"], cls, g["u/dom"]), g["u/segmean"])
+
+
+def test_kcenter_larger_golden_and_at_scale(backend, golden):
+    """kCenterGreedy.select_batch_ (kcenterGreedy.py:60-128) with the labelled rows as already_selected (gcn.py:247): 1000 x 129
+    against the reference's own sequence; on the GPU also 20000 x 129 against the oracle."""
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    kc = sampler.kCenterGreedy(g["kc2/feat"])
+    assert kc.select_batch_(g["kc2/already"], 80) == list(g["kc2/seq"])
+    assert np.array_equal(O.kcenter_greedy(g["kc2/feat"].astype(np.float64), g["kc2/already"], 80), g["kc2/seq"])
+    if backend == "gpu":
+        rng = np.random.default_rng(5)
+        f = rng.normal(0, 1, (20000, 129)).astype(np.float32)
+        already = np.arange(17000, 20000)
+        got = sampler.kCenterGreedy(f).select_batch_(already, 300)
+        assert got == list(O.kcenter_greedy(f.astype(np.float64), already, 300))
+        assert len(set(got)) == 300 and not set(got) & set(already.tolist())
 
 
 def test_edcd_farthest_superpoint_sample_golden(backend, golden):

@@ -61,6 +61,18 @@ def test_chamfer_and_adjacency(golden):
         a = [int(g["f/unl_sp"][i]) for i in seq if g["f/unl_cloud"][i] == 0]
         b = [int(g["f/unl_sp"][i]) for i in seq if g["f/unl_cloud"][i] == 1]
         assert a == list(g["f/gcnfps_A_%d" % gn]) and b == list(g["f/gcnfps_B_%d" % gn])
+    # keep-top mask (fps_gcn_cpu.py:153-160), block by block against the masked global matrix of the reference
+    for gt in (2, 3, 5, 13):
+        masked = np.zeros((N, N))
+        for c in range(2):
+            rows = [i for i, (cc, _) in enumerate(refs) if cc == c]
+            masked[np.ix_(rows, rows)] = S.keep_top(adj[np.ix_(rows, rows)], gt)
+        assert np.allclose(masked, g["f/adj_top%d" % gt], rtol=1e-12, atol=1e-15)
+        for gn in (1, 2):
+            seq = S.farthest_features_sample(S.propagate([masked], [np.arange(N)], V, gn)[:9], 5, int(g["f/gcnfps_start_%d" % gn]))
+            a = [int(g["f/unl_sp"][i]) for i in seq if g["f/unl_cloud"][i] == 0]
+            b = [int(g["f/unl_sp"][i]) for i in seq if g["f/unl_cloud"][i] == 1]
+            assert a == list(g["f/gcnfps_top%d_A_%d" % (gt, gn)]) and b == list(g["f/gcnfps_top%d_B_%d" % (gt, gn)])
 
 
 def test_fps_and_kcenter_sequences(golden):
