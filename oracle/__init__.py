@@ -38,7 +38,7 @@ def _opt(a):
 class _Oracle:
     def __init__(self):
         build()
-        self.lib = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        self.lib = C.CDLL(os.environ.get("SSDR_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so"))      # SSDR_ORACLE_LIB: the sanitizer build (tests/test_sanitizers.py)
         L = self.lib
         L.oracle_grid_subsampling.restype = C.c_long
         L.oracle_grid_subsampling.argtypes = [_f32p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,

@@ -167,7 +167,8 @@ int ssdr_knn_batch_distance_pick(const float* batch_data, size_t batch_size, siz
     std::mt19937 gen(seed);                                   // the reference: mt19937 mt_rand(time(0)), one draw per query (:141, :168)
     std::vector<uint32_t> rnd(batch_size * nqueries);
     for (auto& r : rnd) r = (uint32_t)gen();
-    DevBuf d_rnd, d_used, d_q, d_idx;
+    struct Scratch { DevBuf rnd, used, q, idx; ~Scratch() { rnd.release(); used.release(); q.release(); idx.release(); } } sc;      // freed on every return path
+    DevBuf &d_rnd = sc.rnd, &d_used = sc.used, &d_q = sc.q, &d_idx = sc.idx;
     SSDR_TRY(S.pts.reserve(batch_size * npts * 12 + 16));
     SSDR_TRY(d_rnd.reserve(4 * rnd.size())); SSDR_TRY(d_used.reserve(4 * batch_size * npts));
     SSDR_TRY(d_q.reserve(12 * batch_size * nqueries)); SSDR_TRY(d_idx.reserve(8 * batch_size * nqueries * K));
@@ -181,7 +182,6 @@ int ssdr_knn_batch_distance_pick(const float* batch_data, size_t batch_size, siz
     SSDR_HIP(hipMemcpyAsync(batch_queries, d_q.p, 12 * batch_size * nqueries, hipMemcpyDeviceToHost, s));
     SSDR_HIP(hipMemcpyAsync(batch_indices, d_idx.p, 8 * batch_size * nqueries * K, hipMemcpyDeviceToHost, s));
     SSDR_HIP(hipStreamSynchronize(s));
-    d_rnd.release(); d_used.release(); d_q.release(); d_idx.release();
     return kd_check(S.forest, s);
 }
 

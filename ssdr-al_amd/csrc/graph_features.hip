@@ -10,13 +10,14 @@
 //                          iteration in float64 on the float32 covariance (PARITY UNPINNED: Eigen and Boost are not in the
 //                          build image, the reference cannot be compiled; tolerance against oracle/graph_np.py).
 #include "ssdr_internal.hpp"
+#include <map>
 #include <cfloat>
 
 namespace ssdr {
 namespace {
 
 struct GraphState { KdForest forest; DevBuf idx, d2; };
-GraphState& gst() { static GraphState s; return s; }
+GraphState& gst(hipStream_t st = nullptr) { static std::map<hipStream_t, GraphState> m; return m[st ? st : ctx().stream]; }      // one per stream
 
 // neighbours [n][K] (first column = the point itself) -> the reference's flat arrays (graphs.py:33-38, :62-67)
 __global__ __launch_bounds__(256) void graph_emit(const int* __restrict__ idx, const double* __restrict__ d2, int n, int K, int k1, int k2,
@@ -99,7 +100,7 @@ int ssdr_knn_graph_dev(const float* d_xyz, size_t n, size_t k_nn1, size_t k_nn2,
     if (n <= k_nn2 || n > 0x3fffffff || k_nn2 + 1 > 128) { set_error("knn_graph: need k_nn2 < n and k_nn2 <= 127"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     hipStream_t s = pick_stream(stream);
-    GraphState& G = gst();
+    GraphState& G = gst(s);
     const int K = (int)k_nn2 + 1;
     std::vector<KdTreeDesc> trees(1); trees[0].pts = d_xyz; trees[0].n = (int)n;
     SSDR_TRY(kd_build(G.forest, trees, s));

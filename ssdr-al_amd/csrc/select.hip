@@ -10,6 +10,7 @@
 // Superpoints are CSR: sp_off[S+1] into sp_pts[T] (point ids), the same information as the reference's
 // pickled `components` object array (S3/partition/compute_superpoint.py:63-68).
 #include "ssdr_internal.hpp"
+#include <map>
 #include "block_prims.hpp"
 
 namespace ssdr {
@@ -666,7 +667,8 @@ __global__ __launch_bounds__(256) void kc_init(const double* __restrict__ f, int
 }
 
 struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp; };
-SelState& sst() { static SelState s; return s; }
+// one scratch set per stream: calls on different streams may run concurrently (include/ssdr_al.h)
+SelState& sst(hipStream_t st = nullptr) { static std::map<hipStream_t, SelState> m; return m[st ? st : ctx().stream]; }
 
 inline int grid_for(long n, int cap = 2048) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, cap)); }
 
@@ -702,7 +704,7 @@ int ssdr_dominant_label_dev(const int32_t* d_labels, const int32_t* d_sp_off, co
     if (!d_labels || !d_sp_off || !d_sp_pts || !d_label || !d_purity || num_labels < 1 || num_labels > 64) { set_error("dominant_label: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (S == 0) return SSDR_OK;
-    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     SSDR_TRY(Q.hist.reserve(4 * 64)); SSDR_HIP(hipMemsetAsync(Q.hist.p, 0, 4, s));
     hipLaunchKernelGGL(sel_dominant_label, dim3(grid_for((long)S)), dim3(256), 0, s, d_labels, d_sp_off, d_sp_pts, (int)S, num_labels, d_label, d_purity, Q.hist.as<int>());
     SSDR_HIP(hipGetLastError());
@@ -713,7 +715,7 @@ int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const int32_t* d_se
     if (!d_region_class || !d_region_unc || (n_selected && !d_selected_class_list)) { set_error("clsbal: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (S == 0) return SSDR_OK;
-    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     SSDR_TRY(Q.hist.reserve(4 * 64)); SSDR_HIP(hipMemsetAsync(Q.hist.p, 0, 4 * 64, s));
     hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_selected_class_list, (int)n_selected, Q.hist.as<int>());
     hipLaunchKernelGGL(sel_clsbal, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_class, (int)S, (int)(S + n_selected), Q.hist.as<int>(), d_region_unc);
@@ -745,7 +747,7 @@ int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorte
     if (!d_region_unc || !d_sorted_inds) { set_error("rank_regions: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (S == 0) return SSDR_OK;
-    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     SSDR_TRY(Q.keys.reserve(8 * S)); SSDR_TRY(Q.vals.reserve(4 * S));
     hipLaunchKernelGGL(sel_rank_keys, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_unc, (int)S, Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>());
     SSDR_TRY(Q.sorter.sort(Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>(), (int)S, nullptr, s));
@@ -810,7 +812,7 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     if (!d_xyz || !d_sp_off || !d_sp_pts || !d_sel || !d_centres || !d_cd_dir || !d_adj || max_sp_size == 0) { set_error("cloud_graph: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (nsel == 0) return SSDR_OK;
-    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     const int n = (int)nsel;
     SSDR_TRY(Q.rowsum.reserve(8 * nsel));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
@@ -828,7 +830,7 @@ int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, cons
     if (!d_xyz || !d_sp_off || !d_sp_pts || !d_sel || !d_coff || !d_boff || !d_centres || !d_cd_dir || !d_adj || num_clouds > 65535) { set_error("cloud_graph_batch: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (num_clouds == 0 || n_total == 0 || n_max == 0) return SSDR_OK;
-    SelState& Q = sst(); hipStream_t s = pick_stream(stream);
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     const int nt = (int)n_total, nm = (int)n_max; const unsigned nc = (unsigned)num_clouds;
     SSDR_TRY(Q.rowsum.reserve(8 * n_total));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, nt, d_centres);
@@ -862,7 +864,7 @@ int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, con
 }
 
 static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_already, size_t na, int start, size_t count, int use_sqrt, int32_t* d_out, hipStream_t s) {
-    SelState& Q = sst();
+    SelState& Q = sst(s);
     const int nb = grid_for((long)n, ctx().num_cu * 2);
     SSDR_TRY(Q.part.reserve(sizeof(Part) * 2 * (size_t)nb)); SSDR_TRY(Q.mind.reserve(8 * n));
     Part* p0 = Q.part.as<Part>(); Part* p1 = p0 + nb;
@@ -899,6 +901,8 @@ int ssdr_fps_superpoint_dev(const double* d_centres, const double* d_cd_dir, siz
     if (!d_centres || !d_cd_dir || !d_out || start < 0 || (size_t)start >= n || count > n || n > 8192) { set_error("fps_superpoint: bad arguments (n <= 8192)"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (count == 0) return SSDR_OK;
+    static bool attr_done = false;       // 8 n bytes of dynamic LDS next to the static arrays: beyond the 64 KiB default from n ~ 7800 on
+    if (!attr_done) { SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_superpoint), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192)); attr_done = true; }
     hipLaunchKernelGGL(fps_superpoint, dim3(1), dim3(256), 8 * n, pick_stream(stream), d_centres, d_cd_dir, (int)n, start, (int)count, d_out);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;

@@ -73,3 +73,11 @@ def knn_pyramid(xyz, ratios, K):
                                            arr(*[a.ctypes.data for a in neigh]), arr(*[a.ctypes.data for a in sub]),
                                            arr(*[a.ctypes.data for a in interp])))
     return neigh, sub, interp
+
+
+def knn_status(stream=None):
+    """Waits for `stream` and raises if the last device-flavour KNN call issued on it overflowed a device-side capacity
+    (ssdr_knn_status).  Returns (rows handed to the tree walk for K=16, for K=1, status bits, deepest tree)."""
+    out = (C.c_int32 * 4)()
+    _lib.check(_lib.lib().ssdr_knn_status(stream, out))
+    return tuple(out)

@@ -289,6 +289,10 @@ class HotPath:
         d_out, unl = self._pending
         self._pending = None
         _lib.sync()
+        # the device-flavour KNN calls cannot report what their kernels found (overflowed kd queue / node table / level limit, hand-over
+        # list): ask once per batch, here where the host waits anyway (the pyramid of this batch finished long ago)
+        from . import knn as _knn
+        _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream)
         sel = d_out.to_host()
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
         return sel, unl

@@ -50,6 +50,36 @@ def test_knn_k_larger_than_support(backend, orc):
     assert (out[:, 7:] == 0).all()          # knn_.cxx:30-31: zero-initialised, never written
 
 
+def test_device_path_reports_tree_depth_overflow(backend):
+    """A support set whose exact nanoflann tree is deeper than the level limit (geometric spacing: every split peels one point off)
+    with duplicated points (tie rows -> the tree is needed): the device flavour only enqueues, ssdr_knn_status must report it."""
+    import ctypes as C
+    from ssdr_al import _lib, knn
+    from ssdr_al._lib import DevArray
+    x = np.repeat((2.0 ** -np.arange(110)).astype(np.float32), 2)
+    p = np.stack([x, np.zeros_like(x), np.zeros_like(x)], 1)[None]
+    d_p = DevArray.from_host(p); d_o = DevArray((1, p.shape[1], 16), np.int32)
+    _lib.check(_lib.lib().ssdr_knn_batch_dev(d_p.ptr, 1, p.shape[1], 3, d_p.ptr, p.shape[1], 16, d_o.ptr, None))
+    with pytest.raises(_lib.SsdrError) as e:
+        knn.knn_status()
+    assert "0x4" in str(e.value) or "status" in str(e.value)
+    # a healthy call on the same stream clears it
+    q = np.random.default_rng(0).random((1, 500, 3), dtype=np.float32)
+    d_q = DevArray.from_host(q); d_o2 = DevArray((1, 500, 16), np.int32)
+    _lib.check(_lib.lib().ssdr_knn_batch_dev(d_q.ptr, 1, 500, 3, d_q.ptr, 500, 16, d_o2.ptr, None))
+    assert knn.knn_status()[2] == 0
+
+
+def test_generic_k_up_to_256(backend, orc):
+    """K = 200 goes through the LDS result set (128 KiB of dynamic LDS: needs the opt-in above 64 KiB)."""
+    from ssdr_al import knn
+    rng = np.random.default_rng(12)
+    p = rng.random((700, 3), dtype=np.float32)
+    assert_bits_equal(knn.knn(p, p, 200), orc.knn(p, p, 200), "K=200")
+    idx, qs = knn.knn_batch_distance_pick(p[None], 6, 128, seed=3)       # 64 KiB dynamic + static LDS
+    assert idx.shape == (1, 6, 128)
+
+
 def test_knn_rejects_unsupported_dim(backend):
     from ssdr_al import _lib, knn
     with pytest.raises(_lib.SsdrError) as e:
