@@ -154,6 +154,18 @@ int ssdr_tile_select_possibility_dev(const float* d_points, const float* d_color
                                      float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx,
                                      double* d_possibility, double* d_out_min_possibility, int32_t* d_out_argmin, void* stream);
 
+/* ---- prune: the voxel grid of the superpoint partition (replaces libply_c.prune, S3/partition/ply_c/ply_c.cpp:289-383, called from
+ *      partition/partition.py:126-144) ---------------------------------------------------------------------------------------
+ * bin = floor((p - bbox_min) / voxel_size); per voxel: float32 position sum / count, uint32 colour sum / count truncated to uint8,
+ * histogram of labels [n_labels + 1] and of objects [n_objects + 1] (uint32), rows in the order in which the voxels are first met
+ * in the input.  d_rgb / d_out_rgb may be NULL; labels / objects are skipped when n_labels / n_objects is 0.  Outputs are sized
+ * for n rows; *d_out_m (device int64) receives the number of voxels.  ssdr_prune_status waits for the stream and reports a
+ * grid with more than 2^21 bins along an axis or an id above its declared maximum (the reference's .at() would throw). */
+int ssdr_prune_dev(const float* d_xyz, size_t n, float voxel_size, const uint8_t* d_rgb, const uint8_t* d_labels, int n_labels,
+                   const uint32_t* d_objects, int n_objects, float* d_out_xyz, uint8_t* d_out_rgb, uint32_t* d_out_labels,
+                   uint32_t* d_out_objects, int64_t* d_out_m, void* stream);
+int ssdr_prune_status(void* stream, int32_t* out_status);
+
 /* ---- RandLA-Net inference (replaces the TF1 graph of S3/RandLANet.py:140-180, 505-585 run by
  *      model.sess.run([prob_logits, last_second_features, ...]) in S3/sampler2.py:598 / :327) ----------
  * Activations, accumulation and every non-matrix operation are fp32.  The matrix products run in one of three arithmetic

@@ -47,3 +47,32 @@ def compute_geof(xyz, target, k_nn):
     u = np.einsum("nk,ndk->nd", lam, np.abs(vec).astype(np.float32))
     ver = u[:, 2] / np.sqrt((u * u).sum(1))
     return np.stack([lin, pla, sca, ver], 1).astype(np.float32)
+
+
+def prune(xyz, voxel_size, rgb, labels, objects, n_labels, n_objects):
+    """libply_c.prune (partition/ply_c/ply_c.cpp:289-383 with AttributeGrid :160-287), restated with plain loops.
+    PARITY UNPINNED (the file needs Boost.Python / Eigen; the reference holds no fixture for it): bin = floor((p - bbox_min) / w) in
+    float32; voxels are numbered in the order in which they are first met (add_occurence :172-181); float32 position sums and uint32
+    colour sums in input order; position = sum / (float)count, colour = (uint8)((float)sum / count); label / object histograms with
+    n + 1 columns.  Returns (xyz f4 [m,3], rgb u1 [m,3], labels u4 [m,n_labels+1], objects u4 [m,n_objects+1])."""
+    xyz = np.ascontiguousarray(xyz, np.float32); rgb = np.ascontiguousarray(rgb, np.uint8).reshape(len(xyz), 3)
+    w = np.float32(voxel_size)
+    mn = xyz.min(0)
+    bins = np.floor((xyz - mn) / w).astype(np.uint32)                  # :337-339, float32 arithmetic
+    index = {}
+    for i in range(len(xyz)):
+        index.setdefault((int(bins[i, 0]), int(bins[i, 1]), int(bins[i, 2])), len(index))
+    m = len(index)
+    cnt = np.zeros(m, np.uint32); acc = np.zeros((m, 3), np.float32); col = np.zeros((m, 3), np.uint32)
+    hl = np.zeros((m, n_labels + 1), np.uint32); ho = np.zeros((m, n_objects + 1), np.uint32)
+    for i in range(len(xyz)):
+        v = index[(int(bins[i, 0]), int(bins[i, 1]), int(bins[i, 2]))]
+        cnt[v] += 1
+        acc[v] = acc[v] + xyz[i]                                       # float32 adds, input order
+        col[v] += rgb[i]
+        if n_labels > 0:
+            hl[v, int(labels[i])] += 1
+        if n_objects > 0:
+            ho[v, int(objects[i])] += 1
+    c = cnt.astype(np.float32)[:, None]
+    return acc / c, (col.astype(np.float32) / c).astype(np.uint8), hl, ho

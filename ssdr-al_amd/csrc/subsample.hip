@@ -459,9 +459,75 @@ __global__ __launch_bounds__(BS) void gs_reduce_labels_b(CloudTab t, const int* 
     gs_reduce_labels_body(cls + o * ldim, ldim, vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr, out_c + o * ldim);
 }
 
+// ---- prune: the voxel grid of the superpoint partition (partition/ply_c/ply_c.cpp:289-383, AttributeGrid :160-287) -----------
+// Same family as grid_subsampling with different conventions: origin = the bounding box minimum itself, bin = floor((p - min) / w),
+// float32 position sums and uint32 colour sums in input order, label / object histograms instead of a majority vote, uint8 colours
+// by truncation, and rows in the order in which the voxels are first met.
+struct PruneParams { float mn[3]; float w; int nbin[3]; int pad; };
+__global__ __launch_bounds__(BS) void prune_params(const float* partial, int nparts, float w, PruneParams* pp) {
+    __shared__ float s_mm[(BS / 64) * 6];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = threadIdx.x; i < nparts; i += BS) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], partial[6 * i + d]); mx[d] = fmaxf(mx[d], partial[6 * i + 3 + d]); }
+    }
+    block_minmax3(mn, mx, s_mm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { pp->mn[d] = mn[d]; pp->nbin[d] = (int)(unsigned)ceilf((mx[d] - mn[d]) / w); }      // :329-331 (informational)
+        pp->w = w;
+    }
+}
+// key = the bin triple (21 bits each; a point on the upper face gets bin == nbin, as in the reference's map of triples)
+__global__ __launch_bounds__(BS) void prune_keys(const float* __restrict__ P, int n, const PruneParams* pp, uint64_t* keys, uint32_t* vals, int* status) {
+    const float x0 = pp->mn[0], y0 = pp->mn[1], z0 = pp->mn[2], w = pp->w;
+    for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
+        const unsigned bx = (unsigned)floorf((P[3 * (size_t)i] - x0) / w), by = (unsigned)floorf((P[3 * (size_t)i + 1] - y0) / w), bz = (unsigned)floorf((P[3 * (size_t)i + 2] - z0) / w);   // :337-339
+        if ((bx | by | bz) >> 21) atomicOr(status, 1);
+        keys[i] = (uint64_t)bx | ((uint64_t)by << 21) | ((uint64_t)bz << 42);
+        vals[i] = (uint32_t)i;
+    }
+}
+// voxel -> (index of its first point, voxel): sorted by the first, this is the reference's row order (add_occurence :172-181)
+__global__ __launch_bounds__(BS) void prune_first_keys(const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, const GsParams* prm, uint64_t* fk, uint32_t* fv) {
+    const int m = prm->m;
+    for (int v = blockIdx.x * BS + threadIdx.x; v < m; v += gridDim.x * BS) { fk[v] = vs[seg_start[v]]; fv[v] = (uint32_t)v; }
+}
+__global__ __launch_bounds__(BS) void prune_rows(const uint32_t* __restrict__ fv, const GsParams* prm, int* row_of_voxel) {
+    const int m = prm->m;
+    for (int j = blockIdx.x * BS + threadIdx.x; j < m; j += gridDim.x * BS) row_of_voxel[fv[j]] = j;
+}
+// one lane per voxel: its points in input order (the sort is stable)
+__global__ __launch_bounds__(BS) void prune_reduce(const float* __restrict__ P, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ lab, int n_labels,
+                                                   const uint32_t* __restrict__ obj, int n_objects, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start,
+                                                   const GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, uint8_t* out_rgb, uint32_t* out_lab,
+                                                   uint32_t* out_obj, long long* out_m, int* status) {
+    const int m = prm->m;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out_m) *out_m = m;
+    for (int v = blockIdx.x * BS + threadIdx.x; v < m; v += gridDim.x * BS) {
+        const int lo = seg_start[v], hi = seg_start[v + 1], row = row_of_voxel[v];
+        float sx = 0.f, sy = 0.f, sz = 0.f; unsigned r = 0, g = 0, b = 0;
+        uint32_t* hl = out_lab ? out_lab + (size_t)row * (n_labels + 1) : nullptr;
+        uint32_t* ho = out_obj ? out_obj + (size_t)row * (n_objects + 1) : nullptr;
+        if (hl) for (int c = 0; c <= n_labels; ++c) hl[c] = 0;
+        if (ho) for (int c = 0; c <= n_objects; ++c) ho[c] = 0;
+        for (int j = lo; j < hi; ++j) {
+            const size_t i = vs[j];
+            sx = sx + P[3 * i]; sy = sy + P[3 * i + 1]; sz = sz + P[3 * i + 2];                  // :277-279
+            if (rgb) { r += rgb[3 * i]; g += rgb[3 * i + 1]; b += rgb[3 * i + 2]; }
+            if (hl) { const int l = lab[i]; if (l <= n_labels) hl[l]++; else atomicOr(status, 2); }       // .at() would throw in the reference
+            if (ho) { const unsigned o = obj[i]; if (o <= (unsigned)n_objects) ho[o]++; else atomicOr(status, 2); }
+        }
+        const float cnt = (float)(hi - lo);
+        out_p[3 * (size_t)row] = sx / cnt; out_p[3 * (size_t)row + 1] = sy / cnt; out_p[3 * (size_t)row + 2] = sz / cnt;       // :366-369
+        if (out_rgb) { out_rgb[3 * (size_t)row] = (uint8_t)((float)r / cnt); out_rgb[3 * (size_t)row + 1] = (uint8_t)((float)g / cnt); out_rgb[3 * (size_t)row + 2] = (uint8_t)((float)b / cnt); }   // :373-375
+    }
+}
+
 struct GsState {
     RadixSorter sorter;
-    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec, tidx;
+    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec, tidx, pparams, fk, fv, pstat;
+    RadixSorter sorter2;
     size_t last_m = 0, last_fdim = 0, last_ldim = 0;
 };
 GsState& gs(hipStream_t st = nullptr) { static std::map<hipStream_t, GsState> m; return m[st ? st : ctx().stream]; }
@@ -507,6 +573,36 @@ int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t f
                            row, d_op, d_of, d_oc, (long long*)d_om, (uint64_t*)nullptr, S.keys.as<uint64_t>());
         if (d_c) hipLaunchKernelGGL(gs_reduce_labels, dim3(g), dim3(BS), 0, s, d_c, (int)ldim, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, row, d_oc);
     }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int prune_device(const float* d_p, size_t n, float w, const uint8_t* d_rgb, const uint8_t* d_lab, int n_labels, const uint32_t* d_obj, int n_objects,
+                 float* d_op, uint8_t* d_orgb, uint32_t* d_olab, uint32_t* d_oobj, int64_t* d_om, hipStream_t s) {
+    GsState& S = gs(s);
+    const int ni = (int)n;
+    const int gmm = std::max(1, std::min((ni + BS - 1) / BS, 1024));
+    const int nb = (ni + CHUNK - 1) / CHUNK;
+    SSDR_TRY(S.keys.reserve(8 * n + 16)); SSDR_TRY(S.vals.reserve(4 * n + 16));
+    SSDR_TRY(S.partial.reserve(24 * 1024)); SSDR_TRY(S.params.reserve(sizeof(GsParams))); SSDR_TRY(S.pparams.reserve(sizeof(PruneParams)));
+    SSDR_TRY(S.bsum.reserve(4 * (size_t)nb + 16)); SSDR_TRY(S.seg.reserve(4 * (n + 2)));
+    SSDR_TRY(S.fk.reserve(8 * n + 16)); SSDR_TRY(S.fv.reserve(4 * n + 16)); SSDR_TRY(S.row.reserve(4 * n + 16)); SSDR_TRY(S.pstat.reserve(16));
+    GsParams* prm = S.params.as<GsParams>(); PruneParams* pp = S.pparams.as<PruneParams>();
+    SSDR_HIP(hipMemsetAsync(S.pstat.p, 0, 16, s));
+    hipLaunchKernelGGL(gs_minmax_partial, dim3(gmm), dim3(BS), 0, s, d_p, ni, S.partial.as<float>());
+    hipLaunchKernelGGL(prune_params, dim3(1), dim3(BS), 0, s, S.partial.as<float>(), gmm, w, pp);
+    const int g = std::max(1, std::min((ni + BS - 1) / BS, ctx().num_cu * 16));
+    hipLaunchKernelGGL(prune_keys, dim3(g), dim3(BS), 0, s, d_p, ni, pp, S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), S.pstat.as<int>());
+    SSDR_TRY(S.sorter.sort(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), ni, nullptr, s, 63));
+    hipLaunchKernelGGL(gs_heads_count, dim3(nb), dim3(BS), 0, s, S.keys.as<uint64_t>(), ni, S.bsum.as<int>());
+    hipLaunchKernelGGL(gs_heads_scan, dim3(1), dim3(1024), 0, s, S.bsum.as<int>(), nb, prm, S.seg.as<int>(), ni);
+    hipLaunchKernelGGL(gs_heads_write, dim3(nb), dim3(BS), 0, s, S.keys.as<uint64_t>(), ni, S.bsum.as<int>(), S.seg.as<int>());
+    // rows in first-met order: sort the voxels by the index of their first point
+    hipLaunchKernelGGL(prune_first_keys, dim3(g), dim3(BS), 0, s, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, S.fk.as<uint64_t>(), S.fv.as<uint32_t>());
+    SSDR_TRY(S.sorter2.sort(S.fk.as<uint64_t>(), S.fv.as<uint32_t>(), ni, &prm->m, s, 32));
+    hipLaunchKernelGGL(prune_rows, dim3(g), dim3(BS), 0, s, S.fv.as<uint32_t>(), prm, S.row.as<int>());
+    hipLaunchKernelGGL(prune_reduce, dim3(g), dim3(BS), 0, s, d_p, d_rgb, d_lab, n_labels, d_obj, n_objects, S.vals.as<uint32_t>(), S.seg.as<int>(), prm, S.row.as<int>(),
+                       d_op, d_orgb, d_olab, d_oobj, (long long*)d_om, S.pstat.as<int>());
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
@@ -625,6 +721,31 @@ int ssdr_grid_subsample_fetch(float* out_points, float* out_features, int32_t* o
     if (out_features && S.last_fdim) SSDR_HIP(hipMemcpyAsync(out_features, S.out_f.p, 4 * S.last_m * S.last_fdim, hipMemcpyDeviceToHost, s));
     if (out_classes && S.last_ldim) SSDR_HIP(hipMemcpyAsync(out_classes, S.out_c.p, 4 * S.last_m * S.last_ldim, hipMemcpyDeviceToHost, s));
     SSDR_HIP(hipStreamSynchronize(s));
+    return SSDR_OK;
+}
+
+
+/* libply_c.prune (partition/ply_c/ply_c.cpp:289-383): device flavour.  Outputs are sized for n rows; *d_out_m receives the voxel count. */
+int ssdr_prune_dev(const float* d_xyz, size_t n, float voxel_size, const uint8_t* d_rgb, const uint8_t* d_labels, int n_labels, const uint32_t* d_objects, int n_objects,
+                   float* d_out_xyz, uint8_t* d_out_rgb, uint32_t* d_out_labels, uint32_t* d_out_objects, int64_t* d_out_m, void* stream) {
+    if (!d_xyz || !d_out_xyz || !d_out_m || !(voxel_size > 0.f) || n > 0x3fffffff || n_labels < 0 || n_objects < 0 || (n_labels > 0 && (!d_labels || !d_out_labels)) ||
+        (n_objects > 0 && (!d_objects || !d_out_objects))) { set_error("prune: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream);
+    if (n == 0) { SSDR_HIP(hipMemsetAsync(d_out_m, 0, 8, s)); return SSDR_OK; }
+    return prune_device(d_xyz, n, voxel_size, d_rgb, n_labels > 0 ? d_labels : nullptr, n_labels, n_objects > 0 ? d_objects : nullptr, n_objects,
+                        d_out_xyz, d_out_rgb, n_labels > 0 ? d_out_labels : nullptr, n_objects > 0 ? d_out_objects : nullptr, d_out_m, s);
+}
+/* status of the last ssdr_prune_dev on `stream` (waits for it): bit 0 = more than 2^21 bins along an axis, bit 1 = a label / object id above its declared maximum */
+int ssdr_prune_status(void* stream, int32_t* out_status) {
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream);
+    GsState& S = gs(s);
+    int st = 0;
+    SSDR_HIP(hipStreamSynchronize(s));
+    if (S.pstat.p) SSDR_HIP(hipMemcpy(&st, S.pstat.p, 4, hipMemcpyDeviceToHost));
+    if (out_status) *out_status = st;
+    if (st) { set_error("prune: device status 0x%x (1 = more than 2^21 bins along an axis, 2 = label / object id above its declared maximum)", st); return SSDR_ERR_INVALID; }
     return SSDR_OK;
 }
 

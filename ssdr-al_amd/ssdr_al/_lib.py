@@ -103,6 +103,8 @@ def lib():
         L.ssdr_main_stream.argtypes = [C.POINTER(vp)]
         L.ssdr_mask_regions_dev.argtypes = [vp, vp, sz, sz, vp, vp]
         L.ssdr_gather_rows_dev.argtypes = [vp, vp, sz, sz, vp, vp]
+        L.ssdr_prune_dev.argtypes = [vp, sz, f32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.ssdr_prune_status.argtypes = [vp, vp]
         L.ssdr_prof_enable.argtypes = [i32]
         L.ssdr_prof_report.restype = C.c_char_p
         L.ssdr_dev_alloc.argtypes = [sz, C.POINTER(vp)]

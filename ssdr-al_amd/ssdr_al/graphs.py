@@ -1,6 +1,7 @@
 """k-NN structures of the superpoint partition on the GPU, with the reference's call signatures
-(`partition/graphs.py:7-70`).  Only the `voronoi == 0` branch exists (the Delaunay variant is not used by
-`compute_superpoint.py:47`)."""
+(`partition/graphs.py:7-70`).  The k-NN searches run on the GPU (float64 kd walk, sklearn's semantics).  The `voronoi > 0`
+branch (:38-62, not taken by `compute_superpoint.py:47`) triangulates with `scipy.spatial.Delaunay` exactly as the reference does —
+Qhull on the host, there is no other arithmetic in it to move — and merges its short edges with the GPU's k-NN edges."""
 import numpy as np
 
 from . import _lib
@@ -28,6 +29,19 @@ def compute_graph_nn(xyz, k_nn):
 
 def compute_graph_nn_2(xyz, k_nn1, k_nn2, voronoi=0.0):
     """graphs.py:23-70: (graph of the k_nn1 neighbours, flat targets of the k_nn2 neighbours)"""
-    if voronoi > 0:
-        raise NotImplementedError("the Delaunay / voronoi branch of compute_graph_nn_2 is not built")
-    return _knn_graph(xyz, k_nn1, k_nn2)
+    graph, target2 = _knn_graph(xyz, k_nn1, k_nn2)
+    if voronoi > 0:             # graphs.py:38-62, statement for statement (`tri.vertices` is `tri.simplices` since SciPy 1.11)
+        from scipy.spatial import Delaunay
+        n_ver = xyz.shape[0]
+        v = Delaunay(xyz).simplices
+        src = np.hstack((v[:, 0], v[:, 0], v[:, 0], v[:, 1], v[:, 1], v[:, 2])).astype("uint64")
+        tgt = np.hstack((v[:, 1], v[:, 2], v[:, 3], v[:, 2], v[:, 3], v[:, 3])).astype("uint64")
+        dist = ((xyz[src, :] - xyz[tgt, :]) ** 2).sum(1)
+        keep_edges = dist < voronoi
+        src, tgt = src[keep_edges], tgt[keep_edges]
+        src = np.hstack((src, graph["source"]))                # the k_nn1 edges: repmat(range(n), k_nn1).flatten('F') / neighbours[:, :k_nn1]
+        tgt = np.hstack((tgt, graph["target"]))
+        _, unique_edges = np.unique(src + n_ver * tgt, return_index=True)
+        graph["source"], graph["target"] = src[unique_edges], tgt[unique_edges]
+        graph["distances"] = dist[keep_edges]                   # :60 — the Delaunay edges' squared lengths only, as the reference leaves it
+    return graph, target2

@@ -20,12 +20,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+_GPU = None
+
+
 def _have_gpu():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
+    """A HIP device the product library can initialise (no framework involved: a box without torch must not silently skip the
+    parity tests).  Without libssdr_al.so the answer comes from the device nodes, so a missing build FAILS the gpu tests."""
+    global _GPU
+    if _GPU is None:
+        if os.path.exists(GPU_LIB):
+            import ctypes
+            try:
+                lib = ctypes.CDLL(GPU_LIB)
+                lib.ssdr_init.argtypes = [ctypes.c_int]
+                _GPU = lib.ssdr_init(0) == 0
+            except OSError:
+                _GPU = False
+        else:
+            _GPU = os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
+    return _GPU
 
 
 @pytest.fixture(scope="session")

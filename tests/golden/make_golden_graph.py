@@ -18,5 +18,19 @@ for name, n in (("uniform", 500), ("room", 900)):
     out[name + "/source"], out[name + "/target"], out[name + "/distances"], out[name + "/target2"] = g["source"], g["target"], g["distances"], t2
     g1 = ref.compute_graph_nn(x, 7)
     out[name + "/nn7_target"], out[name + "/nn7_distances"] = g1["target"], g1["distances"]
+# the voronoi > 0 branch (:38-62) reads `tri.vertices`, which SciPy 1.11 renamed to `simplices`: hand the reference a Delaunay with the old name
+from scipy.spatial import Delaunay as _Delaunay
+
+
+class _OldDelaunay(_Delaunay):
+    @property
+    def vertices(self):
+        return self.simplices
+
+
+ref.Delaunay = _OldDelaunay
+x = out["uniform/xyz"][:300]
+g, t2 = ref.compute_graph_nn_2(x, 5, 12, voronoi=0.3)
+out["voronoi/source"], out["voronoi/target"], out["voronoi/distances"], out["voronoi/target2"] = g["source"], g["target"], g["distances"], t2
 np.savez_compressed(os.path.join(HERE, "graph_golden.npz"), **out)
 print({k: v.shape for k, v in out.items()})

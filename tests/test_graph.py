@@ -38,8 +38,11 @@ def test_knn_graph_matches_reference_golden(backend, gg):
         assert_bits_equal(g1["target"], gg[name + "/nn7_target"]); assert_bits_equal(g1["distances"], gg[name + "/nn7_distances"])
     with pytest.raises(AssertionError, match="knn1 must be smaller than knn2"):
         graphs.compute_graph_nn_2(gg["uniform/xyz"], 12, 10)
-    with pytest.raises(NotImplementedError):
-        graphs.compute_graph_nn_2(gg["uniform/xyz"], 5, 10, voronoi=0.5)
+    # Delaunay branch (graphs.py:38-62): Qhull on the host as in the reference, k-NN edges from the GPU
+    g, t2 = graphs.compute_graph_nn_2(gg["uniform/xyz"][:300], 5, 12, voronoi=0.3)
+    for k in ("source", "target", "distances"):
+        assert g[k].dtype == gg["voronoi/" + k].dtype and np.array_equal(g[k], gg["voronoi/" + k]), k
+    assert_bits_equal(t2, gg["voronoi/target2"], "voronoi target2")
 
 
 def test_knn_graph_fresh_inputs_against_oracle(backend):
@@ -72,3 +75,28 @@ def test_geof_against_oracle(backend, gg):
     _, tp = compute_graph_nn_2(p, 5, 20)
     gp = libply_c.compute_geof(p, tp, 20)
     assert (gp[:, 2] < 1e-3).all() and (gp[:, 3] < 1e-3).all()
+
+
+def test_prune_against_restatement(backend):
+    """libply_c.prune (ply_c.cpp:289-383): PARITY UNPINNED by the reference (Boost.Python / Eigen absent); bit-exact against the loop
+    restatement in oracle/graph_np.py, call forms of partition/partition.py:126-144."""
+    from oracle import graph_np as G
+    from ssdr_al import libply_c
+    rng = np.random.default_rng(4)
+    n = 3000 if backend == "emu" else 400000
+    xyz = (rng.random((n, 3)) * np.array([6, 4, 3])).astype(np.float32)
+    xyz[: n // 3, 2] = 0.5                                              # a plane: several points per voxel
+    xyz[n // 2] = xyz.max(0)                                            # a point on the upper faces of the box
+    rgb = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    lab = rng.integers(0, 14, n).astype(np.uint8); obj = rng.integers(0, 40, n).astype(np.uint32)
+    for args in ((0.05 if backend == "gpu" else 0.3, rgb, lab, np.zeros(1, np.uint8), 13, 0), (0.5, rgb, lab, obj, 13, 39),
+                 (0.4, np.zeros(xyz.shape, np.uint8), np.array(1, np.uint8), np.zeros(1, np.uint8), 0, 0)):
+        got = libply_c.prune(xyz, *args)
+        exp = G.prune(xyz, *args)
+        assert got[0].shape == exp[0].shape and got[0].shape[0] < n
+        for a, b, what in zip(got, exp, ("xyz", "rgb", "labels", "objects")):
+            if what == "labels" and args[4] == 0 or what == "objects" and args[5] == 0:
+                assert a.shape == (len(exp[0]), 1) and not a.any()
+                continue
+            assert a.dtype == b.dtype and np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), what
+        assert int(got[2].sum()) == n if args[4] else True
