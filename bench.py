@@ -6,7 +6,8 @@
 
 One "step" = one pass of the full hot path over one batch of 16 synthetic S3DIS-like rooms per GPU, inputs already
 resident in HBM:  grid-subsample (dl 0.04) of each raw room -> 40960-point tile around a picked centre -> 5-level
-KNN pyramid (k 16) -> RandLA-Net inference (fp32) -> point / superpoint uncertainty, class balance, ranking ->
+KNN pyramid (k 16) -> RandLA-Net inference (split-bf16 matrix products, fp32 everywhere else) -> point / superpoint
+uncertainty, class balance, ranking ->
 candidate features -> per-cloud chamfer graph + one propagation hop -> FPS selection.
 Metric = input tile points through that whole pipe per second (BASELINE.json).  Tiles shard across GPUs with no
 data-path collective until the candidates' propagated features are all-gathered before the (replicated) global
@@ -27,7 +28,12 @@ for p in (ROOT, os.path.join(ROOT, "ssdr-al_amd")):
 
 METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+PROFILE_ROUND = "r02"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
+DTYPE = {"f32": "f32 (exact f32-input MFMA)",
+         "bf16x3": "bf16x3: split-bf16 MFMA operands (hi*hi + lo*hi + hi*lo), fp32 accumulate, fp32 activations and non-matrix arithmetic",
+         "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 activations and non-matrix arithmetic"}
 TILES_PER_GPU = 16
 RAW_DENSITY = 5000.0              # points / m^2 -> 0.4-1.2 M raw points per room
 
@@ -35,15 +41,16 @@ RAW_DENSITY = 5000.0              # points / m^2 -> 0.4-1.2 M raw points per roo
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the batches strictly one after the other")
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=(0, 2, 3, 4, 5),
                     help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 4 with the exchanges of N > 1")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
-    ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3", "bf16"),
-                    help="arithmetic of the network's matrix products (activations / accumulation are fp32 in every mode)")
+    ap.add_argument("--precision", default="bf16x3", choices=("f32", "bf16x3", "bf16"),
+                    help="arithmetic of the network's matrix products (activations / accumulation are fp32 in every mode); bf16x3 = split bf16, "
+                         "inside the 1e-3 feature tolerance of the fp32 path (tests/test_randla.py); bf16 = BASELINE configuration 3")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,8 +93,10 @@ def main():
             dist.barrier()
 
     # Consecutive batches are software-pipelined over the stages (front end | KNN pyramid | network | scoring | selection
-    # on separate HIP streams, one buffer set per batch in flight); every batch runs every stage and all K selections
-    # finish inside the timed region.  N > 1: the three small exchanges stay host-synchronous, in the same order on every rank.
+    # on separate HIP streams, one buffer set per batch in flight).  The warm-up call fills the pipe and it stays full
+    # (steady=True): every timed step then issues exactly one launch sequence of EVERY stage (on consecutive batches) and
+    # completes one selection, so the timed region is K full steps of work in steady state, no fill / drain inside it.
+    # N > 1: the three exchanges run on device buffers, ordered on the same streams, in the same order on every rank.
     pipe = None
     if not args.no_pipeline:
         ids = [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)]
@@ -95,19 +104,21 @@ def main():
             return pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision).load_rooms(rooms, ids)
         pipe = pipeline.Pipelined(mk, args.pipeline_depth)
     if pipe is not None:
-        pipe.run(max(args.warmup, 1), gather)
+        pipe.run(max(args.warmup, 1), gather, steady=True)
     else:
         for _ in range(args.warmup):
             hp.step(gather)
     barrier()
     t0 = time.perf_counter()
     if pipe is not None:
-        pipe.run(args.steps, gather)
+        pipe.run(args.steps, gather, steady=True)
     else:
         for _ in range(args.steps):
             hp.step(gather)
     barrier()
     dt = time.perf_counter() - t0
+    if pipe is not None:
+        pipe.finish()
     if use_dist:
         import torch
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -127,42 +138,56 @@ def main():
         L.ssdr_prof_enable(0)
         rows = []
         for ln in rep:
-            name, calls, ms, work = ln.rsplit(" ", 3)
-            rows.append((name, int(calls), float(ms), float(work)))
+            name, calls, ms, work, work2 = ln.rsplit(" ", 4)
+            rows.append((name, int(calls), float(ms), float(work), float(work2)))
         return sorted(rows, key=lambda r: -r[2])
 
     NPROF = 3
+    mfma_kernels = ("dense_kernel", "lfa_att_kernel")
+    mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
+    mfma_insn = "v_mfma_f32_16x16x4_f32" if args.precision == "f32" else "v_mfma_f32_16x16x32_bf16 (LocSE K = 10 and the d = 16 level on v_mfma_f32_16x16x4_f32)"
     # (a) the way the timed region ran (every rank takes part because of the exchanges) ...
-    timed_rows = prof_rows((lambda: pipe.run(NPROF, gather)) if pipe is not None else (lambda: [hp.step(gather) for _ in range(NPROF)]))
+    timed_rows = prof_rows((lambda: (pipe.run(NPROF, gather), pipe.finish())) if pipe is not None else (lambda: [hp.step(gather) for _ in range(NPROF)]))
     roofline = None
     stage_ms = None
+    stage_roofline = None
     if rank == 0:
         # (b) ... and strictly sequential on rank 0: the kernel with the GPU to itself.  (b) is the roofline figure: it is
         # the kernel's own duration (rocprofv3's per-dispatch duration agrees with it, profiles/rNN_bench_seq_kernel_stats.csv),
         # whereas with several batches in flight an event pair on one stream also spans the time the dispatch waits
         # behind / shares the CUs with the other streams' kernels; (a) is reported beside it as "as_timed".
         rows = prof_rows(lambda: [hp.step(None) for _ in range(NPROF)])
-        name, calls, ms, work = rows[0]
-        mfma = name in ("dense_kernel", "lfa_att_kernel")
+        name, calls, ms, work, work2 = rows[0]
+        mfma = name in mfma_kernels
         unit_div = 1e12 if mfma else 1e9
         achieved = work / (ms * 1e-3) / unit_div
-        peak = PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBS
-        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs, FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes); null when that file
-        # has no entry for the kernel.  bench.py cannot collect PMC counters itself.
-        traffic = None
+        peak = mfma_peak if mfma else PEAK_HBM_GBS
+        # HBM bytes per launch of that kernel from the committed PMC passes of this round (tools/collect_profiles.sh: rocprofv3 --pmc
+        # FETCH_SIZE / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes).
+        # bench.py cannot collect PMC counters itself: the figure is a constant of that file, labelled with its source and commit.
+        traffic, traffic_source = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"]
-            traffic = pmc[name]["hbm_bytes_per_launch"]
+            pmcf = os.path.join("profiles", "%s_pmc_summary.json" % PROFILE_ROUND)
+            pmc = json.load(open(os.path.join(ROOT, pmcf)))
+            traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
+            traffic_source = "%s (rocprofv3 --pmc passes at commit %s, not measured in this run)" % (pmcf, pmc.get("commit", "?"))
         except Exception:
             pass
         roofline = {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
-                    "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2), "conditions": "sequential pass, one kernel at a time",
-                    "note": ("algorithmic FLOPs of the reference's formulation (attention dense d x d on every neighbour row); the kernel itself "
-                             "executes the position half on the matrix cores, the neighbour half runs once per point in dense_kernel and is "
-                             "gathered: frac is algorithmic work per second against the MFMA peak, not matrix-core utilisation") if name == "lfa_att_kernel" else None,
-                    "others": {r[0]: {"ms_per_step": round(r[2] / NPROF, 3), "launches_per_step": r[1] // NPROF} for r in rows}}
+                    "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2), "conditions": "sequential pass, one kernel at a time"}
+        if mfma:
+            roofline.update({"instruction": mfma_insn,
+                             "achieved_is": "ALGORITHMIC FLOPs of the reference's formulation (attention dense d x d on every neighbour row) per second",
+                             "executed_mfma": {"achieved": round(work2 / (ms * 1e-3) / 1e12, 3), "frac": round(work2 / (ms * 1e-3) / 1e12 / peak, 4),
+                                               "note": "FLOPs the MFMA instructions execute: tile padding, both orientations of the position-encoding products, "
+                                                       "three bf16 products per split product; the neighbour half of the attention product runs once per point in "
+                                                       "dense_kernel (G rows) and is gathered, so it is not in this kernel"}})
+        roofline["others"] = {r[0]: {"ms_per_step": round(r[2] / NPROF, 3), "launches_per_step": r[1] // NPROF,
+                                     **({"algorithmic_TFLOPs": round(r[3] / (r[2] * 1e-3) / 1e12, 2), "executed_mfma_TFLOPs": round(r[4] / (r[2] * 1e-3) / 1e12, 2),
+                                         "frac_of_mfma_peak": round(r[3] / (r[2] * 1e-3) / 1e12 / mfma_peak, 4)} if r[0] in mfma_kernels else
+                                        ({"algorithmic_GBs": round(r[3] / (r[2] * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(r[3] / (r[2] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} if r[3] > 0 else {}))}
+                              for r in rows}
         for r in timed_rows:
             if r[0] == name and pipe is not None:
                 roofline["as_timed"] = {"conditions": "%d batches in flight on %d streams" % (args.pipeline_depth, args.pipeline_depth),
@@ -171,6 +196,20 @@ def main():
         if world == 1:
             hp.step(None, timed_stages=True)
             stage_ms = {k: round(float(v), 3) for k, v in hp.timing.items()}
+            # per-stage algorithmic work against the roofline that bounds the stage
+            B, N0 = TILES_PER_GPU, ConfigS3DIS.num_points
+            raw = int(sum(len(r[0]) for r in rooms)); sub = int(hp.sub_m.to_host()[:B].sum())
+            stage_work = {"subsample+tile": ("hbm", 28.0 * (raw + sub) + 40.0 * B * N0), "knn_pyramid": ("hbm", 5.0e6 * B),
+                          "randla_infer": ("mfma", 16.71e9 * B), "score": ("hbm", (52.0 + 8.0) * B * N0)}
+            stage_roofline = {}
+            for k, (bound, w) in stage_work.items():
+                t = stage_ms[k] * 1e-3
+                if bound == "hbm":
+                    stage_roofline[k] = {"bound": "hbm", "algorithmic_bytes": int(w), "achieved_GBs": round(w / t / 1e9, 1), "frac": round(w / t / 1e9 / PEAK_HBM_GBS, 4)}
+                else:
+                    stage_roofline[k] = {"bound": "mfma", "algorithmic_flops": int(w), "achieved_TFLOPs": round(w / t / 1e12, 2), "peak_TFLOPs": mfma_peak,
+                                         "frac": round(w / t / 1e12 / mfma_peak, 4), "hbm_bytes": int(63.1e6 * B), "hbm_frac": round(63.1e6 * B / t / 1e9 / PEAK_HBM_GBS, 4)}
+            stage_roofline["select"] = {"bound": "latency", "note": "one-workgroup FPS chain (592 dependent picks) + float64 chamfer graph; overlapped with the other stages"}
             if args.stages:
                 print("stages(ms, sequential):", stage_ms, file=sys.stderr)
 
@@ -180,7 +219,7 @@ def main():
         from oracle import pipeline_np
         cores = os.cpu_count() or 1
         ns = 4
-        one = pipeline.HotPath(weights, ConfigS3DIS).load_rooms(rooms[:ns])
+        one = pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision).load_rooms(rooms[:ns])
         tc = time.perf_counter()
         ref = pipeline_np.run(one, rooms[:ns], weights, threads=min(cores, ns))
         tcpu = time.perf_counter() - tc
@@ -211,14 +250,16 @@ def main():
     if rank == 0:
         out = {"metric": METRIC, "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": DTYPE[args.precision], "data": "synthetic",
                "config": {"workload": "S3DIS-like rooms (synthetic, Area_5 seeds), %d rooms/tiles of 40960 points per GPU per step: grid-subsample "
-                                      "dl=0.04 -> tile -> KNN pyramid k=16 [4,4,4,4,2] -> RandLA-Net infer (random-init, fp32) -> WetSU/sb/clsbal "
-                                      "ranking -> FPS-GCN select (gcn_number=1)" % TILES_PER_GPU,
+                                      "dl=0.04 -> tile -> KNN pyramid k=16 [4,4,4,4,2] -> RandLA-Net infer (random-init weights, %s matrix products) -> WetSU/sb/clsbal "
+                                      "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, FPS start fixed to candidate 0)" % (TILES_PER_GPU, args.precision),
                           "tiles_per_gpu": TILES_PER_GPU, "tile_points": ConfigS3DIS.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
                           "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * TILES_PER_GPU * world), "sharding": "tiles",
-                          "batches_in_flight": args.pipeline_depth if pipe is not None else 1},
-               "stage_ms": stage_ms, "roofline": roofline, "cpu_baseline": cpu}
+                          "batches_in_flight": args.pipeline_depth if pipe is not None else 1,
+                          "timed_region": "steady state: the warm-up fills the pipe, every timed step issues one launch sequence of every stage and "
+                                          "completes one selection" if pipe is not None else "strictly sequential steps"},
+               "stage_ms": stage_ms, "stage_roofline": stage_roofline, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -49,8 +49,9 @@ int  ssdr_stream_destroy(void* stream);
 int  ssdr_main_stream(void** out_stream);            /* the library's own stream (what stream == NULL means) */
 int  ssdr_stream_wait(void* waiter, void* waited);   /* waiter continues after what is enqueued on waited so far */
 /* Optional per-launch timing (HIP events on the launch stream) of the instrumented kernels; used by bench.py for
- * the roofline line.  ssdr_prof_report() synchronises and returns "name calls total_ms total_work\n" lines, where
- * total_work is the summed algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels) of those launches. */
+ * the roofline line.  ssdr_prof_report() synchronises and returns "name calls total_ms total_work total_work2\n" lines, where
+ * total_work is the summed algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels) of those launches and total_work2 the FLOPs
+ * their MFMA instructions execute (0 for the other kernels). */
 int ssdr_prof_enable(int on);
 const char* ssdr_prof_report(void);
 /* Milliseconds spent in the GPU part of the last host-flavour call (HIP events on the library stream). */

@@ -52,7 +52,7 @@ int DevBuf::reserve(size_t bytes) {
 void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 // ---- kernel timing ------------------------------------------------------------------------------------
-struct ProfRec { std::string name; hipEvent_t e0, e1; double work; };
+struct ProfRec { std::string name; hipEvent_t e0, e1; double work, work2; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -63,9 +63,9 @@ static hipEvent_t prof_event() {
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
 
-ProfScope::ProfScope(const char* name, hipStream_t s, double work) : stream(s) {
+ProfScope::ProfScope(const char* name, hipStream_t s, double work, double work2) : stream(s) {
     if (!g_prof_on) return;
-    ProfRec r; r.name = name; r.e0 = prof_event(); r.e1 = prof_event(); r.work = work;
+    ProfRec r; r.name = name; r.e0 = prof_event(); r.e1 = prof_event(); r.work = work; r.work2 = work2;
     (void)hipEventRecord(r.e0, s);
     g_prof_recs.push_back(r); slot = (int)g_prof_recs.size() - 1;
 }
@@ -75,23 +75,23 @@ ProfScope::~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof_recs[slot].
 
 extern "C" {
 int ssdr_prof_enable(int on) { ssdr::g_prof_on = on != 0; return SSDR_OK; }
-/* Synchronises, folds the recorded launches into one line per kernel name: "name calls total_ms total_work\n". */
+/* Synchronises, folds the recorded launches into one line per kernel name: "name calls total_ms total_work total_work2\n". */
 const char* ssdr_prof_report(void) {
     using namespace ssdr;
-    struct Acc { long calls = 0; double ms = 0, work = 0; };
+    struct Acc { long calls = 0; double ms = 0, work = 0, work2 = 0; };
     std::vector<std::pair<std::string, Acc>> acc;
     for (auto& r : g_prof_recs) {
         (void)hipEventSynchronize(r.e1);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         size_t i = 0; for (; i < acc.size(); ++i) if (acc[i].first == r.name) break;
         if (i == acc.size()) acc.push_back({r.name, Acc()});
-        acc[i].second.calls++; acc[i].second.ms += ms; acc[i].second.work += r.work;
+        acc[i].second.calls++; acc[i].second.ms += ms; acc[i].second.work += r.work; acc[i].second.work2 += r.work2;
         g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1);
     }
     g_prof_recs.clear();
     g_prof_text.clear();
     char buf[256];
-    for (auto& a : acc) { snprintf(buf, sizeof(buf), "%s %ld %.6f %.6e\n", a.first.c_str(), a.second.calls, a.second.ms, a.second.work); g_prof_text += buf; }
+    for (auto& a : acc) { snprintf(buf, sizeof(buf), "%s %ld %.6f %.6e %.6e\n", a.first.c_str(), a.second.calls, a.second.ms, a.second.work, a.second.work2); g_prof_text += buf; }
     return g_prof_text.c_str();
 }
 const char* ssdr_version(void) { return "ssdr_al-gfx950 0.1"; }

@@ -14,6 +14,7 @@
 #include "ssdr_internal.hpp"
 #include "randla.hpp"
 #include "randla_dev.hpp"
+#include <cmath>
 
 namespace ssdr {
 
@@ -406,9 +407,13 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
     if (a.N == 8 && a.k2 == 0 && a.k1 <= 16) return launch_dense(a, s);      // thin layers: HBM streams on fp32 FMAs in every mode
     if (!a.wt_hi || (prec == PREC_BF16X3 && !a.wt_lo)) { set_error("dense (bf16): the layer has no bf16 weight pieces"); return SSDR_ERR_INVALID; }
-    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
+    // executed: rows / columns padded to the tile, K to the chunk, one or three bf16 products
+    const bool small = a.M <= 16384;
+    const double tm = small ? 32.0 : 128.0, kc = small ? 64.0 : 32.0;
+    const double exec = 2.0 * std::ceil(a.M / tm) * tm * std::ceil((a.k1 + a.k2) / kc) * kc * std::ceil(a.N / 64.0) * 64.0 * (prec == PREC_BF16X3 ? 3.0 : 1.0);
+    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N, exec);
     const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0;
-    if (a.M <= 16384) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
+    if (small) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
     return launch_dense_bf16_t<128, 32>(a, prec, vec, s);
 }
 
@@ -426,7 +431,11 @@ template <int D> static int launch_lfa_bf16_d(const LfaArgs& a, bool second, int
         attr_done = true;
     }
     const double rows = (double)B * (double)a.n * 16.0;       // algorithmic FLOPs of the reference's formulation (as lfa_att_kernel)
-    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D));
+    // executed on the matrix cores: LocSE on the f32 MFMA (K padded to 12; both orientations in the first half), LFAmlp2 in both orientations and
+    // the position half of the attention product on the bf16 MFMA (one or three products)
+    const double np = terms == 2 ? 3.0 : 1.0;
+    const double exec = rows * (2.0 * 12 * C::H * (second ? 1.0 : 2.0) + (second ? 2.0 * 2.0 * C::H * C::H * np : 0.0) + 2.0 * C::H * D * np);
+    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
     if (terms == 2) {
         if (second) hipLaunchKernelGGL((lfa_bf16_kernel<D, true, 2>), grid, dim3(C::NT), lds, s, a);
         else hipLaunchKernelGGL((lfa_bf16_kernel<D, false, 2>), grid, dim3(C::NT), lds, s, a);

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
 int launch_dense(const DenseArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
     dim3 grid((unsigned)((a.M + DTM - 1) / DTM), (unsigned)((a.N + DTN - 1) / DTN));
-    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
+    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
     const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && a.N % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && ((uintptr_t)a.W & 15) == 0;
     // thin layers over many rows: one row per lane (x2 / y rows must be 16-byte aligned, x1 too unless k1 % 4 != 0)
     if (a.M >= 1024 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && (a.k1 % 4 != 0 || ((uintptr_t)a.x1 & 15) == 0)) {
@@ -672,7 +672,9 @@ template <int D> static int launch_lfa_d(const LfaArgs& a, bool second, int B, h
     }
     // algorithmic FLOPs: LocSE 10->h, (second half) h->h, attention d->d on n*16 neighbour rows, + the weighted sum
     const double rows = (double)B * (double)a.n * 16.0;
-    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D));
+    // executed on the f32 MFMA: LocSE (K padded to 12), LFAmlp2, and the attention product (its position half only when G rows are gathered)
+    const double exec = rows * (2.0 * 12 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + (a.g ? 2.0 * C::H * D : 2.0 * D * D));
+    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
     if (second) hipLaunchKernelGGL((lfa_att_kernel<D, true>), grid, dim3(256), C::LDS_BYTES, s, a);
     else hipLaunchKernelGGL((lfa_att_kernel<D, false>), grid, dim3(256), C::LDS_BYTES, s, a);
     SSDR_HIP(hipGetLastError());

@@ -55,10 +55,11 @@ int ensure_init();
 inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
 
 // ---- in-library kernel timing (context.hip): HIP events on the launch stream around instrumented launches.
-// Off by default; bench.py switches it on for the roofline leg.  `work` is the launch's algorithmic FLOPs or bytes.
+// Off by default; bench.py switches it on for the roofline leg.  `work` is the launch's algorithmic FLOPs or bytes, `work2` the
+// FLOPs its MFMA instructions execute (padding, both product orientations and the three split-bf16 products included).
 struct ProfScope {
     int slot = -1;
-    ProfScope(const char* name, hipStream_t s, double work);
+    ProfScope(const char* name, hipStream_t s, double work, double work2 = 0.0);      // work2: FLOPs the matrix cores execute (MFMA kernels)
     ~ProfScope();
     hipStream_t stream = nullptr;
 };

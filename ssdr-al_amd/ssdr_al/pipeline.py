@@ -361,6 +361,7 @@ class Pipelined:
         for h in self.hp:
             h.front_stream, h.knn_stream = self.streams[self.group["front"]], self.streams[self.group["knn"]]
             h.stream, h.score_stream = self.streams[self.group["infer"]], self.streams[self.group["score"]]
+        self._k = 0
         self._drain()
 
     def _drain(self):
@@ -379,30 +380,39 @@ class Pipelined:
         else:
             {"front": h._front_end, "knn": h._pyramid, "infer": h._infer}[name]()
 
-    def run(self, steps, comm=None):
+    def run(self, steps, comm=None, steady=False):
+        """Finishes `steps` selections.  steady=False: fills the pipe, runs, drains (every issued batch is completed).
+        steady=True keeps the pipe full across calls: the first call fills it, and every later step issues exactly one launch sequence
+        of EVERY stage (on consecutive batches) and completes one selection — what bench.py times; finish() drains."""
         self.comm = comm
         L = _lib.lib()
         out = None
         lead, first = self.lead, self.lead["front"]
-        for b in range(min(steps, first)):                   # prologue: fill the pipe
-            for name in self.STAGES:
-                if b < lead[name]:
-                    self._stage(name, b)
-                    if name == "score":
-                        self.hp[b % self.depth]._score_finish(comm)
-        for k in range(steps):
+        k0 = self._k if steady else 0
+        last = None if steady else steps                     # batches >= last are never issued
+        if k0 == 0:
+            for b in range(first if steady else min(steps, first)):      # prologue: fill the pipe
+                for name in self.STAGES:
+                    if b < lead[name]:
+                        self._stage(name, b)
+        for k in range(k0, k0 + steps):
             _lib.check(L.ssdr_stream_wait(None, self.streams[self.group["score"]]))    # main stream: batch k's scores are ready
             hk = self.hp[k % self.depth]
             hk._select_issue(comm)                           # batch k: host decisions + the whole selection chain enqueued ...
-            late = []
-            for b in range(k + 1, min(steps, k + first + 1)):   # ... the other stages are issued while its FPS chain (one workgroup,
-                for name in self.STAGES:                        # ~1.6 ms) runs, instead of before it ...
+            for b in range(k + 1, k + first + 1):            # ... the other stages are issued while its FPS chain (one workgroup,
+                if last is not None and b >= last:           # ~1.4 ms) runs, instead of before it ...
+                    break
+                for name in self.STAGES:
                     if b == k + lead[name]:
                         self._stage(name, b)                 # the buffer set of batch b was last read by select(b - depth), done
-                        if name == "score":
-                            late.append(b)
             out = hk._select_collect()                       # ... and only then the host waits for the selection
-            for b in late:                                   # with a communicator: exchanges 1 + 2 of batch k+1, host-synchronous, after the
-                self.hp[b % self.depth]._score_finish(comm)  # selection, by when that batch's scoring kernels have long finished
-        self._drain()
+        if steady:
+            self._k = k0 + steps
+        else:
+            self._drain()
         return out
+
+    def finish(self):
+        """end a steady run: wait for everything issued and forget the partially processed batches"""
+        self._drain()
+        self._k = 0

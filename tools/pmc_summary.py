@@ -10,9 +10,14 @@ D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p
 def family(name):
     n = re.sub(r"^void ", "", name).replace("ssdr::", "").replace("(anonymous namespace)::", "")
     n = n.split("(")[0]
-    for fam in ("lfa_att_kernel", "dense_rows_kernel", "dense_small_kernel", "dense_kernel", "kd_split_kernel", "fps_block_reg", "tail_kernel"):
-        if n.startswith(fam):
-            return "dense_kernel" if fam in ("dense_rows_kernel", "dense_small_kernel") else fam     # bench.py's ProfScope names
+    for fam in ("lfa_att_kernel", "lfa_bf16_kernel", "dense_rows_kernel", "dense_small_kernel", "dense_bf16_kernel", "dense_kernel", "kd_split_kernel", "fps_block_reg", "tail_kernel"):
+        if n.startswith(fam):      # bench.py's ProfScope names
+            return "dense_kernel" if fam.startswith("dense_") else ("lfa_att_kernel" if fam.startswith("lfa_") else fam)
+    m = re.match(r"grid_(search|retry)_kernel<(\d+)", n)
+    if m:
+        return "knn_grid_search<%s>" % m.group(2)
+    if n.startswith("grid_"):
+        return "knn_grid_build"
     m = re.match(r"kd_search_kernel<(\d+)", n)
     return "kd_search_kernel<%s>" % m.group(1) if m else n
 
@@ -23,12 +28,30 @@ def load(fn):
     return acc
 
 f, w = load("%s_pmc_fetch_size.csv" % R), load("%s_pmc_write_size.csv" % R)
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 0 --no-cpu-baseline "
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "-C", os.path.dirname(D), "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = "?"
+MFMA = {}
+try:      # optional third pass: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel family (tools/collect_profiles.sh)
+    busy = collections.defaultdict(lambda: [0.0, 0.0])
+    for r in csv.DictReader(open(os.path.join(D, "%s_pmc_mfma_busy.csv" % R))):
+        b = busy[family(r["Kernel_Name"])]
+        if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES": b[0] += float(r["Counter_Value"])
+        elif r["Counter_Name"] == "SQ_BUSY_CYCLES": b[1] += float(r["Counter_Value"])
+    MFMA = {k: v for k, v in busy.items() if v[0] > 0}
+except FileNotFoundError:
+    pass
+out = {"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 0 --no-cpu-baseline "
                  "--no-pipeline` (tools/collect_profiles.sh); counters are KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
                  "128-B requests as 64 B), which over-counts kernels whose reads are mostly 64-B gathers", "kernels": {}}
 for k in sorted(set(f) | set(w), key=lambda k: -(2 * f[k][1] + w[k][1])):
     n = max(f[k][0], w[k][0], 1)
     out["kernels"][k] = {"launches": n, "fetch_size_bytes_per_launch_raw": int(f[k][1] / n), "fetch_size_bytes_per_launch_x2_gfx950": int(2 * f[k][1] / n),
                          "write_size_bytes_per_launch": int(w[k][1] / n), "hbm_bytes_per_launch": int((2 * f[k][1] + w[k][1]) / n)}
+    if k in MFMA:      # SQ_VALU_MFMA_BUSY_CYCLES sums over the 4 SIMDs of every CU and over the XCDs' SQ_BUSY_CYCLES samples: report the raw sums and the
+        out["kernels"][k]["sq_valu_mfma_busy_cycles"] = int(MFMA[k][0]); out["kernels"][k]["sq_busy_cycles"] = int(MFMA[k][1])      # ratio for relative comparison
+        out["kernels"][k]["mfma_busy_over_sq_busy"] = round(MFMA[k][0] / max(MFMA[k][1], 1.0), 3)
 json.dump(out, open(os.path.join(D, "%s_pmc_summary.json" % R), "w"), indent=1)
 print("wrote", len(out["kernels"]), "kernel families")
