@@ -1,6 +1,7 @@
 // Library state of libssdr_al.so: device selection, the library stream, error text, grow-only buffers.
 #include "ssdr_internal.hpp"
 #include <mutex>
+#include <unistd.h>
 
 namespace ssdr {
 
@@ -15,11 +16,22 @@ void set_error(const char* fmt, ...) {
 Context& ctx() { static Context c; return c; }
 
 static std::mutex g_init_mu;
+static pid_t g_init_pid = 0;          // the process that created the HIP context
+
+// The reference calls knn_search from forked DataLoader workers (SURVEY 8b "Threading").  A HIP context does not survive fork():
+// nothing here touches HIP before the first op (importing / loading the library is fork-safe), and a child that inherits an
+// initialised parent is refused with a clear error instead of hanging inside the runtime.
+static int forked_child() {
+    set_error("this process was forked after its parent initialised the HIP context (pid %d -> %d): a HIP context does not survive fork(). "
+              "Fork before the first libssdr_al call (the library initialises HIP lazily, in the first op), or use the 'spawn' start method / "
+              "num_workers=0", (int)g_init_pid, (int)getpid());
+    return SSDR_ERR_INTERNAL;
+}
 
 static int do_init(int device) {
     std::lock_guard<std::mutex> lk(g_init_mu);
     Context& c = ctx();
-    if (c.ready) return SSDR_OK;
+    if (c.ready) return g_init_pid == getpid() ? SSDR_OK : forked_child();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -35,11 +47,11 @@ static int do_init(int device) {
     SSDR_HIP(hipEventCreate(&c.ev1));
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c.num_cu = cu;
-    c.device = device; c.ready = true;
+    c.device = device; c.ready = true; g_init_pid = getpid();
     return SSDR_OK;
 }
 
-int ensure_init() { return ctx().ready ? SSDR_OK : do_init(0); }
+int ensure_init() { return ctx().ready ? (g_init_pid == getpid() ? SSDR_OK : forked_child()) : do_init(0); }
 
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return SSDR_OK;
@@ -96,7 +108,7 @@ const char* ssdr_prof_report(void) {
 }
 const char* ssdr_version(void) { return "ssdr_al-gfx950 0.1"; }
 const char* ssdr_last_error(void) { return ssdr::g_err.c_str(); }
-int ssdr_init(int device) { return ssdr::ctx().ready ? SSDR_OK : ssdr::do_init(device); }
+int ssdr_init(int device) { return ssdr::ctx().ready ? ssdr::ensure_init() : ssdr::do_init(device); }
 void ssdr_shutdown(void) {}
 int ssdr_stream_sync(void* stream) {
     SSDR_TRY(ssdr::ensure_init());

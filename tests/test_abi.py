@@ -51,3 +51,34 @@ def test_missing_library_is_an_error(tmp_path):
             _lib.lib()
     finally:
         _lib.use(None)
+
+
+def test_fork_after_init_is_refused_and_fork_before_init_works(emu_lib):
+    """SURVEY 8b "Threading": the reference calls knn_search from forked DataLoader workers.  Loading the library never touches HIP;
+    a child forked BEFORE the first op initialises its own context, a child forked AFTER it gets a clear error (no hang)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from ssdr_al import _lib, knn
+_lib.use(%r)
+p = np.random.default_rng(0).random((200, 3), dtype=np.float32)
+def child(expect_ok):
+    pid = os.fork()
+    if pid == 0:
+        try:
+            knn.knn(p, p, 4)
+            os._exit(0 if expect_ok else 3)
+        except _lib.SsdrError as e:
+            os._exit(3 if expect_ok else (0 if "fork" in str(e) else 4))
+    return os.waitpid(pid, 0)[1]
+assert child(True) == 0, "a child forked before the first op must be able to use the library"
+knn.knn(p, p, 4)                       # the parent initialises now
+assert child(False) == 0, "a child forked after the parent's init must be refused with the fork message"
+print("ok")
+"""
+    from conftest import PKG, ROOT
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, PKG, emu_lib)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
