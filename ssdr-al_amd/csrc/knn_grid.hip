@@ -31,6 +31,13 @@ constexpr int GS_BINS = 192;             // log-scale histogram of squared dista
 constexpr int GS_BIN0 = (87 << 2);       // first bin: d^2 = 2^-40
 constexpr int GS_RMAX = 3;               // largest block: (2*3+1)^3 cells
 constexpr int SCAN_BLK = 4096;           // cells per scan block
+// A row whose K-th and (K+1)-th distances are closer than this goes to the tree walk.  nanoflann prunes a far branch when its bound
+// m = fl(fl(m + cut) - dists[idx]) exceeds worstDist (searchLevel :1316-1319).  The per-dimension terms are rounded exactly like a point's
+// ((a - b)^2, monotone), so with exact sums the bound never exceeds a point's distance; but m is an incrementally rounded sum: every far
+// transition of the path adds at most 3 ulps of its value, the point's own two additions 2 more.  With at most MAX_LEVELS = 40 transitions
+// (deeper trees are refused) the bound can exceed the computed distance of a point below it by < (3 * 40 + 6) * 2^-24 < 2^-17 relative:
+// only if the reference's K-th and the dropped point are that close can the reference's answer differ from the K smallest distances.
+constexpr float NEAR_TIE = 1.0000076293945312f;      // 1 + 2^-17
 constexpr int RETRY_FROM_R1 = 1 << 30;   // tag on a retry entry's job id: the 3^3 block of that job's grid has not been searched yet
 
 __device__ __forceinline__ int cell_of(float v, float o, float inv_c, int n) {
@@ -212,7 +219,7 @@ __device__ __forceinline__ void grid_finish(const GridSearchArgs& a, const GridJ
     const bool unsettled = hard;
 #pragma unroll
     for (int j = 0; j < K; ++j) hard |= rs.d[j] == rs.d[j + 1];
-    hard |= rs.d[K] <= rs.d[K - 1] * 1.0000019073486328f;       // 1 + 2^-19
+    hard |= rs.d[K] <= rs.d[K - 1] * NEAR_TIE;
     if (hard) {
         if (unsettled) atomicAdd(a.status + 1, 1);                // diagnostics: rows that left the grid for lack of a settled block
         const int w = atomicAdd(a.work_count, 1);
@@ -225,16 +232,93 @@ __device__ __forceinline__ void grid_finish(const GridSearchArgs& a, const GridJ
     for (int j = 0; j < K; ++j) o[j] = (OutT)rs.id[j];
 }
 
-// first pass: grid.y = job (one support set x one query set x one output block), grid.x = blocks of 256 queries.
-// A lane whose candidate passes `dist < worst` makes its whole wave execute the ~70-instruction sorted insertion, and with 64
-// queries of the same cells in a wave that is nearly every candidate.  So the scan of the 3 x 3 rows of cells only MARKS the
-// candidates inside the radius the block guarantees (distance from the query to the nearest block face that has cells beyond it)
-// in one 64-bit mask per row — registers only, four loads in flight — and the sorted insertion then runs over the marked
-// candidates alone.  Fewer than K + 1 marked, a row of more than 64 candidates, or a query outside the support box: second pass.
-//
-// job.job1 >= 0 (pyramid): interp_idx = the nearest of the first n1 support points (tf_map's prefix sub-sampling) falls out of the
-// same scan: the two nearest candidates with index < n1 are tracked, and the answer is final when the nearest lies inside the
-// guaranteed radius and clear of the second.
+// The (2R+1)^3 block around a query by MARKING: a lane whose candidate passes `dist < worst` makes its whole wave execute the
+// ~70-instruction sorted insertion, and with 64 queries of the same cells in a wave that is nearly every candidate.  So the scan of
+// the (2R+1)^2 rows of cells only marks the candidates inside the radius the block guarantees (distance from the query to the
+// nearest block face that has cells beyond it) in one 64-bit mask per row — registers only, four loads in flight — and the
+// sorted insertion then runs over the marked candidates alone.  With n1 > 0 the two nearest marked candidates with index < n1 are
+// tracked as well (interp_idx of a pyramid = nearest of the prefix, tf_map's sub-sampling).
+// Returns 0: rs holds the final K + 1 best; 1: fewer than K + 1 candidates inside the radius (a larger block is needed);
+// 2: the masks cannot hold this block (a row of more than 64 candidates) or the radius is not positive (query outside the support box).
+template <int K, int R>
+__device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
+                                                RegSet<K + 1>& rs, int n1, float& b0, float& b1, int& i0, float& tau) {
+    constexpr int W = 2 * R + 1;
+    const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1);
+    // every point outside the block is at least g away (faces on the grid boundary have nothing beyond them)
+    float g = FLT_MAX;
+    if (x0 > 0) g = fminf(g, qx - (d.lo[0] + (float)x0 * d.c));
+    if (x1 < d.nx - 1) g = fminf(g, (d.lo[0] + (float)(x1 + 1) * d.c) - qx);
+    if (cy - R > 0) g = fminf(g, qy - (d.lo[1] + (float)(cy - R) * d.c));
+    if (cy + R < d.ny - 1) g = fminf(g, (d.lo[1] + (float)(cy + R + 1) * d.c) - qy);
+    if (cz - R > 0) g = fminf(g, qz - (d.lo[2] + (float)(cz - R) * d.c));
+    if (cz + R < d.nz - 1) g = fminf(g, (d.lo[2] + (float)(cz + R + 1) * d.c) - qz);
+    if (!(g > 0.f)) return 2;
+    tau = FLT_MAX;
+    if (g < FLT_MAX) { const float gs = g * 0.99998f; tau = gs * gs; }      // cell boundaries are rounded fp32 products: stay inside
+    unsigned long long m[W * W]; int rs0[W * W];
+    int cnt = 0; bool long_row = false;
+#pragma unroll
+    for (int r = 0; r < W * W; ++r) {
+        const int z = cz + r / W - R, y = cy + r % W - R;
+        m[r] = 0ull; rs0[r] = 0;
+        if (z < 0 || z >= d.nz || y < 0 || y >= d.ny) continue;
+        const int row = (z * d.ny + y) * d.nx;      // x is the fastest cell dimension: the cells x0..x1 of a row are one contiguous range
+        const int s = cell[row + x0], e = cell[row + x1 + 1];
+        rs0[r] = s;
+        if (e - s > 64) { long_row = true; continue; }
+        for (int i = s; i < e; i += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = S[min(i + u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+                if (i + u < e && dist < tau) { m[r] |= 1ull << (i + u - s); ++cnt; }
+            }
+        }
+    }
+    if (long_row) return 2;
+    if (cnt < K + 1) {
+        if (n1 > 0) {      // the prefix job may still be answerable from the few candidates inside the radius
+#pragma unroll
+            for (int r = 0; r < W * W; ++r) {
+                unsigned long long mm = m[r];
+                while (mm) {
+                    const int bpos = __ffsll((unsigned long long)mm) - 1;
+                    mm &= mm - 1ull;
+                    const float4 p = S[rs0[r] + bpos];
+                    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                    float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+                    if (__float_as_int(p.w) < n1 && dist < b1) { if (dist < b0) { b1 = b0; b0 = dist; i0 = __float_as_int(p.w); } else b1 = dist; }
+                }
+            }
+        }
+        return 1;
+    }
+    rs.init();
+#pragma unroll
+    for (int r = 0; r < W * W; ++r) {
+        unsigned long long mm = m[r];
+        while (mm) {
+            const int bpos = __ffsll((unsigned long long)mm) - 1;
+            mm &= mm - 1ull;
+            const float4 p = S[rs0[r] + bpos];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+            const int id = __float_as_int(p.w);
+            if (id < n1 && dist < b1) { if (dist < b0) { b1 = b0; b0 = dist; i0 = id; } else b1 = dist; }
+            if (dist < rs.worst()) rs.add(dist, id);
+        }
+    }
+    return 0;
+}
+
+// first pass: grid.y = job (one support set x one query set x one output block), grid.x = blocks of 256 queries; the 3^3 block.
+// job.job1 >= 0 (pyramid): the K = 1 job over the first n1 support points is answered in the same scan when its nearest prefix point
+// lies inside the guaranteed radius and clear of the runner-up; otherwise that job's own (coarser) grid answers the row in its retry pass.
 template <int K, typename OutT>
 __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
     const int jid = a.job0 + blockIdx.y;
@@ -249,88 +333,32 @@ __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
     } else {
         qx = job.qpts[3 * (size_t)q]; qy = job.qpts[3 * (size_t)q + 1]; qz = job.qpts[3 * (size_t)q + 2];
     }
-    const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
-    const int* cell = a.cell + d.cell_off;
-    const float4* S = a.sorted + d.pt_off;
-
-
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, d.nx - 1);
-    // every point outside the block is at least g away (faces on the grid boundary have nothing beyond them)
-    float g = FLT_MAX;
-    if (x0 > 0) g = fminf(g, qx - (d.lo[0] + (float)x0 * d.c));
-    if (x1 < d.nx - 1) g = fminf(g, (d.lo[0] + (float)(x1 + 1) * d.c) - qx);
-    if (cy > 1) g = fminf(g, qy - (d.lo[1] + (float)(cy - 1) * d.c));
-    if (cy + 1 < d.ny - 1) g = fminf(g, (d.lo[1] + (float)(cy + 2) * d.c) - qy);
-    if (cz > 1) g = fminf(g, qz - (d.lo[2] + (float)(cz - 1) * d.c));
-    if (cz + 1 < d.nz - 1) g = fminf(g, (d.lo[2] + (float)(cz + 2) * d.c) - qz);
-    bool again = !(g > 0.f);
-    float tau = FLT_MAX;
-    if (g < FLT_MAX) { const float gs = g * 0.99998f; tau = gs * gs; }      // cell boundaries are rounded fp32 products: stay inside
-    unsigned long long m[9]; int rs0[9];
-    int cnt = 0;
-    float b0 = FLT_MAX, b1 = FLT_MAX; int i0 = 0;                            // two nearest among the first n1 support points
-    const int n1 = job.job1 >= 0 ? job.n1 : 0;
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
-        m[r] = 0ull; rs0[r] = 0;
-        if (z < 0 || z >= d.nz || y < 0 || y >= d.ny) continue;
-        const int row = (z * d.ny + y) * d.nx;      // x is the fastest cell dimension: the cells x0..x1 of a row are one contiguous range
-        const int s = cell[row + x0], e = cell[row + x1 + 1];
-        rs0[r] = s;
-        if (e - s > 64) { again = true; continue; }
-        for (int i = s; i < e; i += 4) {
-            float4 p[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = S[min(i + u, e - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
-                if (i + u < e) {
-                    if (dist < tau) { m[r] |= 1ull << (i + u - s); ++cnt; }
-                    if (K == 16 && __float_as_int(p[u].w) < n1 && dist < b1) {
-                        if (dist < b0) { b1 = b0; b0 = dist; i0 = __float_as_int(p[u].w); } else b1 = dist;
-                    }
-                }
-            }
-        }
-    }
-    if (K == 16 && job.job1 >= 0) {
-        // final iff the nearest prefix point lies inside the guaranteed radius and the runner-up (seen, or anything beyond the radius) is
-        // clear of it by more than the near-tie margin; otherwise the K = 1 job answers the row itself
-        const float second = fminf(b1, tau);
-        if (!again && b0 < tau && b0 * 1.0000019073486328f < second) {
+    RegSet<K + 1> rs;
+    float b0 = FLT_MAX, b1 = FLT_MAX, tau = 0.f; int i0 = 0;
+    const bool fuse1 = K == 16 && job.job1 >= 0;
+    const int st = grid_mark_select<K, 1>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, rs, fuse1 ? job.n1 : 0, b0, b1, i0, tau);
+    if (fuse1) {
+        // final iff the masks held the block, the nearest prefix point lies inside the guaranteed radius and the runner-up (seen, or anything beyond the
+        // radius) is clear of it by more than the near-tie margin
+        if (st != 2 && b0 < tau && b0 * NEAR_TIE < fminf(b1, tau)) {
             const GridJob j1 = a.jobs[job.job1];
             reinterpret_cast<OutT*>(j1.out)[q] = (OutT)i0;
         } else {
             const int w = atomicAdd(a.retry_count + 1, 1);
             int* r1 = a.retry + 2 * (size_t)a.work_cap;          // retry list of K = 1 follows the one of K = 16
-            r1[2 * (size_t)w] = job.job1 | RETRY_FROM_R1; r1[2 * (size_t)w + 1] = q;      // its own (coarser) grid has not been tried yet
+            r1[2 * (size_t)w] = job.job1 | RETRY_FROM_R1; r1[2 * (size_t)w + 1] = q;      // its own grid has not been tried yet
         }
     }
-    if (again || cnt < K + 1) {
+    if (st != 0) {
         const int w = atomicAdd(a.retry_count, 1);             // < work_cap by construction (one entry per query at most)
-        a.retry[2 * (size_t)w] = again ? (jid | RETRY_FROM_R1) : jid; a.retry[2 * (size_t)w + 1] = q;      // a row too long for the masks can still settle at 3^3
+        a.retry[2 * (size_t)w] = st == 2 ? (jid | RETRY_FROM_R1) : jid; a.retry[2 * (size_t)w + 1] = q;      // st == 2: the 3^3 block can still settle by streaming
         return;
-    }
-    RegSet<K + 1> rs; rs.init();
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        unsigned long long mm = m[r];
-        while (mm) {
-            const int bpos = __ffsll((unsigned long long)mm) - 1;
-            mm &= mm - 1ull;
-            const float4 p = S[rs0[r] + bpos];
-            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-            float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
-            if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
-        }
     }
     grid_finish<K, OutT>(a, job, jid, q, true, rs);
 }
 
-// second pass over the rows the first one left: 5^3, then 7^3 cells
+// second pass over the rows the first one left (compacted: a lane that needs a larger block no longer holds its wave): 3^3
+// (3^3 for the rows the masks could not hold and for K = 1 rows on their own grid), 5^3, 7^3 with the streaming insertion
 template <int K, typename OutT>
 __global__ __launch_bounds__(64) void grid_retry_kernel(GridSearchArgs a) {
     const int n = min(*a.retry_count, a.work_cap);
@@ -343,6 +371,7 @@ __global__ __launch_bounds__(64) void grid_retry_kernel(GridSearchArgs a) {
         const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
         RegSet<K + 1> rs;
         bool settled = false;
+        // (marking the 5^3 block as well was measured slower here: 25 masks + 25 range starts per lane cost more than the insertions they save)
         for (int R = (tag & RETRY_FROM_R1) ? 1 : 2; R <= GS_RMAX && !settled; ++R) settled = grid_scan<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, R, rs);
         grid_finish<K, OutT>(a, job, jid, q, settled, rs);
     }
