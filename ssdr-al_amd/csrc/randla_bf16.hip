@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseArgs a) {
 #pragma unroll
             for (int t = 0; t < TERMS; ++t) {
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (gc < a.N) v = ld128((t ? a.wt_lo : a.wt_hi) + (size_t)gc * a.kp + kc + sk);     // kp is padded: always in range
+                if (gc < a.N && kc + sk < a.kp) v = ld128((t ? a.wt_lo : a.wt_hi) + (size_t)gc * a.kp + kc + sk);     // rows are padded to kp (a multiple of 64)
                 rb[h][t] = v;
             }
         }
