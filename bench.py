@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=("f32", "bf16x3", "bf16"),
                     help="arithmetic of the network's matrix products (activations / accumulation are fp32 in every mode); bf16x3 = split bf16, "
                          "inside the 1e-3 feature tolerance of the fp32 path (tests/test_randla.py); bf16 = BASELINE configuration 3")
+    ap.add_argument("--selector", default="fps", choices=("fps", "kcenter"),
+                    help="final selection over the (gathered) propagated features: FPS (the paper's gcn_fps branch) or the global k-center of BASELINE configuration 4")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,7 +80,7 @@ def main():
 
     weights = synthetic.init_weights(0)         # random-init weights of the reference architecture (helper_tf_util.py:43-48 rule)
     rooms = [synthetic.make_room(5000 + rank * TILES_PER_GPU + i, density=RAW_DENSITY) for i in range(TILES_PER_GPU)]
-    hp = pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
+    hp = pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision, selector=args.selector).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
 
     gather = None
     if use_dist:
@@ -101,7 +103,7 @@ def main():
     if not args.no_pipeline:
         ids = [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)]
         def mk():
-            return pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision).load_rooms(rooms, ids)
+            return pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision, selector=args.selector).load_rooms(rooms, ids)
         pipe = pipeline.Pipelined(mk, args.pipeline_depth)
     if pipe is not None:
         pipe.run(max(args.warmup, 1), gather, steady=True)
@@ -253,7 +255,7 @@ def main():
                "dtype": DTYPE[args.precision], "data": "synthetic",
                "config": {"workload": "S3DIS-like rooms (synthetic, Area_5 seeds), %d rooms/tiles of 40960 points per GPU per step: grid-subsample "
                                       "dl=0.04 -> tile -> KNN pyramid k=16 [4,4,4,4,2] -> RandLA-Net infer (random-init weights, %s matrix products) -> WetSU/sb/clsbal "
-                                      "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, FPS start fixed to candidate 0)" % (TILES_PER_GPU, args.precision),
+                                      "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, %s)" % (TILES_PER_GPU, args.precision, "FPS start fixed to candidate 0" if args.selector == "fps" else "global k-center over candidates + labelled regions"),
                           "tiles_per_gpu": TILES_PER_GPU, "tile_points": ConfigS3DIS.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
                           "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * TILES_PER_GPU * world), "sharding": "tiles",
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,

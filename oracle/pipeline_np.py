@@ -100,7 +100,10 @@ def run(hp, rooms, weights, threads=1, net_outputs=None, stop_after=None):
         cen = S.bbox_centres(flat, so, spts)
         blocks.append(S.keep_top(S.block_adjacency(cen, S.create_cd(flat, so, spts, cen)), hp.gcn_top)); rows_l.append(rows)
     comb = S.propagate(blocks, rows_l, V, hp.gcn_number)
-    seq = S.farthest_features_sample(comb[:len(unl)], sampling_batch, 0)
+    if getattr(hp, "selector", "fps") == "kcenter":      # kCenterGreedy over candidates + labelled rows, the labelled ones already selected (gcn.py:247)
+        seq = S.kcenter_greedy(comb, np.arange(len(unl), len(refs)), sampling_batch)
+    else:
+        seq = S.farthest_features_sample(comb[:len(unl)], sampling_batch, 0)
     t.append(time.perf_counter())
     out.update(selected=seq, unl=unl, comb=comb, stage_ms=dict(zip(("subsample+tile", "knn_pyramid", "randla_infer", "score", "select"), np.diff(t) * 1e3)))
     return out

@@ -17,13 +17,18 @@ from .helper_tool import ConfigS3DIS
 
 class HotPath:
     def __init__(self, weights, config=ConfigS3DIS, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=1, gcn_top=0,
-                 select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32"):
+                 select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32", selector="fps"):
         self.cfg = config
         self.net = randlanet.Network(config).load(weights).set_precision(precision)
         self.sampler_args = list(sampler_args)
         self.gcn_number, self.gcn_top = gcn_number, gcn_top
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
         self.seed = seed
+        # "fps": farthest_features_sample over the candidates' propagated features (the gcn_fps branch, sampler2.py:736-781);
+        # "kcenter": kCenterGreedy.select_batch_ over candidates + labelled regions with the labelled ones as already selected
+        # (the step the reference's gcn branch ends with, gcn.py:247, kcenterGreedy.py:60-128; BASELINE configuration 4's global k-center)
+        assert selector in ("fps", "kcenter")
+        self.selector = selector
         self.stream = None          # stream of the pyramid .. scoring stages (None = the library's main stream)
         self.front_stream = None    # stream of the front end (grid-subsample + tiles)
         self.knn_stream = None      # stream of the KNN pyramid (None = self.stream)
@@ -147,6 +152,7 @@ class HotPath:
         batch = self.select_per_tile * int(S_all[:, 1].sum())
         self._dist = dict(comm=comm, Smax=Smax, Bmax=Bmax, valid=lab == 0, gcloud=gcloud, room=room, spin=spin, batch=batch,
                           S_total=int(S_all[:, 0].sum()), nu_max=int(min(2 * batch, Smax)),
+                          nlab=comm.allgather_host(np.array([int(self.labeled_mask.sum())], np.int64)).reshape(-1),
                           d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)),
                           d_masked=DevArray((Smax,), np.float64), d_all=DevArray((W * Smax,), np.float64), d_ord=DevArray((W * Smax,), np.int32))
         return self._dist
@@ -262,19 +268,39 @@ class HotPath:
             src_v = dst
         keep = [d_pack, d_cen, d_dir, d_adj, d_v, d_tmp, d_mf, d_comb]
         self.unl_cloud_ids, self.unl_sp = gl_room, gl_sp          # (room id, superpoint inside its room) of every candidate, global order
+        n_lab = len(lab)
         if comm is not None:                                 # exchange 3: the candidates' propagated features, on the selection stream
             D = self.global_order
-            d_gath = DevArray((comm.world, D["nu_max"], 32), np.float64)
-            comm.allgather_(_Prefix(d_comb, D["nu_max"] * 32), d_gath, None)
+            kc = self.selector == "kcenter"                  # k-center also needs the labelled regions' rows of every rank
+            nl_max = int(D["nlab"].max()) if kc else 0
+            per = D["nu_max"] + nl_max
+            d_send = d_comb
+            if kc:                                           # [candidates, padded to nu_max | labelled, padded to nl_max]
+                send_idx = np.zeros(per, np.int32)
+                send_idx[: len(unl)] = np.arange(len(unl)); send_idx[D["nu_max"]: D["nu_max"] + n_lab] = len(unl) + np.arange(n_lab)
+                d_sidx = DevArray.from_host(send_idx); d_send = DevArray((per, 32), np.float64)
+                _lib.check(L.ssdr_gather_rows_dev(d_comb.ptr, d_sidx.ptr, per, 32 * 8, d_send.ptr, None))
+                keep += [d_sidx, d_send]
+                src = np.concatenate([r * per + np.arange(c) for r, c in enumerate(counts_r)] +
+                                     [r * per + D["nu_max"] + np.arange(c) for r, c in enumerate(D["nlab"])]).astype(np.int32)
+                d_src_a = DevArray.from_host(src); d_src = d_src_a.ptr; keep.append(d_src_a)
+                n_lab = int(D["nlab"].sum())
+            d_gath = DevArray((comm.world, per, 32), np.float64)
+            comm.allgather_(_Prefix(d_send, per * 32), d_gath, None)
             n_unl = int(counts_r.sum())
-            d_glob = DevArray((max(n_unl, 1), 32), np.float64)
-            _lib.check(L.ssdr_gather_rows_dev(d_gath.ptr, d_src, n_unl, 32 * 8, d_glob.ptr, None))
+            n_rows = n_unl + (n_lab if kc else 0)
+            d_glob = DevArray((max(n_rows, 1), 32), np.float64)
+            _lib.check(L.ssdr_gather_rows_dev(d_gath.ptr, d_src, n_rows, 32 * 8, d_glob.ptr, None))
             keep += [d_gath, d_glob]
             d_comb = d_glob
-            self._comb_dev, self._comb_n = d_glob, n_unl
+            self._comb_dev, self._comb_n = d_glob, n_rows
         d_out = DevArray((sampling_batch,), np.int32)
-        start = 0                                            # np.random.randint(0, n) in the reference (:133); fixed here
-        _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
+        if self.selector == "kcenter":
+            d_already = DevArray.from_host((n_unl + np.arange(n_lab)).astype(np.int32)); keep.append(d_already)
+            _lib.check(L.ssdr_kcenter_dev(d_comb.ptr, n_unl + n_lab, 32, d_already.ptr, n_lab, sampling_batch, d_out.ptr, None))
+        else:
+            start = 0                                        # np.random.randint(0, n) in the reference (:133); fixed here
+            _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
         self._keep = keep
         self._pending = (d_out, unl)
 

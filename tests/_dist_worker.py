@@ -32,12 +32,19 @@ def main():
     # the same batches kept in flight on separate streams, exchanges included (what bench.py runs for N > 1)
     pipe = pipeline.Pipelined(lambda: pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine), 3)
     psel, _ = pipe.run(2, comm)
-    res = {"pipelined_equal": bool(np.array_equal(psel, sel)), "pipelined_selected": pipe.hp[1].selected,"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
+    # BASELINE configuration 4: all-gather of the candidates' AND the labelled regions' features, then the global k-center (replicated)
+    hk = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2, selector="kcenter").load_rooms([all_rooms[i] for i in mine], mine)
+    hk.step(comm)
+    kc_sharded = hk.selected
+    res = {"kcenter": kc_sharded, "pipelined_equal": bool(np.array_equal(psel, sel)), "pipelined_selected": pipe.hp[1].selected,"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
            "expect": [int(x) for x in S.farthest_features_sample(hp.comb_all, len(sel), 0)]}
     if rank == 0:      # the same job in ONE process over the union of the rooms
         one = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms(all_rooms, list(range(per * world)))
         one.step()
         res["single"] = one.selected
+        onek = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2, selector="kcenter").load_rooms(all_rooms, list(range(per * world)))
+        onek.step()
+        res["single_kcenter"] = onek.selected
     with open(os.path.join(os.environ["SSDR_TEST_OUT"], "rank%d.json" % rank), "w") as f:
         json.dump(res, f)
     dist.destroy_process_group()

@@ -22,6 +22,7 @@ def test_two_rank_sharded_selection_equals_single_process(tmp_path, emu_lib):
     assert len(r[0]["selected"]) == 20 and len(set(map(tuple, r[0]["selected"]))) == 20
     assert {c for c, _ in r[0]["selected"]} <= {0, 1, 2, 3}
     assert r[0]["selected"] == r[0]["single"]          # sharded == single process, index for index
+    assert r[0]["kcenter"] == r[1]["kcenter"] == r[0]["single_kcenter"] and len(r[0]["kcenter"]) == 20      # global k-center (configuration 4)
     assert all(x["pipelined_equal"] and x["pipelined_selected"] == x["selected"] for x in r)    # batches in flight: same result
 
 

@@ -46,10 +46,10 @@ def test_hot_path_matches_oracle_stage_by_stage(backend):
     assert np.array_equal(sel, ref2["selected"])
 
 
-@pytest.mark.parametrize("gcn_number,gcn_top,precision", [(2, 4, "f32"), (1, 100, "f32"), (1, 0, "bf16x3")])
-def test_hot_path_selection_variants(backend, gcn_number, gcn_top, precision):
+@pytest.mark.parametrize("gcn_number,gcn_top,precision,selector", [(2, 4, "f32", "fps"), (1, 100, "f32", "fps"), (1, 0, "bf16x3", "fps"), (1, 0, "f32", "kcenter")])
+def test_hot_path_selection_variants(backend, gcn_number, gcn_top, precision, selector):
     """gcn_top > 0 (the keep-top mask of fps_gcn_cpu.py:153-160; the reference's scripts run --gcn_top 100), two propagation hops,
-    and the split-bf16 network arithmetic: the selection is exact given the network outputs, the features stay inside 1e-3."""
+    the split-bf16 network arithmetic, and the global k-center selector (BASELINE configuration 4): the selection is exact given the network outputs, the features stay inside 1e-3."""
     from oracle import pipeline_np
     from oracle import randla_np as R
     from ssdr_al import pipeline, synthetic
@@ -61,7 +61,7 @@ def test_hot_path_selection_variants(backend, gcn_number, gcn_top, precision):
     W = R.init_weights(0)
     rooms = [synthetic.make_room(5100 + i, density=150.0 if backend == "emu" else 2500.0) for i in range(2)]
     spt, lpt = (12, 4) if backend == "emu" else (37, 15)
-    hp = pipeline.HotPath(W, Cfg, select_per_tile=spt, labeled_per_tile=lpt, gcn_number=gcn_number, gcn_top=gcn_top, precision=precision).load_rooms(rooms)
+    hp = pipeline.HotPath(W, Cfg, select_per_tile=spt, labeled_per_tile=lpt, gcn_number=gcn_number, gcn_top=gcn_top, precision=precision, selector=selector).load_rooms(rooms)
     sel, unl = hp.step()
     gp, gf = hp.probs.to_host(), hp.f32.to_host()
     ref = pipeline_np.run(hp, rooms, W, threads=4)
