@@ -39,6 +39,14 @@ constexpr int PREC_BF16 = 2;      // plain bf16 operands, fp32 accumulate
 
 int launch_dense(const DenseArgs& a, hipStream_t s);
 int launch_lfa(int D, const LfaArgs& a, bool second, int B, hipStream_t s);
+struct TailArgs {         // fc1 + fc2 + fc + softmax on the bf16 cores
+    const float* x; int M, C;
+    const uint16_t *w1h, *w1l; int kp1; const float* b1;
+    const uint16_t *w2h, *w2l; int kp2; const float* b2;
+    const uint16_t *w3h, *w3l; int kp3; const float* b3;
+    float* feat32; float* probs;
+};
+int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s);      // SSDR_ERR_UNSUPPORTED (no error text) when it has no instantiation
 // randla_bf16.hip: the same two operations on the bf16 matrix cores (prec = PREC_BF16X3 / PREC_BF16)
 int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s);
 int launch_lfa_bf16(int D, const LfaArgs& a, bool second, int B, int prec, hipStream_t s);

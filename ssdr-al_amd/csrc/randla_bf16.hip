@@ -388,6 +388,106 @@ __global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) 
     }
 }
 
+// ---- fc1 (32 -> 64) + fc2 (64 -> 32 = last_second_features) + fc (32 -> C) + softmax (RandLANet.py:174-178, :84) ----------------
+// One wave per 16 points, no LDS, no barriers: the point rows arrive in the MFMA operand layout straight from global memory,
+// and each layer is computed TRANSPOSED (A = weight fragment, B = activation fragment), which leaves four consecutive output
+// channels of one point in a lane — exactly the next layer's operand shape once the k slots of that layer are numbered to match
+// (slot (g, j) of a 32-wide k block = channel 4g + j of the block's first 16-channel tile for j < 4, of its second tile for j >= 4;
+// the weight fragments are fetched in the same numbering: two 8-byte loads per lane instead of one 16-byte load).  fc2 is also
+// computed in the other orientation for the coalesced fp32 store of last_second_features.  The class axis of the logits ends up in
+// the accumulator registers x 4 lane rows: softmax as in the LFA kernels.
+template <int TERMS, int C>
+__global__ __launch_bounds__(256) void tail_bf16_kernel(const float* __restrict__ x, const uint16_t* __restrict__ w1h, const uint16_t* __restrict__ w1l, int kp1,
+                                                        const float* __restrict__ b1, const uint16_t* __restrict__ w2h, const uint16_t* __restrict__ w2l, int kp2,
+                                                        const float* __restrict__ b2, const uint16_t* __restrict__ w3h, const uint16_t* __restrict__ w3l, int kp3,
+                                                        const float* __restrict__ b3, int M, float* __restrict__ feat32, float* __restrict__ probs) {
+    const int lane = threadIdx.x & 63, lc = lane & 15, lg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    auto ld64x2 = [](const uint16_t* p0, const uint16_t* p1) {       // two 4-element pieces -> one 8-element fragment
+        const u32x2 a = *reinterpret_cast<const u32x2*>(p0), b = *reinterpret_cast<const u32x2*>(p1);
+        return u32x4{a[0], a[1], b[0], b[1]};
+    };
+    // weight fragments (both pieces), kept in registers for every tile of this wave
+    u32x4 W1[4][2], W2[2][2][2], W3[2];
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) {
+        const uint16_t* p1 = t ? w1l : w1h; const uint16_t* p2 = t ? w2l : w2h; const uint16_t* p3 = t ? w3l : w3h;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) W1[ct][t] = ld128(p1 + (size_t)(16 * ct + lc) * kp1 + 8 * lg);          // fc1: k = input channel, natural order
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) W2[kb][ct][t] = ld64x2(p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 4 * lg, p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 16 + 4 * lg);
+        W3[t] = lc < C ? ld64x2(p3 + (size_t)lc * kp3 + 4 * lg, p3 + (size_t)lc * kp3 + 16 + 4 * lg) : u32x4{0u, 0u, 0u, 0u};
+    }
+    float4 B1[4], B2t[2], B3; float B2c[2];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) B1[ct] = *reinterpret_cast<const float4*>(b1 + 16 * ct + 4 * lg);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) { B2t[ct] = *reinterpret_cast<const float4*>(b2 + 16 * ct + 4 * lg); B2c[ct] = b2[16 * ct + lc]; }
+    {
+        float t[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = 4 * lg + r < C ? b3[4 * lg + r] : 0.f;
+        B3 = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    auto frag = [](const float (&v)[8], u32x4 (&f)[2]) {            // eight fp32 values -> hi / lo fragments
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { unsigned h, l; split_bf16(v[2 * q], v[2 * q + 1], h, l); f[0][q] = h; f[1][q] = l; }
+    };
+    const int ntiles = (M + 15) / 16;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int row = tile * 16 + lc;
+        float xin[8];
+        {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            if (row < M) { a0 = *reinterpret_cast<const float4*>(x + (size_t)row * 32 + 8 * lg); a1 = *reinterpret_cast<const float4*>(x + (size_t)row * 32 + 8 * lg + 4); }
+            xin[0] = a0.x; xin[1] = a0.y; xin[2] = a0.z; xin[3] = a0.w; xin[4] = a1.x; xin[5] = a1.y; xin[6] = a1.z; xin[7] = a1.w;
+        }
+        u32x4 xf[2]; frag(xin, xf);
+        // fc1, transposed: lane (point lc, g) gets channels 16 ct + 4 g + reg
+        float h1[4][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x4 acc = f32x4{B1[ct].x, B1[ct].y, B1[ct].z, B1[ct].w};
+            acc = mma_split<TERMS>(W1[ct], xf, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[ct][r] = lrelu(acc[r]);
+        }
+        // fc2 in both orientations
+        f32x4 at[2] = {f32x4{B2t[0].x, B2t[0].y, B2t[0].z, B2t[0].w}, f32x4{B2t[1].x, B2t[1].y, B2t[1].z, B2t[1].w}};
+        f32x4 ac[2] = {f32x4{B2c[0], B2c[0], B2c[0], B2c[0]}, f32x4{B2c[1], B2c[1], B2c[1], B2c[1]}};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float v[8] = {h1[2 * kb][0], h1[2 * kb][1], h1[2 * kb][2], h1[2 * kb][3], h1[2 * kb + 1][0], h1[2 * kb + 1][1], h1[2 * kb + 1][2], h1[2 * kb + 1][3]};
+            u32x4 hf[2]; frag(v, hf);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) { at[ct] = mma_split<TERMS>(W2[kb][ct], hf, at[ct]); ac[ct] = mma_split<TERMS>(hf, W2[kb][ct], ac[ct]); }
+        }
+        // last_second_features: accumulator layout (point 4 lg + reg, channel 16 ct + lc): 64 contiguous bytes per 16 lanes
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int rr = tile * 16 + 4 * lg + r; if (rr < M) feat32[(size_t)rr * 32 + 16 * ct + lc] = lrelu(ac[ct][r]); }
+        // fc, transposed: classes 4 g + reg of point lc
+        const float v2[8] = {lrelu(at[0][0]), lrelu(at[0][1]), lrelu(at[0][2]), lrelu(at[0][3]), lrelu(at[1][0]), lrelu(at[1][1]), lrelu(at[1][2]), lrelu(at[1][3])};
+        u32x4 ff[2]; frag(v2, ff);
+        f32x4 lg3 = f32x4{B3.x, B3.y, B3.z, B3.w};
+        lg3 = mma_split<TERMS>(W3, ff, lg3);
+        float z[4], m = -3.402823466e+38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z[r] = 4 * lg + r < C ? lg3[r] : -3.402823466e+38f; m = fmaxf(m, z[r]); }
+        m = rows_max(m);
+        float e[4], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = 4 * lg + r < C ? expf(z[r] - m) : 0.f; sum += e[r]; }
+        sum = rows_sum(sum);
+        if (row < M)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * lg + r < C) probs[(size_t)row * C + 4 * lg + r] = e[r] / sum;
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------
 template <int TM, int KC>
 static int launch_dense_bf16_t(const DenseArgs& a, int prec, bool vec, hipStream_t s) {
@@ -415,6 +515,20 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0;
     if (small) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
     return launch_dense_bf16_t<128, 32>(a, prec, vec, s);
+}
+
+int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s) {
+    if (t.M <= 0) return SSDR_OK;
+    if ((t.C != 13 && t.C != 8) || ((uintptr_t)t.x & 15) || !t.w1h || !t.w2h || !t.w3h || (prec == PREC_BF16X3 && (!t.w1l || !t.w2l || !t.w3l))) return SSDR_ERR_UNSUPPORTED;
+    const double m16 = std::ceil(t.M / 16.0) * 16.0;
+    ProfScope prof("tail_kernel", s, (double)t.M * 4.0 * (32 + 32 + t.C), 2.0 * m16 * (32.0 * 64 + 2.0 * 64 * 32 + 32.0 * 16) * (prec == PREC_BF16X3 ? 3.0 : 1.0));
+    const dim3 g((unsigned)std::max(1, std::min((t.M + 63) / 64, ctx().num_cu * 8)));
+#define SSDR_TAIL(TERMS_, C_) hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_>), g, dim3(256), 0, s, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs)
+    if (prec == PREC_BF16X3) { if (t.C == 13) SSDR_TAIL(2, 13); else SSDR_TAIL(2, 8); }
+    else { if (t.C == 13) SSDR_TAIL(1, 13); else SSDR_TAIL(1, 8); }
+#undef SSDR_TAIL
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
 }
 
 template <int D> static int launch_lfa_bf16_d(const LfaArgs& a, bool second, int B, int prec, hipStream_t s) {

@@ -224,7 +224,12 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
     }
     const Layer& l1 = m->layers[li]; const Layer& l2 = m->layers[li + 1]; const Layer& fc = m->layers[li + 2];
     int fused = SSDR_ERR_UNSUPPORTED;
-    if (feat_c == 32 && l1.out == 64 && l2.out == 32 && l1.has_b && l2.has_b)                                // fc1 + fc2 + fc + softmax in one pass
+    if (m->prec != PREC_F32 && feat_c == 32 && l1.out == 64 && l2.out == 32 && l1.has_b && l2.has_b && fc.has_b) {     // ... on the bf16 matrix cores
+        TailArgs t{feat, Bi * N[0], m->C, l1.Wh.as<uint16_t>(), l1.Wl.as<uint16_t>(), l1.kp, l1.b.as<float>(), l2.Wh.as<uint16_t>(), l2.Wl.as<uint16_t>(), l2.kp,
+                   l2.b.as<float>(), fc.Wh.as<uint16_t>(), fc.Wl.as<uint16_t>(), fc.kp, fc.b.as<float>(), d_feat32, d_probs};
+        fused = launch_tail_bf16(t, m->prec, s);
+    }
+    if (fused == SSDR_ERR_UNSUPPORTED && feat_c == 32 && l1.out == 64 && l2.out == 32 && l1.has_b && l2.has_b)          // fc1 + fc2 + fc + softmax in one pass
         fused = launch_tail(feat, l1.W.as<float>(), l1.b.as<float>(), l2.W.as<float>(), l2.b.as<float>(), fc.W.as<float>(), fc.b.as<float>(),
                             Bi * N[0], m->C, d_feat32, d_probs, s);
     if (fused == SSDR_ERR_UNSUPPORTED) {
