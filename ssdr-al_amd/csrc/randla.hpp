@@ -45,6 +45,9 @@ struct TailArgs {         // fc1 + fc2 + fc + softmax on the bf16 cores
     const uint16_t *w2h, *w2l; int kp2; const float* b2;
     const uint16_t *w3h, *w3l; int kp3; const float* b3;
     float* feat32; float* probs;
+    // optional: the last decoder layer in front (x is then unused): x = lrelu([skip | up[idx]] Wd + bd), 32 + 32 -> 32
+    const float* skip; const float* up; const int* idx; int m_per_batch, up_rows_per_batch;
+    const uint16_t *wdh, *wdl; int kpd; const float* bd;
 };
 int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s);      // SSDR_ERR_UNSUPPORTED (no error text) when it has no instantiation
 // randla_bf16.hip: the same two operations on the bf16 matrix cores (prec = PREC_BF16X3 / PREC_BF16)

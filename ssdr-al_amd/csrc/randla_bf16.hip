@@ -396,8 +396,15 @@ __global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) 
 // the weight fragments are fetched in the same numbering: two 8-byte loads per lane instead of one 16-byte load).  fc2 is also
 // computed in the other orientation for the coalesced fp32 store of last_second_features.  The class axis of the logits ends up in
 // the accumulator registers x 4 lane rows: softmax as in the LFA kernels.
-template <int TERMS, int C>
-__global__ __launch_bounds__(256) void tail_bf16_kernel(const float* __restrict__ x, const uint16_t* __restrict__ w1h, const uint16_t* __restrict__ w1l, int kp1,
+//
+// PRE: the last decoder layer (conv2d_transpose over concat[skip, nearest_interpolation(feature)], 32 + 32 -> 32, RandLANet.py:165-172) runs
+// in front of fc1 in the same way, so its output never travels through HBM (84 MB written and read back per step otherwise).
+struct TailPre {          // x = lrelu([skip | gathered] Wd + bd)
+    const float* skip; const float* up; const int* idx; int m_per_batch, up_rows_per_batch;
+    const uint16_t *wh, *wl; int kp; const float* b;
+};
+template <int TERMS, int C, bool PRE>
+__global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float* __restrict__ x, const uint16_t* __restrict__ w1h, const uint16_t* __restrict__ w1l, int kp1,
                                                         const float* __restrict__ b1, const uint16_t* __restrict__ w2h, const uint16_t* __restrict__ w2l, int kp2,
                                                         const float* __restrict__ b2, const uint16_t* __restrict__ w3h, const uint16_t* __restrict__ w3l, int kp3,
                                                         const float* __restrict__ b3, int M, float* __restrict__ feat32, float* __restrict__ probs) {
@@ -408,18 +415,28 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(const float* __restrict_
         return u32x4{a[0], a[1], b[0], b[1]};
     };
     // weight fragments (both pieces), kept in registers for every tile of this wave
-    u32x4 W1[4][2], W2[2][2][2], W3[2];
+    u32x4 W1[4][2], W2[2][2][2], W3[2], WD[PRE ? 2 : 1][2][2];
+    float4 BD[2];
 #pragma unroll
     for (int t = 0; t < TERMS; ++t) {
         const uint16_t* p1 = t ? w1l : w1h; const uint16_t* p2 = t ? w2l : w2h; const uint16_t* p3 = t ? w3l : w3h;
+        if (PRE) {
+            const uint16_t* pd = t ? pre.wl : pre.wh;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) W1[ct][t] = ld128(p1 + (size_t)(16 * ct + lc) * kp1 + 8 * lg);          // fc1: k = input channel, natural order
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) WD[PRE ? kb : 0][ct][t] = ld128(pd + (size_t)(16 * ct + lc) * pre.kp + 32 * kb + 8 * lg);      // k block 0: skip channels, 1: gathered channels
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)      // fc1: k = input channel; natural order when the input comes from memory, the transposed numbering behind the decoder layer
+            W1[ct][t] = PRE ? ld64x2(p1 + (size_t)(16 * ct + lc) * kp1 + 4 * lg, p1 + (size_t)(16 * ct + lc) * kp1 + 16 + 4 * lg) : ld128(p1 + (size_t)(16 * ct + lc) * kp1 + 8 * lg);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) W2[kb][ct][t] = ld64x2(p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 4 * lg, p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 16 + 4 * lg);
         W3[t] = lc < C ? ld64x2(p3 + (size_t)lc * kp3 + 4 * lg, p3 + (size_t)lc * kp3 + 16 + 4 * lg) : u32x4{0u, 0u, 0u, 0u};
     }
+    if (PRE) { BD[0] = *reinterpret_cast<const float4*>(pre.b + 4 * lg); BD[1] = *reinterpret_cast<const float4*>(pre.b + 16 + 4 * lg); }
     float4 B1[4], B2t[2], B3; float B2c[2];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) B1[ct] = *reinterpret_cast<const float4*>(b1 + 16 * ct + 4 * lg);
@@ -438,13 +455,28 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(const float* __restrict_
     const int ntiles = (M + 15) / 16;
     for (int tile = wave; tile < ntiles; tile += nwaves) {
         const int row = tile * 16 + lc;
-        float xin[8];
-        {
+        auto load8 = [&](const float* p, float (&v)[8]) {
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-            if (row < M) { a0 = *reinterpret_cast<const float4*>(x + (size_t)row * 32 + 8 * lg); a1 = *reinterpret_cast<const float4*>(x + (size_t)row * 32 + 8 * lg + 4); }
-            xin[0] = a0.x; xin[1] = a0.y; xin[2] = a0.z; xin[3] = a0.w; xin[4] = a1.x; xin[5] = a1.y; xin[6] = a1.z; xin[7] = a1.w;
+            if (row < M) { a0 = *reinterpret_cast<const float4*>(p + 8 * lg); a1 = *reinterpret_cast<const float4*>(p + 8 * lg + 4); }
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        };
+        u32x4 xf[2];
+        if (PRE) {
+            float sk[8], up[8];
+            const int rw = row < M ? row : 0;
+            load8(pre.skip + (size_t)rw * 32, sk);
+            load8(pre.up + ((size_t)(rw / pre.m_per_batch) * pre.up_rows_per_batch + (size_t)pre.idx[rw]) * 32, up);
+            u32x4 sf[2], uf[2]; frag(sk, sf); frag(up, uf);
+            f32x4 d0 = f32x4{BD[0].x, BD[0].y, BD[0].z, BD[0].w}, d1 = f32x4{BD[1].x, BD[1].y, BD[1].z, BD[1].w};
+            d0 = mma_split<TERMS>(WD[0][0], sf, d0); d0 = mma_split<TERMS>(WD[PRE ? 1 : 0][0], uf, d0);
+            d1 = mma_split<TERMS>(WD[0][1], sf, d1); d1 = mma_split<TERMS>(WD[PRE ? 1 : 0][1], uf, d1);
+            const float v[8] = {lrelu(d0[0]), lrelu(d0[1]), lrelu(d0[2]), lrelu(d0[3]), lrelu(d1[0]), lrelu(d1[1]), lrelu(d1[2]), lrelu(d1[3])};
+            frag(v, xf);
+        } else {
+            float xin[8];
+            load8(x + (size_t)(row < M ? row : 0) * 32, xin);
+            frag(xin, xf);
         }
-        u32x4 xf[2]; frag(xin, xf);
         // fc1, transposed: lane (point lc, g) gets channels 16 ct + 4 g + reg
         float h1[4][4];
 #pragma unroll
@@ -519,11 +551,13 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
 
 int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s) {
     if (t.M <= 0) return SSDR_OK;
-    if ((t.C != 13 && t.C != 8) || ((uintptr_t)t.x & 15) || !t.w1h || !t.w2h || !t.w3h || (prec == PREC_BF16X3 && (!t.w1l || !t.w2l || !t.w3l))) return SSDR_ERR_UNSUPPORTED;
+    if ((t.C != 13 && t.C != 8) || (!t.skip && ((uintptr_t)t.x & 15)) || (t.skip && (((uintptr_t)t.skip | (uintptr_t)t.up) & 15)) || !t.w1h || !t.w2h || !t.w3h || (prec == PREC_BF16X3 && (!t.w1l || !t.w2l || !t.w3l))) return SSDR_ERR_UNSUPPORTED;
     const double m16 = std::ceil(t.M / 16.0) * 16.0;
-    ProfScope prof("tail_kernel", s, (double)t.M * 4.0 * (32 + 32 + t.C), 2.0 * m16 * (32.0 * 64 + 2.0 * 64 * 32 + 32.0 * 16) * (prec == PREC_BF16X3 ? 3.0 : 1.0));
+    ProfScope prof("tail_kernel", s, (double)t.M * 4.0 * (32 + 32 + t.C), 2.0 * m16 * ((t.skip ? 64.0 * 32 : 0.0) + 32.0 * 64 + 2.0 * 64 * 32 + 32.0 * 16) * (prec == PREC_BF16X3 ? 3.0 : 1.0));
     const dim3 g((unsigned)std::max(1, std::min((t.M + 63) / 64, ctx().num_cu * 8)));
-#define SSDR_TAIL(TERMS_, C_) hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_>), g, dim3(256), 0, s, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs)
+    TailPre pre{t.skip, t.up, t.idx, t.m_per_batch, t.up_rows_per_batch, t.wdh, t.wdl, t.kpd, t.bd};
+#define SSDR_TAIL(TERMS_, C_) do { if (t.skip) hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_, true>), g, dim3(256), 0, s, pre, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs); \
+                               else hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_, false>), g, dim3(256), 0, s, pre, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs); } while (0)
     if (prec == PREC_BF16X3) { if (t.C == 13) SSDR_TAIL(2, 13); else SSDR_TAIL(2, 8); }
     else { if (t.C == 13) SSDR_TAIL(1, 13); else SSDR_TAIL(1, 8); }
 #undef SSDR_TAIL

@@ -213,21 +213,35 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
     float* dec = buf(6 * L + 1, B * (size_t)N[L] * d_in); if (!dec) return SSDR_ERR_HIP;
     SSDR_TRY(run_dense(*m, dense(enc.back(), d_in, m->layers[li++], dec, Bi * N[L], 1), s));                  // decoder_0
     const float* feat = dec; int feat_c = d_in, feat_n = N[L];
+    // the last decoder layer (32 + 32 -> 32 in the reference's configurations) rides in front of the fused tail in the bf16 modes
+    const Layer& l1 = m->layers[li + L]; const Layer& l2 = m->layers[li + L + 1]; const Layer& fc = m->layers[li + L + 2];
+    const bool tail16 = m->prec != PREC_F32 && l1.in == 32 && l1.out == 64 && l2.out == 32 && l1.has_b && l2.has_b && fc.has_b && (m->C == 13 || m->C == 8);
+    TailArgs t{};
     for (int j = 0; j < L; ++j) {
         const int e = (int)enc.size() - j - 2;
         const int skip_c = enc_ch[e], n = enc_n[e];
+        const Layer& ld = m->layers[li];
+        if (j == L - 1 && tail16 && skip_c == 32 && feat_c == 32 && ld.has_b) {
+            t.skip = enc[e]; t.up = feat; t.idx = d_interp_idx[L - 1 - j]; t.m_per_batch = n; t.up_rows_per_batch = feat_n;
+            t.wdh = ld.Wh.as<uint16_t>(); t.wdl = ld.Wl.as<uint16_t>(); t.kpd = ld.kp; t.bd = ld.b.as<float>();
+            ++li; feat = nullptr; feat_c = skip_c; feat_n = n;
+            break;
+        }
         float* y = buf(6 * L + 2 + (j & 1), B * (size_t)n * skip_c); if (!y) return SSDR_ERR_HIP;
         DenseArgs a = dense(enc[e], skip_c, m->layers[li++], y, Bi * n, 1);
         a.x2 = feat; a.k2 = feat_c; a.idx2 = d_interp_idx[L - 1 - j]; a.m_per_batch = n; a.x2_rows_per_batch = feat_n;
         SSDR_TRY(run_dense(*m, a, s));
         feat = y; feat_c = skip_c; feat_n = n;
     }
-    const Layer& l1 = m->layers[li]; const Layer& l2 = m->layers[li + 1]; const Layer& fc = m->layers[li + 2];
     int fused = SSDR_ERR_UNSUPPORTED;
-    if (m->prec != PREC_F32 && feat_c == 32 && l1.out == 64 && l2.out == 32 && l1.has_b && l2.has_b && fc.has_b) {     // ... on the bf16 matrix cores
-        TailArgs t{feat, Bi * N[0], m->C, l1.Wh.as<uint16_t>(), l1.Wl.as<uint16_t>(), l1.kp, l1.b.as<float>(), l2.Wh.as<uint16_t>(), l2.Wl.as<uint16_t>(), l2.kp,
-                   l2.b.as<float>(), fc.Wh.as<uint16_t>(), fc.Wl.as<uint16_t>(), fc.kp, fc.b.as<float>(), d_feat32, d_probs};
+    if (tail16 && feat_c == 32) {     // fc1 + fc2 + fc + softmax (+ the decoder layer) on the bf16 matrix cores
+        t.x = feat; t.M = Bi * N[0]; t.C = m->C;
+        t.w1h = l1.Wh.as<uint16_t>(); t.w1l = l1.Wl.as<uint16_t>(); t.kp1 = l1.kp; t.b1 = l1.b.as<float>();
+        t.w2h = l2.Wh.as<uint16_t>(); t.w2l = l2.Wl.as<uint16_t>(); t.kp2 = l2.kp; t.b2 = l2.b.as<float>();
+        t.w3h = fc.Wh.as<uint16_t>(); t.w3l = fc.Wl.as<uint16_t>(); t.kp3 = fc.kp; t.b3 = fc.b.as<float>();
+        t.feat32 = d_feat32; t.probs = d_probs;
         fused = launch_tail_bf16(t, m->prec, s);
+        if (fused == SSDR_ERR_UNSUPPORTED && t.skip) { set_error("randla: the fused decoder + tail kernel refused its arguments"); return SSDR_ERR_INTERNAL; }
     }
     if (fused == SSDR_ERR_UNSUPPORTED && feat_c == 32 && l1.out == 64 && l2.out == 32 && l1.has_b && l2.has_b)          // fc1 + fc2 + fc + softmax in one pass
         fused = launch_tail(feat, l1.W.as<float>(), l1.b.as<float>(), l2.W.as<float>(), l2.b.as<float>(), fc.W.as<float>(), fc.b.as<float>(),
