@@ -179,24 +179,9 @@ struct GridSearchArgs {
     int* work; int* work_count; int work_cap; int* need; int* status;
 };
 
-// One query against the block of (2R+1)^3 cells around its cell.  Returns true when the K + 1 best found are final: every point
-// outside the block is farther than the (K+1)-th.
+// true when the K + 1 best found inside the block [x0..x1] x [y0..y1] x [z0..z1] are final: every point outside it is farther than the (K+1)-th
 template <int K>
-__device__ __forceinline__ bool grid_scan(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
-                                          int cx, int cy, int cz, int R, RegSet<K + 1>& rs) {
-    rs.init();
-    const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1), y0 = max(cy - R, 0), y1 = min(cy + R, d.ny - 1), z0 = max(cz - R, 0), z1 = min(cz + R, d.nz - 1);
-    for (int z = z0; z <= z1; ++z)
-        for (int y = y0; y <= y1; ++y) {
-            const int row = (z * d.ny + y) * d.nx;      // x is the fastest cell dimension: the cells x0..x1 of a row are one contiguous range
-            const int s = cell[row + x0], e = cell[row + x1 + 1];
-            for (int i = s; i < e; ++i) {
-                const float4 p = S[i];
-                const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
-                if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
-            }
-        }
+__device__ __forceinline__ bool grid_settled(const GridDesc& d, float qx, float qy, float qz, int x0, int x1, int y0, int y1, int z0, int z1, const RegSet<K + 1>& rs) {
     // every point outside the scanned block is at least g away (faces on the grid boundary have nothing beyond them)
     float g = FLT_MAX;
     if (x0 > 0) g = fminf(g, qx - (d.lo[0] + (float)x0 * d.c));
@@ -209,6 +194,74 @@ __device__ __forceinline__ bool grid_scan(const GridDesc& d, const int* __restri
     if (!(g > 0.f)) return false;
     const float gs = g * 0.99998f;                          // cell boundaries are rounded fp32 products: stay inside
     return rs.worst() <= gs * gs;
+}
+
+template <int K>
+__device__ __forceinline__ void grid_scan_range(const float4* __restrict__ S, int s, int e, float qx, float qy, float qz, RegSet<K + 1>& rs) {
+    for (int i = s; i < e; ++i) {
+        const float4 p = S[i];
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+        if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
+    }
+}
+
+// One query against the block of (2R+1)^3 cells around its cell.  Returns true when the K + 1 best found are final.
+template <int K>
+__device__ __forceinline__ bool grid_scan(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
+                                          int cx, int cy, int cz, int R, RegSet<K + 1>& rs) {
+    rs.init();
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1), y0 = max(cy - R, 0), y1 = min(cy + R, d.ny - 1), z0 = max(cz - R, 0), z1 = min(cz + R, d.nz - 1);
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+            const int row = (z * d.ny + y) * d.nx;      // x is the fastest cell dimension: the cells x0..x1 of a row are one contiguous range
+            grid_scan_range<K>(S, cell[row + x0], cell[row + x1 + 1], qx, qy, qz, rs);
+        }
+    return grid_settled<K>(d, qx, qy, qz, x0, x1, y0, y1, z0, z1, rs);
+}
+
+// distance from q to the slab of cell index i along one axis, shortened by the margin (cell boundaries are rounded fp32 products and
+// a point's cell comes from a rounded quotient: the margin is far above both)
+__device__ __forceinline__ float slab_gap(float q, float lo, float c, int i, int ci, float mg) {
+    const float gap = i == ci ? 0.f : (i > ci ? (lo + (float)i * c) - q : q - (lo + (float)(i + 1) * c));
+    return fmaxf(gap - mg, 0.f);
+}
+
+// Widens a scanned block of radius R - 1 (its K + 1 best are in rs) to radius R: only the cells of the new shell that the ball of
+// the current (K+1)-th distance around the query reaches are read — anything outside that ball cannot enter the set, so the result
+// is that of the full block scan.
+template <int K>
+__device__ __forceinline__ bool grid_scan_shell(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
+                                                int cx, int cy, int cz, int R, RegSet<K + 1>& rs) {
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1), y0 = max(cy - R, 0), y1 = min(cy + R, d.ny - 1), z0 = max(cz - R, 0), z1 = min(cz + R, d.nz - 1);
+    const float mg = d.c * 1.0e-3f + 1.0e-6f * fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+    const float r = sqrtf(rs.worst()) * 1.00001f + mg;      // fewer than K + 1 found so far: worst is FLT_MAX and the ball is everything
+    const float r2 = r * r;
+    const int zs = max(z0, cell_of(qz - r, d.lo[2], d.inv_c, d.nz)), ze = min(z1, cell_of(qz + r, d.lo[2], d.inv_c, d.nz));
+    const int ix0 = cx - (R - 1), ix1 = cx + (R - 1);
+    for (int z = zs; z <= ze; ++z) {
+        const float gz = slab_gap(qz, d.lo[2], d.c, z, cz, mg);
+        const float remz = r2 - gz * gz;
+        if (!(remz > 0.f)) continue;
+        const float hy = sqrtf(remz);
+        const int ys = max(y0, cell_of(qy - hy, d.lo[1], d.inv_c, d.ny)), ye = min(y1, cell_of(qy + hy, d.lo[1], d.inv_c, d.ny));
+        for (int y = ys; y <= ye; ++y) {
+            const float gy = slab_gap(qy, d.lo[1], d.c, y, cy, mg);
+            const float rem = remz - gy * gy;
+            if (!(rem > 0.f)) continue;
+            const float h = sqrtf(rem);
+            const int xs = max(x0, cell_of(qx - h, d.lo[0], d.inv_c, d.nx)), xe = min(x1, cell_of(qx + h, d.lo[0], d.inv_c, d.nx));
+            if (xs > xe) continue;
+            const int row = (z * d.ny + y) * d.nx;
+            const bool inner = abs(z - cz) < R && abs(y - cy) < R;      // this row of cells crosses the block already scanned
+            if (!inner) grid_scan_range<K>(S, cell[row + xs], cell[row + xe + 1], qx, qy, qz, rs);
+            else {
+                if (xs < ix0) grid_scan_range<K>(S, cell[row + xs], cell[row + min(xe + 1, ix0)], qx, qy, qz, rs);
+                if (xe > ix1) grid_scan_range<K>(S, cell[row + max(xs, ix1 + 1)], cell[row + xe + 1], qx, qy, qz, rs);
+            }
+        }
+    }
+    return grid_settled<K>(d, qx, qy, qz, x0, x1, y0, y1, z0, z1, rs);
 }
 
 // rows whose answer depends on the tree (ties, a near-tie at the K-th boundary, too few support points, no settled block) go to the
@@ -371,8 +424,10 @@ __global__ __launch_bounds__(64) void grid_retry_kernel(GridSearchArgs a) {
         const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
         RegSet<K + 1> rs;
         bool settled = false;
-        // (marking the 5^3 block as well was measured slower here: 25 masks + 25 range starts per lane cost more than the insertions they save)
-        for (int R = (tag & RETRY_FROM_R1) ? 1 : 2; R <= GS_RMAX && !settled; ++R) settled = grid_scan<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, R, rs);
+        // the 3^3 block again with the streaming insertion (its K + 1 best bound the ball the wider shells are cut to), then the
+        // shells of 5^3 and 7^3.  (Marking the 5^3 block in masks as well was measured slower: 25 masks + 25 range starts per lane.)
+        settled = grid_scan<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, 1, rs);
+        for (int R = 2; R <= GS_RMAX && !settled; ++R) settled = grid_scan_shell<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, R, rs);
         grid_finish<K, OutT>(a, job, jid, q, settled, rs);
     }
 }
