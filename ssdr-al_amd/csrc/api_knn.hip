@@ -18,6 +18,10 @@ constexpr int GRID_TARGET_PTS = 22;      // the measured cell radius holds about
 
 // grid search of a job table split as [jobs16 | jobs1], then the tree walk for the rows the grid handed over
 int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<GridJob>& jobs16, const std::vector<GridJob>& jobs1, bool i64, hipStream_t s) {
+    // squared radius of a handed-over row's ball / its (K+1)-th squared distance (see the tree hand-over below); <= 0: complete trees at once
+    const char* bs = getenv("SSDR_KNN_BALL_SCALE");
+    const float ball_scale = bs ? (float)atof(bs) : 9.f;
+    S.grid.ball_scale = ball_scale > 0.f ? ball_scale : 1.f;
     SSDR_TRY(grid_build(S.grid, sets, GRID_TARGET_PTS, s));
     std::vector<GridJob> jobs(jobs16); jobs.insert(jobs.end(), jobs1.begin(), jobs1.end());
     SSDR_TRY(grid_set_jobs(S.grid, jobs, s));
@@ -42,9 +46,19 @@ int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<G
     std::vector<KdTreeDesc> trees(sets.size());
     for (size_t i = 0; i < sets.size(); ++i) { trees[i].pts = sets[i].pts; trees[i].n = sets[i].n; }
     ProfScope prof("knn_tree_handover", s, 0.0);
-    SSDR_TRY(kd_build(S.forest, trees, s, S.grid.need.as<int>()));
-    if (!jobs16.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(0), S.grid.counters() + 0, S.grid.work_cap, 16, i64, s));
-    if (!jobs1.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(1), S.grid.counters() + 1, S.grid.work_cap, 1, i64, s));
+    // the trees are split only where the balls of the handed-over rows reach; a walk that leaves them (it may, while it has not found
+    // K points yet) puts its row on the fall-back list, and those rows are answered on complete trees
+    KdBalls balls{S.grid.ball_q(), S.grid.ball_tree(), S.grid.counters() + 6, GRID_BALL_CAP};
+    const bool cut = ball_scale > 0.f;
+    SSDR_TRY(kd_build(S.forest, trees, s, S.grid.need.as<int>(), cut ? &balls : nullptr));
+    int* ctr = S.grid.counters();
+    if (!jobs16.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(0), ctr + 0, S.grid.work_cap, 16, i64, s, S.grid.work_list(2), ctr + 8, S.grid.need2()));
+    if (!jobs1.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(1), ctr + 1, S.grid.work_cap, 1, i64, s, S.grid.work_list(3), ctr + 9, S.grid.need2()));
+    if (cut) {
+        SSDR_TRY(kd_rebuild(S.forest, S.grid.need2(), s));
+        if (!jobs16.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(2), ctr + 8, S.grid.work_cap, 16, i64, s));
+        if (!jobs1.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(3), ctr + 9, S.grid.work_cap, 1, i64, s));
+    }
     return SSDR_OK;
 }
 
@@ -130,11 +144,11 @@ int ssdr_knn_status(void* stream, int32_t* out4) {
     int32_t h[4] = {0, 0, 0, 0};
     SSDR_HIP(hipStreamSynchronize(s));
     if (S.grid.need.p && S.grid.nsets > 0) {
-        int g[6] = {0, 0, 0, 0, 0, 0};
+        int g[10] = {0};
         SSDR_HIP(hipMemcpy(g, S.grid.counters(), sizeof(g), hipMemcpyDeviceToHost));
         h[0] = g[0]; h[1] = g[1]; h[2] |= g[2];
         if (getenv("SSDR_KNN_DEBUG")) {
-            fprintf(stderr, "knn grid: second pass for %d (K=16) + %d (K=1) rows; handed over to the tree %d + %d rows, %d of them unsettled\n", g[4], g[5], g[0], g[1], g[3]);
+            fprintf(stderr, "knn grid: second pass for %d (K=16) + %d (K=1) rows; handed over to the tree %d + %d rows, %d of them unsettled; %d + %d again on complete trees\n", g[4], g[5], g[0], g[1], g[3], g[8], g[9]);
             std::vector<GridDesc> d(S.grid.nsets); std::vector<int> need(S.grid.nsets);
             SSDR_HIP(hipMemcpy(d.data(), S.grid.desc.p, sizeof(GridDesc) * d.size(), hipMemcpyDeviceToHost));
             SSDR_HIP(hipMemcpy(need.data(), S.grid.need.p, 4 * need.size(), hipMemcpyDeviceToHost));

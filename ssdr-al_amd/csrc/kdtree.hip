@@ -34,9 +34,9 @@ namespace {
 constexpr int LEAF_MAX = 10;         // knn_.cxx:28 / KDTreeTableAdaptor.h:134
 constexpr int MAX_LEVELS = 40;       // levels launched per build == search stack depth
 constexpr int BIG_LEVELS = 24;       // levels at which nodes above 64 points are still split
-constexpr int CTR_NODES = 0, CTR_STATUS = 1, CTR_DEPTH = 2, CTR_SQ = 3, CTR_QUEUE0 = 8, CTR_TOTAL = CTR_QUEUE0 + MAX_LEVELS + 8;
+constexpr int CTR_STATUS = 1, CTR_DEPTH = 2, CTR_SQ = 3, CTR_QUEUE0 = 8, CTR_TOTAL = CTR_QUEUE0 + MAX_LEVELS + 8;
 constexpr int SMALL_MAX = 64;        // a node of at most one wavefront of points: its whole subtree is built by one wave (kd_small_subtree_kernel)
-constexpr int ST_QUEUE_OVF = 1, ST_NODE_OVF = 2, ST_DEPTH_OVF = 4;
+constexpr int ST_QUEUE_OVF = 1, ST_NODE_OVF = 2, ST_DEPTH_OVF = 4, ST_CLOSED = 16;
 
 // The two-pointer sweep of nanoflann.hpp:951-961 (and :966-973) in closed form: positions [start,end)
 // hold `lim - start` elements with left(i) == true; the k-th left-side element with !left swaps with the
@@ -61,7 +61,9 @@ struct ForestPtrs {
     int* squeue;     // open nodes with <= SMALL_MAX points, [2][queue_cap]
     int ntrees;
     const int* need; // optional: build tree t only if need[t] != 0
+    KdBalls balls;   // optional: split only the nodes a ball reaches
 };
+constexpr int CLOSED = -2;           // node_a.z of a node above LEAF_MAX points that was left unsplit (no ball reaches it)
 
 __global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
     __shared__ float s_mm[(BS / 64) * 6];
@@ -96,8 +98,11 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
     __shared__ int s_sum[(NT / 64) * 2];
     __shared__ int s_w[2][U][NT / 64];
     __shared__ int s_child;
+    __shared__ int s_reach[2];
     const int tid = threadIdx.x;
     const int nq = min(f.ctr[CTR_QUEUE0 + level], f.queue_cap);
+    const int nballs = f.balls.q ? *f.balls.count : 0;
+    const bool cut_to_balls = f.balls.q && nballs <= f.balls.cap;       // more rows than the list holds: build everything
     const int* qin = f.queue + (level & 1) * f.queue_cap;
     int* qout = f.queue + ((level + 1) & 1) * f.queue_cap;
     if (blockIdx.x == 0 && tid == 0 && nq > 0) {
@@ -184,8 +189,29 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
             int c = f.ntrees + 2 * (left + idx);
             if (c + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c = -1; }
             s_child = c;
+            s_reach[0] = s_reach[1] = cut_to_balls ? 0 : 1;
         }
         __syncthreads();
+        if (cut_to_balls) {
+            // does a ball of this tree reach the child's box?  (the box the walk prices it with: the node's box, tight along the cut)
+            int r0 = 0, r1 = 0;
+            for (int i = tid; i < nballs; i += NT) {
+                if (f.balls.tree[i] != tree) continue;
+                const float4 b = f.balls.q[i];
+                const float q[3] = {b.x, b.y, b.z};
+                float lb0 = 0.f, lb1 = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float h0 = d == cf ? m3x[0] : hi[d], l1 = d == cf ? m3n[0] : lo[d];
+                    const float g0 = fmaxf(fmaxf(lo[d] - q[d], q[d] - h0), 0.f), g1 = fmaxf(fmaxf(l1 - q[d], q[d] - hi[d]), 0.f);
+                    lb0 += g0 * g0; lb1 += g1 * g1;
+                }
+                r0 |= lb0 <= b.w; r1 |= lb1 <= b.w;
+            }
+            if (r0) atomicOr(&s_reach[0], 1);
+            if (r1) atomicOr(&s_reach[1], 1);
+            __syncthreads();
+        }
         const int c1 = s_child;
         if (c1 >= 0 && tid < 2) {
             const int c = c1 + tid;
@@ -198,7 +224,8 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
                 f.node_box[6 * (size_t)c + d] = (tid == 1 && d == cf) ? cut : lo[d];
                 f.node_box[6 * (size_t)c + 3 + d] = (tid == 0 && d == cf) ? cut : hi[d];
             }
-            if (cr - cl > SMALL_MAX) {
+            if (cr - cl > LEAF_MAX && !s_reach[tid]) f.node_a[2 * (size_t)(c)] = make_int4(cl, cr, CLOSED, CLOSED);
+            else if (cr - cl > SMALL_MAX) {
                 if (level + 1 >= BIG_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
                 int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
                 if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
@@ -364,8 +391,10 @@ struct LdsSet {   // same rule, slots in LDS ([slot][lane]) for arbitrary K
     __device__ __forceinline__ int get(int j) const { return id[j * 64]; }
 };
 
+// Returns true when the walk wanted to enter a closed node of a partly built tree (the result is then not the reference's).
 template <class RS>
-__device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& td, float qx, float qy, float qz, RS& rs) {
+__device__ __forceinline__ bool kd_walk(const SearchArgs& a, const KdTreeDesc& td, float qx, float qy, float qz, RS& rs) {
+    bool met_closed = false;
     int stk_node[MAX_LEVELS]; float stk_m[MAX_LEVELS], stk_0[MAX_LEVELS], stk_1[MAX_LEVELS], stk_2[MAX_LEVELS];
     int sp = 0;
     // computeInitialDistances (:977-993)
@@ -400,7 +429,8 @@ __device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& t
                 ++sp;
             } else atomicOr(&a.ctr[CTR_STATUS], ST_DEPTH_OVF);
         }
-        {   // leaf (:1275-1289)
+        if (na.z == CLOSED) met_closed = true;
+        else {   // leaf (:1275-1289)
             const float worst = rs.worst();
             for (int i0 = na.x; i0 < na.y; i0 += 4) {
                 float4 pv[4];
@@ -427,6 +457,7 @@ __device__ __forceinline__ void kd_walk(const SearchArgs& a, const KdTreeDesc& t
         }
         if (!found) break;
     }
+    return met_closed;
 }
 
 template <int K, typename OutT>
@@ -466,15 +497,24 @@ __global__ __launch_bounds__(64) void kd_search_any_kernel(SearchArgs a, int K) 
 // Rows handed over by the grid search (knn_grid.hip): pairs (job, query); one lane per row.
 template <int K, typename OutT>
 __global__ __launch_bounds__(64) void kd_search_worklist_kernel(SearchArgs a, const GridJob* __restrict__ jobs, const int* __restrict__ work,
-                                                                const int* __restrict__ count, int cap) {
+                                                                const int* __restrict__ count, int cap, int* fallback, int* fallback_count, int* need2) {
     const int n = min(*count, cap);
     for (int e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
-        const GridJob job = jobs[work[2 * (size_t)e]];
+        const int jid = work[2 * (size_t)e];
+        const GridJob job = jobs[jid];
         const int q = work[2 * (size_t)e + 1];
         const KdTreeDesc td = a.desc[job.sup];
         const float qx = job.qpts[3 * (size_t)q], qy = job.qpts[3 * (size_t)q + 1], qz = job.qpts[3 * (size_t)q + 2];
         RegSet<K> rs; rs.init();
-        if (td.n > 0) kd_walk(a, td, qx, qy, qz, rs);
+        bool met_closed = false;
+        if (td.n > 0) met_closed = kd_walk(a, td, qx, qy, qz, rs);
+        if (met_closed) {       // the tree was built for the balls of the handed-over rows and this walk left them: again on the complete tree
+            if (fallback) {
+                const int w = atomicAdd(fallback_count, 1);      // at most as many entries as the list the rows come from
+                fallback[2 * (size_t)w] = jid; fallback[2 * (size_t)w + 1] = q; need2[job.sup] = 1;
+            } else atomicOr(&a.ctr[CTR_STATUS], ST_CLOSED);
+            continue;
+        }
         OutT* o = reinterpret_cast<OutT*>(job.out) + (size_t)q * K;
 #pragma unroll
         for (int j = 0; j < K; ++j) o[j] = (OutT)rs.get(j);
@@ -634,19 +674,36 @@ ForestPtrs ptrs(const KdForest& f) {
     p.node_box = f.node_box.as<float>();
     p.node_tree = f.node_tree.as<int>(); p.queue = f.queue.as<int>(); p.ctr = f.counters.as<int>();
     p.tmp = f.tmp.as<int>(); p.node_cap = f.node_cap; p.queue_cap = f.queue_cap;
-    p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap; p.ntrees = f.ntrees; p.need = nullptr;
+    p.squeue = f.queue.as<int>() + 2 * (size_t)f.queue_cap; p.ntrees = f.ntrees; p.need = nullptr; p.balls = KdBalls{};
     return p;
 }
 
 }  // namespace
 
-int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s, const int* d_need) {
+// init + one launch per level + the small subtrees, for the trees p.need flags (all without flags)
+static int launch_build(const KdForest& f, const ForestPtrs& p, hipStream_t s) {
+    hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(BS), 0, s, p);
+    const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
+    // nodes above 64 points: one workgroup each, level by level; deeper than BIG_LEVELS a node that large means a
+    // degenerate cloud (flagged, not mis-built).  Everything at or below 64 points: one launch, one wavefront per subtree.
+    for (int level = 0; level < BIG_LEVELS && f.max_n > SMALL_MAX; ++level) {
+        // the first levels have few, large nodes: 8 waves per node (16 would spill at the 128-VGPR cap); later 4
+        if ((f.max_n >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<512>), dim3(grid), dim3(512), 0, s, p, level);
+        else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);
+    }
+    hipLaunchKernelGGL(kd_small_subtree_kernel, dim3(std::max(1, std::min(f.queue_cap / 2 + 1, ctx().num_cu * 16))), dim3(BS), 0, s, p);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s, const int* d_need, const KdBalls* balls) {
     std::vector<KdTreeDesc> trees = trees_in;
     long total = 0;
     for (auto& t : trees) { t.voff = (int)total; t.root = 0; total += t.n; if (total > 0x3fffffffL) { set_error("kd_build: too many points"); return SSDR_ERR_INVALID; } }
     f.ntrees = (int)trees.size(); f.total_pts = (int)total;
     f.node_cap = f.ntrees + 2 * (int)total + 2;
     f.queue_cap = (int)(total / (LEAF_MAX + 1)) + f.ntrees + 16;
+    f.max_n = 0; for (auto& t : trees) f.max_n = std::max(f.max_n, t.n);
     const size_t tp = (size_t)(total ? total : 1);
     SSDR_TRY(f.desc.reserve(sizeof(KdTreeDesc) * (trees.size() + 1)));
     SSDR_TRY(f.sorted.reserve(16 * tp)); SSDR_TRY(f.tmp.reserve(4 * tp));
@@ -667,19 +724,16 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     SSDR_HIP(hipEventRecord(f.staging_ev, s));
     SSDR_HIP(hipMemsetAsync(f.counters.p, 0, 4 * CTR_TOTAL, s));
     ForestPtrs p = ptrs(f); p.need = d_need;
-    hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(BS), 0, s, p);
-    const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
-    // nodes above 64 points: one workgroup each, level by level; deeper than BIG_LEVELS a node that large means a
-    // degenerate cloud (flagged, not mis-built).  Everything at or below 64 points: one launch, one wavefront per subtree.
-    int maxn0 = 0; for (auto& t : trees) maxn0 = std::max(maxn0, t.n);
-    for (int level = 0; level < BIG_LEVELS && maxn0 > SMALL_MAX; ++level) {
-        // the first levels have few, large nodes: 8 waves per node (16 would spill at the 128-VGPR cap); later 4
-        if ((maxn0 >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<512>), dim3(grid), dim3(512), 0, s, p, level);
-        else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);
-    }
-    hipLaunchKernelGGL(kd_small_subtree_kernel, dim3(std::max(1, std::min(f.queue_cap / 2 + 1, ctx().num_cu * 16))), dim3(BS), 0, s, p);
-    SSDR_HIP(hipGetLastError());
-    return SSDR_OK;
+    if (balls) p.balls = *balls;
+    return launch_build(f, p, s);
+}
+
+int kd_rebuild(KdForest& f, const int* d_need, hipStream_t s) {
+    if (f.ntrees == 0) return SSDR_OK;
+    // the queues start empty again; status and depth of the first build stay
+    SSDR_HIP(hipMemsetAsync(f.counters.as<int>() + CTR_SQ, 0, 4 * (CTR_TOTAL - CTR_SQ), s));
+    ForestPtrs p = ptrs(f); p.need = d_need;
+    return launch_build(f, p, s);
 }
 
 int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, size_t q_stride, int nq, int K,
@@ -716,18 +770,19 @@ int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, 
     return SSDR_OK;
 }
 
-int kd_search_worklist(const KdForest& f, const GridJob* d_jobs, const int* d_work, const int* d_count, int work_cap, int K, bool out_i64, hipStream_t s) {
+int kd_search_worklist(const KdForest& f, const GridJob* d_jobs, const int* d_work, const int* d_count, int work_cap, int K, bool out_i64, hipStream_t s,
+                       int* d_fallback, int* d_fallback_count, int* d_need2) {
     if (K != 16 && K != 1) { set_error("work-list search: K=%d has no instantiation (1, 16)", K); return SSDR_ERR_UNSUPPORTED; }
     ForestPtrs p = ptrs(f);
     SearchArgs a{p.desc, p.sorted, p.node_a, p.node_b, 0, nullptr, 0, 0, -1, nullptr, 0, p.ctr};
     // the list is usually empty or short (tie rows of padded tiles): a modest grid-stride launch, one wave per workgroup
     const dim3 grid((unsigned)std::max(1, std::min(work_cap / 64 + 1, ctx().num_cu * 8)));
     if (K == 16) {
-        if (out_i64) hipLaunchKernelGGL((kd_search_worklist_kernel<16, int64_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
-        else hipLaunchKernelGGL((kd_search_worklist_kernel<16, int32_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
+        if (out_i64) hipLaunchKernelGGL((kd_search_worklist_kernel<16, int64_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap, d_fallback, d_fallback_count, d_need2);
+        else hipLaunchKernelGGL((kd_search_worklist_kernel<16, int32_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap, d_fallback, d_fallback_count, d_need2);
     } else {
-        if (out_i64) hipLaunchKernelGGL((kd_search_worklist_kernel<1, int64_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
-        else hipLaunchKernelGGL((kd_search_worklist_kernel<1, int32_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap);
+        if (out_i64) hipLaunchKernelGGL((kd_search_worklist_kernel<1, int64_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap, d_fallback, d_fallback_count, d_need2);
+        else hipLaunchKernelGGL((kd_search_worklist_kernel<1, int32_t>), grid, dim3(64), 0, s, a, d_jobs, d_work, d_count, work_cap, d_fallback, d_fallback_count, d_need2);
     }
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
@@ -768,7 +823,7 @@ int kd_check(const KdForest& f, hipStream_t s) {
     SSDR_HIP(hipMemcpyAsync(h, f.counters.p, sizeof(h), hipMemcpyDeviceToHost, s));
     SSDR_HIP(hipStreamSynchronize(s));
     if (h[CTR_STATUS]) {
-        set_error("kd-tree device status 0x%x (1=queue overflow 2=node overflow 4=tree deeper than %d levels), depth=%d",
+        set_error("kd-tree device status 0x%x (1=queue overflow 2=node overflow 4=tree deeper than %d levels 16=walk into an unbuilt node), depth=%d",
                   h[CTR_STATUS], MAX_LEVELS, h[CTR_DEPTH]);
         return SSDR_ERR_INTERNAL;
     }

@@ -177,6 +177,7 @@ struct GridSearchArgs {
     int* retry; int* retry_count;       // rows whose 3^3 block did not settle: answered by the second pass (compacted: a lane that needs a
                                         // larger block would otherwise hold its whole wave in the loop)
     int* work; int* work_count; int work_cap; int* need; int* status;
+    float4* ball_q; int* ball_tree; int* ball_count; float ball_scale;      // what the tree build is cut to (KdBalls)
 };
 
 // true when the K + 1 best found inside the block [x0..x1] x [y0..y1] x [z0..z1] are final: every point outside it is farther than the (K+1)-th
@@ -278,6 +279,13 @@ __device__ __forceinline__ void grid_finish(const GridSearchArgs& a, const GridJ
         const int w = atomicAdd(a.work_count, 1);
         if (w < a.work_cap) { a.work[2 * (size_t)w] = jid; a.work[2 * (size_t)w + 1] = q; a.need[job.sup] = 1; }
         else atomicOr(a.status, 8);
+        // the walk of this row stays (mostly) inside the ball of its (K+1)-th distance: the tree is built where the balls are
+        const int bi = atomicAdd(a.ball_count, 1);
+        if (bi < GRID_BALL_CAP) {
+            const float* qp = job.qpts + 3 * (size_t)q;
+            a.ball_q[bi] = make_float4(qp[0], qp[1], qp[2], unsettled ? FLT_MAX : rs.d[K] * a.ball_scale);
+            a.ball_tree[bi] = job.sup;
+        }
         return;
     }
     OutT* o = reinterpret_cast<OutT*>(job.out) + (size_t)q * K;
@@ -448,7 +456,8 @@ int grid_build(GridForest& g, const std::vector<GridDesc>& sets_in, int target_p
     SSDR_TRY(g.desc.reserve(sizeof(GridDesc) * sets.size()));
     SSDR_TRY(g.cell.reserve(4 * (size_t)cl + 16)); SSDR_TRY(g.rank.reserve(4 * (size_t)std::max(pt, 1L))); SSDR_TRY(g.sorted.reserve(16 * (size_t)std::max(pt, 1L)));
     SSDR_TRY(g.bsum.reserve(4 * (size_t)g.nsets * g.max_blk));
-    SSDR_TRY(g.need.reserve(4 * (size_t)g.nsets + 32));
+    SSDR_TRY(g.need.reserve(4 * (2 * (size_t)g.nsets + 16)));
+    SSDR_TRY(g.balls.reserve((size_t)GRID_BALL_CAP * 20));
     // descriptors travel through a pinned staging buffer; the event guards its reuse by the next build
     if (g.staging_cap < sets.size()) {
         if (g.staging) (void)hipHostFree(g.staging);
@@ -459,7 +468,7 @@ int grid_build(GridForest& g, const std::vector<GridDesc>& sets_in, int target_p
     memcpy(g.staging, sets.data(), sizeof(GridDesc) * sets.size());
     SSDR_HIP(hipMemcpyAsync(g.desc.p, g.staging, sizeof(GridDesc) * sets.size(), hipMemcpyHostToDevice, s));
     SSDR_HIP(hipEventRecord(g.staging_ev, s));
-    SSDR_HIP(hipMemsetAsync(g.need.p, 0, 4 * (size_t)g.nsets + 32, s));      // need[nsets], [nsets + 1]: work counts, [nsets + 2]: status
+    SSDR_HIP(hipMemsetAsync(g.need.p, 0, 4 * (2 * (size_t)g.nsets + 16), s));      // need[nsets], counters()[16], need2[nsets]
     GridDesc* dd = g.desc.as<GridDesc>();
     const dim3 gp((unsigned)((maxn + 255) / 256), (unsigned)g.nsets), gb((unsigned)g.max_blk, (unsigned)g.nsets);
     ProfScope prof("knn_grid_build", s, 28.0 * (double)pt);
@@ -479,7 +488,8 @@ int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, boo
     const int wl = K == 16 ? 0 : 1;
     int* ctr = g.counters();            // [0], [1]: work counts of the two lists, [2]: status, [3]: unsettled rows, [4], [5]: retry counts
     GridSearchArgs a{g.desc.as<GridDesc>(), g.cell.as<int>(), g.sorted.as<float4>(), g.jobs.as<GridJob>(), job0,
-                     g.work_list(2 + wl), ctr + 4 + wl, g.work_list(wl), ctr + wl, g.work_cap, g.need.as<int>(), ctr + 2};      // K = 16: the retry list / counter of K = 1 lie right behind its own
+                     g.work_list(2 + wl), ctr + 4 + wl, g.work_list(wl), ctr + wl, g.work_cap, g.need.as<int>(), ctr + 2,
+                     g.ball_q(), g.ball_tree(), ctr + 6, g.ball_scale};      // K = 16: the retry list / counter of K = 1 lie right behind its own
     const dim3 grid((unsigned)((max_nq + 255) / 256), (unsigned)njobs);
     const dim3 rgrid((unsigned)std::max(1, std::min(g.work_cap / 64 + 1, ctx().num_cu * 16)));
     const bool first = max_nq > 0;      // max_nq == 0: the jobs were answered inside another scan, only their left-over rows remain

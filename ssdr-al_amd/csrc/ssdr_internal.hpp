@@ -101,11 +101,20 @@ struct KdForest {
     int total_pts = 0;
     int node_cap = 0;
     int queue_cap = 0;
+    int max_n = 0;
 };
+
+// Queries that will walk the forest, known before it is built: (x, y, z, r^2) and the tree each belongs to.  A build that is given
+// them splits only the nodes whose box one of the balls reaches; the other nodes stay closed, and a walk that wants to enter a
+// closed node reports its row instead of answering it (kd_search_worklist's fall-back list).
+struct KdBalls { const float4* q = nullptr; const int* tree = nullptr; const int* count = nullptr; int cap = 0; };
 
 // Builds `ntrees` trees described by host descriptors (pts/n filled in; voff/root/lo/hi are computed).
 // d_need (optional, device int[ntrees]): only trees whose flag is non-zero when the build runs are built.
-int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees, hipStream_t s, const int* d_need = nullptr);
+// balls (optional): see KdBalls; more than balls->cap balls: everything is built.
+int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees, hipStream_t s, const int* d_need = nullptr, const KdBalls* balls = nullptr);
+// Builds the flagged trees of the forest of the last kd_build again, completely.
+int kd_rebuild(KdForest& f, const int* d_need, hipStream_t s);
 // For every tree t in [tree0, tree0+ntrees): queries q = d_queries + (t-tree0)*q_stride floats, nq each.
 // qorder_tree >= 0: visit queries in the vind order of forest tree (qorder_tree0 + (t-tree0)) (must have n == nq).
 // out: int32 or int64 [ntrees][nq][K].
@@ -141,21 +150,29 @@ struct GridJob {         // one search: queries of one batch element against one
     void* out;           // [nq][K] int32 / int64
     int n1; int pad;
 };
+constexpr int GRID_BALL_CAP = 2048;
 struct GridForest {
-    DevBuf desc, cell, rank, sorted, bsum, work, need, jobs;
+    DevBuf desc, cell, rank, sorted, bsum, work, need, jobs, balls;
     GridDesc* staging = nullptr; size_t staging_cap = 0; hipEvent_t staging_ev = nullptr;
     GridJob* jstaging = nullptr; size_t jstaging_cap = 0; hipEvent_t jstaging_ev = nullptr;
     int nsets = 0, total_pts = 0, max_n = 0, max_blk = 0, work_cap = 0;
     // device ints behind the per-set `need` flags: [0], [1] hand-over list lengths (K = 16, K = 1), [2] status, [3] unsettled rows,
-    // [4], [5] retry list lengths; work_list(0..1): hand-over lists, work_list(2..3): retry lists
+    // [4], [5] retry list lengths, [6] balls, [8], [9] rows the partly built trees could not answer (fall-back lists);
+    // work_list(0..1): hand-over lists, work_list(2..3): retry lists, afterwards the fall-back lists
     int* counters() const { return need.as<int>() + nsets; }
+    int* need2() const { return need.as<int>() + nsets + 16; }          // per set: its tree must be built completely
+    float4* ball_q() const { return balls.as<float4>(); }
+    int* ball_tree() const { return reinterpret_cast<int*>(balls.as<float4>() + GRID_BALL_CAP); }
+    float ball_scale = 9.f;     // squared radius of a hand-over row's ball / its (K+1)-th squared distance
     int* work_list(int which) const { return work.as<int>() + (size_t)which * 2 * work_cap; }
 };
 // Bins every set (pts / n filled in by the caller).  target_pts: number of points the measured cell radius should hold.
 int grid_build(GridForest& g, const std::vector<GridDesc>& sets, int target_pts, hipStream_t s);
 int grid_set_jobs(GridForest& g, const std::vector<GridJob>& jobs, hipStream_t s);
 int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, bool out_i64, hipStream_t s);
-// Answers the rows of a work list (pairs job id, query) by the exact tree walk; tree ids == set ids.
-int kd_search_worklist(const KdForest& f, const GridJob* d_jobs, const int* d_work, const int* d_count, int work_cap, int K, bool out_i64, hipStream_t s);
+// Answers the rows of a work list (pairs job id, query) by the exact tree walk; tree ids == set ids.  d_fallback (optional): rows whose
+// walk met a closed node of a partly built tree are appended there (and their tree flagged in d_need2) instead of being written.
+int kd_search_worklist(const KdForest& f, const GridJob* d_jobs, const int* d_work, const int* d_count, int work_cap, int K, bool out_i64, hipStream_t s,
+                       int* d_fallback = nullptr, int* d_fallback_count = nullptr, int* d_need2 = nullptr);
 
 }  // namespace ssdr

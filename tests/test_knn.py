@@ -99,6 +99,33 @@ def test_knn_fresh_inputs_against_oracle(backend, orc):
     assert_bits_equal(knn.knn_batch(p[:, : n // 4], p, 1), orc.knn_batch(p[:, : n // 4], p, 1, threads=4))
 
 
+@pytest.mark.parametrize("scale", ["1e-9", "0.25", "0"])
+def test_tree_hand_over_cut_to_balls(backend, orc, scale, monkeypatch, capfd):
+    """The hand-over trees are split only where the balls of the handed-over rows reach (SSDR_KNN_BALL_SCALE x the (K+1)-th squared
+    distance; 0 = complete trees).  Balls far too small make the walks leave them: those rows must come back through the fall-back
+    list and the complete trees with the reference's answer."""
+    from ssdr_al import knn
+    rng = np.random.default_rng(21)
+    n = 4000 if backend == "emu" else 40960
+    p = (rng.random((n, 3), dtype=np.float32) * np.array([8, 6, 3], np.float32)).astype(np.float32)
+    p[-40:] = p[:40]                          # a few duplicated points: tie rows around them, answered by the tree (fewer than the ball list holds)
+    p = p[rng.permutation(n)][None]
+    monkeypatch.setenv("SSDR_KNN_BALL_SCALE", scale)
+    monkeypatch.setenv("SSDR_KNN_DEBUG", "1")
+    got16 = knn.knn_batch(p, p, 16)
+    st = knn.knn_status()
+    err = capfd.readouterr().err
+    got1 = knn.knn_batch(p[:, : n // 4], p, 1)
+    assert 0 < st[0] < 2048, "the case must hand over some rows, fewer than the ball list holds (%d)" % st[0]
+    again = int(err.split(";")[-1].split()[0]) if "again on complete trees" in err else -1
+    if scale == "1e-9":
+        assert again > 0, err
+    if scale == "0":
+        assert again == 0, err
+    assert_bits_equal(got16, orc.knn_batch(p, p, 16, threads=4), "K=16 scale " + scale)
+    assert_bits_equal(got1, orc.knn_batch(p[:, : n // 4], p, 1, threads=4), "K=1 scale " + scale)
+
+
 @pytest.mark.gpu
 def test_pyramid_full_size_properties():
     """BASELINE config 2 shape: B=16 tiles of 40960 points.  Size-independent properties + oracle on 2 tiles."""
