@@ -134,10 +134,15 @@ __global__ __launch_bounds__(256) void sel_dominant_label(const int* __restrict_
 
 // ---- clsbal (sampler2.py:262-266): u *= exp(-freq(dominant class among candidates + already selected)) -------
 __global__ __launch_bounds__(256) void sel_class_hist(const int* __restrict__ region_class, int S, const int* __restrict__ extra, int n_extra, int* hist) {
+    __shared__ int s_h[64];          // thousands of regions on a dozen classes: count in LDS, one global add per class and workgroup
+    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    __syncthreads();
     for (int i = blockIdx.x * 256 + threadIdx.x; i < S + n_extra; i += gridDim.x * 256) {
         const int c = i < S ? region_class[i] : extra[i - S];
-        if (c >= 0 && c < 64) atomicAdd(&hist[c], 1);
+        if (c >= 0 && c < 64) atomicAdd(&s_h[c], 1);
     }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void sel_clsbal(const int* __restrict__ region_class, int S, int total, const int* __restrict__ hist, double* region_unc) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
@@ -163,7 +168,17 @@ __global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict_
         const int q = e / D, c = e % D, s = sel ? sel[q] : q;
         const int lo = sp_off[s], hi = sp_off[s + 1], d = dom[s];
         float sum = 0.f; int cnt = 0;
-        for (int j = lo; j < hi; ++j) { const int p = sp_pts[j]; if (cls[p] == d) { sum = sum + feat[(size_t)p * D + c]; ++cnt; } }
+        // eight members at a time: their three dependent loads (member, class, feature) are in flight together; the additions stay in
+        // member order
+        for (int j0 = lo; j0 < hi; j0 += 8) {
+            int p[8], k[8]; float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = sp_pts[min(j0 + u, hi - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { k[u] = cls[p[u]]; v[u] = feat[(size_t)p[u] * D + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < hi && k[u] == d) { sum = sum + v[u]; ++cnt; }
+        }
         out[(size_t)q * D + c] = cnt ? sum / (float)cnt : 0.f;
     }
 }
@@ -189,6 +204,126 @@ __global__ __launch_bounds__(256) void sel_centres(const float* __restrict__ xyz
     }
 }
 
+// min of two non-NaN doubles in ONE instruction (`a < b ? a : b` compiles to a compare and two 32-bit selects, fmin() to a
+// canonicalising v_max in front of the v_min: 3 of the 10 vector instructions of one point pair)
+__device__ __forceinline__ double min_f64(double a, double b) {
+#ifndef HIPEMU
+    double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return a < b ? a : b;
+#endif
+}
+
+constexpr int CH_TILE = 1536;   // target points staged per step (36 KiB of float64 coordinates)
+constexpr int PACK_MAX = 4096;  // superpoints of one cloud the packer lays out (two int tables in LDS)
+constexpr int ITEM = 256;       // source points one wave takes against a target
+constexpr int NV = ITEM / 64;   // ... per lane
+constexpr int SEQ_MAX = 16;     // superpoints up to this size are summed by one lane each, larger ones by the whole wave
+
+// The staged target is the same for every lane, and a wave-wide LDS read of 24 bytes per lane costs the LDS pipe 12 cycles whether
+// or not the addresses agree: with one source point per lane the kernel waited on LDS (33 % instruction issue), and a wave per
+// (source, target) pair left the lanes beyond the source's size idle.  Hence:
+//   * sel_chamfer_pack lays the centred points of the superpoints of a cloud out in 256-slot ITEMS — as many whole superpoints as
+//     fit, in order, never split — and sel_chamfer_dir takes one item per wave and target: every lane owns FOUR source points
+//     (slots l, l + 64, l + 128, l + 192), so one read of a target point serves four distance evaluations;
+//   * the roots of a superpoint's points are added up in an order that depends on its size alone (segment_sum), so the mean does
+//     not depend on what else shares the item;
+//   * superpoints above 256 points (and empty ones) are taken pair by pair in passes of 256 with the same summation rule.
+struct ChamferPack {
+    double* x; double* y; double* z;      // per slot: the centred point
+    int* seg; int* cnt;                   // per slot: local index of its superpoint (-1: padding); the superpoint's size on its first slot, else 0
+    int* item_slot;                       // per item: its first slot
+    int* big;                             // superpoints taken pair by pair
+    int* start;                           // per superpoint: first slot, -1 for the pair-by-pair ones
+    int* counts;                          // per cloud: items, pair-by-pair superpoints
+};
+
+// The lay-out of one cloud (one workgroup): slots of the cloud start at ITEM * (its first row), the per-superpoint tables at its first row.
+__device__ void chamfer_plan_body(const int* __restrict__ sp_off, const int* __restrict__ sel, int n, ChamferPack P, int* counts, int* s_n) {
+    const int tid = threadIdx.x;
+    if (n > PACK_MAX) {
+        for (int i = tid; i < n; i += 256) { P.big[i] = i; P.start[i] = -1; }
+        if (tid == 0) { counts[0] = 0; counts[1] = n; }
+        return;
+    }
+    for (int i = tid; i < n; i += 256) { const int sp = sel[i]; s_n[i] = sp_off[sp + 1] - sp_off[sp]; }
+    __syncthreads();
+    if (tid == 0) {
+        int cur = 0, nitems = 0, nbig = 0;
+        for (int i = 0; i < n; ++i) {
+            const int ni = s_n[i];
+            if (ni == 0 || ni > ITEM) { P.start[i] = -1; P.big[nbig++] = i; continue; }
+            if ((cur & (ITEM - 1)) + ni > ITEM) cur = (cur + ITEM - 1) & ~(ITEM - 1);
+            if ((cur & (ITEM - 1)) == 0) P.item_slot[nitems++] = cur;
+            P.start[i] = cur; cur += ni;
+        }
+        counts[0] = nitems; counts[1] = nbig;
+    }
+}
+// ... and its slots: one wave per superpoint (seg / cnt of the padding slots were preset by the launcher: -1 / 0)
+__device__ void chamfer_fill_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts, const int* __restrict__ sel, int n,
+                                  const double* __restrict__ centres, ChamferPack P) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        const int st = P.start[i];
+        if (st < 0) continue;
+        const int sp = sel[i], lo = sp_off[sp], ni = sp_off[sp + 1] - lo;
+        const double cx = centres[3 * i], cy = centres[3 * i + 1], cz = centres[3 * i + 2];
+        for (int a = lane; a < ni; a += 64) {
+            const size_t q = sp_pts[lo + a];
+            const int k = st + a;
+            P.x[k] = (double)xyz[3 * q] - cx; P.y[k] = (double)xyz[3 * q + 1] - cy; P.z[k] = (double)xyz[3 * q + 2] - cz;
+            P.seg[k] = i; P.cnt[k] = a == 0 ? ni : 0;
+        }
+    }
+}
+
+// squared distances from NV centred source points to the nearest point of target j: its staged points (tb), or streamed
+__device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&out)[NV], const double* tb, int nj, bool staged,
+                                            const float* __restrict__ xyz, const int* __restrict__ sp_pts, int loj, double cjx, double cjy, double cjz) {
+    if (staged) {
+        double m[NV][2];      // independent chains: min is order-free
+#pragma unroll
+        for (int v = 0; v < NV; ++v) m[v][0] = m[v][1] = 1.0e300;
+        int b = 0;
+        for (; b + 4 <= nj; b += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double tx = tb[3 * (b + u)], ty = tb[3 * (b + u) + 1], tz = tb[3 * (b + u) + 2];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const double dx = ax[v] - tx, dy = ay[v] - ty, dz = az[v] - tz;
+                    const double d = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
+                    m[v][u & 1] = min_f64(d, m[v][u & 1]);
+                }
+            }
+        }
+        for (; b < nj; ++b) {
+            const double tx = tb[3 * b], ty = tb[3 * b + 1], tz = tb[3 * b + 2];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double dx = ax[v] - tx, dy = ay[v] - ty, dz = az[v] - tz;
+                double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+                m[v][0] = min_f64(d, m[v][0]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) out[v] = fmin(m[v][0], m[v][1]);
+        return;
+    }
+    double m[NV];                        // very large target: stream it from global memory
+#pragma unroll
+    for (int v = 0; v < NV; ++v) m[v] = 1.0e300;
+    for (int b = 0; b < nj; ++b) {
+        const size_t q = sp_pts[loj + b];
+        const double tx = (double)xyz[3 * q] - cjx, ty = (double)xyz[3 * q + 1] - cjy, tz = (double)xyz[3 * q + 2] - cjz;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { const double dx = ax[v] - tx, dy = ay[v] - ty, dz = az[v] - tz; double d = dx * dx; d = d + dy * dy; d = d + dz * dz; m[v] = fmin(m[v], d); }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = m[v];
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -199,81 +334,128 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-constexpr int CH_TILE = 1536;   // target points staged per step (36 KiB of float64 coordinates)
+// v[0] + ... + v[n-1], n <= SEQ_MAX, by one lane
+__device__ __forceinline__ double sum_short(const double* v, int n) {
+    double a = 0.0;
+    for (int t = 0; t < n; ++t) a += v[t];
+    return a;
+}
+// v[0] + ... + v[n-1] by the whole wave (uniform arguments): lane l adds v[l], v[l + 64], ... up, then the xor tree
+__device__ __forceinline__ double sum_wave(const double* v, int n, int lane) {
+    double a = 0.0;
+    for (int t = lane; t < n; t += 64) a += v[t];
+    return wave_sum_f64(a);
+}
 
 // dir[i*nsel + j] = mean over points a of sp_i of min over points b of sp_j of |(a-c_i) - (b-c_j)|   (float64).
-// One workgroup per target superpoint j: its centred points are staged in LDS once and re-used against every
-// source superpoint i (one wave per i, one lane per source point).  The mean is a wave tree sum, so it can differ
-// from NumPy's pairwise np.mean in the last ulp (the min distances themselves are exact).
+// One workgroup per target superpoint j (and slice of the sources): its centred points are staged in LDS once and re-used against
+// every source item.  The mean is (sum_short | sum_wave) / size, so it can differ from NumPy's pairwise np.mean in the last ulps
+// (sqrt is monotone: min of roots == root of min).
 __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                 const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, double* tb) {
+                                 const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P, const int* counts,
+                                 double* tb, double (*s_val)[ITEM]) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nitems = counts[0], nbig = counts[1];
     for (int j = blockIdx.x; j < nsel; j += gridDim.x) {
         const int sj = sel[j], loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
         const double cjx = centres[3 * j], cjy = centres[3 * j + 1], cjz = centres[3 * j + 2];
-        if (nj <= CH_TILE) {
+        const bool staged = nj <= CH_TILE;
+        if (staged) {
             __syncthreads();
-            for (int b = threadIdx.x; b < nj; b += 256) {
-                const size_t q = sp_pts[loj + b];
-                tb[3 * b] = (double)xyz[3 * q] - cjx; tb[3 * b + 1] = (double)xyz[3 * q + 1] - cjy; tb[3 * b + 2] = (double)xyz[3 * q + 2] - cjz;
+            const int st = P.start[j];
+            if (st >= 0) {
+                for (int b = threadIdx.x; b < nj; b += 256) { tb[3 * b] = P.x[st + b]; tb[3 * b + 1] = P.y[st + b]; tb[3 * b + 2] = P.z[st + b]; }
+            } else {
+                for (int b = threadIdx.x; b < nj; b += 256) {
+                    const size_t q = sp_pts[loj + b];
+                    tb[3 * b] = (double)xyz[3 * q] - cjx; tb[3 * b + 1] = (double)xyz[3 * q + 1] - cjy; tb[3 * b + 2] = (double)xyz[3 * q + 2] - cjz;
+                }
             }
             __syncthreads();
         }
-        for (int i = blockIdx.y * 4 + wid; i < nsel; i += 4 * gridDim.y) {
+        for (int it = blockIdx.y * 4 + wid; it < nitems; it += 4 * gridDim.y) {          // NV source points per lane, whole superpoints per wave
+            const int k = P.item_slot[it] + lane;
+            double ax[NV], ay[NV], az[NV], m[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { ax[v] = P.x[k + 64 * v]; ay[v] = P.y[k + 64 * v]; az[v] = P.z[k + 64 * v]; }
+            chamfer_min(ax, ay, az, m, tb, nj, staged, xyz, sp_pts, loj, cjx, cjy, cjz);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+            (void)__ballot(1);                               // the wave's LDS writes are visible to its lanes
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cnt = P.cnt[k + 64 * v], seg = P.seg[k + 64 * v];
+                if (cnt > 0 && cnt <= SEQ_MAX) dir[(size_t)seg * nsel + j] = seg == j ? 0.0 : sum_short(&s_val[wid][lane + 64 * v], cnt) / (double)cnt;
+                unsigned long long todo = __ballot(cnt > SEQ_MAX);          // the larger ones, one after the other, all lanes on each
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int c = __shfl(cnt, src), sg = __shfl(seg, src);
+                    const double sum = sum_wave(&s_val[wid][src + 64 * v], c, lane);
+                    if (lane == 0) dir[(size_t)sg * nsel + j] = sg == j ? 0.0 : sum / (double)c;
+                }
+            }
+            (void)__ballot(1);
+        }
+        for (int bi = blockIdx.y * 4 + wid; bi < nbig; bi += 4 * gridDim.y) {            // pair by pair: more than ITEM points (or none)
+            const int i = P.big[bi];
             if (i == j) { if (lane == 0) dir[(size_t)i * nsel + j] = 0.0; continue; }
             const int si = sel[i], loi = sp_off[si], ni = sp_off[si + 1] - loi;
             const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
             double acc = 0.0;
-            for (int a = lane; a < ni; a += 64) {
-                const size_t p = sp_pts[loi + a];
-                const double ax = (double)xyz[3 * p] - cix, ay = (double)xyz[3 * p + 1] - ciy, az = (double)xyz[3 * p + 2] - ciz;
-                double m = 1.0e300;
-                if (nj <= CH_TILE) {
-                    double m4[4] = {1.0e300, 1.0e300, 1.0e300, 1.0e300};   // independent chains: min is order-free
-                    int b = 0;
-                    for (; b + 4 <= nj; b += 4) {
+            for (int a0 = 0; a0 < ni; a0 += ITEM) {
+                double ax[NV], ay[NV], az[NV], m[NV];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const double dx = ax - tb[3 * (b + u)], dy = ay - tb[3 * (b + u) + 1], dz = az - tb[3 * (b + u) + 2];
-                            const double d = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
-                            m4[u] = d < m4[u] ? d : m4[u];
-                        }
-                    }
-                    for (; b < nj; ++b) {
-                        const double dx = ax - tb[3 * b], dy = ay - tb[3 * b + 1], dz = az - tb[3 * b + 2];
-                        double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
-                        m4[0] = d < m4[0] ? d : m4[0];
-                    }
-                    m = fmin(fmin(m4[0], m4[1]), fmin(m4[2], m4[3]));
-                } else {                       // very large target: stream it from global memory
-                    for (int b = 0; b < nj; ++b) {
-                        const size_t q = sp_pts[loj + b];
-                        const double dx = ax - ((double)xyz[3 * q] - cjx), dy = ay - ((double)xyz[3 * q + 1] - cjy), dz = az - ((double)xyz[3 * q + 2] - cjz);
-                        double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
-                        m = fmin(m, d);
-                    }
+                for (int v = 0; v < NV; ++v) {
+                    const int a = min(a0 + lane + 64 * v, ni - 1);          // beyond the end: the last point again, not summed
+                    const size_t p = sp_pts[loi + a];
+                    ax[v] = (double)xyz[3 * p] - cix; ay[v] = (double)xyz[3 * p + 1] - ciy; az[v] = (double)xyz[3 * p + 2] - ciz;
                 }
-                acc += sqrt(m);        // sqrt is monotone: min of roots == root of min
+                chamfer_min(ax, ay, az, m, tb, nj, staged, xyz, sp_pts, loj, cjx, cjy, cjz);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+                (void)__ballot(1);
+                if (ni <= SEQ_MAX) { if (lane == 0) acc = sum_short(&s_val[wid][0], ni); }      // same rule as inside an item
+                else acc += sum_wave(&s_val[wid][0], min(ITEM, ni - a0), lane);
+                (void)__ballot(1);
             }
-            acc = wave_sum_f64(acc);
             if (lane == 0) dir[(size_t)i * nsel + j] = ni > 0 ? acc / (double)ni : 0.0;
         }
     }
 }
 
+__device__ __forceinline__ ChamferPack pack_at(ChamferPack P, int row0) {
+    const size_t s0 = (size_t)ITEM * (size_t)row0;
+    P.x += s0; P.y += s0; P.z += s0; P.seg += s0; P.cnt += s0; P.item_slot += row0; P.big += row0; P.start += row0;
+    return P;
+}
+
+__global__ __launch_bounds__(256) void sel_chamfer_plan(const int* __restrict__ sp_off, const int* __restrict__ sel, const int* __restrict__ coff, int nsingle, ChamferPack P) {
+    __shared__ int s_n[PACK_MAX];
+    const int c = blockIdx.x, lo = coff ? coff[c] : 0, n = coff ? coff[c + 1] - lo : nsingle;
+    chamfer_plan_body(sp_off, sel + lo, n, pack_at(P, lo), P.counts + 2 * c, s_n);
+}
+__global__ __launch_bounds__(256) void sel_chamfer_fill(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                        const int* __restrict__ sel, const int* __restrict__ coff, int nsingle, const double* __restrict__ centres, ChamferPack P) {
+    const int c = blockIdx.y, lo = coff ? coff[c] : 0, n = coff ? coff[c + 1] - lo : nsingle;
+    chamfer_fill_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, pack_at(P, lo));
+}
+
 __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir) {
+                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P) {
     __shared__ double tb[CH_TILE * 3];
-    chamfer_dir_body(xyz, sp_off, sp_pts, sel, nsel, centres, dir, tb);
+    __shared__ double s_val[4][ITEM];
+    chamfer_dir_body(xyz, sp_off, sp_pts, sel, nsel, centres, dir, P, P.counts, tb, s_val);
 }
 // all clouds of a batch in one launch: blockIdx.z = cloud, coff[c] = first row of cloud c in sel / centres, boff[c] = first
 // element of its n_c x n_c blocks in dir / adj
 __global__ __launch_bounds__(256) void sel_chamfer_dir_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                              const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
-                                                             const double* __restrict__ centres, double* dir) {
+                                                             const double* __restrict__ centres, double* dir, ChamferPack P) {
     __shared__ double tb[CH_TILE * 3];
+    __shared__ double s_val[4][ITEM];
     const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
-    chamfer_dir_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], tb);
+    chamfer_dir_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, s_val);
 }
 
 // adj = exp(-(ED + CD)) - I (fps_gcn_cpu.py:102-104); rowsum (:106)
@@ -666,7 +848,26 @@ __global__ __launch_bounds__(256) void kc_init(const double* __restrict__ f, int
     if (tid == 0) pout[blockIdx.x] = s_p[0];
 }
 
-struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp; };
+struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int; };
+
+// scratch of the chamfer packer for nrows superpoints in nclouds clouds
+int chamfer_pack_buffers(SelState& Q, size_t nrows, size_t nclouds, ChamferPack& P) {
+    const size_t slots = (size_t)ITEM * nrows;
+    SSDR_TRY(Q.pack_xyz.reserve(3 * 8 * slots + 64)); SSDR_TRY(Q.pack_int.reserve(4 * (2 * slots + 3 * nrows + 2 * nclouds) + 64));
+    P.x = Q.pack_xyz.as<double>(); P.y = P.x + slots; P.z = P.y + slots;
+    P.seg = Q.pack_int.as<int>(); P.cnt = P.seg + slots; P.item_slot = P.cnt + slots; P.big = P.item_slot + nrows; P.start = P.big + nrows; P.counts = P.start + nrows;
+    return SSDR_OK;
+}
+// plan + fill of the packer for nclouds clouds (coff == nullptr: one cloud of nsingle superpoints)
+int chamfer_pack_launch(const ChamferPack& P, const float* d_xyz, const int* d_sp_off, const int* d_sp_pts, const int* d_sel, const int* d_coff, int nsingle,
+                        size_t nrows, int n_max, unsigned nclouds, const double* d_centres, hipStream_t s) {
+    const size_t slots = (size_t)ITEM * nrows;
+    SSDR_HIP(hipMemsetAsync(P.seg, 0xff, 4 * slots, s));          // padding slots: no superpoint ...
+    SSDR_HIP(hipMemsetAsync(P.cnt, 0, 4 * slots, s));             // ... and nothing to sum
+    hipLaunchKernelGGL(sel_chamfer_plan, dim3(nclouds), dim3(256), 0, s, d_sp_off, d_sel, d_coff, nsingle, P);
+    hipLaunchKernelGGL(sel_chamfer_fill, dim3(std::max(1, std::min((n_max + 3) / 4, 1024)), nclouds), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, nsingle, d_centres, P);
+    return SSDR_OK;
+}
 // one scratch set per stream: calls on different streams may run concurrently (include/ssdr_al.h)
 SelState& sst(hipStream_t st = nullptr) { static std::map<hipStream_t, SelState> m; return m[st ? st : ctx().stream]; }
 
@@ -816,7 +1017,9 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     const int n = (int)nsel;
     SSDR_TRY(Q.rowsum.reserve(8 * nsel));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
-    hipLaunchKernelGGL(sel_chamfer_dir, dim3(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir);
+    ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, nsel, 1, P));
+    SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, d_sel, nullptr, n, nsel, n, 1, d_centres, s));
+    hipLaunchKernelGGL(sel_chamfer_dir, dim3(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir, P);
     hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_adj, n, gcn_top);
@@ -834,8 +1037,10 @@ int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, cons
     const int nt = (int)n_total, nm = (int)n_max; const unsigned nc = (unsigned)num_clouds;
     SSDR_TRY(Q.rowsum.reserve(8 * n_total));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, nt, d_centres);
+    ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, n_total, num_clouds, P));
+    SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, 0, n_total, nm, nc, d_centres, s));
     hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel,
-                       d_coff, (const long long*)d_boff, d_centres, d_cd_dir);
+                       d_coff, (const long long*)d_boff, d_centres, d_cd_dir, P);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, d_centres, d_cd_dir, d_coff, (const long long*)d_boff, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), d_coff, (const long long*)d_boff, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(std::max(1, std::min((nm + 3) / 4, 1024)), 1, nc), dim3(256), 0, s, d_adj, d_coff, (const long long*)d_boff, gcn_top);

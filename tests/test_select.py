@@ -71,6 +71,28 @@ def test_chamfer_adjacency_gcnfps_golden(backend, golden):
         sampler.GCN_FPS_sampling(list(g["f/lab_feat"]), lab, list(g["f/unl_feat"]), unl, clouds, 5, 1, 14, 0)
 
 
+def test_chamfer_mixed_superpoint_sizes(backend):
+    """create_cd over superpoints of 1 ... 1700 points: several small ones share a wave (256-slot items), those above 256 points go pair
+    by pair in passes, the one above 1536 points is streamed as a target; a subset in a shuffled order as `sel`."""
+    from ssdr_al import sampler
+    rng = np.random.default_rng(31)
+    sizes = [1, 2, 3, 17, 40, 24, 64, 63, 2, 65, 130, 128, 127, 129, 100, 30, 256, 257, 16, 16, 17, 300, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 9, 700, 31, 33, 1700, 12, 64, 1]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(off[-1])
+    xyz = (rng.random((n, 3)) * np.array([4, 3, 2])).astype(np.float32)
+    for s_, (a, b) in enumerate(zip(off[:-1], off[1:])):             # compact blobs around random seats
+        xyz[a:b] = (rng.random(3) * np.array([4, 3, 2]) + rng.normal(0, 0.08, (b - a, 3))).astype(np.float32)
+    pts = rng.permutation(n).astype(np.int32)
+    xyz = xyz[np.argsort(pts)]                                        # superpoint s = the points listed in pts[off[s]:off[s+1]]
+    cent = O.bbox_centres(xyz, off, pts)
+    want = O.create_cd(xyz, off, pts, cent)
+    got = sampler.create_cd(xyz, off, pts, np.arange(len(sizes)))
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
+    sel = rng.permutation(len(sizes))[:20]
+    got = sampler.create_cd(xyz, off, pts, sel)
+    assert np.allclose(got, want[np.ix_(sel, sel)], rtol=1e-12, atol=1e-14)
+
+
 def test_fps_and_kcenter_golden(backend, golden):
     from ssdr_al import sampler
     g = golden("select_golden.npz")
