@@ -499,7 +499,11 @@ template <int K, typename OutT>
 __global__ __launch_bounds__(64) void kd_search_worklist_kernel(SearchArgs a, const GridJob* __restrict__ jobs, const int* __restrict__ work,
                                                                 const int* __restrict__ count, int cap, int* fallback, int* fallback_count, int* need2) {
     const int n = min(*count, cap);
-    for (int e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
+    // a walk is a chain of dependent loads and the walks of a wave's lanes serialise where they diverge: short lists are spread four
+    // rows to a wave, long ones (tie-heavy inputs) fill the lanes
+    const int per = n <= (int)gridDim.x * 4 ? 4 : 64;
+    if ((int)threadIdx.x >= per) return;
+    for (int e = blockIdx.x * per + threadIdx.x; e < n; e += gridDim.x * per) {
         const int jid = work[2 * (size_t)e];
         const GridJob job = jobs[jid];
         const int q = work[2 * (size_t)e + 1];
