@@ -65,18 +65,19 @@ struct ForestPtrs {
 };
 constexpr int CLOSED = -2;           // node_a.z of a node above LEAF_MAX points that was left unsplit (no ball reaches it)
 
-__global__ __launch_bounds__(BS) void kd_init_kernel(ForestPtrs f) {
-    __shared__ float s_mm[(BS / 64) * 6];
+constexpr int INIT_NT = 1024;      // one workgroup per tree: sixteen waves to cover the latency of its tens of thousands of points
+__global__ __launch_bounds__(INIT_NT) void kd_init_kernel(ForestPtrs f) {
+    __shared__ float s_mm[(INIT_NT / 64) * 6];
     const int t = blockIdx.x, tid = threadIdx.x;
     if (f.need && !f.need[t]) return;          // nobody will walk this tree
     const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = tid; i < n; i += BS) {
+    for (int i = tid; i < n; i += INIT_NT) {
         const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
         f.sorted[voff + i] = make_float4(x, y, z, __int_as_float(i));      // vind[i] = i, the point travels with its index
         mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x); mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y); mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
     }
-    block_minmax3(mn, mx, s_mm);
+    block_minmax3<INIT_NT>(mn, mx, s_mm);
     if (tid == 0) {
         for (int d = 0; d < 3; ++d) { f.desc[t].lo[d] = mn[d]; f.desc[t].hi[d] = mx[d]; f.node_box[6 * t + d] = mn[d]; f.node_box[6 * t + 3 + d] = mx[d]; }
         f.desc[t].root = t;
@@ -686,7 +687,7 @@ ForestPtrs ptrs(const KdForest& f) {
 
 // init + one launch per level + the small subtrees, for the trees p.need flags (all without flags)
 static int launch_build(const KdForest& f, const ForestPtrs& p, hipStream_t s) {
-    hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(BS), 0, s, p);
+    hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(INIT_NT), 0, s, p);
     const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
     // nodes above 64 points: one workgroup each, level by level; deeper than BIG_LEVELS a node that large means a
     // degenerate cloud (flagged, not mis-built).  Everything at or below 64 points: one launch, one wavefront per subtree.

@@ -47,20 +47,21 @@ __device__ __forceinline__ int cell_of(float v, float o, float inv_c, int n) {
 }
 
 // bounding box, cell size, grid dimensions; zeroes the set's cell counters
-__global__ __launch_bounds__(256) void grid_prepare_kernel(GridDesc* desc, int* cell, int target_pts) {
-    __shared__ float s_mm[(256 / 64) * 6];
+constexpr int PREP_NT = 1024;      // one workgroup per set, and a set is tens of thousands of points: sixteen waves to cover the load latency
+__global__ __launch_bounds__(PREP_NT) void grid_prepare_kernel(GridDesc* desc, int* cell, int target_pts) {
+    __shared__ float s_mm[(PREP_NT / 64) * 6];
     __shared__ float s_smp[GS_SAMPLES][3];
     __shared__ int s_hist[GS_BINS];
     const int t = blockIdx.x, tid = threadIdx.x;
     GridDesc d = desc[t];
     const float* P = d.pts; const int n = d.n;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += PREP_NT) {
         const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
         mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x); mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y); mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
     }
-    block_minmax3(mn, mx, s_mm);
-    for (int i = tid; i < GS_BINS; i += 256) s_hist[i] = 0;
+    block_minmax3<PREP_NT>(mn, mx, s_mm);
+    for (int i = tid; i < GS_BINS; i += PREP_NT) s_hist[i] = 0;
     if (tid < GS_SAMPLES && n > 0) {
         const int i = (int)(((long long)tid * n) / GS_SAMPLES + n / (2 * GS_SAMPLES));
         s_smp[tid][0] = P[3 * (size_t)i]; s_smp[tid][1] = P[3 * (size_t)i + 1]; s_smp[tid][2] = P[3 * (size_t)i + 2];
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void grid_prepare_kernel(GridDesc* desc, int* 
     __syncthreads();
     // distances of every stride-th point to the samples -> histogram over log2(d^2) (LDS atomics)
     const int stride = n > 8192 ? n / 8192 : 1;
-    for (int i = tid * stride; i < n; i += 256 * stride) {
+    for (int i = tid * stride; i < n; i += PREP_NT * stride) {
         const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
 #pragma unroll
         for (int j = 0; j < GS_SAMPLES; ++j) {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void grid_prepare_kernel(GridDesc* desc, int* 
     }
     __syncthreads();
     const int ncell = __float_as_int(s_mm[0]);
-    for (int i = tid; i <= ncell; i += 256) cell[d.cell_off + i] = 0;
+    for (int i = tid; i <= ncell; i += PREP_NT) cell[d.cell_off + i] = 0;
 }
 
 // per point: its rank inside its cell (returning atomic on the cell counter)
@@ -472,7 +473,7 @@ int grid_build(GridForest& g, const std::vector<GridDesc>& sets_in, int target_p
     GridDesc* dd = g.desc.as<GridDesc>();
     const dim3 gp((unsigned)((maxn + 255) / 256), (unsigned)g.nsets), gb((unsigned)g.max_blk, (unsigned)g.nsets);
     ProfScope prof("knn_grid_build", s, 28.0 * (double)pt);
-    hipLaunchKernelGGL(grid_prepare_kernel, dim3(g.nsets), dim3(256), 0, s, dd, g.cell.as<int>(), target_pts);
+    hipLaunchKernelGGL(grid_prepare_kernel, dim3(g.nsets), dim3(PREP_NT), 0, s, dd, g.cell.as<int>(), target_pts);
     hipLaunchKernelGGL(grid_count_kernel, gp, dim3(256), 0, s, dd, g.cell.as<int>(), g.rank.as<int>());
     hipLaunchKernelGGL(grid_scan_sums_kernel, gb, dim3(256), 0, s, dd, g.cell.as<int>(), g.bsum.as<int>(), g.max_blk);
     hipLaunchKernelGGL(grid_scan_apply_kernel, gb, dim3(256), 0, s, dd, g.cell.as<int>(), g.bsum.as<int>(), g.max_blk);
