@@ -22,7 +22,8 @@ int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<G
     const char* bs = getenv("SSDR_KNN_BALL_SCALE");
     const float ball_scale = bs ? (float)atof(bs) : 9.f;
     S.grid.ball_scale = ball_scale > 0.f ? ball_scale : 1.f;
-    SSDR_TRY(grid_build(S.grid, sets, GRID_TARGET_PTS, s));
+    const char* tp = getenv("SSDR_KNN_TARGET_PTS");      // tuning knob of the cell size (development)
+    SSDR_TRY(grid_build(S.grid, sets, tp ? std::max(1, atoi(tp)) : GRID_TARGET_PTS, s));
     std::vector<GridJob> jobs(jobs16); jobs.insert(jobs.end(), jobs1.begin(), jobs1.end());
     SSDR_TRY(grid_set_jobs(S.grid, jobs, s));
     int mq16 = 0, mq1 = 0;

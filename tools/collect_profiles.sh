@@ -7,10 +7,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. the bench line itself (default flags = what the driver runs)
-python3 bench.py > $OUT/${R}_bench_line.json 2> $OUT/${R}_bench_line.err
+python3 bench.py 2> $OUT/${R}_bench_line.err | grep '^{"metric"' > $OUT/${R}_bench_line.json
 # 2. kernel trace + stats of the same command (batches in flight) and of the strictly sequential variant
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> $OUT/kt.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kts -o kts -- python3 bench.py --no-cpu-baseline --no-pipeline > $OUT/${R}_bench_seq_under_rocprof.json 2> $OUT/kts.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline 2> $OUT/kt.err | grep '^{"metric"' > $OUT/${R}_bench_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kts -o kts -- python3 bench.py --no-cpu-baseline --no-pipeline 2> $OUT/kts.err | grep '^{"metric"' > $OUT/${R}_bench_seq_under_rocprof.json
 cp $OUT/kt/kt_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 cp $OUT/kts/kts_kernel_stats.csv $OUT/${R}_bench_seq_kernel_stats.csv
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one pass), sequential, one step
@@ -22,6 +22,6 @@ cp $OUT/pw/pw_counter_collection.csv $OUT/${R}_pmc_write_size.csv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/pm -o pm -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/pm.err
 cp $OUT/pm/pm_counter_collection.csv $OUT/${R}_pmc_mfma_busy.csv
 # 5. the N > 1 code path (RCCL exchanges on device buffers) on this one GPU, with its kernel stats
-MASTER_ADDR=127.0.0.1 MASTER_PORT=29561 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 SSDR_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline > $OUT/${R}_bench_rccl_world1_line.json 2> $OUT/rccl.err
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29561 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 SSDR_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline 2> $OUT/rccl.err | grep '^{"metric"' > $OUT/${R}_bench_rccl_world1_line.json
 rm -rf $OUT/kt $OUT/kts $OUT/pf $OUT/pw $OUT/pm
 ls -la $OUT
