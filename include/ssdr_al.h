@@ -81,6 +81,10 @@ int ssdr_knn_batch_dev(const float* d_batch_data, size_t batch_size, size_t npts
  * out4 (optional, host): rows handed from the grid search to the exact tree walk for K = 16 and K = 1 (tie rows, see
  * csrc/knn_grid.hip), the status bits, and the depth of the deepest tree built. */
 int ssdr_knn_status(void* stream, int32_t* out4);
+/* The same check without waiting: every device-flavour KNN call leaves a ticket (its counters copied to pinned memory behind its
+ * kernels); this folds the tickets of the calls that HAVE finished and returns SSDR_ERR_INTERNAL if one of them overflowed.  For
+ * callers that keep several batches in flight on `stream` and must not wait for the newest one (ssdr_al/pipeline.py). */
+int ssdr_knn_status_poll(void* stream, int32_t* out4);
 
 /* ---- KNN pyramid (replaces the loop of tf_map, S3/s3dis_dataset.py:156-183) ------------------
  * For level i in [0,num_layers): N_0 = npts, N_{i+1} = N_i / ratio[i] (integer division);
@@ -286,6 +290,10 @@ int ssdr_dev_alloc(size_t bytes, void** d_ptr);
 int ssdr_dev_free(void* d_ptr);
 int ssdr_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int ssdr_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+/* the same, ordered on `stream` (NULL = library stream) and waiting for that stream only: a selection that runs on its own stream
+ * uploads its index tables and reads its result back without waiting for what the other streams hold */
+int ssdr_memcpy_h2d_on(void* d_dst, const void* src, size_t bytes, void* stream);
+int ssdr_memcpy_d2h_on(void* dst, const void* d_src, size_t bytes, void* stream);
 
 /* cpp_knn_batch_distance_pick (knn_.h:21-23, knn_.cxx:136-203, knn.pyx:111-149): nqueries "least used first" query points
  * per batch element and their K neighbours.  The reference seeds std::mt19937 with time(0); here the seed is an argument

@@ -7,12 +7,36 @@ namespace ssdr {
 namespace {
 
 // One state per stream: calls on different streams own different forests / grids / scratch and may run concurrently.
+// what a finished device-flavour call found, copied behind its kernels: [0..9] the grid counters, [10..12] the forest's status words
+struct KnnTicket { hipEvent_t ev = nullptr; int32_t* host = nullptr; bool pending = false; };
+constexpr int TICKETS = 16, TICKET_WORDS = 16;
 struct KnnState {
     KdForest forest;
     GridForest grid;
     DevBuf pts, qry, out;
+    KnnTicket ticket[TICKETS]; int next_ticket = 0;
+    int32_t folded[4] = {0, 0, 0, 0};       // hand-over rows (K = 16, K = 1) of the last finished call, status bits so far, deepest tree
 };
 KnnState& st(hipStream_t s = nullptr) { static std::map<hipStream_t, KnnState> m; return m[s ? s : ctx().stream]; }
+
+// leaves the counters of the call just enqueued on s where ssdr_knn_status_poll finds them
+int fold_ticket(KnnState& S, KnnTicket& t) {
+    S.folded[0] = t.host[0]; S.folded[1] = t.host[1]; S.folded[2] |= t.host[2] | t.host[11]; S.folded[3] = t.host[12];
+    t.pending = false;
+    return SSDR_OK;
+}
+int leave_ticket(KnnState& S, hipStream_t s) {
+    KnnTicket& t = S.ticket[S.next_ticket];
+    S.next_ticket = (S.next_ticket + 1) % TICKETS;
+    if (!t.ev) { SSDR_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming)); SSDR_HIP(hipHostMalloc(reinterpret_cast<void**>(&t.host), 4 * TICKET_WORDS)); }
+    if (t.pending) { SSDR_HIP(hipEventSynchronize(t.ev)); fold_ticket(S, t); }      // sixteen calls ago: long finished
+    for (int i = 0; i < TICKET_WORDS; ++i) t.host[i] = 0;
+    if (S.grid.need.p && S.grid.nsets > 0) SSDR_HIP(hipMemcpyAsync(t.host, S.grid.counters(), 4 * 10, hipMemcpyDeviceToHost, s));
+    if (S.forest.counters.p) SSDR_HIP(hipMemcpyAsync(t.host + 10, S.forest.counters.p, 4 * 3, hipMemcpyDeviceToHost, s));
+    SSDR_HIP(hipEventRecord(t.ev, s));
+    t.pending = true;
+    return SSDR_OK;
+}
 
 constexpr int GRID_TARGET_PTS = 22;      // the measured cell radius holds about this many points (K + 1 = 17 and a margin)
 
@@ -60,6 +84,7 @@ int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<G
         if (!jobs16.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(2), ctr + 8, S.grid.work_cap, 16, i64, s));
         if (!jobs1.empty()) SSDR_TRY(kd_search_worklist(S.forest, S.grid.jobs.as<GridJob>(), S.grid.work_list(3), ctr + 9, S.grid.work_cap, 1, i64, s));
     }
+    SSDR_TRY(leave_ticket(S, s));
     return SSDR_OK;
 }
 
@@ -87,7 +112,8 @@ int knn_batch_device(const float* d_pts, size_t B, size_t npts, const float* d_q
     for (size_t b = 0; b < B; ++b) { trees[b].pts = d_pts + b * npts * 3; trees[b].n = (int)npts; }
     SSDR_TRY(kd_build(S.forest, trees, s));
     SSDR_TRY(kd_search(S.forest, 0, (int)B, d_q, nq * 3, (int)nq, (int)K, self_order ? 0 : -1, d_out, i64, nq * K, s));
-    return SSDR_OK;
+    S.grid.nsets = 0;           // no grid in this call: the ticket carries the forest's words only
+    return leave_ticket(S, s);
 }
 
 int knn_batch_host(const float* pts, size_t B, size_t npts, size_t dim, const float* q, size_t nq, size_t K,
@@ -144,6 +170,8 @@ int ssdr_knn_status(void* stream, int32_t* out4) {
     KnnState& S = st(s);
     int32_t h[4] = {0, 0, 0, 0};
     SSDR_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < TICKETS; ++i) S.ticket[i].pending = false;      // everything has finished: what follows is the direct read
+    S.folded[2] = 0;
     if (S.grid.need.p && S.grid.nsets > 0) {
         int g[10] = {0};
         SSDR_HIP(hipMemcpy(g, S.grid.counters(), sizeof(g), hipMemcpyDeviceToHost));
@@ -167,6 +195,23 @@ int ssdr_knn_status(void* stream, int32_t* out4) {
     if (h[2]) {
         set_error("KNN device status 0x%x (1 = kd queue overflow, 2 = kd node overflow, 4 = kd tree deeper than its level limit, 8 = hand-over list overflow): "
                   "the neighbour lists of the last call on this stream are not trustworthy", h[2]);
+        return SSDR_ERR_INTERNAL;
+    }
+    return SSDR_OK;
+}
+
+int ssdr_knn_status_poll(void* stream, int32_t* out4) {
+    SSDR_TRY(ensure_init());
+    KnnState& S = st(pick_stream(stream));
+    for (int i = 0; i < TICKETS; ++i) {
+        KnnTicket& t = S.ticket[i];
+        if (t.pending && hipEventQuery(t.ev) == hipSuccess) fold_ticket(S, t);
+    }
+    if (out4) for (int i = 0; i < 4; ++i) out4[i] = S.folded[i];
+    if (S.folded[2]) {
+        set_error("KNN device status 0x%x (1 = kd queue overflow, 2 = kd node overflow, 4 = kd tree deeper than its level limit, 8 = hand-over list overflow, "
+                  "16 = walk into an unbuilt node): the neighbour lists of an earlier call on this stream are not trustworthy", S.folded[2]);
+        S.folded[2] = 0;
         return SSDR_ERR_INTERNAL;
     }
     return SSDR_OK;
@@ -247,7 +292,8 @@ int ssdr_knn_pyramid_dev(const float* d_xyz, size_t B, size_t npts, size_t num_l
             SSDR_HIP(hipMemcpy2DAsync(d_sub_idx[l], N[l + 1] * K * 4, d_neigh_idx[l], N[l] * K * 4, N[l + 1] * K * 4, B,
                                       hipMemcpyDeviceToDevice, s));
     }
-    return SSDR_OK;
+    S.grid.nsets = 0;
+    return leave_ticket(S, s);
 }
 
 int ssdr_knn_pyramid(const float* xyz, size_t B, size_t npts, size_t num_layers, const int32_t* ratios, size_t K,

@@ -155,6 +155,20 @@ int ssdr_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
     SSDR_HIP(hipStreamSynchronize(ssdr::ctx().stream));
     return SSDR_OK;
 }
+int ssdr_memcpy_h2d_on(void* d_dst, const void* src, size_t bytes, void* stream) {
+    SSDR_TRY(ssdr::ensure_init());
+    hipStream_t s = ssdr::pick_stream(stream);
+    SSDR_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s));
+    SSDR_HIP(hipStreamSynchronize(s));
+    return SSDR_OK;
+}
+int ssdr_memcpy_d2h_on(void* dst, const void* d_src, size_t bytes, void* stream) {
+    SSDR_TRY(ssdr::ensure_init());
+    hipStream_t s = ssdr::pick_stream(stream);
+    SSDR_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+    SSDR_HIP(hipStreamSynchronize(s));
+    return SSDR_OK;
+}
 int ssdr_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
     SSDR_TRY(ssdr::ensure_init());
     SSDR_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ssdr::ctx().stream));

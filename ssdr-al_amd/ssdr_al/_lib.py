@@ -111,6 +111,9 @@ def lib():
         L.ssdr_dev_free.argtypes = [vp]
         L.ssdr_memcpy_h2d.argtypes = [vp, vp, sz]
         L.ssdr_memcpy_d2h.argtypes = [vp, vp, sz]
+        L.ssdr_memcpy_h2d_on.argtypes = [vp, vp, sz, vp]
+        L.ssdr_memcpy_d2h_on.argtypes = [vp, vp, sz, vp]
+        L.ssdr_knn_status_poll.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -158,10 +161,14 @@ class DevArray:
             self.ptr = p.value
 
     @classmethod
-    def from_host(cls, a):
+    def from_host(cls, a, stream=None):
+        """stream: order the copy on that stream and wait for it alone (None: the library stream)"""
         a = np.ascontiguousarray(a)
         d = cls(a.shape, a.dtype)
-        check(lib().ssdr_memcpy_h2d(d.ptr, ptr(a), d.nbytes))
+        if stream is None:
+            check(lib().ssdr_memcpy_h2d(d.ptr, ptr(a), d.nbytes))
+        else:
+            check(lib().ssdr_memcpy_h2d_on(d.ptr, ptr(a), d.nbytes, stream))
         return d
 
     @property
@@ -174,9 +181,12 @@ class DevArray:
         buf = (C.c_char * self.nbytes).from_address(int(self.ptr))
         return np.frombuffer(buf, self.dtype).reshape(self.shape)
 
-    def to_host(self):
+    def to_host(self, stream=None):
         out = np.empty(self.shape, self.dtype)
-        check(lib().ssdr_memcpy_d2h(ptr(out), self.ptr, self.nbytes))
+        if stream is None:
+            check(lib().ssdr_memcpy_d2h(ptr(out), self.ptr, self.nbytes))
+        else:
+            check(lib().ssdr_memcpy_d2h_on(ptr(out), self.ptr, self.nbytes, stream))
         return out
 
     def __del__(self):

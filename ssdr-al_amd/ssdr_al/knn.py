@@ -75,9 +75,11 @@ def knn_pyramid(xyz, ratios, K):
     return neigh, sub, interp
 
 
-def knn_status(stream=None):
+def knn_status(stream=None, wait=True):
     """Waits for `stream` and raises if the last device-flavour KNN call issued on it overflowed a device-side capacity
-    (ssdr_knn_status).  Returns (rows handed to the tree walk for K=16, for K=1, status bits, deepest tree)."""
+    (ssdr_knn_status).  wait=False (ssdr_knn_status_poll): only the calls that have finished are looked at — for a caller that keeps
+    several batches in flight on the stream.  Returns (rows handed to the tree walk for K=16, for K=1, status bits, deepest tree)."""
     out = (C.c_int32 * 4)()
-    _lib.check(_lib.lib().ssdr_knn_status(stream, out))
+    L = _lib.lib()
+    _lib.check(L.ssdr_knn_status(stream, out) if wait else L.ssdr_knn_status_poll(stream, out))
     return tuple(out)

@@ -33,6 +33,7 @@ class HotPath:
         self.front_stream = None    # stream of the front end (grid-subsample + tiles)
         self.knn_stream = None      # stream of the KNN pyramid (None = self.stream)
         self.score_stream = None    # stream of the scoring stage (None = self.stream)
+        self.sel_stream = None      # stream of the selection chain (None = the library stream)
         self.global_order = None
         self.rooms = []
         self.timing = None
@@ -215,14 +216,15 @@ class HotPath:
     def _select_issue(self, comm=None):
         """everything of the selection up to the enqueued FPS chain (the host decisions and uploads happen here)"""
         L = _lib.lib()
-        if self.global_order is None:          # (the D2H below runs on the main stream, which already waits for the scoring stream's work)
-            cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(), ~self.labeled_mask, self.sp_cloud_h, self.select_per_tile * self.B)
+        st = self.sel_stream          # None: the library stream; a stream of its own lets the selections of consecutive batches overlap
+        if self.global_order is None:          # (the D2H below runs on the selection stream, which already waits for the scoring stream's work)
+            cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(st), ~self.labeled_mask, self.sp_cloud_h, self.select_per_tile * self.B)
             unl = [(int(b), int(s)) for b, s in zip(ccloud, cand)]
             gl_room = np.asarray(self.room_ids, np.int64)[ccloud]; gl_sp = cand - np.asarray(self.sp_base, np.int64)[ccloud]
             counts_r = None
         else:       # every rank derives the global candidate list from the global ranking, then keeps its own rows
             D = self.global_order
-            gcand, gcloud, sampling_batch = self._candidates(D["d_ord"].to_host(), D["valid"], D["gcloud"], D["batch"])
+            gcand, gcloud, sampling_batch = self._candidates(D["d_ord"].to_host(st), D["valid"], D["gcloud"], D["batch"])
             r_of = gcand // D["Smax"]
             counts_r = np.bincount(r_of, minlength=comm.world)
             mine = r_of == comm.rank
@@ -249,22 +251,22 @@ class HotPath:
         pack = np.zeros(offs[-1], np.int32)
         for p, o in zip(parts, offs):
             pack[o:o + len(p)] = p
-        d_pack = DevArray.from_host(pack)
+        d_pack = DevArray.from_host(pack, st)
         d_sel, d_gsel, d_rows, d_coff, d_boff, d_src = (d_pack.ptr + 4 * int(o) for o in offs[:-1])
         rows = max(len(sel), self.global_order["nu_max"] if counts_r is not None else 0)
         d_mf = DevArray((len(sel), 32), np.float32)
         d_v = DevArray((len(sel), 32), np.float64); d_comb = DevArray((rows, 32), np.float64)
         d_tmp = [DevArray(d_v.shape, np.float64), DevArray(d_v.shape, np.float64)]
-        _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel, len(sel), d_mf.ptr, None))
+        _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel, len(sel), d_mf.ptr, st))
         # float32 -> float64 as np.concatenate / np.matmul promote it (V and the running sum comb start as the same values)
-        _lib.check(L.ssdr_widen_f32_f64_dev(d_mf.ptr, len(sel) * 32, d_v.ptr, d_comb.ptr, None))
+        _lib.check(L.ssdr_widen_f32_f64_dev(d_mf.ptr, len(sel) * 32, d_v.ptr, d_comb.ptr, st))
         d_cen = DevArray((ntot, 3), np.float64); d_dir = DevArray((nsq,), np.float64); d_adj = DevArray((nsq,), np.float64)
         _lib.check(L.ssdr_cloud_graph_batch_dev(self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_gsel, d_coff, d_boff, len(clouds), ntot, nmax,
-                                                int(self.gcn_top), d_cen.ptr, d_dir.ptr, d_adj.ptr, None))
+                                                int(self.gcn_top), d_cen.ptr, d_dir.ptr, d_adj.ptr, st))
         src_v = d_v
         for hop in range(int(self.gcn_number)):
             dst = d_tmp[hop & 1]
-            _lib.check(L.ssdr_propagate_batch_dev(d_adj.ptr, d_coff, d_boff, len(clouds), nmax, d_rows, src_v.ptr, 32, dst.ptr, d_comb.ptr, None))
+            _lib.check(L.ssdr_propagate_batch_dev(d_adj.ptr, d_coff, d_boff, len(clouds), nmax, d_rows, src_v.ptr, 32, dst.ptr, d_comb.ptr, st))
             src_v = dst
         keep = [d_pack, d_cen, d_dir, d_adj, d_v, d_tmp, d_mf, d_comb]
         self.unl_cloud_ids, self.unl_sp = gl_room, gl_sp          # (room id, superpoint inside its room) of every candidate, global order
@@ -278,29 +280,29 @@ class HotPath:
             if kc:                                           # [candidates, padded to nu_max | labelled, padded to nl_max]
                 send_idx = np.zeros(per, np.int32)
                 send_idx[: len(unl)] = np.arange(len(unl)); send_idx[D["nu_max"]: D["nu_max"] + n_lab] = len(unl) + np.arange(n_lab)
-                d_sidx = DevArray.from_host(send_idx); d_send = DevArray((per, 32), np.float64)
-                _lib.check(L.ssdr_gather_rows_dev(d_comb.ptr, d_sidx.ptr, per, 32 * 8, d_send.ptr, None))
+                d_sidx = DevArray.from_host(send_idx, st); d_send = DevArray((per, 32), np.float64)
+                _lib.check(L.ssdr_gather_rows_dev(d_comb.ptr, d_sidx.ptr, per, 32 * 8, d_send.ptr, st))
                 keep += [d_sidx, d_send]
                 src = np.concatenate([r * per + np.arange(c) for r, c in enumerate(counts_r)] +
                                      [r * per + D["nu_max"] + np.arange(c) for r, c in enumerate(D["nlab"])]).astype(np.int32)
-                d_src_a = DevArray.from_host(src); d_src = d_src_a.ptr; keep.append(d_src_a)
+                d_src_a = DevArray.from_host(src, st); d_src = d_src_a.ptr; keep.append(d_src_a)
                 n_lab = int(D["nlab"].sum())
             d_gath = DevArray((comm.world, per, 32), np.float64)
-            comm.allgather_(_Prefix(d_send, per * 32), d_gath, None)
+            comm.allgather_(_Prefix(d_send, per * 32), d_gath, st)
             n_unl = int(counts_r.sum())
             n_rows = n_unl + (n_lab if kc else 0)
             d_glob = DevArray((max(n_rows, 1), 32), np.float64)
-            _lib.check(L.ssdr_gather_rows_dev(d_gath.ptr, d_src, n_rows, 32 * 8, d_glob.ptr, None))
+            _lib.check(L.ssdr_gather_rows_dev(d_gath.ptr, d_src, n_rows, 32 * 8, d_glob.ptr, st))
             keep += [d_gath, d_glob]
             d_comb = d_glob
             self._comb_dev, self._comb_n = d_glob, n_rows
         d_out = DevArray((sampling_batch,), np.int32)
         if self.selector == "kcenter":
-            d_already = DevArray.from_host((n_unl + np.arange(n_lab)).astype(np.int32)); keep.append(d_already)
-            _lib.check(L.ssdr_kcenter_dev(d_comb.ptr, n_unl + n_lab, 32, d_already.ptr, n_lab, sampling_batch, d_out.ptr, None))
+            d_already = DevArray.from_host((n_unl + np.arange(n_lab)).astype(np.int32), st); keep.append(d_already)
+            _lib.check(L.ssdr_kcenter_dev(d_comb.ptr, n_unl + n_lab, 32, d_already.ptr, n_lab, sampling_batch, d_out.ptr, st))
         else:
             start = 0                                        # np.random.randint(0, n) in the reference (:133); fixed here
-            _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, None))
+            _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, st))
         self._keep = keep
         self._pending = (d_out, unl)
 
@@ -314,12 +316,12 @@ class HotPath:
         """wait for the FPS chain of _select_issue and read the selection back"""
         d_out, unl = self._pending
         self._pending = None
-        _lib.sync()
+        sel = d_out.to_host(self.sel_stream)                 # waits for the selection stream alone
         # the device-flavour KNN calls cannot report what their kernels found (overflowed kd queue / node table / level limit, hand-over
-        # list): ask once per batch, here where the host waits anyway (the pyramid of this batch finished long ago)
+        # list): ask once per batch, here where the host waits anyway — without waiting for the pyramids of the LATER batches that the
+        # KNN stream already holds (the finished calls' tickets are looked at; Pipelined.finish / the sequential step wait for all)
         from . import knn as _knn
-        _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream)
-        sel = d_out.to_host()
+        _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream, wait=self.sel_stream is None)
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
         return sel, unl
 
@@ -364,7 +366,7 @@ class Pipelined:
     STAGES = ("front", "knn", "infer", "score")
     GROUPS = {2: (0, 0, 0, 0), 3: (0, 1, 1, 1), 4: (0, 0, 1, 2), 5: (0, 1, 2, 3)}     # stage -> stream group
 
-    def __init__(self, make_hot_path, depth=5, groups=None):
+    def __init__(self, make_hot_path, depth=5, groups=None, overlap_select=True):
         """groups: optional stage -> stream-group tuple for (front, knn, infer, score), non-decreasing from 0; depth = last group + 2"""
         if groups is not None:
             depth = groups[-1] + 2
@@ -382,6 +384,13 @@ class Pipelined:
             st = C.c_void_p()
             _lib.check(L.ssdr_stream_create(C.byref(st)))
             self.streams.append(st.value)
+        self.overlap_select = overlap_select
+        self.sel_streams = [None]                            # selections alternate between the library stream and one of their own
+        if overlap_select:
+            st = C.c_void_p()
+            _lib.check(L.ssdr_stream_create(C.byref(st)))
+            self.sel_streams.append(st.value)
+        self._uncollected = None
         self.lead = {n: depth - 1 - g for n, g in self.group.items()}      # batches ahead of the selection
         self.hp = [make_hot_path() for _ in range(depth)]
         for h in self.hp:
@@ -392,7 +401,7 @@ class Pipelined:
 
     def _drain(self):
         _lib.sync()
-        for st in self.streams:
+        for st in self.streams + [x for x in self.sel_streams if x is not None]:
             _lib.sync(st)
 
     def _stage(self, name, b):
@@ -409,7 +418,12 @@ class Pipelined:
     def run(self, steps, comm=None, steady=False):
         """Finishes `steps` selections.  steady=False: fills the pipe, runs, drains (every issued batch is completed).
         steady=True keeps the pipe full across calls: the first call fills it, and every later step issues exactly one launch sequence
-        of EVERY stage (on consecutive batches) and completes one selection — what bench.py times; finish() drains."""
+        of EVERY stage (on consecutive batches) and completes one selection — what bench.py times; finish() drains.
+
+        The selection chain (host decisions, ~3 ms of dependent launches ending in the one-workgroup FPS) is the longest stage and the only
+        one the host waits for.  With overlap_select the host enqueues the selection of batch k, then the other stages, and only then
+        waits for the selection of batch k - 1 (alternating selection streams): the chains of consecutive batches overlap and the step
+        is no longer the latency of one chain.  The stage that reuses the buffer set of batch k - 1 is enqueued after that wait."""
         self.comm = comm
         L = _lib.lib()
         out = None
@@ -417,28 +431,49 @@ class Pipelined:
         k0 = self._k if steady else 0
         last = None if steady else steps                     # batches >= last are never issued
         if k0 == 0:
+            self._uncollected = None
             for b in range(first if steady else min(steps, first)):      # prologue: fill the pipe
                 for name in self.STAGES:
                     if b < lead[name]:
                         self._stage(name, b)
         for k in range(k0, k0 + steps):
-            _lib.check(L.ssdr_stream_wait(None, self.streams[self.group["score"]]))    # main stream: batch k's scores are ready
             hk = self.hp[k % self.depth]
+            hk.sel_stream = self.sel_streams[k % len(self.sel_streams)] if self.overlap_select else None
+            _lib.check(L.ssdr_stream_wait(hk.sel_stream, self.streams[self.group["score"]]))    # selection stream: batch k's scores are ready
             hk._select_issue(comm)                           # batch k: host decisions + the whole selection chain enqueued ...
+            deferred = []
             for b in range(k + 1, k + first + 1):            # ... the other stages are issued while its FPS chain (one workgroup,
                 if last is not None and b >= last:           # ~1.4 ms) runs, instead of before it ...
                     break
                 for name in self.STAGES:
                     if b == k + lead[name]:
-                        self._stage(name, b)                 # the buffer set of batch b was last read by select(b - depth), done
-            out = hk._select_collect()                       # ... and only then the host waits for the selection
+                        if self.overlap_select and b - k == self.depth - 1:
+                            deferred.append((name, b))       # writes the buffer set of batch k - 1, whose selection may still run
+                        else:
+                            self._stage(name, b)             # the buffer set of batch b was last read by select(b - depth), done
+            if self.overlap_select:
+                if self._uncollected is not None:
+                    out = self.hp[self._uncollected % self.depth]._select_collect()
+                self._uncollected = k
+                for name, b in deferred:
+                    self._stage(name, b)
+            else:
+                out = hk._select_collect()                   # ... and only then the host waits for the selection
         if steady:
             self._k = k0 + steps
+            if out is None and self._uncollected is not None:      # a one-step call right after the fill: nothing older to hand back
+                out = self.hp[self._uncollected % self.depth]._select_collect(); self._uncollected = None
         else:
+            if self.overlap_select and self._uncollected is not None:
+                out = self.hp[self._uncollected % self.depth]._select_collect(); self._uncollected = None
             self._drain()
         return out
 
     def finish(self):
         """end a steady run: wait for everything issued and forget the partially processed batches"""
+        if getattr(self, "_uncollected", None) is not None:
+            self.hp[self._uncollected % self.depth]._select_collect(); self._uncollected = None
         self._drain()
+        from . import knn as _knn
+        _knn.knn_status(self.streams[self.group["knn"]])     # everything has finished: the blocking check
         self._k = 0
