@@ -319,7 +319,8 @@ int RadixSorter::reserve(size_t slots) {
     return SSDR_OK;
 }
 
-int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t st, int key_bits, bool input_in_alt) {
+int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t st, int key_bits, bool input_in_alt,
+                                const unsigned long long* d_andor) {
     if (nseg <= 0) return SSDR_OK;
     if (nseg > RADIX_MAX_SEG) { set_error("radix sort: more than %d segments", RADIX_MAX_SEG); return SSDR_ERR_INVALID; }
     const int slots = off[nseg];
@@ -339,8 +340,11 @@ int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const i
     const int g = std::max(1, std::min(nb, ctx().num_cu * 8));
     const int gseg = std::max(1, std::min((maxn + RS_BS * 8 - 1) / (RS_BS * 8), ctx().num_cu * 4));
     const int gao = std::max(1, std::min(std::min(gseg, RS_ANDOR_G), std::max(1, ctx().num_cu * 16 / nseg)));
-    hipLaunchKernelGGL(rs_andor, dim3(gao, nseg), dim3(RS_BS), 0, st, s);
-    hipLaunchKernelGGL(rs_andor_fold, dim3(nseg), dim3(64), 0, st, s, gao);
+    if (d_andor) SSDR_HIP(hipMemcpyAsync(s.andor, d_andor, 16 * (size_t)nseg, hipMemcpyDeviceToDevice, st));
+    else {
+        hipLaunchKernelGGL(rs_andor, dim3(gao, nseg), dim3(RS_BS), 0, st, s);
+        hipLaunchKernelGGL(rs_andor_fold, dim3(nseg), dim3(64), 0, st, s, gao);
+    }
     const int npass = std::min(4, (std::max(key_bits, 1) + 7) / 8);      // wide passes for the low 32 bits ...
     for (int p = 0; p < npass; ++p) {
         hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);

@@ -81,8 +81,10 @@ struct RadixSorter {
     uint32_t* alt_vals() { return v1.as<uint32_t>(); }
     // nseg independent segments in the same launches: segment i lives in slots [off[i], off[i+1]) (tile-aligned), holds
     // n_host[i] pairs (d_cnt[i] when given, device side).  off has nseg + 1 entries.
+    // d_andor (optional, device, [nseg][2]): AND and OR of every segment's keys when the producer knows them (any AND' subset of the true AND and
+    // OR' superset of the true OR will do: a digit is skipped when AND' and OR' agree on it) — saves the pass that reads all keys to find out
     int sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t s, int key_bits = 64,
-                      bool input_in_alt = false);
+                      bool input_in_alt = false, const unsigned long long* d_andor = nullptr);
 };
 
 // ---- kd-tree forest (kdtree.hip) ----------------------------------------------------------------

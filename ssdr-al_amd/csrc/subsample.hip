@@ -32,6 +32,7 @@ struct GsParams {
     unsigned long long nx, ny;
     int m;            // number of voxels
     int status;       // 1 = more than LAB_CAP distinct labels in one voxel
+    unsigned long long key_and, key_or;      // what the sorter needs to know about the keys: no bit is set in all of them / only these can be set
 };
 
 __device__ __forceinline__ void gs_minmax_partial_body(const float* __restrict__ P, int n, float* partial) {
@@ -66,6 +67,12 @@ __device__ __forceinline__ void gs_params_body(const float* partial, int nparts,
         prm->nx = (unsigned long long)(long long)floorf((mx[0] - org[0]) / dl) + 1ull;
         prm->ny = (unsigned long long)(long long)floorf((mx[1] - org[1]) / dl) + 1ull;
         prm->m = 0; prm->status = 0;
+        // keys are ix + nx (iy + ny iz) with ix < nx, iy < ny, iz < nz (the same rounded quotients as the key kernel's): all below nx ny nz
+        const unsigned long long nz = (unsigned long long)(long long)floorf((mx[2] - org[2]) / dl) + 1ull;
+        unsigned long long top = prm->nx * prm->ny * nz - 1ull, m = 0;
+        if (prm->nx == 0 || prm->ny == 0 || nz == 0 || (prm->nx * prm->ny) / prm->ny != prm->nx || (prm->nx * prm->ny * nz) / nz != prm->nx * prm->ny) m = ~0ull;      // wrapped: anything goes
+        else while (m < top) m = (m << 1) | 1ull;
+        prm->key_and = 0ull; prm->key_or = m;
     }
 }
 
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(BS) void prune_reduce(const float* __restrict__ P, 
 
 struct GsState {
     RadixSorter sorter;
-    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec, tidx, pparams, fk, fv, pstat;
+    DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec, tidx, pparams, fk, fv, pstat, andor;
     RadixSorter sorter2;
     size_t last_m = 0, last_fdim = 0, last_ldim = 0;
 };
@@ -622,7 +629,7 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
     t.off[nr] = (int)room_off[nr]; t.toff[nr] = toff;
     const int nb_max = (maxn + CHUNK - 1) / CHUNK;
     SSDR_TRY(S.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(S.vals.reserve(4 * (size_t)toff + 16));
-    SSDR_TRY(S.partial.reserve(24 * (size_t)PB * nr)); SSDR_TRY(S.params.reserve(sizeof(GsParams) * nr));
+    SSDR_TRY(S.partial.reserve(24 * (size_t)PB * nr)); SSDR_TRY(S.params.reserve(sizeof(GsParams) * nr)); SSDR_TRY(S.andor.reserve(16 * (size_t)nr));
     SSDR_TRY(S.bsum.reserve(4 * (size_t)nb_max * nr + 16)); SSDR_TRY(S.seg.reserve(4 * ((size_t)toff + nr + 2)));
     GsParams* prm = S.params.as<GsParams>();
     const unsigned R = (unsigned)nr;
@@ -638,7 +645,10 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
     SSDR_TRY(S.sorter.reserve((size_t)toff));
     uint64_t* const k_in = S.sorter.alt_keys(); uint32_t* const v_in = S.sorter.alt_vals();
     hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, k_in, v_in, d_f, (int)fdim, (const int*)d_c, (int)ldim, rec);
-    SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), (int)nr, t.toff, n_host.data(), nullptr, s, 64, true));
+    // the key range follows from the grid dimensions (gs_params): no pass over the keys to find the digits that vary
+    static_assert(sizeof(GsParams) % 8 == 0 && offsetof(GsParams, key_or) == offsetof(GsParams, key_and) + 8, "AND / OR pair");
+    SSDR_HIP(hipMemcpy2DAsync(S.andor.p, 16, reinterpret_cast<const char*>(prm) + offsetof(GsParams, key_and), sizeof(GsParams), 16, nr, hipMemcpyDeviceToDevice, s));
+    SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), (int)nr, t.toff, n_host.data(), nullptr, s, 64, true, S.andor.as<unsigned long long>()));
     hipLaunchKernelGGL(gs_heads_count_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max);
     hipLaunchKernelGGL(gs_heads_scan_b, dim3(R), dim3(1024), 0, s, t, S.bsum.as<int>(), nb_max, prm, S.seg.as<int>());
     hipLaunchKernelGGL(gs_heads_write_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, S.seg.as<int>());
