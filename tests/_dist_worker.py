@@ -30,7 +30,7 @@ def main():
     comm = Comm(dist, "cpu")
     sel, unl = hp.step(comm)
     # the same batches kept in flight on separate streams, exchanges included (what bench.py runs for N > 1)
-    pipe = pipeline.Pipelined(lambda: pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine), 3)
+    pipe = pipeline.Pipelined(lambda: pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine), 2)
     psel, _ = pipe.run(2, comm)
     # BASELINE configuration 4: all-gather of the candidates' AND the labelled regions' features, then the global k-center (replicated)
     hk = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2, selector="kcenter").load_rooms([all_rooms[i] for i in mine], mine)

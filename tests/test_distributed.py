@@ -12,7 +12,7 @@ from conftest import ROOT
 
 
 def test_two_rank_sharded_selection_equals_single_process(tmp_path, emu_lib):
-    env = dict(os.environ, SSDR_TEST_OUT=str(tmp_path), OMP_NUM_THREADS="2")
+    env = dict(os.environ, SSDR_TEST_OUT=str(tmp_path), OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(ROOT, "tests", "_dist_worker.py")]
     subprocess.run(cmd, check=True, env=env, timeout=1200, cwd=ROOT)
