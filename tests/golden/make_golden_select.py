@@ -155,6 +155,51 @@ def main():
     g["kc2/already"] = np.arange(900, 1000, dtype=np.int64)
     g["kc2/seq"] = np.array(kc2.select_batch_(g["kc2/already"], 80), np.int32)
     g["f6/seq"] = sampler2.farthest_superpoint_sample([xyzA[c] for c in compsA], cenA, 5, 0)
+    # G: 70 + 60 superpoints, so that the reference scripts' own --gcn_top 100 (S3/run_graph_reasoning_analysis.sh:9-11) is a valid mask
+    # width (the reference's mask assignment needs gcn_top <= #regions, :159) and cuts inside a 130-row matrix
+    tmp2 = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp2, "data", "superpoint")); os.makedirs(os.path.join(tmp2, "input"))
+    big = {}
+    for name, nsp in (("cloudC", 70), ("cloudD", 60)):
+        szs = rng.integers(4, 30, nsp)
+        centres = rng.random((nsp, 3)) * np.array([6.0, 5.0, 2.5])
+        xyz = np.concatenate([c + rng.normal(0, 0.12, (s, 3)) for c, s in zip(centres, szs)]).astype(np.float32)
+        perm = rng.permutation(len(xyz)); inv = np.argsort(perm); xyz = xyz[perm]
+        o = np.concatenate([[0], np.cumsum(szs)])
+        comps = np.empty(nsp, dtype=object)
+        for s in range(nsp):
+            comps[s] = list(inv[o[s]:o[s + 1]])
+        write_ply(os.path.join(tmp2, "input", name + ".ply"), [xyz, np.zeros((len(xyz), 3), np.uint8), np.zeros(len(xyz), np.uint8)],
+                  ["x", "y", "z", "red", "green", "blue", "class"])
+        with open(os.path.join(tmp2, "data", "superpoint", name + ".superpoint"), "wb") as f:
+            pickle.dump({"components": comps, "in_component": np.zeros(len(xyz))}, f)
+        big[name] = (xyz, comps)
+        g["g/%s/xyz" % name] = xyz
+        g["g/%s/offsets" % name] = o.astype(np.int32)
+        g["g/%s/points" % name] = np.concatenate([np.asarray(c, np.int32) for c in comps])
+    # candidates: C0..C54, D0..D44; labelled: C55..C69 and D45..D59 interleaved (the order the sampler builds is arbitrary)
+    unl2 = [{"cloud_name": "cloudC", "sp_idx": i} for i in range(55)] + [{"cloud_name": "cloudD", "sp_idx": i} for i in range(45)]
+    lab2 = []
+    for i in range(15):
+        lab2 += [{"cloud_name": "cloudC", "sp_idx": 55 + i}, {"cloud_name": "cloudD", "sp_idx": 45 + i}]
+    adj2, _ = fps_gcn_cpu.fps_adj_all(lab2, unl2, os.path.join(tmp2, "input"), os.path.join(tmp2, "data"))
+    names2 = ["cloudC", "cloudD"]
+    g["g/unl_cloud"] = np.array([names2.index(r["cloud_name"]) for r in unl2], np.int32); g["g/unl_sp"] = np.array([r["sp_idx"] for r in unl2], np.int32)
+    g["g/lab_cloud"] = np.array([names2.index(r["cloud_name"]) for r in lab2], np.int32); g["g/lab_sp"] = np.array([r["sp_idx"] for r in lab2], np.int32)
+    uf2 = rng.normal(0, 1, (len(unl2), 32)).astype(np.float32); lf2 = rng.normal(0, 1, (len(lab2), 32)).astype(np.float32)
+    g["g/unl_feat"], g["g/lab_feat"] = uf2, lf2
+    for gt in (5, 100):
+        mask = np.zeros(adj2.shape)
+        mask[np.repeat(np.expand_dims(np.arange(adj2.shape[0]), axis=1), repeats=gt, axis=1), np.argsort(adj2, axis=1)[:, -gt:]] = 1.0
+        g["g/adj_top%d" % gt] = np.multiply(adj2, mask).astype(np.float32)      # compared at 1e-6: float32 keeps the fixture small
+        for gn in (1, 2):
+            np.random.seed(9)
+            start = np.random.randint(0, len(unl2))
+            np.random.seed(9)
+            fl = fps_gcn_cpu.GCN_FPS_sampling(list(lf2), lab2, list(uf2), unl2, os.path.join(tmp2, "input"), os.path.join(tmp2, "data"), 20, gn, gt)
+            g["g/start"] = np.int32(start)
+            g["g/gcnfps_top%d_C_%d" % (gt, gn)] = np.array(fl.get("cloudC", []), np.int32)
+            g["g/gcnfps_top%d_D_%d" % (gt, gn)] = np.array(fl.get("cloudD", []), np.int32)
     np.savez_compressed(os.path.join(HERE, "select_golden.npz"), **g)
     print("select_golden.npz", os.path.getsize(os.path.join(HERE, "select_golden.npz")) // 1024, "KiB")
 

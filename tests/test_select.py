@@ -71,6 +71,29 @@ def test_chamfer_adjacency_gcnfps_golden(backend, golden):
         sampler.GCN_FPS_sampling(list(g["f/lab_feat"]), lab, list(g["f/unl_feat"]), unl, clouds, 5, 1, 14, 0)
 
 
+def test_gcn_top_100_golden(backend, golden):
+    """fps_gcn_cpu.GCN_FPS_sampling with the reference scripts' own --gcn_top 100 (and 5) on 70 + 60 superpoints: the masked adjacency
+    (:153-160) and the selections, gcn_number 1 and 2."""
+    from ssdr_al import sampler
+    g = golden("select_golden.npz")
+    names = ["cloudC", "cloudD"]
+    clouds = {n: (g["g/%s/xyz" % n], g["g/%s/offsets" % n], g["g/%s/points" % n]) for n in names}
+    unl = [{"cloud_name": names[c], "sp_idx": int(s)} for c, s in zip(g["g/unl_cloud"], g["g/unl_sp"])]
+    lab = [{"cloud_name": names[c], "sp_idx": int(s)} for c, s in zip(g["g/lab_cloud"], g["g/lab_sp"])]
+    refs = unl + lab
+    for gt in (5, 100):
+        for name in names:
+            rows = [i for i, r in enumerate(refs) if r["cloud_name"] == name]
+            _, _, adj = sampler.cloud_graph(*clouds[name], [refs[i]["sp_idx"] for i in rows], gcn_top=gt)
+            want = g["g/adj_top%d" % gt][np.ix_(rows, rows)]                   # stored as float32
+            assert np.allclose(adj, want, rtol=2e-7, atol=1e-12), (gt, name)
+            assert np.array_equal(adj != 0, want != 0), (gt, name)             # the same entries survive the mask
+        for gn in (1, 2):
+            fl = sampler.GCN_FPS_sampling(list(g["g/lab_feat"]), lab, list(g["g/unl_feat"]), unl, clouds, 20, gn, gt, int(g["g/start"]))
+            assert fl.get("cloudC", []) == list(g["g/gcnfps_top%d_C_%d" % (gt, gn)]), (gt, gn)
+            assert fl.get("cloudD", []) == list(g["g/gcnfps_top%d_D_%d" % (gt, gn)]), (gt, gn)
+
+
 def test_chamfer_mixed_superpoint_sizes(backend):
     """create_cd over superpoints of 1 ... 1700 points: several small ones share a wave (256-slot items), those above 256 points go pair
     by pair in passes, the one above 1536 points is streamed as a target; a subset in a shuffled order as `sel`."""

@@ -75,6 +75,35 @@ def test_chamfer_and_adjacency(golden):
             assert a == list(g["f/gcnfps_top%d_A_%d" % (gt, gn)]) and b == list(g["f/gcnfps_top%d_B_%d" % (gt, gn)])
 
 
+def test_gcn_top_100(golden):
+    """the oracle against the reference's run with its scripts' own --gcn_top 100 (70 + 60 superpoints)"""
+    g = _g(golden)
+    names = ("cloudC", "cloudD")
+    refs = list(zip(g["g/unl_cloud"], g["g/unl_sp"])) + list(zip(g["g/lab_cloud"], g["g/lab_sp"]))
+    N, nu = len(refs), len(g["g/unl_sp"])
+    adj = np.zeros((N, N))
+    for c, name in enumerate(names):
+        xyz, off, pts = g["g/%s/xyz" % name], g["g/%s/offsets" % name], g["g/%s/points" % name]
+        rows = [i for i, (cc, _) in enumerate(refs) if cc == c]
+        sp = [refs[i][1] for i in rows]
+        sub_off = np.concatenate([[0], np.cumsum([off[s + 1] - off[s] for s in sp])]).astype(np.int32)
+        sub_pts = np.concatenate([pts[off[s]:off[s + 1]] for s in sp])
+        cen_s = S.bbox_centres(xyz, sub_off, sub_pts)
+        adj[np.ix_(rows, rows)] = S.block_adjacency(cen_s, S.create_cd(xyz, sub_off, sub_pts, cen_s))
+    V = np.concatenate([g["g/unl_feat"], g["g/lab_feat"]]).astype(np.float64)
+    for gt in (5, 100):
+        masked = np.zeros((N, N))
+        for c in range(2):
+            rows = [i for i, (cc, _) in enumerate(refs) if cc == c]
+            masked[np.ix_(rows, rows)] = S.keep_top(adj[np.ix_(rows, rows)], gt)
+        assert np.allclose(masked, g["g/adj_top%d" % gt], rtol=2e-7, atol=1e-12)
+        for gn in (1, 2):
+            seq = S.farthest_features_sample(S.propagate([masked], [np.arange(N)], V, gn)[:nu], 20, int(g["g/start"]))
+            a = [int(g["g/unl_sp"][i]) for i in seq if g["g/unl_cloud"][i] == 0]
+            b = [int(g["g/unl_sp"][i]) for i in seq if g["g/unl_cloud"][i] == 1]
+            assert a == list(g["g/gcnfps_top%d_C_%d" % (gt, gn)]) and b == list(g["g/gcnfps_top%d_D_%d" % (gt, gn)])
+
+
 def test_fps_and_kcenter_sequences(golden):
     g = _g(golden)
     assert np.array_equal(S.farthest_features_sample(g["fps/feat"], 50, int(g["fps/start"])), g["fps/seq"])
