@@ -63,6 +63,12 @@ def test_device_path_reports_tree_depth_overflow(backend):
     with pytest.raises(_lib.SsdrError) as e:
         knn.knn_status()
     assert "0x4" in str(e.value) or "status" in str(e.value)
+    # the non-waiting flavour (ssdr_knn_status_poll) reports the same through the call's ticket once the call has finished
+    _lib.check(_lib.lib().ssdr_knn_batch_dev(d_p.ptr, 1, p.shape[1], 3, d_p.ptr, p.shape[1], 16, d_o.ptr, None))
+    _lib.sync()
+    with pytest.raises(_lib.SsdrError):
+        knn.knn_status(wait=False)
+    assert knn.knn_status(wait=False)[2] == 0            # reported once, then clear
     # a healthy call on the same stream clears it
     q = np.random.default_rng(0).random((1, 500, 3), dtype=np.float32)
     d_q = DevArray.from_host(q); d_o2 = DevArray((1, 500, 16), np.int32)
