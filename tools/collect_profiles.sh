@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collects the round's judged profiles on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
-# then copy gpurun_out/profiles_$1/* into profiles/ (tools/pmc_summary.py builds the PMC summary).
+# then copy gpurun_out/profiles_$1/* into profiles/; tools/pmc_summary.py builds the PMC summary bench.py reads, tools/kernel_table.py the per-kernel
+# table (time, HBM rate, vector-issue time, matrix instructions) profiles/$1_kernel_table.md.
 R=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
