@@ -28,6 +28,8 @@ static int forked_child() {
     return SSDR_ERR_INTERNAL;
 }
 
+__global__ void bind_kernel(int* p) { if (threadIdx.x == 0) *p = 1; }
+
 static int do_init(int device) {
     std::lock_guard<std::mutex> lk(g_init_mu);
     Context& c = ctx();
@@ -47,6 +49,16 @@ static int do_init(int device) {
     SSDR_HIP(hipEventCreate(&c.ev1));
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c.num_cu = cu;
+    // The runtime spreads the streams over its few hardware queues as they come into use, the legacy NULL stream included — and a
+    // plain hipMemcpy (weight upload, status read-back) goes through the NULL stream.  A pipeline whose stage streams were created
+    // BEFORE the NULL stream's first use ran 6.4 ms per step instead of 4.8 (same kernels, worse overlap: the late-comer ends up sharing a
+    // queue with a busy stage).  Bring the NULL stream and the library stream into use now, before a caller creates anything.
+    void* probe = nullptr; int zero = 0;
+    SSDR_HIP(hipMalloc(&probe, 256));
+    SSDR_HIP(hipMemcpy(probe, &zero, sizeof(zero), hipMemcpyHostToDevice));           // NULL stream
+    hipLaunchKernelGGL(bind_kernel, dim3(1), dim3(64), 0, c.stream, reinterpret_cast<int*>(probe));
+    SSDR_HIP(hipStreamSynchronize(c.stream));
+    SSDR_HIP(hipFree(probe));
     c.device = device; c.ready = true; g_init_pid = getpid();
     return SSDR_OK;
 }

@@ -374,22 +374,21 @@ class Pipelined:
         L = _lib.lib()
         self.depth = depth
         self.group = dict(zip(self.STAGES, groups if groups is not None else self.GROUPS[depth]))
-        # The first stream created after the library's own shares its hardware queue on this runtime (measured on
-        # MI355X / ROCm 7.2: whatever stage sat on it serialised with the selection kernels of the main stream, 67 vs
-        # 81 Mpoints/s at depth 4, for any GPU_MAX_HW_QUEUES): leave that one unused.
-        self._spare = C.c_void_p()
-        _lib.check(L.ssdr_stream_create(C.byref(self._spare)))
-        self.streams = []
-        for _ in range(depth - 1):
+        # The runtime spreads the streams over its (4) hardware queues in the order they are created, after the NULL stream and the
+        # library's own (both brought into use by ssdr_init); streams that share a queue serialise.  Which stage shares with which decides
+        # the overlap: measured on MI355X / ROCm 7.2 at depth 5 with one unused stream created in front of the stage streams 4.8 ms per
+        # step, without it 6.4, with two 6.1, with three 5.3, with the unused one in any later position 5.7-6.2 (`GPU_MAX_HW_QUEUES=8`, every
+        # stream on a queue of its own: 4.8 as well).  So: one spare in front.
+        def mkstream():
             st = C.c_void_p()
             _lib.check(L.ssdr_stream_create(C.byref(st)))
-            self.streams.append(st.value)
+            return st.value
+        self._spare = mkstream()
+        self.streams = [mkstream() for _ in range(depth - 1)]
         self.overlap_select = overlap_select
         self.sel_streams = [None]                            # selections alternate between the library stream and one of their own
         if overlap_select:
-            st = C.c_void_p()
-            _lib.check(L.ssdr_stream_create(C.byref(st)))
-            self.sel_streams.append(st.value)
+            self.sel_streams.append(mkstream())
         self._uncollected = None
         self.lead = {n: depth - 1 - g for n, g in self.group.items()}      # batches ahead of the selection
         # one buffer set per batch in flight (a spare set, so that no stage has to wait for the previous selection's buffers, was
