@@ -116,6 +116,33 @@ def test_chamfer_mixed_superpoint_sizes(backend):
     assert np.allclose(got, want[np.ix_(sel, sel)], rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.gpu
+def test_chamfer_more_superpoints_than_the_packer_lays_out():
+    """4300 superpoints in one cloud (> PACK_MAX = 4096): the packer hands every superpoint to the pair-by-pair path.  The summation
+    rule depends on a superpoint's size alone, so any sub-block must equal the packed computation over just those superpoints, bit for bit."""
+    from conftest import GPU_LIB, _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    from ssdr_al import _lib, sampler
+    _lib.use(GPU_LIB)
+    try:
+        rng = np.random.default_rng(41)
+        sizes = rng.integers(1, 40, 4300); sizes[:5] = (130, 300, 16, 17, 1)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        n = int(off[-1])
+        seats = rng.random((4300, 3)) * np.array([20, 15, 3])
+        xyz = np.concatenate([c + rng.normal(0, 0.1, (s_, 3)) for c, s_ in zip(seats, sizes)]).astype(np.float32)
+        pts = np.arange(n, dtype=np.int32)
+        full = sampler.create_cd(xyz, off, pts, np.arange(4300))
+        sub = np.concatenate([np.arange(8), rng.choice(4300, 60, replace=False)])
+        part = sampler.create_cd(xyz, off, pts, sub)
+        assert np.array_equal(full[np.ix_(sub, sub)], part)
+        cent = O.bbox_centres(xyz, off[: 9], pts[: off[8]])
+        assert np.allclose(part[:8, :8], O.create_cd(xyz, off[: 9], pts[: off[8]], cent), rtol=1e-12, atol=1e-14)
+    finally:
+        _lib.use(None)
+
+
 def test_fps_and_kcenter_golden(backend, golden):
     from ssdr_al import sampler
     g = golden("select_golden.npz")
