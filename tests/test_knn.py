@@ -76,6 +76,20 @@ def test_device_path_reports_tree_depth_overflow(backend):
     assert knn.knn_status()[2] == 0
 
 
+def test_status_tickets_wrap_around(backend, orc):
+    """more device-flavour calls on a stream than it has status tickets (16) between two polls: the oldest are folded, nothing is lost or stuck"""
+    from ssdr_al import _lib, knn
+    from ssdr_al._lib import DevArray
+    q = np.random.default_rng(3).random((1, 300, 3), dtype=np.float32)
+    d_q = DevArray.from_host(q); d_o = DevArray((1, 300, 16), np.int32)
+    for _ in range(40):
+        _lib.check(_lib.lib().ssdr_knn_batch_dev(d_q.ptr, 1, 300, 3, d_q.ptr, 300, 16, d_o.ptr, None))
+    _lib.sync()
+    assert knn.knn_status(wait=False)[2] == 0
+    assert knn.knn_status()[2] == 0
+    assert_bits_equal(d_o.to_host(), orc.knn_batch(q, q, 16, threads=2))
+
+
 def test_generic_k_up_to_256(backend, orc):
     """K = 200 goes through the LDS result set (128 KiB of dynamic LDS: needs the opt-in above 64 KiB)."""
     from ssdr_al import knn
