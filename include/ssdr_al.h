@@ -134,6 +134,9 @@ int ssdr_grid_subsample_dev(const float* d_points, size_t n,
 int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features, size_t fdim, const int32_t* d_classes, size_t ldim,
                                   const int64_t* cloud_offsets, size_t num_clouds, float sampleDl,
                                   float* d_out_points, float* d_out_features, int32_t* d_out_classes, int64_t* d_out_m, void* stream);
+/* The device flavours only enqueue work: what their kernels found is read here (waits for `stream`).  bit 0 = a voxel with more labels in one
+ * column than the per-voxel table holds (the host flavour returns SSDR_ERR_UNSUPPORTED for the same). */
+int ssdr_grid_subsample_status(void* stream, int32_t* out_status);
 
 /* ---- tile generator (spatially_regular_gen, S3/s3dis_dataset.py:115-154; data_aug, S3/helper_tool.py:185-199) --
  * From a (sub-sampled) cloud resident on the device — d_points [*,3], d_colors [*,color_dim], live row count

@@ -536,6 +536,7 @@ struct GsState {
     DevBuf keys, vals, partial, params, bsum, seg, in_p, in_f, in_c, out_p, out_f, out_c, out_m, row, rec, tidx, pparams, fk, fv, pstat, andor;
     RadixSorter sorter2;
     size_t last_m = 0, last_fdim = 0, last_ldim = 0;
+    int last_clouds = 0;        // clouds of the last device-flavour call (their GsParams sit at the front of `params`)
 };
 GsState& gs(hipStream_t st = nullptr) { static std::map<hipStream_t, GsState> m; return m[st ? st : ctx().stream]; }
 
@@ -547,6 +548,7 @@ int subsample_order_reference(const uint64_t* d_ks, const uint32_t* d_vs, const 
 int grid_subsample_device(const float* d_p, size_t n, const float* d_f, size_t fdim, const int32_t* d_c, size_t ldim, float dl,
                           int order, float* d_op, float* d_of, int32_t* d_oc, int64_t* d_om, hipStream_t s) {
     GsState& S = gs(s);
+    S.last_clouds = 1;
     const int ni = (int)n;
     const int gmm = std::max(1, std::min((ni + BS - 1) / BS, 1024));
     const int nb = (ni + CHUNK - 1) / CHUNK;
@@ -627,6 +629,7 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
         if (toff > 0x3fffffff) { set_error("grid_subsample_batch: too many points"); return SSDR_ERR_INVALID; }
     }
     t.off[nr] = (int)room_off[nr]; t.toff[nr] = toff;
+    S.last_clouds = (int)nr;
     const int nb_max = (maxn + CHUNK - 1) / CHUNK;
     SSDR_TRY(S.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(S.vals.reserve(4 * (size_t)toff + 16));
     SSDR_TRY(S.partial.reserve(24 * (size_t)PB * nr)); SSDR_TRY(S.params.reserve(sizeof(GsParams) * nr)); SSDR_TRY(S.andor.reserve(16 * (size_t)nr));
@@ -746,6 +749,24 @@ int ssdr_prune_dev(const float* d_xyz, size_t n, float voxel_size, const uint8_t
     return prune_device(d_xyz, n, voxel_size, d_rgb, n_labels > 0 ? d_labels : nullptr, n_labels, n_objects > 0 ? d_objects : nullptr, n_objects,
                         d_out_xyz, d_out_rgb, n_labels > 0 ? d_out_labels : nullptr, n_objects > 0 ? d_out_objects : nullptr, d_out_m, s);
 }
+/* what the kernels of the last device-flavour grid subsample on `stream` found (waits for it): bit 0 = a voxel with more than LAB_CAP distinct
+ * labels in one column (its majority label may be wrong) — the host flavour reports the same through its return value */
+int ssdr_grid_subsample_status(void* stream, int32_t* out_status) {
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream);
+    GsState& S = gs(s);
+    int st = 0;
+    SSDR_HIP(hipStreamSynchronize(s));
+    if (S.params.p && S.last_clouds > 0) {
+        std::vector<GsParams> h((size_t)S.last_clouds);
+        SSDR_HIP(hipMemcpy(h.data(), S.params.p, sizeof(GsParams) * h.size(), hipMemcpyDeviceToHost));
+        for (auto& g : h) st |= g.status;
+    }
+    if (out_status) *out_status = st;
+    if (st) { set_error("grid_subsample: device status 0x%x (1 = a voxel holds more than %d distinct labels in one column: unsupported)", st, LAB_CAP); return SSDR_ERR_UNSUPPORTED; }
+    return SSDR_OK;
+}
+
 /* status of the last ssdr_prune_dev on `stream` (waits for it): bit 0 = more than 2^21 bins along an axis, bit 1 = a label / object id above its declared maximum */
 int ssdr_prune_status(void* stream, int32_t* out_status) {
     SSDR_TRY(ensure_init());

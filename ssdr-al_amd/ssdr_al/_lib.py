@@ -114,6 +114,7 @@ def lib():
         L.ssdr_memcpy_h2d_on.argtypes = [vp, vp, sz, vp]
         L.ssdr_memcpy_d2h_on.argtypes = [vp, vp, sz, vp]
         L.ssdr_knn_status_poll.argtypes = [vp, vp]
+        L.ssdr_grid_subsample_status.argtypes = [vp, vp]
         _lib = L
     return _lib
 

@@ -322,6 +322,8 @@ class HotPath:
         # KNN stream already holds (the finished calls' tickets are looked at; Pipelined.finish / the sequential step wait for all)
         from . import knn as _knn
         _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream, wait=self.sel_stream is None)
+        if self.sel_stream is None:                          # sequential use: the front end of this batch has finished, ask it too
+            _lib.check(_lib.lib().ssdr_grid_subsample_status(self.front_stream if self.front_stream is not None else self.stream, None))
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
         return sel, unl
 
@@ -477,5 +479,6 @@ class Pipelined:
             self.hp[self._uncollected % self.slots]._select_collect(); self._uncollected = None
         self._drain()
         from . import knn as _knn
-        _knn.knn_status(self.streams[self.group["knn"]])     # everything has finished: the blocking check
+        _knn.knn_status(self.streams[self.group["knn"]])     # everything has finished: the blocking checks
+        _lib.check(_lib.lib().ssdr_grid_subsample_status(self.streams[self.group["front"]], None))
         self._k = 0

@@ -120,3 +120,26 @@ def test_subsample_row_layouts(backend, orc, fdim, ldim, nlab):
         exp = orc.grid_subsampling(pts, feat, lab, dl, order=order)
         for x, y in zip(got, exp):
             assert_bits_equal(x, y, "%s fdim %d ldim %d" % (order, fdim, ldim))
+
+
+def test_device_flavour_reports_label_table_overflow(backend):
+    """A voxel with more distinct labels than the per-voxel table holds: the host flavour returns SSDR_ERR_UNSUPPORTED; the device flavour only
+    enqueues, ssdr_grid_subsample_status must report it (and a healthy call after it must not)."""
+    import ctypes as C
+    from ssdr_al import _lib
+    from ssdr_al._lib import DevArray
+    n = 64
+    p = (np.random.default_rng(2).random((n, 3)) * 0.01).astype(np.float32)          # one voxel at dl = 0.04
+    f = np.zeros((n, 3), np.float32); lab = np.arange(n, dtype=np.int32).reshape(-1, 1)   # 64 distinct labels
+    d_p, d_f, d_l = DevArray.from_host(p), DevArray.from_host(f), DevArray.from_host(lab)
+    o_p, o_f, o_l, o_m = DevArray((n, 3), np.float32), DevArray((n, 3), np.float32), DevArray((n, 1), np.int32), DevArray((2,), np.int64)
+    off = np.array([0, n], np.int64)
+    L = _lib.lib()
+    _lib.check(L.ssdr_grid_subsample_batch_dev(d_p.ptr, d_f.ptr, 3, d_l.ptr, 1, _lib.ptr(off), 1, 0.04, o_p.ptr, o_f.ptr, o_l.ptr, o_m.ptr, None))
+    st = C.c_int32(0)
+    assert L.ssdr_grid_subsample_status(None, C.byref(st)) != 0 and st.value & 1
+    lab2 = (np.arange(n, dtype=np.int32) % 5).reshape(-1, 1)
+    d_l2 = DevArray.from_host(lab2)
+    _lib.check(L.ssdr_grid_subsample_batch_dev(d_p.ptr, d_f.ptr, 3, d_l2.ptr, 1, _lib.ptr(off), 1, 0.04, o_p.ptr, o_f.ptr, o_l.ptr, o_m.ptr, None))
+    _lib.check(L.ssdr_grid_subsample_status(None, C.byref(st)))
+    assert st.value == 0 and int(o_m.to_host()[0]) == 1
