@@ -31,8 +31,11 @@ struct SortPtrs {
     const int* d_cnt;            // optional device counts per segment
     int home;                    // which of k[] / v[] is the caller's buffer (the sorted pairs end up there); the input is always in k[0] / v[0]
     int nblocks_max;
+    int shift;                   // the sort key is the part of the 64-bit word from this bit up (pass p: bits [shift + 8p, shift + 8p + 8))
+    int kv;                      // 0: keys only — no value array is read or written (a payload may sit below `shift` inside the word)
     SegTab seg;
 };
+__device__ __forceinline__ unsigned digit_of(const SortPtrs& s, unsigned long long key, int p) { return (unsigned)((key >> (s.shift + 8 * p)) & 0xffull); }
 
 __device__ __forceinline__ int seg_count(const SortPtrs& s, int sg) { return s.d_cnt ? min(s.d_cnt[sg], s.seg.n_host[sg]) : s.seg.n_host[sg]; }
 __device__ __forceinline__ int seg_of_tile(const SortPtrs& s, int b) {
@@ -49,7 +52,7 @@ __device__ __forceinline__ unsigned long long union_diff(const SortPtrs& s) {
     return diff;
 }
 __device__ __forceinline__ bool pass_runs(const SortPtrs& s, int p, int& parity) {
-    const unsigned long long diff = union_diff(s);
+    const unsigned long long diff = union_diff(s) >> s.shift;
     int par = 0;
     for (int q = 0; q < p; ++q) par ^= ((diff >> (8 * q)) & 0xffull) != 0;
     parity = par;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(RS_BS) void rs_hist(SortPtrs s, int p) {
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             int i = b * RS_TILE + j * RS_BS + threadIdx.x;
-            if (i < end) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
+            if (i < end) atomicAdd(&h[digit_of(s, K[i], p)], 1u);
         }
         __syncthreads();
         s.hist[(size_t)threadIdx.x * s.nblocks_max + b] = h[threadIdx.x];
@@ -157,13 +160,14 @@ __global__ __launch_bounds__(RS_BS) void rs_scan(SortPtrs s, int p) {
 // The tile is first ordered by digit in LDS (stable: waves in order, rounds in order, lanes in order), then written
 // out position by position, so consecutive threads store consecutive pairs of one digit's run: whole 64-128 B pieces
 // of a cache line per run instead of 64 isolated 8-byte stores per wave.
+template <bool KV>
 __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
     constexpr int NW = RS_BS / 64;
     __shared__ unsigned s_cnt[NW][256];      // per wave: running count of each digit, then the wave's start inside the tile
     __shared__ unsigned s_run[256];          // global position of the digit's run of this tile minus its start inside the tile
     __shared__ unsigned s_wt[2][NW];
     __shared__ uint64_t s_key[RS_TILE];
-    __shared__ uint32_t s_val[RS_TILE];
+    __shared__ uint32_t s_val[KV ? RS_TILE : 1];
     int par; if (!pass_runs(s, p, par)) return;
     const int nb = s.seg.off[s.seg.nseg] / RS_TILE;
     const uint64_t* K = s.k[par]; const uint32_t* V = s.v[par];
@@ -182,13 +186,13 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
         for (int j = 0; j < RS_ITEMS; ++j) {
             const int i = b * RS_TILE + wid * (RS_TILE / NW) + j * 64 + lane;
             key[j] = 0; val[j] = 0;
-            if (i < end) { key[j] = K[i]; val[j] = V[i]; }
+            if (i < end) { key[j] = K[i]; if (KV) val[j] = V[i]; }
         }
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             const int i = b * RS_TILE + wid * (RS_TILE / NW) + j * 64 + lane;
             const bool valid = i < end;
-            const unsigned d = valid ? (unsigned)((key[j] >> (8 * p)) & 0xff) : 0u;
+            const unsigned d = valid ? digit_of(s, key[j], p) : 0u;
             unsigned long long m = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
@@ -228,9 +232,9 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             if (rk[j] != 0xffffffffu) {
-                const unsigned d = (unsigned)((key[j] >> (8 * p)) & 0xff);
+                const unsigned d = digit_of(s, key[j], p);
                 const unsigned l = s_cnt[wid][d] + rk[j];
-                s_key[l] = key[j]; s_val[l] = val[j];
+                s_key[l] = key[j]; if (KV) s_val[l] = val[j];
             }
         }
         __syncthreads();
@@ -241,8 +245,8 @@ __global__ __launch_bounds__(RS_BS) void rs_scatter(SortPtrs s, int p) {
             const int l = j * RS_BS + tid;
             if (l < ntile) {
                 const uint64_t k = s_key[l];
-                const unsigned pos = s_run[(unsigned)((k >> (8 * p)) & 0xff)] + (unsigned)l;
-                KO[pos] = k; VO[pos] = s_val[l];
+                const unsigned pos = s_run[digit_of(s, k, p)] + (unsigned)l;
+                KO[pos] = k; if (KV) VO[pos] = s_val[l];
             }
         }
         __syncthreads();
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(1024) void rs_high_passes(SortPtrs s) {
             uint64_t* KO = s.k[par ^ 1] + so; uint32_t* VO = s.v[par ^ 1] + so;
             if (tid < 256) h[tid] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += 1024) atomicAdd(&h[(unsigned)((K[i] >> (8 * p)) & 0xff)], 1u);
+            for (int i = tid; i < n; i += 1024) atomicAdd(&h[digit_of(s, K[i], p)], 1u);
             __syncthreads();
             if (tid == 0) { unsigned run = 0; for (int d = 0; d < 256; ++d) { unsigned c = h[d]; h[d] = run; run += c; } }
             __syncthreads();
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(1024) void rs_high_passes(SortPtrs s) {
                 const int i = base + tid;
                 const bool valid = i < n;
                 uint64_t key = 0; uint32_t val = 0; unsigned d = 0;
-                if (valid) { key = K[i]; val = V[i]; d = (unsigned)((key >> (8 * p)) & 0xff); }
+                if (valid) { key = K[i]; if (s.kv) val = V[i]; d = digit_of(s, key, p); }
                 for (int w = 0; w < 16; ++w) if (tid < 256) s_cnt[w][tid] = 0;
                 __syncthreads();
                 unsigned long long m = __ballot(valid);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(1024) void rs_high_passes(SortPtrs s) {
                 if (valid) {
                     unsigned pos = h[d] + rank;
                     for (int w = 0; w < wid; ++w) pos += s_cnt[w][d];
-                    KO[pos] = key; VO[pos] = val;
+                    KO[pos] = key; if (s.kv) VO[pos] = val;
                 }
                 __syncthreads();
                 if (tid < 256) { unsigned t = 0; for (int w = 0; w < 16; ++w) t += s_cnt[w][tid]; h[tid] += t; }
@@ -302,12 +306,12 @@ __global__ __launch_bounds__(1024) void rs_high_passes(SortPtrs s) {
 
 // after the last pass the result may sit in the other buffer: bring it home to the caller's (grid.y = segment)
 __global__ __launch_bounds__(RS_BS) void rs_finish(SortPtrs s) {
-    const unsigned long long diff = union_diff(s);
+    const unsigned long long diff = union_diff(s) >> s.shift;
     int par = 0;
     for (int q = 0; q < 8; ++q) par ^= ((diff >> (8 * q)) & 0xffull) != 0;
     if (par == s.home) return;                            // already in the caller's buffer
     const int sg = blockIdx.y, n = seg_count(s, sg), so = s.seg.off[sg];
-    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { s.k[s.home][so + i] = s.k[par][so + i]; s.v[s.home][so + i] = s.v[par][so + i]; }
+    for (int i = blockIdx.x * RS_BS + threadIdx.x; i < n; i += gridDim.x * RS_BS) { s.k[s.home][so + i] = s.k[par][so + i]; if (s.kv) s.v[s.home][so + i] = s.v[par][so + i]; }
 }
 
 }  // namespace
@@ -320,7 +324,7 @@ int RadixSorter::reserve(size_t slots) {
 }
 
 int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t st, int key_bits, bool input_in_alt,
-                                const unsigned long long* d_andor) {
+                                const unsigned long long* d_andor, int shift) {
     if (nseg <= 0) return SSDR_OK;
     if (nseg > RADIX_MAX_SEG) { set_error("radix sort: more than %d segments", RADIX_MAX_SEG); return SSDR_ERR_INVALID; }
     const int slots = off[nseg];
@@ -330,6 +334,8 @@ int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const i
     if (input_in_alt) { std::swap(s.k[0], s.k[1]); std::swap(s.v[0], s.v[1]); s.home = 1; }     // the producer wrote into alt_keys() / alt_vals()
     s.andor = andor.as<unsigned long long>(); s.andor_part = s.andor + 2 * RADIX_MAX_SEG; s.hist = hist.as<unsigned>(); s.tot = hist.as<unsigned>() + 256 * (size_t)nblocks_max;
     s.d_cnt = d_cnt; s.nblocks_max = nblocks_max; s.seg.nseg = nseg;
+    s.shift = shift; s.kv = vals != nullptr;
+    if (shift < 0 || shift + key_bits > 64) { set_error("radix sort: key bits [%d, %d) do not fit 64", shift, shift + key_bits); return SSDR_ERR_INVALID; }
     int maxn = 0;
     for (int i = 0; i < nseg; ++i) {
         if (off[i] % RS_TILE || off[i + 1] < off[i] + n_host[i]) { set_error("radix sort: segment offsets must be tile-aligned and hold the segment"); return SSDR_ERR_INVALID; }
@@ -349,7 +355,8 @@ int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const i
     for (int p = 0; p < npass; ++p) {
         hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
         hipLaunchKernelGGL(rs_scan, dim3(256, nseg), dim3(RS_BS), 0, st, s, p);
-        hipLaunchKernelGGL(rs_scatter, dim3(g), dim3(RS_BS), 0, st, s, p);
+        if (s.kv) hipLaunchKernelGGL(rs_scatter<true>, dim3(g), dim3(RS_BS), 0, st, s, p);
+        else hipLaunchKernelGGL(rs_scatter<false>, dim3(g), dim3(RS_BS), 0, st, s, p);
     }
     if (key_bits > 32) hipLaunchKernelGGL(rs_high_passes, dim3(1), dim3(1024), 0, st, s);   // ... one kernel for the rest
     hipLaunchKernelGGL(rs_finish, dim3(std::min(gseg, std::max(1, 2048 / nseg)), nseg), dim3(RS_BS), 0, st, s);     // usually nothing to copy: keep the (empty) launch small

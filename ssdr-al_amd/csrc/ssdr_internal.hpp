@@ -83,8 +83,10 @@ struct RadixSorter {
     // n_host[i] pairs (d_cnt[i] when given, device side).  off has nseg + 1 entries.
     // d_andor (optional, device, [nseg][2]): AND and OR of every segment's keys when the producer knows them (any AND' subset of the true AND and
     // OR' superset of the true OR will do: a digit is skipped when AND' and OR' agree on it) — saves the pass that reads all keys to find out
+    // vals == nullptr: keys only.  shift: the sort key is bits [shift, shift + key_bits) of the word — whatever sits below travels with it
+    // (a stable sort of (key << b | index) words needs no value array at all).
     int sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const int* off, const int* n_host, const int* d_cnt, hipStream_t s, int key_bits = 64,
-                      bool input_in_alt = false, const unsigned long long* d_andor = nullptr);
+                      bool input_in_alt = false, const unsigned long long* d_andor = nullptr, int shift = 0);
 };
 
 // ---- kd-tree forest (kdtree.hip) ----------------------------------------------------------------

@@ -80,8 +80,11 @@ __device__ __forceinline__ void gs_params_body(const float* partial, int nparts,
 // record: the per-voxel reduction then gathers ONE memory sector per point in sorted order instead of one from each of
 // three arrays (PMC: the three-array reduction fetched 6-11x its algorithmic bytes, a random 4-12 byte read pays for a
 // whole sector).
-__device__ __forceinline__ void gs_keys_body(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals,
-                                              const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) {
+// idx_bits > 0: the sort word is (voxel key << idx_bits) | point index and no value array is written — the stable sort on the upper part keeps
+// the indices of a voxel ascending, and the sorter moves 8 bytes per point instead of 12.  A voxel key that does not leave room for the
+// index (a grid of more than 2^(64 - idx_bits) cells) sets status bit 1: that cloud needs the (key, value) flavour.
+__device__ __forceinline__ void gs_keys_body(const float* __restrict__ P, int n, GsParams* prm, uint64_t* keys, uint32_t* vals,
+                                              const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec, int idx_bits = 0) {
     const float ox = prm->org[0], oy = prm->org[1], oz = prm->org[2], dl = prm->dl;
     const unsigned long long nx = prm->nx, ny = prm->ny;
     for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
@@ -90,8 +93,11 @@ __device__ __forceinline__ void gs_keys_body(const float* __restrict__ P, int n,
         const unsigned long long ix = (unsigned long long)(long long)floorf((x - ox) / dl);
         const unsigned long long iy = (unsigned long long)(long long)floorf((y - oy) / dl);
         const unsigned long long iz = (unsigned long long)(long long)floorf((z - oz) / dl);
-        keys[i] = ix + nx * iy + nx * ny * iz;
-        vals[i] = (uint32_t)i;
+        const unsigned long long key = ix + nx * iy + nx * ny * iz;
+        if (idx_bits > 0) {
+            if (key >> (64 - idx_bits)) atomicOr(&prm->status, 2);
+            keys[i] = (key << idx_bits) | (unsigned long long)i;
+        } else { keys[i] = key; vals[i] = (uint32_t)i; }
         if (rec) {
             uint32_t w[REC_W];
             w[0] = __float_as_uint(x); w[1] = __float_as_uint(y); w[2] = __float_as_uint(z);
@@ -109,12 +115,21 @@ __device__ __forceinline__ void gs_keys_body(const float* __restrict__ P, int n,
 }
 
 // ---- segment heads: 3-step compaction -------------------------------------------------------------
-__device__ __forceinline__ void gs_heads_count_body(const uint64_t* __restrict__ ks, int n, int* bsum) {
+// shift > 0: composite words (see gs_keys_body) — the voxel key is the part above `shift`; the kernel then also unpacks the point indices
+// into `vals_out` for the reduction, which is written against a value array
+__device__ __forceinline__ void gs_heads_count_body(const uint64_t* __restrict__ ks, int n, int* bsum, int shift = 0, uint32_t* vals_out = nullptr) {
     __shared__ int s_sum[(BS / 64) * 2];
     const int base = blockIdx.x * CHUNK;
     int c = 0, z = 0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { int i = base + u * BS + threadIdx.x; if (i < n) c += (i == 0) || (ks[i] != ks[i - 1]); }
+    for (int u = 0; u < U; ++u) {
+        int i = base + u * BS + threadIdx.x;
+        if (i < n) {
+            const uint64_t k = ks[i];
+            c += (i == 0) || ((k >> shift) != (ks[i - 1] >> shift));
+            if (vals_out) vals_out[i] = (uint32_t)(k & ((1ull << shift) - 1ull));
+        }
+    }
     block_sum2(c, z, s_sum);
     if (threadIdx.x == 0) bsum[blockIdx.x] = c;
 }
@@ -145,11 +160,11 @@ __device__ __forceinline__ void gs_heads_scan_body(int* bsum, int nb, GsParams* 
     if (tid == 0) { prm->m = carry_s; seg_start[carry_s] = n; }
 }
 
-__device__ __forceinline__ void gs_heads_write_body(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) {
+__device__ __forceinline__ void gs_heads_write_body(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start, int shift = 0) {
     __shared__ int s_w[2][U][BS / 64];
     const int base = blockIdx.x * CHUNK, off = bsum[blockIdx.x];
     const int hi = min(n, base + CHUNK);
-    block_compact(base, hi, [&](int i) { return (i == 0) || (ks[i] != ks[i - 1]); },
+    block_compact(base, hi, [&](int i) { return (i == 0) || ((ks[i] >> shift) != (ks[i - 1] >> shift)); },
                   [&](int k, int i) { seg_start[off + k] = i; }, s_w);
 }
 
@@ -401,7 +416,7 @@ __device__ __forceinline__ void gs_reduce_staged_body(const uint32_t* __restrict
 // ---- kernel entry points: one cloud, or all clouds of a batch (blockIdx.y = cloud) -----------------------------
 __global__ __launch_bounds__(BS) void gs_minmax_partial(const float* __restrict__ P, int n, float* partial) { gs_minmax_partial_body(P, n, partial); }
 __global__ __launch_bounds__(BS) void gs_params(const float* partial, int nparts, float dl, GsParams* prm) { gs_params_body(partial, nparts, dl, prm); }
-__global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, const GsParams* prm, uint64_t* keys, uint32_t* vals, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) { gs_keys_body(P, n, prm, keys, vals, F, fdim, cls, ldim, rec); }
+__global__ __launch_bounds__(BS) void gs_keys(const float* __restrict__ P, int n, GsParams* prm, uint64_t* keys, uint32_t* vals, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) { gs_keys_body(P, n, prm, keys, vals, F, fdim, cls, ldim, rec); }
 __global__ __launch_bounds__(BS) void gs_tile_index(const int* __restrict__ seg_start, const GsParams* prm, int n, int* first_ge) { gs_tile_index_body(seg_start, prm, n, first_ge); }
 __global__ __launch_bounds__(BS) void gs_reduce_packed(const uint32_t* __restrict__ rec, int fdim, int ldim, int n, const int* __restrict__ first_ge, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m) { gs_reduce_staged_body(rec, fdim, ldim, n, first_ge, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m); }
 __global__ __launch_bounds__(BS) void gs_heads_count(const uint64_t* __restrict__ ks, int n, int* bsum) { gs_heads_count_body(ks, n, bsum); }
@@ -419,14 +434,18 @@ __global__ __launch_bounds__(BS) void gs_minmax_partial_b(CloudTab t, const floa
     const int r = blockIdx.y;
     gs_minmax_partial_body(P + 3 * (size_t)t.off[r], t.off[r + 1] - t.off[r], partial + (size_t)r * PB * 6);
 }
-__global__ __launch_bounds__(BS) void gs_params_b(const float* partial, float dl, GsParams* prm) {
+__global__ __launch_bounds__(BS) void gs_params_b(const float* partial, float dl, GsParams* prm, int idx_bits) {
     gs_params_body(partial + (size_t)blockIdx.x * PB * 6, PB, dl, prm + blockIdx.x);
+    if (threadIdx.x == 0 && idx_bits > 0) {      // composite sort words: the voxel key sits above the point index (gs_keys_body)
+        const unsigned long long m = prm[blockIdx.x].key_or;
+        prm[blockIdx.x].key_or = (m >> (64 - idx_bits)) ? ~0ull : (m << idx_bits);
+    }
 }
-__global__ __launch_bounds__(BS) void gs_keys_b(CloudTab t, const float* __restrict__ P, const GsParams* prm, uint64_t* keys, uint32_t* vals,
-                                                const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec) {
+__global__ __launch_bounds__(BS) void gs_keys_b(CloudTab t, const float* __restrict__ P, GsParams* prm, uint64_t* keys, uint32_t* vals,
+                                                const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, uint32_t* rec, int idx_bits) {
     const int r = blockIdx.y; const size_t o = (size_t)t.off[r];
-    gs_keys_body(P + 3 * o, t.off[r + 1] - t.off[r], prm + r, keys + t.toff[r], vals + t.toff[r],
-                 F ? F + o * fdim : nullptr, fdim, cls ? cls + o * ldim : nullptr, ldim, rec ? rec + o * REC_W : nullptr);
+    gs_keys_body(P + 3 * o, t.off[r + 1] - t.off[r], prm + r, keys + t.toff[r], vals ? vals + t.toff[r] : nullptr,
+                 F ? F + o * fdim : nullptr, fdim, cls ? cls + o * ldim : nullptr, ldim, rec ? rec + o * REC_W : nullptr, idx_bits);
 }
 __global__ __launch_bounds__(BS) void gs_tile_index_b(CloudTab t, const int* __restrict__ seg_start, const GsParams* prm, int* first_ge) {
     const int r = blockIdx.y;
@@ -439,19 +458,19 @@ __global__ __launch_bounds__(BS) void gs_reduce_packed_b(CloudTab t, const uint3
     gs_reduce_staged_body(rec + o * REC_W, fdim, ldim, t.off[r + 1] - t.off[r], first_ge + t.toff[r] / GS_T + 2 * r, vs + t.toff[r], seg_start + t.toff[r] + r, prm + r, nullptr,
                           out_p + 3 * o, out_f ? out_f + o * fdim : nullptr, out_c ? out_c + o * ldim : nullptr, out_m ? out_m + r : nullptr);
 }
-__global__ __launch_bounds__(BS) void gs_heads_count_b(CloudTab t, const uint64_t* __restrict__ ks, int* bsum, int nb_max) {
+__global__ __launch_bounds__(BS) void gs_heads_count_b(CloudTab t, const uint64_t* __restrict__ ks, int* bsum, int nb_max, int shift, uint32_t* vals_out) {
     const int r = blockIdx.y, n = t.off[r + 1] - t.off[r];
     if ((int)blockIdx.x * CHUNK >= n) { if (threadIdx.x == 0) bsum[(size_t)r * nb_max + blockIdx.x] = 0; return; }
-    gs_heads_count_body(ks + t.toff[r], n, bsum + (size_t)r * nb_max);
+    gs_heads_count_body(ks + t.toff[r], n, bsum + (size_t)r * nb_max, shift, vals_out ? vals_out + t.toff[r] : nullptr);
 }
 __global__ __launch_bounds__(1024) void gs_heads_scan_b(CloudTab t, int* bsum, int nb_max, GsParams* prm, int* seg_start) {
     const int r = blockIdx.x, n = t.off[r + 1] - t.off[r];
     gs_heads_scan_body(bsum + (size_t)r * nb_max, (n + CHUNK - 1) / CHUNK, prm + r, seg_start + t.toff[r] + r, n);
 }
-__global__ __launch_bounds__(BS) void gs_heads_write_b(CloudTab t, const uint64_t* __restrict__ ks, const int* bsum, int nb_max, int* seg_start) {
+__global__ __launch_bounds__(BS) void gs_heads_write_b(CloudTab t, const uint64_t* __restrict__ ks, const int* bsum, int nb_max, int* seg_start, int shift) {
     const int r = blockIdx.y, n = t.off[r + 1] - t.off[r];
     if ((int)blockIdx.x * CHUNK >= n) return;
-    gs_heads_write_body(ks + t.toff[r], n, bsum + (size_t)r * nb_max, seg_start + t.toff[r] + r);
+    gs_heads_write_body(ks + t.toff[r], n, bsum + (size_t)r * nb_max, seg_start + t.toff[r] + r, shift);
 }
 __global__ __launch_bounds__(BS) void gs_reduce_b(CloudTab t, const float* __restrict__ P, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim,
                                                   const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm,
@@ -637,7 +656,9 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
     GsParams* prm = S.params.as<GsParams>();
     const unsigned R = (unsigned)nr;
     hipLaunchKernelGGL(gs_minmax_partial_b, dim3(PB, R), dim3(BS), 0, s, t, d_p, S.partial.as<float>());
-    hipLaunchKernelGGL(gs_params_b, dim3(R), dim3(BS), 0, s, S.partial.as<float>(), dl, prm);
+    // sort words (voxel key << idx_bits) | index inside the cloud: 8 bytes per point through the sorter instead of 12
+    int idx_bits = 1; while ((1L << idx_bits) < (long)maxn) ++idx_bits;
+    hipLaunchKernelGGL(gs_params_b, dim3(R), dim3(BS), 0, s, S.partial.as<float>(), dl, prm, idx_bits);
     const int g = std::max(1, std::min((maxn + BS - 1) / BS, 256));
     const bool packed = 3 + fdim + ldim <= (size_t)REC_W;
     uint32_t* rec = nullptr;
@@ -647,14 +668,15 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
     // still ends there, through the sorter's final copy).
     SSDR_TRY(S.sorter.reserve((size_t)toff));
     uint64_t* const k_in = S.sorter.alt_keys(); uint32_t* const v_in = S.sorter.alt_vals();
-    hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, k_in, v_in, d_f, (int)fdim, (const int*)d_c, (int)ldim, rec);
+    (void)v_in;
+    hipLaunchKernelGGL(gs_keys_b, dim3(g, R), dim3(BS), 0, s, t, d_p, prm, k_in, (uint32_t*)nullptr, d_f, (int)fdim, (const int*)d_c, (int)ldim, rec, idx_bits);
     // the key range follows from the grid dimensions (gs_params): no pass over the keys to find the digits that vary
     static_assert(sizeof(GsParams) % 8 == 0 && offsetof(GsParams, key_or) == offsetof(GsParams, key_and) + 8, "AND / OR pair");
     SSDR_HIP(hipMemcpy2DAsync(S.andor.p, 16, reinterpret_cast<const char*>(prm) + offsetof(GsParams, key_and), sizeof(GsParams), 16, nr, hipMemcpyDeviceToDevice, s));
-    SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), S.vals.as<uint32_t>(), (int)nr, t.toff, n_host.data(), nullptr, s, 64, true, S.andor.as<unsigned long long>()));
-    hipLaunchKernelGGL(gs_heads_count_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max);
+    SSDR_TRY(S.sorter.sort_segments(S.keys.as<uint64_t>(), nullptr, (int)nr, t.toff, n_host.data(), nullptr, s, 64 - idx_bits, true, S.andor.as<unsigned long long>(), idx_bits));
+    hipLaunchKernelGGL(gs_heads_count_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, idx_bits, S.vals.as<uint32_t>());
     hipLaunchKernelGGL(gs_heads_scan_b, dim3(R), dim3(1024), 0, s, t, S.bsum.as<int>(), nb_max, prm, S.seg.as<int>());
-    hipLaunchKernelGGL(gs_heads_write_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, S.seg.as<int>());
+    hipLaunchKernelGGL(gs_heads_write_b, dim3(nb_max, R), dim3(BS), 0, s, t, S.keys.as<uint64_t>(), S.bsum.as<int>(), nb_max, S.seg.as<int>(), idx_bits);
     if (packed) {
         SSDR_TRY(S.tidx.reserve(4 * ((size_t)toff / GS_T + 2 * nr + 4)));
         hipLaunchKernelGGL(gs_tile_index_b, dim3(g, R), dim3(BS), 0, s, t, S.seg.as<int>(), prm, S.tidx.as<int>());
@@ -763,7 +785,8 @@ int ssdr_grid_subsample_status(void* stream, int32_t* out_status) {
         for (auto& g : h) st |= g.status;
     }
     if (out_status) *out_status = st;
-    if (st) { set_error("grid_subsample: device status 0x%x (1 = a voxel holds more than %d distinct labels in one column: unsupported)", st, LAB_CAP); return SSDR_ERR_UNSUPPORTED; }
+    if (st) { set_error("grid_subsample: device status 0x%x (1 = a voxel holds more than %d distinct labels in one column; 2 = a cloud's grid has too many cells for "
+                        "the batch flavour's sort words: use ssdr_grid_subsample_dev for it)", st, LAB_CAP); return SSDR_ERR_UNSUPPORTED; }
     return SSDR_OK;
 }
 
