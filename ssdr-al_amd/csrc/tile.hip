@@ -21,8 +21,10 @@ __device__ __forceinline__ void tile_keys_body(const float* __restrict__ pts, co
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
         const float dx = pts[3 * (size_t)i] - cx, dy = pts[3 * (size_t)i + 1] - cy, dz = pts[3 * (size_t)i + 2] - cz;
         const float d = (dx * dx + dy * dy) + dz * dz;
-        keys[i] = (uint64_t)__float_as_uint(d);        // non-negative floats order like their bit patterns
-        vals[i] = (uint32_t)i;
+        // non-negative floats order like their bit patterns.  Without a value array the index rides in the low word of the sort word
+        // (distance bits << 32 | index): the sorter then moves 8 bytes per point and the gather reads the low words
+        if (vals) { keys[i] = (uint64_t)__float_as_uint(d); vals[i] = (uint32_t)i; }
+        else keys[i] = ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)(uint32_t)i;
     }
 }
 
@@ -32,7 +34,7 @@ __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, 
                                                    const uint32_t* __restrict__ sorted, const int* __restrict__ d_count,
                                                    const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
                                                    float cx, float cy, float cz, float color_scale,
-                                                   float* out_xyz, float* out_feat, int* out_idx) {
+                                                   float* out_xyz, float* out_feat, int* out_idx, int stride = 1) {
     const int m = *d_count;
     const int avail = min(m, num_points);
     for (int r = blockIdx.x * 256 + threadIdx.x; r < num_points; r += gridDim.x * 256) {
@@ -50,7 +52,7 @@ __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, 
             int seen = 0; pos = 0;
             for (int q = 0; q < num_points; ++q) { const int v = perm[q]; if (v < avail) { if (seen == want) { pos = v; break; } ++seen; } }
         }
-        const uint32_t id = sorted[pos];
+        const uint32_t id = sorted[(size_t)pos * stride];        // stride 2: the low words of 64-bit sort words
         const float x = pts[3 * (size_t)id] - cx, y = pts[3 * (size_t)id + 1] - cy, z = pts[3 * (size_t)id + 2] - cz;
         out_xyz[3 * (size_t)r] = x; out_xyz[3 * (size_t)r + 1] = y; out_xyz[3 * (size_t)r + 2] = z;
         if (out_feat) {
@@ -71,14 +73,14 @@ struct TileTab { int nr; int off[RADIX_MAX_SEG + 1]; int toff[RADIX_MAX_SEG + 1]
 
 __global__ __launch_bounds__(256) void tile_keys_b(TileTab t, const float* __restrict__ pts, const long long* __restrict__ d_m, uint64_t* keys, uint32_t* vals, int* d_count) {
     const int r = blockIdx.y;
-    tile_keys_body(pts + 3 * (size_t)t.off[r], d_m + r, t.off[r + 1] - t.off[r], t.cx[r], t.cy[r], t.cz[r], keys + t.toff[r], vals + t.toff[r], d_count + r);
+    tile_keys_body(pts + 3 * (size_t)t.off[r], d_m + r, t.off[r + 1] - t.off[r], t.cx[r], t.cy[r], t.cz[r], keys + t.toff[r], vals ? vals + t.toff[r] : nullptr, d_count + r);
 }
 __global__ __launch_bounds__(256) void tile_gather_b(TileTab t, const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted,
                                                      const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
-                                                     float color_scale, float* out_xyz, float* out_feat, int* out_idx) {
+                                                     float color_scale, float* out_xyz, float* out_feat, int* out_idx, int stride) {
     const int r = blockIdx.y; const size_t o = (size_t)t.off[r], q = (size_t)r * num_points;
-    tile_gather_body(pts + 3 * o, colors ? colors + o * cdim : nullptr, cdim, sorted + t.toff[r], d_count + r, perm + q, dup_u + q, num_points, t.cx[r], t.cy[r], t.cz[r],
-                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr);
+    tile_gather_body(pts + 3 * o, colors ? colors + o * cdim : nullptr, cdim, sorted + (size_t)t.toff[r] * stride, d_count + r, perm + q, dup_u + q, num_points, t.cx[r], t.cy[r], t.cz[r],
+                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, stride);
 }
 
 // Possibility map of the test-time generator (S3/s3dis_dataset_test.py:140-143): for the `avail` points of the tile,
@@ -175,11 +177,11 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
     SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.vals.reserve(4 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
     const unsigned R = (unsigned)num_clouds;
     const int g = std::max(1, std::min((maxn + 255) / 256, 256));
-    hipLaunchKernelGGL(tile_keys_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), T.count.as<int>());
-    SSDR_TRY(T.sorter.sort_segments(T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), (int)num_clouds, t.toff, n_host.data(), T.count.as<int>(), s, 32));
+    hipLaunchKernelGGL(tile_keys_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.keys.as<uint64_t>(), (uint32_t*)nullptr, T.count.as<int>());
+    SSDR_TRY(T.sorter.sort_segments(T.keys.as<uint64_t>(), nullptr, (int)num_clouds, t.toff, n_host.data(), T.count.as<int>(), s, 32, false, nullptr, 32));      // keys only: distance bits above the index
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
-    hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, T.vals.as<uint32_t>(), T.count.as<int>(), d_perm, d_dup_u,
-                       (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx);
+    hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, reinterpret_cast<const uint32_t*>(T.keys.as<uint64_t>()), T.count.as<int>(),
+                       d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
