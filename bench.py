@@ -38,10 +38,23 @@ TILES_PER_GPU = 16
 RAW_DENSITY = 5000.0              # points / m^2 -> 0.4-1.2 M raw points per room
 
 
+def launch_ranks(n):
+    """One process per GPU on this node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a
+    child process (never an exec: this process may not have touched the GPU, and it must stay that way until the child is started)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: > 1 s of timed region)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the batches strictly one after the other")
@@ -53,11 +66,24 @@ def main():
                          "inside the 1e-3 feature tolerance of the fp32 path (tests/test_randla.py); bf16 = BASELINE configuration 3")
     ap.add_argument("--selector", default="fps", choices=("fps", "kcenter"),
                     help="final selection over the (gathered) propagated features: FPS (the paper's gcn_fps branch) or the global k-center of BASELINE configuration 4")
+    ap.add_argument("--emu", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launch.py): CPU logic build of the kernels + gloo, a tiny workload; exercises the launcher and the "
+                         "N > 1 control flow on a box without GPUs, measures nothing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as CHILDREN, through
+        # torch.distributed.run, before this process has made any GPU call; rank 0's JSON line comes through on the
+        # inherited stdout and the exit code is non-zero if any rank failed.
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not os.environ.get("SSDR_BENCH_FORCE_DIST"):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)" % (args.gpus, world, args.gpus))
+    if os.environ.get("SSDR_AL_BENCH_FAIL_RANK") == str(rank):       # tests/test_bench_launch.py: a failing rank must fail the whole launch
+        raise SystemExit("bench.py: rank %d told to fail" % rank)
     dist = None
     use_dist = world > 1 or bool(os.environ.get("SSDR_BENCH_FORCE_DIST"))      # the latter: exercise the RCCL path on one GPU
     if args.pipeline_depth == 0:
@@ -65,7 +91,10 @@ def main():
         # exchanges torch / RCCL bring their own streams into the process and the 4 hardware queues get shared: the grouping
         # front end + KNN | network | scoring | selection then wins by far (one GPU through RCCL: 92 vs 63 Mpoints/s).
         args.pipeline_depth = 4 if use_dist else 5
-    if use_dist:
+    if use_dist and args.emu:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    elif use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -76,58 +105,71 @@ def main():
 
     from ssdr_al import _lib, pipeline, synthetic
     from ssdr_al.helper_tool import ConfigS3DIS
-    _lib.check(_lib.lib().ssdr_init(local_rank))
+    Cfg, tiles_per_gpu, density, hp_kw = ConfigS3DIS, TILES_PER_GPU, RAW_DENSITY, {}
+    if args.emu:
+        _lib.use(os.path.join(ROOT, "tests", "hipemu", "libssdr_al_emu.so"))
+
+        class Cfg(ConfigS3DIS):
+            num_points = 1024
+        tiles_per_gpu, density, hp_kw = 2, 80.0, dict(select_per_tile=5, labeled_per_tile=2)
+        args.no_cpu_baseline = True
+    _lib.check(_lib.lib().ssdr_init(0 if args.emu else local_rank))
 
     weights = synthetic.init_weights(0)         # random-init weights of the reference architecture (helper_tf_util.py:43-48 rule)
-    rooms = [synthetic.make_room(5000 + rank * TILES_PER_GPU + i, density=RAW_DENSITY) for i in range(TILES_PER_GPU)]
-    hp = pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision, selector=args.selector).load_rooms(rooms, [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)])
+    ids = [rank * tiles_per_gpu + i for i in range(tiles_per_gpu)]
+    rooms = [synthetic.make_room(5000 + i, density=density) for i in ids]
+
+    def mk():
+        return pipeline.HotPath(weights, Cfg, precision=args.precision, selector=args.selector, **hp_kw).load_rooms(rooms, ids)
+    hp = mk()
 
     gather = None
     if use_dist:
         from ssdr_al.distributed import Comm
-        gather = Comm(dist, "cuda")             # the three small exchanges of the selection stage (RCCL)
-
-    def barrier():
-        _lib.sync()
-        if use_dist:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        gather = Comm(dist, "cpu" if args.emu else "cuda")             # the three small exchanges of the selection stage (RCCL)
 
     # Consecutive batches are software-pipelined over the stages (front end | KNN pyramid | network | scoring | selection
-    # on separate HIP streams, one buffer set per batch in flight).  The warm-up call fills the pipe and it stays full
-    # (steady=True): every timed step then issues exactly one launch sequence of EVERY stage (on consecutive batches) and
-    # completes one selection, so the timed region is K full steps of work in steady state, no fill / drain inside it.
-    # N > 1: the three exchanges run on device buffers, ordered on the same streams, in the same order on every rank.
+    # on separate HIP streams, one buffer set per batch in flight).  N > 1: the three exchanges run on device buffers,
+    # ordered on the same streams, in the same order on every rank.
     pipe = None
     if not args.no_pipeline:
-        ids = [rank * TILES_PER_GPU + i for i in range(TILES_PER_GPU)]
-        def mk():
-            return pipeline.HotPath(weights, ConfigS3DIS, precision=args.precision, selector=args.selector).load_rooms(rooms, ids)
         pipe = pipeline.Pipelined(mk, args.pipeline_depth)
+
+    def barrier():
+        # EVERYTHING issued so far has finished on this rank (all stage and selection streams, not only the library stream), then all ranks meet
+        if pipe is not None:
+            pipe.finish()
+        _lib.sync()
+        if use_dist:
+            if not args.emu:
+                import torch
+                torch.cuda.synchronize()
+            dist.barrier()
+
+    # Timed region: K steps between two points at which the GPU is idle.  With batches in flight the region therefore holds the fill and
+    # the drain of the pipe as well (the first steps find it empty, the last batches are completed before the clock stops): K launch
+    # sequences of every stage, K completed selections, nothing left in flight at either end.
     if pipe is not None:
-        pipe.run(max(args.warmup, 1), gather, steady=True)
+        pipe.run(max(args.warmup, 1), gather)
     else:
         for _ in range(args.warmup):
             hp.step(gather)
     barrier()
     t0 = time.perf_counter()
     if pipe is not None:
-        pipe.run(args.steps, gather, steady=True)
+        pipe.run(args.steps, gather)
     else:
         for _ in range(args.steps):
             hp.step(gather)
     barrier()
     dt = time.perf_counter() - t0
-    if pipe is not None:
-        pipe.finish()
     if use_dist:
         import torch
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.emu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    npts = world * TILES_PER_GPU * ConfigS3DIS.num_points * args.steps
+    npts = world * tiles_per_gpu * Cfg.num_points * args.steps
     value = npts / dt / 1e6
 
     # ---- roofline leg (untimed): per-launch HIP-event timing of the instrumented kernels ------------------
@@ -149,11 +191,11 @@ def main():
     mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
     mfma_insn = "v_mfma_f32_16x16x4_f32" if args.precision == "f32" else "v_mfma_f32_16x16x32_bf16 (LocSE K = 10 and the d = 16 level on v_mfma_f32_16x16x4_f32)"
     # (a) the way the timed region ran (every rank takes part because of the exchanges) ...
-    timed_rows = prof_rows((lambda: (pipe.run(NPROF, gather), pipe.finish())) if pipe is not None else (lambda: [hp.step(gather) for _ in range(NPROF)]))
+    timed_rows = [] if args.emu else prof_rows((lambda: (pipe.run(NPROF, gather), pipe.finish())) if pipe is not None else (lambda: [hp.step(gather) for _ in range(NPROF)]))
     roofline = None
     stage_ms = None
     stage_roofline = None
-    if rank == 0:
+    if rank == 0 and not args.emu:
         # (b) ... and strictly sequential on rank 0: the kernel with the GPU to itself.  (b) is the roofline figure: it is
         # the kernel's own duration (rocprofv3's per-dispatch duration agrees with it, profiles/rNN_bench_seq_kernel_stats.csv),
         # whereas with several batches in flight an event pair on one stream also spans the time the dispatch waits
@@ -251,17 +293,18 @@ def main():
                                          "knn pyramid (reference C++, OpenMP over %d tiles)" % ns: round(t_knn * 1e3, 1)}
 
     if rank == 0:
+        assert world == args.gpus or os.environ.get("SSDR_BENCH_FORCE_DIST"), "n_gpus must be what --gpus asked for"
         out = {"metric": METRIC, "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": DTYPE[args.precision], "data": "synthetic",
+               "dtype": DTYPE[args.precision], "data": "synthetic" if not args.emu else "synthetic (TEST MODE: CPU logic build, tiny workload - not a measurement)",
                "config": {"workload": "S3DIS-like rooms (synthetic, Area_5 seeds), %d rooms/tiles of 40960 points per GPU per step: grid-subsample "
                                       "dl=0.04 -> tile -> KNN pyramid k=16 [4,4,4,4,2] -> RandLA-Net infer (random-init weights, %s matrix products) -> WetSU/sb/clsbal "
-                                      "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, %s)" % (TILES_PER_GPU, args.precision, "FPS start fixed to candidate 0" if args.selector == "fps" else "global k-center over candidates + labelled regions"),
-                          "tiles_per_gpu": TILES_PER_GPU, "tile_points": ConfigS3DIS.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
-                          "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * TILES_PER_GPU * world), "sharding": "tiles",
+                                      "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, %s)" % (tiles_per_gpu, args.precision, "FPS start fixed to candidate 0" if args.selector == "fps" else "global k-center over candidates + labelled regions"),
+                          "tiles_per_gpu": tiles_per_gpu, "tile_points": Cfg.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
+                          "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * tiles_per_gpu * world), "sharding": "tiles",
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,
-                          "timed_region": "steady state: the warm-up fills the pipe, every timed step issues one launch sequence of every stage and "
-                                          "completes one selection" if pipe is not None else "strictly sequential steps"},
+                          "timed_region": "GPU idle at both ends (every stream drained): K launch sequences of every stage and K completed selections, fill and "
+                                          "drain of the %d-deep pipe included" % args.pipeline_depth if pipe is not None else "strictly sequential steps"},
                "stage_ms": stage_ms, "stage_roofline": stage_roofline, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if use_dist:

@@ -16,8 +16,9 @@ struct KnnState {
     DevBuf pts, qry, out;
     KnnTicket ticket[TICKETS]; int next_ticket = 0;
     int32_t folded[4] = {0, 0, 0, 0};       // hand-over rows (K = 16, K = 1) of the last finished call, status bits so far, deepest tree
+    ~KnnState() { for (auto& t : ticket) { if (t.ev) (void)hipEventDestroy(t.ev); if (t.host) (void)hipHostFree(t.host); } }
 };
-KnnState& st(hipStream_t s = nullptr) { static std::map<hipStream_t, KnnState> m; return m[s ? s : ctx().stream]; }
+KnnState& st(hipStream_t s = nullptr) { return per_stream<KnnState>(s); }
 
 // leaves the counters of the call just enqueued on s where ssdr_knn_status_poll finds them
 int fold_ticket(KnnState& S, KnnTicket& t) {
@@ -170,7 +171,10 @@ int ssdr_knn_status(void* stream, int32_t* out4) {
     KnnState& S = st(s);
     int32_t h[4] = {0, 0, 0, 0};
     SSDR_HIP(hipStreamSynchronize(s));
-    for (int i = 0; i < TICKETS; ++i) S.ticket[i].pending = false;      // everything has finished: what follows is the direct read
+    // everything has finished: the earlier calls' tickets are folded first (their status bits must not be lost: the direct read below
+    // only sees the counters of the NEWEST call), then the direct read
+    for (int i = 0; i < TICKETS; ++i) if (S.ticket[i].pending) fold_ticket(S, S.ticket[i]);
+    h[2] = S.folded[2];
     S.folded[2] = 0;
     if (S.grid.need.p && S.grid.nsets > 0) {
         int g[10] = {0};

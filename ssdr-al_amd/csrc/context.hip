@@ -63,6 +63,15 @@ static int do_init(int device) {
     return SSDR_OK;
 }
 
+static std::mutex g_forget_mu;
+static std::vector<void (*)(hipStream_t)>& forgetters() { static auto* v = new std::vector<void (*)(hipStream_t)>; return *v; }
+void register_stream_forgetter(void (*f)(hipStream_t)) { std::lock_guard<std::mutex> lk(g_forget_mu); forgetters().push_back(f); }
+void forget_stream(hipStream_t s) {
+    std::vector<void (*)(hipStream_t)> fs;
+    { std::lock_guard<std::mutex> lk(g_forget_mu); fs = forgetters(); }
+    for (auto f : fs) f(s);
+}
+
 int ensure_init() { return ctx().ready ? (g_init_pid == getpid() ? SSDR_OK : forked_child()) : do_init(0); }
 
 int DevBuf::reserve(size_t bytes) {
@@ -143,7 +152,14 @@ int ssdr_main_stream(void** out_stream) {
     *out_stream = ssdr::ctx().stream;
     return SSDR_OK;
 }
-int ssdr_stream_destroy(void* stream) { if (stream) SSDR_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream))); return SSDR_OK; }
+int ssdr_stream_destroy(void* stream) {
+    if (!stream) return SSDR_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    SSDR_HIP(hipStreamSynchronize(s));            // the per-stream scratch below may still be in use by what the stream holds
+    ssdr::forget_stream(s);
+    SSDR_HIP(hipStreamDestroy(s));
+    return SSDR_OK;
+}
 /* work enqueued on `waiter` after this call starts only after everything enqueued on `waited` so far has finished */
 int ssdr_stream_wait(void* waiter, void* waited) {
     SSDR_TRY(ssdr::ensure_init());

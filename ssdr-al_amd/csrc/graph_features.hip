@@ -17,7 +17,7 @@ namespace ssdr {
 namespace {
 
 struct GraphState { KdForest forest; DevBuf idx, d2; };
-GraphState& gst(hipStream_t st = nullptr) { static std::map<hipStream_t, GraphState> m; return m[st ? st : ctx().stream]; }      // one per stream
+GraphState& gst(hipStream_t st = nullptr) { return per_stream<GraphState>(st); }      // one per stream
 
 // neighbours [n][K] (first column = the point itself) -> the reference's flat arrays (graphs.py:33-38, :62-67)
 __global__ __launch_bounds__(256) void graph_emit(const int* __restrict__ idx, const double* __restrict__ d2, int n, int K, int k1, int k2,

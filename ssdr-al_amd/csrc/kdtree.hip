@@ -762,12 +762,13 @@ int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, 
     } else {
         dim3 g2((unsigned)((nq + 63) / 64), (unsigned)ntrees);
         size_t lds = (size_t)64 * K * 8;
-        static bool attr_done = false;       // K up to 256: 128 KiB of dynamic LDS needs the opt-in above 64 KiB
-        if (!attr_done) {
-            SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_any_kernel<int64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8));
-            SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_any_kernel<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8));
-            attr_done = true;
-        }
+        static std::once_flag attr_once;     // K up to 256: 128 KiB of dynamic LDS needs the opt-in above 64 KiB
+        hipError_t ae = hipSuccess;
+        std::call_once(attr_once, [&] {
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_any_kernel<int64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8);
+            if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_any_kernel<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8);
+        });
+        SSDR_HIP(ae);
         if (out_i64) hipLaunchKernelGGL((kd_search_any_kernel<int64_t>), g2, dim3(64), lds, s, a, K);
         else hipLaunchKernelGGL((kd_search_any_kernel<int32_t>), g2, dim3(64), lds, s, a, K);
     }
@@ -801,8 +802,10 @@ int kd_search_f64(const KdForest& f, int tree0, int ntrees, const float* d_queri
     SearchArgs a{p.desc, p.sorted, p.node_a, p.node_b, tree0, d_queries, q_stride, nq, qorder_tree0, d_out, out_stride, p.ctr};
     dim3 g((unsigned)((nq + 63) / 64), (unsigned)ntrees);
     const size_t lds = (size_t)64 * K * 12;
-    static bool attr_done = false;
-    if (!attr_done) { SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 128 * 12)); attr_done = true; }
+    static std::once_flag attr_once;
+    hipError_t ae = hipSuccess;
+    std::call_once(attr_once, [&] { ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_search_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 128 * 12); });
+    SSDR_HIP(ae);
     hipLaunchKernelGGL(kd_search_f64_kernel, g, dim3(64), lds, s, a, K, d_out_d2);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
@@ -814,8 +817,10 @@ int kd_distance_pick(const KdForest& f, int ntrees, int npts, const uint32_t* d_
     if (K > 256) { set_error("K=%d > 256 is not supported", K); return SSDR_ERR_UNSUPPORTED; }
     ForestPtrs p = ptrs(f);
     SearchArgs a{p.desc, p.sorted, p.node_a, p.node_b, 0, nullptr, 0, nq, -1, nullptr, 0, p.ctr};
-    static bool attr_done = false;           // 512 K bytes of dynamic LDS + 1 KiB static: opt in for K >= 126
-    if (!attr_done) { SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_distance_pick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8)); attr_done = true; }
+    static std::once_flag attr_once;         // 512 K bytes of dynamic LDS + 1 KiB static: opt in for K >= 126
+    hipError_t ae = hipSuccess;
+    std::call_once(attr_once, [&] { ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&kd_distance_pick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8); });
+    SSDR_HIP(ae);
     hipLaunchKernelGGL(kd_distance_pick_kernel, dim3((unsigned)ntrees), dim3(256), (size_t)64 * K * 8, s, a, d_rnd, K, npts, d_used, d_out_q,
                        reinterpret_cast<long long*>(d_out_idx));
     SSDR_HIP(hipGetLastError());

@@ -108,6 +108,12 @@ __global__ __launch_bounds__(PREP_NT) void grid_prepare_kernel(GridDesc* desc, i
         d.ncell = d.nx * d.ny * d.nz;
         for (int k = 0; k < 3; ++k) { d.lo[k] = mn[k]; d.hi[k] = mx[k]; }
         if (n == 0) { d.nx = d.ny = d.nz = 1; d.ncell = 1; d.lo[0] = d.lo[1] = d.lo[2] = 0.f; d.c = 1.f; d.inv_c = 1.f; }
+        {
+            float mag = 0.f;
+            for (int k = 0; k < 3; ++k) mag = fmaxf(mag, fmaxf(fabsf(d.lo[k]), fabsf(d.hi[k])));
+            d.slack = 8.f * FLT_EPSILON * (2.f * mag + (float)(max(d.nx, max(d.ny, d.nz)) + 1) * d.c);
+            d.pad_ = 0;
+        }
         desc[t] = d;
         s_mm[0] = __int_as_float(d.ncell);
     }
@@ -194,8 +200,8 @@ __device__ __forceinline__ bool grid_settled(const GridDesc& d, float qx, float 
     if (z1 < d.nz - 1) g = fminf(g, (d.lo[2] + (float)(z1 + 1) * d.c) - qz);
     if (g == FLT_MAX) return true;                          // the block is the whole grid
     if (!(g > 0.f)) return false;
-    const float gs = g * 0.99998f;                          // cell boundaries are rounded fp32 products: stay inside
-    return rs.worst() <= gs * gs;
+    const float gs = g * 0.99998f - d.slack;                // cell boundaries are rounded fp32 products: stay inside, relatively and absolutely
+    return gs > 0.f && rs.worst() <= gs * gs;
 }
 
 template <int K>
@@ -318,7 +324,7 @@ __device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __
     if (cz + R < d.nz - 1) g = fminf(g, (d.lo[2] + (float)(cz + R + 1) * d.c) - qz);
     if (!(g > 0.f)) return 2;
     tau = FLT_MAX;
-    if (g < FLT_MAX) { const float gs = g * 0.99998f; tau = gs * gs; }      // cell boundaries are rounded fp32 products: stay inside
+    if (g < FLT_MAX) { const float gs = g * 0.99998f - d.slack; if (!(gs > 0.f)) return 2; tau = gs * gs; }      // cell boundaries are rounded fp32 products: stay inside, relatively and absolutely
     unsigned long long m[W * W]; int rs0[W * W];
     int cnt = 0; bool long_row = false;
 #pragma unroll

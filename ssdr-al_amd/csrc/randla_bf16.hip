@@ -570,14 +570,15 @@ template <int D> static int launch_lfa_bf16_d(const LfaArgs& a, bool second, int
     dim3 grid((unsigned)((a.n + C::PTS - 1) / C::PTS), (unsigned)B);
     const int terms = prec == PREC_BF16X3 ? 2 : 1;
     const size_t lds = C::lds_bytes(terms);
-    static bool attr_done = false;
-    if (!attr_done) {
-        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2)));
-        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2)));
-        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1)));
-        SSDR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1)));
-        attr_done = true;
-    }
+    static std::once_flag attr_once;
+    hipError_t ae = hipSuccess;
+    std::call_once(attr_once, [&] {
+        ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa_bf16_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1));
+    });
+    SSDR_HIP(ae);
     const double rows = (double)B * (double)a.n * 16.0;       // algorithmic FLOPs of the reference's formulation (as lfa_att_kernel)
     // executed on the matrix cores: LocSE on the f32 MFMA (K padded to 12; both orientations in the first half), LFAmlp2 in both orientations and
     // the position half of the attention product on the bf16 MFMA (one or three products)

@@ -31,7 +31,7 @@ struct Model {
 int n_layers(const Model& m) { return 1 + 8 * m.L + 1 + m.L + 3; }
 
 void shapes(Model& m) {
-    m.layers.assign(n_layers(m), Layer());
+    m.layers.clear(); m.layers.resize(n_layers(m));
     auto set = [&](int i, int in, int out, bool b) { m.layers[i].in = in; m.layers[i].out = out; m.layers[i].has_b = b; };
     set(0, m.in_dim, 8, true);
     int d_in = 8;

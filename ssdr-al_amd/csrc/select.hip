@@ -879,7 +879,7 @@ int chamfer_pack_launch(const ChamferPack& P, const float* d_xyz, const int* d_s
     return SSDR_OK;
 }
 // one scratch set per stream: calls on different streams may run concurrently (include/ssdr_al.h)
-SelState& sst(hipStream_t st = nullptr) { static std::map<hipStream_t, SelState> m; return m[st ? st : ctx().stream]; }
+SelState& sst(hipStream_t st = nullptr) { return per_stream<SelState>(st); }
 
 inline int grid_for(long n, int cap = 2048) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, cap)); }
 

@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include "../../include/ssdr_al.h"
 
 #ifndef HIPEMU
@@ -37,6 +39,12 @@ void set_error(const char* fmt, ...);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    ~DevBuf() { release(); }
     int reserve(size_t bytes);
     void release();
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -53,6 +61,26 @@ struct Context {
 Context& ctx();
 int ensure_init();
 inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
+
+// ---- per-stream scratch state --------------------------------------------------------------------
+// Every *_dev entry point keeps its scratch (grow-only buffers, tickets, forests) per stream, so that calls on different streams run
+// concurrently.  Host threads may make their first call on different streams at the same time (the reference calls knn_search from
+// DataLoader workers): the lookup is serialised, the returned reference stays valid (node-based map) until ssdr_stream_destroy forgets
+// the stream — which releases the state, so a recycled stream handle starts clean.  The maps live on the heap and are never destroyed:
+// their buffers must not be freed after the runtime has shut down.
+void register_stream_forgetter(void (*f)(hipStream_t));
+void forget_stream(hipStream_t s);          // context.hip: called by ssdr_stream_destroy
+template <class T>
+T& per_stream(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<hipStream_t, T>* m = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!m) {
+        m = new std::map<hipStream_t, T>;
+        register_stream_forgetter([](hipStream_t st) { std::lock_guard<std::mutex> lk2(mu); m->erase(st); });
+    }
+    return (*m)[s ? s : ctx().stream];
+}
 
 // ---- in-library kernel timing (context.hip): HIP events on the launch stream around instrumented launches.
 // Off by default; bench.py switches it on for the roofline leg.  `work` is the launch's algorithmic FLOPs or bytes, `work2` the
@@ -106,6 +134,10 @@ struct KdForest {
     int node_cap = 0;
     int queue_cap = 0;
     int max_n = 0;
+    KdForest() = default;
+    KdForest(const KdForest&) = delete;
+    KdForest& operator=(const KdForest&) = delete;
+    ~KdForest() { if (staging) (void)hipHostFree(staging); if (staging_ev) (void)hipEventDestroy(staging_ev); }
 };
 
 // Queries that will walk the forest, known before it is built: (x, y, z, r^2) and the tree each belongs to.  A build that is given
@@ -143,6 +175,9 @@ struct GridDesc {        // one support set
     float c, inv_c;      // cell size (measured on the device)
     int nx, ny, nz, ncell;
     float lo[3], hi[3];  // bounding box; lo is the grid origin
+    float slack;         // absolute bound on the rounding of a face position lo + k c against a point's binning floor((v - lo) / c): both carry
+                         // a few ulps of the coordinates' magnitude and of k c, whatever the size of the gap to the face itself
+    int pad_;
 };
 struct GridJob {         // one search: queries of one batch element against one support set, one output block [nq][K]
     int sup;             // support set
@@ -169,6 +204,15 @@ struct GridForest {
     int* ball_tree() const { return reinterpret_cast<int*>(balls.as<float4>() + GRID_BALL_CAP); }
     float ball_scale = 9.f;     // squared radius of a hand-over row's ball / its (K+1)-th squared distance
     int* work_list(int which) const { return work.as<int>() + (size_t)which * 2 * work_cap; }
+    GridForest() = default;
+    GridForest(const GridForest&) = delete;
+    GridForest& operator=(const GridForest&) = delete;
+    ~GridForest() {
+        if (staging) (void)hipHostFree(staging);
+        if (staging_ev) (void)hipEventDestroy(staging_ev);
+        if (jstaging) (void)hipHostFree(jstaging);
+        if (jstaging_ev) (void)hipEventDestroy(jstaging_ev);
+    }
 };
 // Bins every set (pts / n filled in by the caller).  target_pts: number of points the measured cell radius should hold.
 int grid_build(GridForest& g, const std::vector<GridDesc>& sets, int target_pts, hipStream_t s);

@@ -557,7 +557,7 @@ struct GsState {
     size_t last_m = 0, last_fdim = 0, last_ldim = 0;
     int last_clouds = 0;        // clouds of the last device-flavour call (their GsParams sit at the front of `params`)
 };
-GsState& gs(hipStream_t st = nullptr) { static std::map<hipStream_t, GsState> m; return m[st ? st : ctx().stream]; }
+GsState& gs(hipStream_t st = nullptr) { return per_stream<GsState>(st); }
 
 }  // namespace
 

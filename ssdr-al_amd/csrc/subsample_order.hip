@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BS) void ord_store_list(OrdPtrs o, int r) {
 }
 
 struct OrdState { RadixSorter sorter; DevBuf skey, sval, kt, seq, L, pfirst, tfirst, cnt, major; };
-OrdState& ost(hipStream_t st) { static std::map<hipStream_t, OrdState> m; return m[st]; }
+OrdState& ost(hipStream_t st) { return per_stream<OrdState>(st); }
 
 }  // namespace
 

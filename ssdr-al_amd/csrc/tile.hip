@@ -115,7 +115,7 @@ __global__ __launch_bounds__(1024) void possibility_min(const double* __restrict
 }
 
 struct TileState { RadixSorter sorter; DevBuf keys, vals, count; };
-TileState& tst(hipStream_t st) { static std::map<hipStream_t, TileState> m; return m[st]; }
+TileState& tst(hipStream_t st) { return per_stream<TileState>(st); }
 
 }  // namespace
 }  // namespace ssdr

@@ -34,6 +34,7 @@ class HotPath:
         self.knn_stream = None      # stream of the KNN pyramid (None = self.stream)
         self.score_stream = None    # stream of the scoring stage (None = self.stream)
         self.sel_stream = None      # stream of the selection chain (None = the library stream)
+        self.pipelined = False      # set by Pipelined: later batches are in flight on the stage streams when a selection is collected
         self.global_order = None
         self.rooms = []
         self.timing = None
@@ -45,6 +46,7 @@ class HotPath:
         cfg = self.cfg
         N = cfg.num_points
         self.B = len(rooms)
+        self._dist = None           # the sharded run's static tables (labelled mask, sizes, exchange buffers) belong to the loaded rooms
         self.room_ids = list(range(len(rooms))) if room_ids is None else list(room_ids)
         self.rooms = []
         centers, perms, dups = [], [], []
@@ -321,8 +323,8 @@ class HotPath:
         # list): ask once per batch, here where the host waits anyway — without waiting for the pyramids of the LATER batches that the
         # KNN stream already holds (the finished calls' tickets are looked at; Pipelined.finish / the sequential step wait for all)
         from . import knn as _knn
-        _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream, wait=self.sel_stream is None)
-        if self.sel_stream is None:                          # sequential use: the front end of this batch has finished, ask it too
+        _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream, wait=not self.pipelined)
+        if not self.pipelined:                               # sequential use: the front end of this batch has finished, ask it too
             _lib.check(_lib.lib().ssdr_grid_subsample_status(self.front_stream if self.front_stream is not None else self.stream, None))
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
         return sel, unl
@@ -398,6 +400,7 @@ class Pipelined:
         self.slots = depth
         self.hp = [make_hot_path() for _ in range(self.slots)]
         for h in self.hp:
+            h.pipelined = True
             h.front_stream, h.knn_stream = self.streams[self.group["front"]], self.streams[self.group["knn"]]
             h.stream, h.score_stream = self.streams[self.group["infer"]], self.streams[self.group["score"]]
         self._k = 0

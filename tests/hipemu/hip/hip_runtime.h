@@ -142,7 +142,7 @@ template <class T> inline T from_bits(uint64_t u) { T v; memcpy(&v, &u, sizeof(T
 }  // namespace hipemu
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
+    hipemu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })      /* launches complete before they return here: by reference (the states hold move-only buffers) */
 #define SSDR_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(hipemu::g_dynshared)
 
 static inline void __syncthreads() { hipemu::g_bs->cur->state = hipemu::WAIT_BLOCK; hipemu::yield_to_sched(); }
@@ -260,9 +260,10 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }
-static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
+// every stream gets a handle of its own (the library keeps its scratch per stream); all of them execute synchronously
+static inline hipError_t hipStreamCreate(hipStream_t* s) { static uintptr_t next = 0; *s = (void*)__atomic_add_fetch(&next, 16, __ATOMIC_SEQ_CST); return hipSuccess; }
 #define hipStreamNonBlocking 1
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -71,3 +71,37 @@ def test_error_channel_reports_message(backend):
     assert L.ssdr_knn(None, 5, 3, None, 5, 3, None) != 0
     assert b"NULL" in L.ssdr_last_error()
     assert L.ssdr_version().startswith(b"ssdr_al")
+
+
+def test_first_calls_on_different_streams_from_threads_and_stream_reuse(backend, orc):
+    """The reference calls knn_search from several workers: first calls on different streams from different host threads must not race on
+    the library's per-stream scratch table, and a destroyed stream's scratch (status tickets, forests) is forgotten."""
+    import ctypes as C
+    import threading
+    from ssdr_al import _lib, knn
+    from ssdr_al._lib import DevArray
+    L = _lib.lib()
+    _lib.check(L.ssdr_init(0))
+    rng = np.random.default_rng(5)
+    pts = [rng.random((1, 400 + 37 * i, 3), dtype=np.float32) for i in range(4)]
+    d_in = [DevArray.from_host(p) for p in pts]
+    d_out = [DevArray((1, p.shape[1], 16), np.int32) for p in pts]
+    for rounds in range(2):                    # second round: fresh streams (handles may be recycled by the runtime)
+        streams = []
+        for _ in pts:
+            s = C.c_void_p(); _lib.check(L.ssdr_stream_create(C.byref(s))); streams.append(s.value)
+        errs = []
+
+        def work(i):
+            try:
+                _lib.check(L.ssdr_knn_batch_dev(d_in[i].ptr, 1, pts[i].shape[1], 3, d_in[i].ptr, pts[i].shape[1], 16, d_out[i].ptr, streams[i]))
+                assert knn.knn_status(streams[i])[2] == 0
+            except Exception as e:             # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(pts))]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert not errs, errs
+        for i, p in enumerate(pts):
+            assert np.array_equal(d_out[i].to_host(streams[i]), orc.knn_batch(p, p, 16).astype(np.int32))
+        for s in streams:
+            _lib.check(L.ssdr_stream_destroy(s))

@@ -76,6 +76,23 @@ def test_device_path_reports_tree_depth_overflow(backend):
     assert knn.knn_status()[2] == 0
 
 
+def test_blocking_status_keeps_an_earlier_calls_error(backend):
+    """bad call, then a good call on the same stream: the blocking ssdr_knn_status reads only the newest call's counters directly, so
+    it must fold the earlier call's ticket instead of dropping it (batches in flight: the host asks once per step, not once per call)"""
+    from ssdr_al import _lib, knn
+    from ssdr_al._lib import DevArray
+    x = np.repeat((2.0 ** -np.arange(110)).astype(np.float32), 2)
+    p = np.stack([x, np.zeros_like(x), np.zeros_like(x)], 1)[None]
+    d_p = DevArray.from_host(p); d_o = DevArray((1, p.shape[1], 16), np.int32)
+    q = np.random.default_rng(0).random((1, 500, 3), dtype=np.float32)
+    d_q = DevArray.from_host(q); d_o2 = DevArray((1, 500, 16), np.int32)
+    _lib.check(_lib.lib().ssdr_knn_batch_dev(d_p.ptr, 1, p.shape[1], 3, d_p.ptr, p.shape[1], 16, d_o.ptr, None))      # tree too deep
+    _lib.check(_lib.lib().ssdr_knn_batch_dev(d_q.ptr, 1, 500, 3, d_q.ptr, 500, 16, d_o2.ptr, None))                  # healthy
+    with pytest.raises(_lib.SsdrError):
+        knn.knn_status(wait=True)
+    assert knn.knn_status(wait=True)[2] == 0             # reported once
+
+
 def test_status_tickets_wrap_around(backend, orc):
     """more device-flavour calls on a stream than it has status tickets (16) between two polls: the oldest are folded, nothing is lost or stuck"""
     from ssdr_al import _lib, knn

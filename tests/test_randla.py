@@ -155,9 +155,11 @@ def test_randla_bf16_modes_against_fp32_oracle(backend, mode):
 
 
 @pytest.mark.gpu
-def test_randla_full_size_batch16_properties():
-    """BASELINE config 3 shape (B=16 x 40960): probabilities are a distribution, outputs finite, and the result of
-    a tile does not depend on which batch slot it sits in (tiles are independent units)."""
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_randla_full_size_batch16_properties(mode):
+    """BASELINE config 3 shape (B=16 x 40960) in every arithmetic of the matrix products (plain bf16 IS configuration 3): probabilities
+    are a distribution, outputs finite, and the result of a tile does not depend on which batch slot it sits in (tiles are independent
+    units).  Level 0 (d = 16) runs on the exact-f32 MFMA kernel in every mode."""
     from conftest import GPU_LIB, _have_gpu
     if not _have_gpu():
         pytest.skip("no GPU")
@@ -171,11 +173,37 @@ def test_randla_full_size_batch16_properties():
         xyz[5] = xyz[2]
         feat = np.concatenate([xyz - xyz.mean(1, keepdims=True), rng.random((B, N, 3), dtype=np.float32)], -1)
         feat[5] = feat[2]
-        net = randlanet.Network().load(R.init_weights(0))
+        net = randlanet.Network().load(R.init_weights(0)).set_precision(mode)
         p, f = net.infer(feat, xyz)
         assert np.isfinite(p).all() and np.isfinite(f).all()
         assert np.abs(p.sum(1) - 1).max() < 1e-5 and p.min() >= 0
         p = p.reshape(B, N, 13); f = f.reshape(B, N, 32)
         assert np.array_equal(p[5], p[2]) and np.array_equal(f[5], f[2])
+    finally:
+        _lib.use(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_randla_bf16_modes_full_tile_against_fp32_oracle(mode):
+    """One full 40960-point tile against the fp32 oracle in both bf16 arithmetics: level 0 has 40960 rows (> 16384), so the per-point
+    convolutions take the 128-row tiles of dense_bf16_kernel (the 8192-point cases above only ever take its small-tile branch)."""
+    from conftest import GPU_LIB, _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    from oracle import randla_np as R
+    from ssdr_al import _lib, randlanet
+    _lib.use(GPU_LIB)
+    try:
+        B, N = 1, 40960
+        W = R.init_weights(0)
+        xyz0, feat, (xyz, neigh, sub, interp) = _inputs(B, N, seed=4)
+        p, f = R.forward(W, feat, xyz, neigh, sub, interp, dtype=np.float32)
+        gp, gf = randlanet.Network().load(W).set_precision(mode).infer(feat, xyz0)
+        ep, ef = np.abs(gp - p).max(), np.abs(gf - f).max()
+        tol_p, tol_f = (TOL, TOL) if mode == "bf16x3" else (TOL_BF16_PROBS, TOL_BF16_FEAT)
+        print("\n%s, 1 x 40960: max |probs - oracle| = %.3g (tolerance %.3g), max |feat32 - oracle| = %.3g (tolerance %.3g, |feat| max %.3g)"
+              % (mode, ep, tol_p, ef, tol_f, np.abs(f).max()))
+        assert ep < tol_p and ef < tol_f, (ep, ef)
     finally:
         _lib.use(None)
