@@ -136,6 +136,16 @@ int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features
                                   float* d_out_points, float* d_out_features, int32_t* d_out_classes, int64_t* d_out_m, void* stream);
 /* The device flavours only enqueue work: what their kernels found is read here (waits for `stream`).  bit 0 = a voxel with more labels in one
  * column than the per-voxel table holds (the host flavour returns SSDR_ERR_UNSUPPORTED for the same). */
+/* Which implementation ssdr_grid_subsample_batch_dev uses (process-wide).
+ *   SSDR_SUBSAMPLE_AUTO (default)  rows of at most 7 words (3 + fdim + ldim <= 7): one partition pass into spatial buckets of 8 x 8 x 8 (or
+ *                                  16 x 8 x 8) voxels and one workgroup per bucket that orders and reduces its voxels in LDS; clouds whose grid
+ *                                  needs more than 16384 such buckets, or that hold a voxel of more than 1536 points, are reported by
+ *                                  ssdr_grid_subsample_status (bits 2 / 4) and must be repeated with SSDR_SUBSAMPLE_SORT.  Other rows: the sort.
+ *   SSDR_SUBSAMPLE_SORT            segmented radix sort of (voxel key, index) words: any grid, any voxel population.
+ * Both give the reference's rows bit for bit (grid_subsampling.cpp:5-106), by ascending voxel key. */
+#define SSDR_SUBSAMPLE_AUTO 0
+#define SSDR_SUBSAMPLE_SORT 1
+int ssdr_grid_subsample_set_method(int method);
 int ssdr_grid_subsample_status(void* stream, int32_t* out_status);
 
 /* ---- tile generator (spatially_regular_gen, S3/s3dis_dataset.py:115-154; data_aug, S3/helper_tool.py:185-199) --

@@ -18,36 +18,13 @@
 //            iteration order of the reference's unordered_map<size_t,...> (subsample_order.hip).
 #include "ssdr_internal.hpp"
 #include "block_prims.hpp"
+#include "voxel_label.hpp"
+#include "subsample_types.hpp"
 #include <map>
+#include <cstring>
 
 namespace ssdr {
 namespace {
-
-constexpr int LAB_CAP = 29;
-constexpr int REC_W = 8;        // words of a packed point record (rows of at most 8 words: the hot path's 3 + 3 + 1)
-constexpr int GS_UNROLL = 8;    // gathers in flight per lane in the voxel reductions (a lane's loop is a latency chain otherwise)
-
-struct GsParams {
-    float org[3]; float dl;
-    unsigned long long nx, ny;
-    int m;            // number of voxels
-    int status;       // 1 = more than LAB_CAP distinct labels in one voxel
-    unsigned long long key_and, key_or;      // what the sorter needs to know about the keys: no bit is set in all of them / only these can be set
-};
-
-__device__ __forceinline__ void gs_minmax_partial_body(const float* __restrict__ P, int n, float* partial) {
-    __shared__ float s_mm[(BS / 64) * 6];
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = blockIdx.x * BS + threadIdx.x; i < n; i += gridDim.x * BS) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { float v = P[3 * (size_t)i + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
-    }
-    block_minmax3(mn, mx, s_mm);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { partial[6 * blockIdx.x + d] = mn[d]; partial[6 * blockIdx.x + 3 + d] = mx[d]; }
-    }
-}
 
 __device__ __forceinline__ void gs_params_body(const float* partial, int nparts, float dl, GsParams* prm) {
     __shared__ float s_mm[(BS / 64) * 6];
@@ -169,66 +146,12 @@ __device__ __forceinline__ void gs_heads_write_body(const uint64_t* __restrict__
 }
 
 // ---- per-voxel reduction ----------------------------------------------------------------------------
-__device__ __forceinline__ unsigned lab_bucket(int l, unsigned nb) { return (unsigned)((unsigned long long)(long long)l % nb); }
-
-// Majority label of one voxel column with the reference's tie rule (grid_subsampling.cpp:97-101 over
-// grid_subsampling.h:19,46-49): the histogram is an unordered_map<int,int>; std::max_element returns the
-// first maximum in *iteration order*.  The list below is kept in that order.
+// majority label with the reference's tie rule: voxel_label.hpp (labels through a getter, in input order)
 __device__ int voxel_label(const int* __restrict__ cls, int ldim, int col, const uint32_t* __restrict__ vs, int s, int e, int* status) {
-    int lab[LAB_CAP], cnt[LAB_CAP];
-    int nl = 0; unsigned nbk = 13;
-    for (int j = s; j < e; ++j) {
-        const int L = cls[(size_t)vs[j] * ldim + col];
-        int t = 0;
-        for (; t < nl; ++t) if (lab[t] == L) { cnt[t]++; break; }
-        if (t < nl) continue;
-        if (nl == 13 && nbk == 13) {
-            // rehash 13 -> 29 before the 14th insert: runs by first occurrence, members in list order, all reversed
-            int tl[13], tc[13]; unsigned used = 0; int w = 0;
-            for (int i = 0; i < 13; ++i) if (!((used >> i) & 1)) {
-                const unsigned b = lab_bucket(lab[i], 29);
-                for (int k = i; k < 13; ++k) if (!((used >> k) & 1) && lab_bucket(lab[k], 29) == b) { used |= 1u << k; tl[w] = lab[k]; tc[w] = cnt[k]; ++w; }
-            }
-            for (int i = 0; i < 13; ++i) { lab[i] = tl[12 - i]; cnt[i] = tc[12 - i]; }
-            nbk = 29;
-        }
-        if (nl == LAB_CAP) { atomicOr(status, 1); break; }
-        const unsigned b = lab_bucket(L, nbk);
-        int pos = 0;
-        for (int i = 0; i < nl; ++i) if (lab_bucket(lab[i], nbk) == b) { pos = i; break; }
-        for (int i = nl; i > pos; --i) { lab[i] = lab[i - 1]; cnt[i] = cnt[i - 1]; }
-        lab[pos] = L; cnt[pos] = 1; ++nl;
-    }
-    int best = 0;
-    for (int t = 1; t < nl; ++t) if (cnt[best] < cnt[t]) best = t;
-    return nl ? lab[best] : 0;
+    return voxel_label_t([&](int j) { return cls[(size_t)vs[j] * ldim + col]; }, s, e, status);
 }
-
-// Fast path of voxel_label for labels in [0,13): they hash to distinct buckets of the 13-bucket table and can never
-// trigger the rehash, so the reference's iteration order is simply "most recently first-seen first" and the first
-// maximum is the largest count, ties to the label first seen LAST.  Returns -1 when a label falls outside [0,13).
 __device__ __forceinline__ int voxel_label_fast(const int* __restrict__ cls, int ldim, int col, const uint32_t* __restrict__ vs, int s, int e) {
-    int cnt[13], seen[13];
-#pragma unroll
-    for (int k = 0; k < 13; ++k) { cnt[k] = 0; seen[k] = -1; }
-    for (int j0 = s; j0 < e; j0 += GS_UNROLL) {
-        int lv[GS_UNROLL];
-#pragma unroll
-        for (int u = 0; u < GS_UNROLL; ++u) lv[u] = cls[(size_t)vs[min(j0 + u, e - 1)] * ldim + col];
-#pragma unroll
-        for (int u = 0; u < GS_UNROLL; ++u) {
-            const int j = j0 + u, L = lv[u];
-            if (j < e) {
-                if (L < 0 || L >= 13) return -1;
-#pragma unroll
-                for (int k = 0; k < 13; ++k) if (L == k) { if (cnt[k] == 0) seen[k] = j; cnt[k]++; }
-            }
-        }
-    }
-    int best = 0;
-#pragma unroll
-    for (int k = 1; k < 13; ++k) if (cnt[k] > cnt[best] || (cnt[k] == cnt[best] && seen[k] > seen[best])) best = k;
-    return best;
+    return voxel_label_fast_t([&](int j) { return cls[(size_t)vs[j] * ldim + col]; }, s, e);
 }
 
 __device__ __forceinline__ void gs_reduce_labels_body(const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start,
@@ -325,24 +248,8 @@ __device__ __forceinline__ void gs_reduce_voxel(Get get, int s, int en, int c, i
     } else if (!is_label) {
         out_f[(size_t)row * fdim + (c - 3)] = sum / (float)count;      // :90-94
     } else {
-        int best = 0, bestc = -1, nbest = 0;
-#pragma unroll
-        for (int k = 0; k < 13; ++k) {
-            const int ck = (int)(((k < 8 ? pk0 : pk1) >> ((k & 7) * 8)) & 0xffull);
-            if (ck > bestc) { bestc = ck; best = k; nbest = 1; } else if (ck == bestc) ++nbest;
-        }
-        if (exact) {                                         // labels outside [0,13) or more than 255 points: the exact routines
-            const int* rc = reinterpret_cast<const int*>(rec);
-            best = voxel_label_fast(rc, REC_W, c, vs, gs0, gen);
-            if (best < 0) best = voxel_label(rc, REC_W, c, vs, gs0, gen, &prm->status);
-        } else if (nbest > 1) {                              // shared maximum: the label first seen LAST wins (see voxel_label_fast)
-            unsigned seen = 0;
-            for (int j = s; j < en; ++j) {
-                const unsigned L = get(j, c);
-                const int ck = (int)(((L < 8 ? pk0 : pk1) >> ((L & 7) * 8)) & 0xffull);
-                if (ck == bestc && !((seen >> L) & 1u)) { seen |= 1u << L; best = (int)L; }
-            }
-        }
+        // labels outside [0,13) or more than 255 points, or a shared maximum: re-scanned from the record source (same values in the same order)
+        const int best = voxel_label_packed(pk0, pk1, exact, [&](int j) { return (int)get(j, c); }, s, en, &prm->status);
         out_c[(size_t)row * ldim + (c - CH)] = best;
     }
 }
@@ -424,11 +331,6 @@ __global__ __launch_bounds__(1024) void gs_heads_scan(int* bsum, int nb, GsParam
 __global__ __launch_bounds__(BS) void gs_heads_write(const uint64_t* __restrict__ ks, int n, const int* bsum, int* seg_start) { gs_heads_write_body(ks, n, bsum, seg_start); }
 __global__ __launch_bounds__(BS) void gs_reduce_labels(const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, int* out_c) { gs_reduce_labels_body(cls, ldim, vs, seg_start, prm, row_of_voxel, out_c); }
 __global__ __launch_bounds__(BS) void gs_reduce(const float* __restrict__ P, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim, const uint32_t* __restrict__ vs, const int* __restrict__ seg_start, GsParams* prm, const int* __restrict__ row_of_voxel, float* out_p, float* out_f, int* out_c, long long* out_m, uint64_t* out_first, const uint64_t* ks) { gs_reduce_body(P, F, fdim, cls, ldim, vs, seg_start, prm, row_of_voxel, out_p, out_f, out_c, out_m, out_first, ks); }
-
-// Per-cloud tables of a batch, passed by value.  Cloud r: input rows [off[r], off[r+1]) of the concatenated arrays,
-// sort slots [toff[r], toff[r+1]) (tile-aligned), segment-start slots from toff[r] + r.
-struct CloudTab { int nr; int off[RADIX_MAX_SEG + 1]; int toff[RADIX_MAX_SEG + 1]; };
-constexpr int PB = 256;     // partial min/max blocks per cloud
 
 __global__ __launch_bounds__(BS) void gs_minmax_partial_b(CloudTab t, const float* __restrict__ P, float* partial) {
     const int r = blockIdx.y;
@@ -635,9 +537,19 @@ int prune_device(const float* d_p, size_t n, float w, const uint8_t* d_rgb, cons
     return SSDR_OK;
 }
 
+// frontend.hip: bucket partition + per-bucket LDS reduction (rows of at most 7 words, grids of at most 16384 buckets of 1024 voxels)
+bool frontend_fits(size_t fdim, size_t ldim);
+int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const int32_t* d_c, size_t ldim, const int64_t* room_off, size_t nr, float dl,
+                          float* d_op, float* d_of, int32_t* d_oc, int64_t* d_om, GsParams* prm, hipStream_t s);
+
 int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim, const int32_t* d_c, size_t ldim, const int64_t* room_off, size_t nr, float dl,
-                                float* d_op, float* d_of, int32_t* d_oc, int64_t* d_om, hipStream_t s) {
+                                float* d_op, float* d_of, int32_t* d_oc, int64_t* d_om, hipStream_t s, int method) {
     GsState& S = gs(s);
+    if (method != SSDR_SUBSAMPLE_SORT && frontend_fits(fdim, ldim)) {
+        S.last_clouds = (int)nr;
+        SSDR_TRY(S.params.reserve(sizeof(GsParams) * nr));
+        return frontend_batch_device(d_p, d_f, fdim, d_c, ldim, room_off, nr, dl, d_op, d_of, d_oc, d_om, S.params.as<GsParams>(), s);
+    }
     CloudTab t; t.nr = (int)nr;
     int toff = 0, maxn = 0; std::vector<int> n_host(nr);
     for (size_t r = 0; r < nr; ++r) {
@@ -694,6 +606,8 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
 
 using namespace ssdr;
 
+static int g_batch_method = [] { const char* e = getenv("SSDR_SUBSAMPLE_METHOD"); return e && !strcmp(e, "sort") ? SSDR_SUBSAMPLE_SORT : SSDR_SUBSAMPLE_AUTO; }();
+
 extern "C" {
 
 int ssdr_grid_subsample_dev(const float* d_points, size_t n, const float* d_features, size_t fdim, const int32_t* d_classes,
@@ -718,7 +632,16 @@ int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features
     if (d_classes && (!ldim || !d_out_classes)) { set_error("grid_subsample_batch: classes given without ldim / output"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     return grid_subsample_batch_device(d_points, d_features, d_features ? fdim : 0, d_classes, d_classes ? ldim : 0, cloud_offsets, num_clouds, sampleDl,
-                                       d_out_points, d_out_features, d_out_classes, d_out_m, pick_stream(stream));
+                                       d_out_points, d_out_features, d_out_classes, d_out_m, pick_stream(stream), g_batch_method);
+}
+
+/* which implementation ssdr_grid_subsample_batch_dev uses: SSDR_SUBSAMPLE_AUTO (default: the bucket partition of frontend.hip for rows of at most 7 words,
+ * the sort-based path otherwise) or SSDR_SUBSAMPLE_SORT (always the sort: any grid, any voxel population).  A cloud the partition path cannot take is
+ * reported by ssdr_grid_subsample_status (bits 2, 4); the caller then repeats the call with SSDR_SUBSAMPLE_SORT. */
+int ssdr_grid_subsample_set_method(int method) {
+    if (method != SSDR_SUBSAMPLE_AUTO && method != SSDR_SUBSAMPLE_SORT) { set_error("grid_subsample_set_method: unknown method %d", method); return SSDR_ERR_INVALID; }
+    g_batch_method = method;
+    return SSDR_OK;
 }
 
 int ssdr_grid_subsample(const float* points, size_t n, const float* features, size_t fdim, const int32_t* classes, size_t ldim,
@@ -785,8 +708,10 @@ int ssdr_grid_subsample_status(void* stream, int32_t* out_status) {
         for (auto& g : h) st |= g.status;
     }
     if (out_status) *out_status = st;
-    if (st) { set_error("grid_subsample: device status 0x%x (1 = a voxel holds more than %d distinct labels in one column; 2 = a cloud's grid has too many cells for "
-                        "the batch flavour's sort words: use ssdr_grid_subsample_dev for it)", st, LAB_CAP); return SSDR_ERR_UNSUPPORTED; }
+    if (st) { set_error("grid_subsample: device status 0x%x (1 = a voxel holds more than %d distinct labels in one column; 2 = a cloud's grid is too large for "
+                        "the batch flavour (partition path: more than 16384 buckets of 1024 voxels, or coordinates outside the grid; sort path: no room for the index in "
+                        "the sort words); 4 = a voxel of more than 1536 points in the partition path: repeat with ssdr_grid_subsample_set_method(SSDR_SUBSAMPLE_SORT), or "
+                        "use ssdr_grid_subsample_dev)", st, LAB_CAP); return SSDR_ERR_UNSUPPORTED; }
     return SSDR_OK;
 }
 

@@ -83,6 +83,103 @@ __global__ __launch_bounds__(256) void tile_gather_b(TileTab t, const float* __r
                      color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, stride);
 }
 
+// ---- batch flavour: only the rows that can be among the num_points nearest are sorted ------------------------------------------
+// A room holds ~4 x num_points rows; sorting all of them by distance was a third of the front end.  Non-negative float distances order like
+// their bit patterns, so a histogram over the top TS_BITS bits of the pattern finds the first bin T whose cumulative count reaches
+// num_points; rows with bin <= T (all num_points nearest and the rest of bin T, ties included) are compacted and sorted as before.
+constexpr int TS_BITS = 12, TS_BINS = 1 << TS_BITS, TS_SHIFT = 31 - TS_BITS;       // bit 31 (sign) is clear: 8 exponent + 4 mantissa bits
+
+__device__ __forceinline__ float tile_dist(const float* __restrict__ pts, int i, float cx, float cy, float cz) {
+    const float dx = pts[3 * (size_t)i] - cx, dy = pts[3 * (size_t)i + 1] - cy, dz = pts[3 * (size_t)i + 2] - cz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+__global__ __launch_bounds__(256) void tile_hist_b(TileTab t, const float* __restrict__ pts, const long long* __restrict__ d_m, unsigned* hist, int* d_count) {
+    __shared__ unsigned s_h[TS_BINS];
+    const int r = blockIdx.y, n_host = t.off[r + 1] - t.off[r];
+    const int m = (int)min((long long)n_host, d_m[r]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) d_count[r] = m;
+    if ((int)blockIdx.x * 256 >= m) return;
+    for (int b = threadIdx.x; b < TS_BINS; b += 256) s_h[b] = 0u;
+    __syncthreads();
+    const float* P = pts + 3 * (size_t)t.off[r];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256)
+        atomicAdd(&s_h[__float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r])) >> TS_SHIFT], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < TS_BINS; b += 256) if (s_h[b]) atomicAdd(&hist[(size_t)r * TS_BINS + b], s_h[b]);
+}
+// one workgroup per room: first bin whose cumulative count reaches num_points (the last bin when the room is smaller); clears the histogram
+__global__ __launch_bounds__(256) void tile_thresh_b(unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand) {
+    __shared__ unsigned s_part[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    unsigned* h = hist + (size_t)r * TS_BINS;
+    constexpr int PER = TS_BINS / 256;
+    unsigned c[PER], tot = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { c[k] = h[tid * PER + k]; tot += c[k]; h[tid * PER + k] = 0u; }
+    s_part[tid] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned want = (unsigned)min(num_points, d_count[r]);
+        unsigned run = 0; int w = 0;
+        while (w < 255 && run + s_part[w] < want) { run += s_part[w]; ++w; }
+        s_part[0] = (unsigned)w; s_part[1] = run;
+    }
+    __syncthreads();
+    if (tid == (int)s_part[0]) {
+        const unsigned want = (unsigned)min(num_points, d_count[r]);
+        unsigned run = s_part[1]; int k = 0;
+        while (k < PER - 1 && run + c[k] < want) { run += c[k]; ++k; }
+        thr[r] = (unsigned)(tid * PER + k);
+        d_cand[r] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, uint64_t* keys, int* d_cand) {
+    __shared__ int s_w[2][U][256 / 64];
+    __shared__ int s_base;
+    const int r = blockIdx.y, m = d_count[r];
+    const float* P = pts + 3 * (size_t)t.off[r];
+    const unsigned T = thr[r];
+    uint64_t* K = keys + t.toff[r];
+    for (int base = blockIdx.x * CHUNK; base < m; base += gridDim.x * CHUNK) {
+        const int hi = min(m, base + CHUNK);
+        // candidates of this chunk: counted first, then written behind one reservation (their order is settled by the sort: keys are unique)
+        int cnt = 0;
+        unsigned bits[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * 256 + threadIdx.x;
+            bits[u] = i < hi ? __float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r])) : 0xffffffffu;
+            cnt += (i < hi && (bits[u] >> TS_SHIFT) <= T) ? 1 : 0;
+        }
+        int zero = 0;
+        block_sum2<256>(cnt, zero, &s_w[0][0][0]);
+        if (threadIdx.x == 0) s_base = cnt ? atomicAdd(&d_cand[r], cnt) : 0;
+        __syncthreads();
+        const int at = s_base;
+        block_compact<256>(base, hi, [&](int i) { const int u = (i - base - (int)threadIdx.x) / 256; return (bits[u] >> TS_SHIFT) <= T; },
+                           [&](int k, int i) { const int u = (i - base - (int)threadIdx.x) / 256; K[at + k] = ((uint64_t)bits[u] << 32) | (uint64_t)(uint32_t)i; }, s_w);
+    }
+}
+
+// The sort orders by distance bits and is stable, but the compacted candidates are not in index order: rows at EQUAL distance (a few pairs
+// per room) are put into index order here — the head of every run of equal distances sorts its run (the full words: index in the low half)
+__global__ __launch_bounds__(256) void tile_fix_ties_b(TileTab t, uint64_t* keys, const int* __restrict__ d_cand) {
+    const int r = blockIdx.y, n = min(d_cand[r], t.off[r + 1] - t.off[r]);
+    uint64_t* K = keys + t.toff[r];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j + 1 < n; j += gridDim.x * 256) {
+        const unsigned d = (unsigned)(K[j] >> 32);
+        if ((j == 0 || (unsigned)(K[j - 1] >> 32) != d) && (unsigned)(K[j + 1] >> 32) == d) {
+            int e = j + 2;
+            while (e < n && (unsigned)(K[e] >> 32) == d) ++e;
+            for (int x = j + 1; x < e; ++x) {
+                const uint64_t kx = K[x]; int y = x - 1;
+                while (y >= j && K[y] > kx) { K[y + 1] = K[y]; --y; }
+                K[y + 1] = kx;
+            }
+        }
+    }
+}
+
 // Possibility map of the test-time generator (S3/s3dis_dataset_test.py:140-143): for the `avail` points of the tile,
 // dists = (dx*dx + dy*dy) + dz*dz in float32, delta = (1 - dists / max(dists))^2, possibility[idx] += delta (float64).
 // The tile's points are the first `avail` entries of the distance-sorted list, so max(dists) is the key of the last one.
@@ -114,7 +211,7 @@ __global__ __launch_bounds__(1024) void possibility_min(const double* __restrict
     if (tid == 0) { *out_min = s_v[0]; *out_arg = s_i[0]; }
 }
 
-struct TileState { RadixSorter sorter; DevBuf keys, vals, count; };
+struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand; bool hist_clear = false; };
 TileState& tst(hipStream_t st) { return per_stream<TileState>(st); }
 
 }  // namespace
@@ -174,11 +271,17 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
         toff += ((int)n + RADIX_TILE - 1) / RADIX_TILE * RADIX_TILE;
     }
     t.off[num_clouds] = (int)cloud_offsets[num_clouds]; t.toff[num_clouds] = toff;
-    SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.vals.reserve(4 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
+    SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
+    SSDR_TRY(T.hist.reserve(4 * (size_t)TS_BINS * RADIX_MAX_SEG)); SSDR_TRY(T.thr.reserve(4 * RADIX_MAX_SEG)); SSDR_TRY(T.cand.reserve(4 * RADIX_MAX_SEG));
+    if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_thresh_b leaves it clear
     const unsigned R = (unsigned)num_clouds;
-    const int g = std::max(1, std::min((maxn + 255) / 256, 256));
-    hipLaunchKernelGGL(tile_keys_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.keys.as<uint64_t>(), (uint32_t*)nullptr, T.count.as<int>());
-    SSDR_TRY(T.sorter.sort_segments(T.keys.as<uint64_t>(), nullptr, (int)num_clouds, t.toff, n_host.data(), T.count.as<int>(), s, 32, false, nullptr, 32));      // keys only: distance bits above the index
+    const int g = std::max(1, std::min((maxn + 255) / 256, 64));
+    hipLaunchKernelGGL(tile_hist_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.hist.as<unsigned>(), T.count.as<int>());
+    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>());
+    const int gc = std::max(1, std::min((maxn + CHUNK - 1) / CHUNK, 64));
+    hipLaunchKernelGGL(tile_compact_b, dim3(gc, R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(), T.keys.as<uint64_t>(), T.cand.as<int>());
+    SSDR_TRY(T.sorter.sort_segments(T.keys.as<uint64_t>(), nullptr, (int)num_clouds, t.toff, n_host.data(), T.cand.as<int>(), s, 32, false, nullptr, 32));      // keys only: distance bits above the index
+    hipLaunchKernelGGL(tile_fix_ties_b, dim3(gc, R), dim3(256), 0, s, t, T.keys.as<uint64_t>(), T.cand.as<int>());
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
     hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, reinterpret_cast<const uint32_t*>(T.keys.as<uint64_t>()), T.count.as<int>(),
                        d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2);

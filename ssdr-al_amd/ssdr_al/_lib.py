@@ -115,6 +115,7 @@ def lib():
         L.ssdr_memcpy_d2h_on.argtypes = [vp, vp, sz, vp]
         L.ssdr_knn_status_poll.argtypes = [vp, vp]
         L.ssdr_grid_subsample_status.argtypes = [vp, vp]
+        L.ssdr_grid_subsample_set_method.argtypes = [i32]
         _lib = L
     return _lib
 

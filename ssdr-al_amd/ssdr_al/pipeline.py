@@ -79,9 +79,21 @@ class HotPath:
         self.interp = [DevArray((B, self.sizes[i], 1), np.int32) for i in range(L)]
         self.probs = DevArray((B * N, cfg.num_classes), np.float32); self.f32 = DevArray((B * N, 32), np.float32)
         self.unc = DevArray((B * N,), np.float32); self.cls = DevArray((B * N,), np.int32)
-        # superpoints of the (fixed) tiles: computed once from a dry run of the geometric front end
+        # superpoints of the (fixed) tiles: computed once from a dry run of the geometric front end.  The dry run also settles which
+        # implementation of the batched grid subsample these rooms get: the bucket partition reports a cloud it cannot take (a grid of
+        # more than 16384 buckets, a voxel of more than 1536 points) through its status, and the rooms then go through the sort
+        self.subsample_method = 0
         self._front_end()
         _lib.sync()
+        st = C.c_int32()
+        rc = _lib.lib().ssdr_grid_subsample_status(self.front_stream, C.byref(st))
+        if rc != 0 and (st.value & 6):
+            self.subsample_method = 1
+            self._front_end()
+            _lib.sync()
+            _lib.check(_lib.lib().ssdr_grid_subsample_status(self.front_stream, None))
+        else:
+            _lib.check(rc)
         from .synthetic import superpoints_from_tile
         tiles = self.xyz.to_host()
         offs, pts, cloud = [np.zeros(1, np.int32)], [], []
@@ -114,6 +126,7 @@ class HotPath:
         """grid-subsample + tile of every room of the batch, one batched launch sequence per stage (on front_stream)."""
         cfg, L = self.cfg, _lib.lib()
         st = self.front_stream
+        _lib.check(L.ssdr_grid_subsample_set_method(self.subsample_method))
         _lib.check(L.ssdr_grid_subsample_batch_dev(self.raw_p.ptr, self.raw_c.ptr, 3, self.raw_l.ptr, 1, _lib.ptr(self.room_off), self.B, cfg.sub_grid_size,
                                                    self.sub_p.ptr, self.sub_c.ptr, self.sub_l.ptr, self.sub_m.ptr, st))
         _lib.check(L.ssdr_tile_select_batch_dev(self.sub_p.ptr, self.sub_c.ptr, 3, self.sub_m.ptr, _lib.ptr(self.room_off), self.B, _lib.ptr(self.centers),

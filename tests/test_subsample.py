@@ -143,3 +143,72 @@ def test_device_flavour_reports_label_table_overflow(backend):
     _lib.check(L.ssdr_grid_subsample_batch_dev(d_p.ptr, d_f.ptr, 3, d_l2.ptr, 1, _lib.ptr(off), 1, 0.04, o_p.ptr, o_f.ptr, o_l.ptr, o_m.ptr, None))
     _lib.check(L.ssdr_grid_subsample_status(None, C.byref(st)))
     assert st.value == 0 and int(o_m.to_host()[0]) == 1
+
+
+def _batch(clouds, dl, method=None):
+    from ssdr_al import _lib
+    from ssdr_al._lib import DevArray
+    L = _lib.lib()
+    sizes = [len(c[0]) for c in clouds]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    P = np.concatenate([c[0] for c in clouds]); Fe = np.concatenate([c[1] for c in clouds]); Lb = np.concatenate([c[2] for c in clouds])
+    d_p, d_f, d_l = DevArray.from_host(P), DevArray.from_host(Fe), DevArray.from_host(Lb)
+    o_p, o_f, o_l = DevArray(P.shape, np.float32), DevArray(Fe.shape, np.float32), DevArray(Lb.shape, np.int32)
+    d_m = DevArray((len(sizes),), np.int64)
+    if method is not None:
+        _lib.check(L.ssdr_grid_subsample_set_method(method))
+    try:
+        _lib.check(L.ssdr_grid_subsample_batch_dev(d_p.ptr, d_f.ptr, Fe.shape[1], d_l.ptr, Lb.shape[1], _lib.ptr(off), len(sizes), dl, o_p.ptr, o_f.ptr, o_l.ptr, d_m.ptr, None))
+        import ctypes
+        st = ctypes.c_int32()
+        rc = L.ssdr_grid_subsample_status(None, ctypes.byref(st))
+    finally:
+        _lib.check(L.ssdr_grid_subsample_set_method(0))
+    m = d_m.to_host(); gp, gf, gl = o_p.to_host(), o_f.to_host(), o_l.to_host()
+    return rc, st.value, [(gp[int(off[r]):int(off[r]) + int(m[r])], gf[int(off[r]):int(off[r]) + int(m[r])], gl[int(off[r]):int(off[r]) + int(m[r])]) for r in range(len(sizes))]
+
+
+def _cloud(rng, n, box, shift=0.0, nlab=13):
+    p = (rng.random((n, 3), dtype=np.float32) * np.asarray(box, np.float32) + np.float32(shift)).astype(np.float32)
+    return p, rng.integers(0, 256, (n, 3)).astype(np.float32), rng.integers(0, nlab, (n, 1)).astype(np.int32)
+
+
+def test_subsample_batch_partition_paths(backend, orc):
+    """The bucket-partition implementation of the batch flavour (frontend.hip) on the shapes that leave its common case: a bucket with more
+    records than its LDS holds (cut into slices of voxels, rows through the overflow region), the 16-voxel-wide bucket geometry of a long
+    grid, negative coordinates, a plane — against the oracle, and against the sort-based implementation of the same entry point."""
+    rng = np.random.default_rng(77)
+    big = backend != "emu"
+    clouds = [_cloud(rng, 9000 if not big else 60000, (0.33, 0.33, 0.33), shift=-0.2),      # ~512 voxels, 18+ points each: buckets of > 1536 records
+              _cloud(rng, 3000 if not big else 400000, (21.0, 13.0, 3.0)),                   # 525 x 325 x 75 voxels: 16 x 8 x 8 buckets
+              _cloud(rng, 2500 if not big else 300000, (5.0, 4.0, 0.0), shift=-3.0),          # a plane at z = -3
+              _cloud(rng, 64, (0.01, 0.01, 0.01))]                                            # one voxel
+    rc, st, got = _batch(clouds, 0.04)
+    assert rc == 0 and st == 0
+    rc2, st2, got_sort = _batch(clouds, 0.04, method=1)
+    assert rc2 == 0 and st2 == 0
+    for r, (p, f, l) in enumerate(clouds):
+        exp = orc.grid_subsampling(p, f, l, 0.04, order="key")
+        for x, y, z in zip(got[r], exp, got_sort[r]):
+            assert_bits_equal(x, y, "cloud %d" % r); assert_bits_equal(z, y, "cloud %d (sort)" % r)
+
+
+def test_subsample_batch_partition_reports_what_it_cannot_take(backend, orc):
+    """A grid of more than 16384 buckets, and a voxel of more than 1536 points: reported by ssdr_grid_subsample_status; the sort-based
+    implementation of the same entry point then gives the reference's rows."""
+    rng = np.random.default_rng(78)
+    wide = [_cloud(rng, 4000, (60.0, 40.0, 3.0)), _cloud(rng, 500, (1.0, 1.0, 1.0))]
+    rc, st, _ = _batch(wide, 0.04)
+    assert rc != 0 and st & 2
+    dense = [_cloud(rng, 500, (1.0, 1.0, 1.0)), _cloud(rng, 2500, (0.01, 0.01, 0.01), shift=0.5)]
+    rc, st, got = _batch(dense, 0.04)
+    assert rc != 0 and st & 4
+    exp0 = orc.grid_subsampling(*dense[0], 0.04, order="key")          # the other cloud of the call is not affected
+    for x, y in zip(got[0], exp0):
+        assert_bits_equal(x, y)
+    for clouds in (wide, dense):
+        rc, st, got = _batch(clouds, 0.04, method=1)
+        assert rc == 0 and st == 0
+        for r, (p, f, l) in enumerate(clouds):
+            for x, y in zip(got[r], orc.grid_subsampling(p, f, l, 0.04, order="key")):
+                assert_bits_equal(x, y)
