@@ -51,6 +51,18 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 #endif
 
+// Orders the LDS traffic of the lanes of ONE wave (waves of a workgroup that take different trip counts cannot use the workgroup barrier):
+// everything the wave's lanes wrote before is visible to its lanes after.
+__device__ __forceinline__ void wave_sync() {
+#ifndef HIPEMU
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    (void)__shfl(0, 0);      // the CPU stand-in completes a wave operation once every live lane of the wave has reached it
+#endif
+}
+
 // min/max of 3 coordinates over the workgroup; result broadcast to every thread.
 template <int NT = BS>
 __device__ inline void block_minmax3(float (&mn)[3], float (&mx)[3], float* s /* [NT/64][6] */) {

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(FE_NT) void fe_scatter(FeTab t, const float* __rest
             int ix, iy, iz;
             if (i < hi && fe_voxel(g, cur[k].x, cur[k].y, cur[k].z, ix, iy, iz)) {
                 const unsigned slot = atomicAdd(&s_cur[fe_bucket(g, ix, iy, iz)], 1u);
+                // (non-temporal stores here: 2.6x slower — the L2 merges the two halves of a record, and little else: a chunk adds ~4 records to a bucket)
                 R[2 * (size_t)slot] = make_uint4(__float_as_uint(cur[k].x), __float_as_uint(cur[k].y), __float_as_uint(cur[k].z), cur[k].w[0]);
                 R[2 * (size_t)slot + 1] = make_uint4(cur[k].w[1], cur[k].w[2], cur[k].w[3], (uint32_t)i);
             }

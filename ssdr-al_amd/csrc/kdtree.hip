@@ -89,17 +89,153 @@ __global__ __launch_bounds__(INIT_NT) void kd_init_kernel(ForestPtrs f) {
     }
 }
 
+// LDS of one node split
+template <int NT>
+struct SplitLds { float mm[(NT / 64) * 6]; int sum[(NT / 64) * 2]; int w[2][U][NT / 64]; int child; int reach[2]; };
+
+// One node of divideTree (nanoflann.hpp:848-896) split by the calling workgroup; an open child above SMALL_MAX points is handed to
+// push_big(child) by ONE thread, a smaller open one joins the forest's list of small subtrees.
+template <int NT, class Push>
+__device__ __forceinline__ void kd_split_node(const ForestPtrs& f, SplitLds<NT>& L, int node, int level, bool cut_to_balls, int nballs, Push push_big) {
+    float (&s_mm)[(NT / 64) * 6] = L.mm; int (&s_sum)[(NT / 64) * 2] = L.sum; int (&s_w)[2][U][NT / 64] = L.w; int& s_child = L.child; int (&s_reach)[2] = L.reach;
+    const int tid = threadIdx.x;
+    const int4 na = f.node_a[2 * (size_t)(node)];
+    const int left = na.x, count = na.y - na.x;
+    const int tree = f.node_tree[node];
+    float4* S = f.sorted + left; int* tmp = f.tmp + left;
+    const float* Sf = reinterpret_cast<const float*>(S);
+    float lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = f.node_box[6 * (size_t)node + d]; hi[d] = f.node_box[6 * (size_t)node + 3 + d]; }
+
+    // computeMinMax (:837-846) for all three dimensions at once; the records are in position order, so every pass
+    // streams (four 16-byte loads in flight per thread)
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i0 = tid; i0 < count; i0 += 4 * NT) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = S[min(i0 + u * NT, count - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mn[0] = fminf(mn[0], v[u].x); mx[0] = fmaxf(mx[0], v[u].x); mn[1] = fminf(mn[1], v[u].y); mx[1] = fmaxf(mx[1], v[u].y);
+            mn[2] = fminf(mn[2], v[u].z); mx[2] = fmaxf(mx[2], v[u].z);
+        }
+    }
+    block_minmax3<NT>(mn, mx, s_mm);
+
+    // middleSplit_ (:898-937)
+    const float EPS = 0.00001f;
+    float max_span = hi[0] - lo[0];
+#pragma unroll
+    for (int d = 1; d < 3; ++d) { float s = hi[d] - lo[d]; if (s > max_span) max_span = s; }
+    float max_spread = -1.f; int cf = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float s = hi[d] - lo[d];
+        if (s > (1 - EPS) * max_span) { float spread = mx[d] - mn[d]; if (spread > max_spread) { cf = d; max_spread = spread; } }
+    }
+    const float lo_c = cf == 0 ? lo[0] : (cf == 1 ? lo[1] : lo[2]);
+    const float hi_c = cf == 0 ? hi[0] : (cf == 1 ? hi[1] : hi[2]);
+    const float mn_c = cf == 0 ? mn[0] : (cf == 1 ? mn[1] : mn[2]);
+    const float mx_c = cf == 0 ? mx[0] : (cf == 1 ? mx[1] : mx[2]);
+    const float split_val = (lo_c + hi_c) / 2;
+    const float cut = split_val < mn_c ? mn_c : (split_val > mx_c ? mx_c : split_val);
+
+    // count "< cut" and "== cut"
+    int cL = 0, cE = 0;
+    for (int i0 = tid; i0 < count; i0 += 4 * NT) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = Sf[4 * (size_t)min(i0 + u * NT, count - 1) + cf];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * NT < count) { cL += v[u] < cut; cE += v[u] == cut; }
+    }
+    block_sum2<NT>(cL, cE, s_sum);
+
+    // planeSplit (:948-975)
+    const int lim1 = cL, lim2 = cL + cE;
+    hoare_sweep<NT>(S, tmp, 0, count, lim1, [&](int i) { return Sf[4 * (size_t)i + cf] < cut; }, s_w);
+    if (cE > 0) hoare_sweep<NT>(S, tmp, lim1, count, lim2, [&](int i) { return Sf[4 * (size_t)i + cf] <= cut; }, s_w);
+    int idx;
+    if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
+
+    // tight child boxes along the cut dimension (:878-882): divlow = max over left, divhigh = min over right
+    float m3n[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, m3x[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i0 = tid; i0 < count; i0 += 4 * NT) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = Sf[4 * (size_t)min(i0 + u * NT, count - 1) + cf];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT;
+            if (i < idx) m3x[0] = fmaxf(m3x[0], v[u]); else if (i < count) m3n[0] = fminf(m3n[0], v[u]);
+        }
+    }
+    block_minmax3<NT>(m3n, m3x, s_mm);
+
+    if (tid == 0) {
+        int c = f.ntrees + 2 * (left + idx);
+        if (c + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c = -1; }
+        s_child = c;
+        s_reach[0] = s_reach[1] = cut_to_balls ? 0 : 1;
+    }
+    __syncthreads();
+    if (cut_to_balls) {
+        // does a ball of this tree reach the child's box?  (the box the walk prices it with: the node's box, tight along the cut)
+        int r0 = 0, r1 = 0;
+        for (int i = tid; i < nballs; i += NT) {
+            if (f.balls.tree[i] != tree) continue;
+            const float4 b = f.balls.q[i];
+            const float q[3] = {b.x, b.y, b.z};
+            float lb0 = 0.f, lb1 = 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float h0 = d == cf ? m3x[0] : hi[d], l1 = d == cf ? m3n[0] : lo[d];
+                const float g0 = fmaxf(fmaxf(lo[d] - q[d], q[d] - h0), 0.f), g1 = fmaxf(fmaxf(l1 - q[d], q[d] - hi[d]), 0.f);
+                lb0 += g0 * g0; lb1 += g1 * g1;
+            }
+            r0 |= lb0 <= b.w; r1 |= lb1 <= b.w;
+        }
+        if (r0) atomicOr(&s_reach[0], 1);
+        if (r1) atomicOr(&s_reach[1], 1);
+        __syncthreads();
+    }
+    const int c1 = s_child;
+    if (c1 >= 0 && tid < 2) {
+        const int c = c1 + tid;
+        const int cl = tid == 0 ? left : left + idx, cr = tid == 0 ? left + idx : left + count;
+        f.node_a[2 * (size_t)(c)] = make_int4(cl, cr, -1, -1);
+        f.node_b[2 * (size_t)(c)] = make_float4(0.f, 0.f, 0.f, 0.f);
+        f.node_tree[c] = tree;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            f.node_box[6 * (size_t)c + d] = (tid == 1 && d == cf) ? cut : lo[d];
+            f.node_box[6 * (size_t)c + 3 + d] = (tid == 0 && d == cf) ? cut : hi[d];
+        }
+        if (cr - cl > LEAF_MAX && !s_reach[tid]) f.node_a[2 * (size_t)(c)] = make_int4(cl, cr, CLOSED, CLOSED);
+        else if (cr - cl > SMALL_MAX) {
+            if (level + 1 >= BIG_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
+            push_big(c);
+        } else if (cr - cl > LEAF_MAX) {
+            f.node_b[2 * (size_t)(c)] = make_float4(0.f, 0.f, 0.f, __int_as_float(level + 1));      // depth of this small root
+            int q = atomicAdd(&f.ctr[CTR_SQ], 1);
+            if (q < 2 * f.queue_cap) f.squeue[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+        }
+    }
+    if (c1 >= 0 && tid == 0) {
+        f.node_a[2 * (size_t)(node)] = make_int4(na.x, na.y, c1, c1 + 1);
+        f.node_b[2 * (size_t)(node)] = make_float4(m3x[0], m3n[0], __int_as_float(cf), 0.f);
+    }
+    __syncthreads();
+}
+
 // Children get node ids without atomics: a node split at absolute vind position m hands its children the ids
 // ntrees + 2*m and ntrees + 2*m + 1 (split positions are unique in the forest; tens of thousands of waves adding to one
 // counter would serialise at ~10 ns each).
-// One level of divideTree (nanoflann.hpp:848-896) for every open node.
+// One level of divideTree for every open node of the forest (complete builds of many trees: the nodes of a level fill the chip).
 template <int NT>
 __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
-    __shared__ float s_mm[(NT / 64) * 6];
-    __shared__ int s_sum[(NT / 64) * 2];
-    __shared__ int s_w[2][U][NT / 64];
-    __shared__ int s_child;
-    __shared__ int s_reach[2];
+    __shared__ SplitLds<NT> L;
     const int tid = threadIdx.x;
     const int nq = min(f.ctr[CTR_QUEUE0 + level], f.queue_cap);
     const int nballs = f.balls.q ? *f.balls.count : 0;
@@ -111,136 +247,66 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
         if (level + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
     }
     for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
-        const int node = qin[qi];
-        const int4 na = f.node_a[2 * (size_t)(node)];
-        const int left = na.x, count = na.y - na.x;
-        const int tree = f.node_tree[node];
-        float4* S = f.sorted + left; int* tmp = f.tmp + left;
-        const float* Sf = reinterpret_cast<const float*>(S);
-        float lo[3], hi[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { lo[d] = f.node_box[6 * (size_t)node + d]; hi[d] = f.node_box[6 * (size_t)node + 3 + d]; }
+        kd_split_node<NT>(f, L, qin[qi], level, cut_to_balls, nballs, [&](int c) {
+            int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
+            if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+        });
+    }
+}
 
-        // computeMinMax (:837-846) for all three dimensions at once; the records are in position order, so every pass
-        // streams (four 16-byte loads in flight per thread)
+// The hand-over's build: ONE workgroup per flagged tree does everything above the small subtrees — the root record (kd_init_kernel's
+// work), then its open nodes one after the other from a queue in LDS, level by level.  A tree that is cut to the balls of its few
+// handed-over rows opens one to three nodes per level: the level-wide launches above spent 2 x 26 launches (0.6 ms of stream time) on what is a
+// few tens of microseconds of work per tree.  Trees are independent, so no grid-wide step is needed.
+constexpr int TREE_NT = 512, TREE_Q = 4096;
+__global__ __launch_bounds__(TREE_NT) void kd_tree_kernel(ForestPtrs f) {
+    __shared__ SplitLds<TREE_NT> L;
+    __shared__ int s_q[TREE_Q];            // open nodes above SMALL_MAX points (a ring) and their levels
+    __shared__ unsigned char s_lv[TREE_Q];
+    __shared__ int s_head, s_tail;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (f.need && !f.need[t]) return;
+    const int nballs = f.balls.q ? *f.balls.count : 0;
+    const bool cut_to_balls = f.balls.q && nballs <= f.balls.cap;
+    // root (kd_init_kernel)
+    {
+        const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
         float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int i0 = tid; i0 < count; i0 += 4 * NT) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = S[min(i0 + u * NT, count - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                mn[0] = fminf(mn[0], v[u].x); mx[0] = fmaxf(mx[0], v[u].x); mn[1] = fminf(mn[1], v[u].y); mx[1] = fmaxf(mx[1], v[u].y);
-                mn[2] = fminf(mn[2], v[u].z); mx[2] = fmaxf(mx[2], v[u].z);
-            }
+        for (int i = tid; i < n; i += TREE_NT) {
+            const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+            f.sorted[voff + i] = make_float4(x, y, z, __int_as_float(i));
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x); mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y); mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         }
-        block_minmax3<NT>(mn, mx, s_mm);
-
-        // middleSplit_ (:898-937)
-        const float EPS = 0.00001f;
-        float max_span = hi[0] - lo[0];
-#pragma unroll
-        for (int d = 1; d < 3; ++d) { float s = hi[d] - lo[d]; if (s > max_span) max_span = s; }
-        float max_spread = -1.f; int cf = 0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float s = hi[d] - lo[d];
-            if (s > (1 - EPS) * max_span) { float spread = mx[d] - mn[d]; if (spread > max_spread) { cf = d; max_spread = spread; } }
-        }
-        const float lo_c = cf == 0 ? lo[0] : (cf == 1 ? lo[1] : lo[2]);
-        const float hi_c = cf == 0 ? hi[0] : (cf == 1 ? hi[1] : hi[2]);
-        const float mn_c = cf == 0 ? mn[0] : (cf == 1 ? mn[1] : mn[2]);
-        const float mx_c = cf == 0 ? mx[0] : (cf == 1 ? mx[1] : mx[2]);
-        const float split_val = (lo_c + hi_c) / 2;
-        const float cut = split_val < mn_c ? mn_c : (split_val > mx_c ? mx_c : split_val);
-
-        // count "< cut" and "== cut"
-        int cL = 0, cE = 0;
-        for (int i0 = tid; i0 < count; i0 += 4 * NT) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = Sf[4 * (size_t)min(i0 + u * NT, count - 1) + cf];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (i0 + u * NT < count) { cL += v[u] < cut; cE += v[u] == cut; }
-        }
-        block_sum2<NT>(cL, cE, s_sum);
-
-        // planeSplit (:948-975)
-        const int lim1 = cL, lim2 = cL + cE;
-        hoare_sweep<NT>(S, tmp, 0, count, lim1, [&](int i) { return Sf[4 * (size_t)i + cf] < cut; }, s_w);
-        if (cE > 0) hoare_sweep<NT>(S, tmp, lim1, count, lim2, [&](int i) { return Sf[4 * (size_t)i + cf] <= cut; }, s_w);
-        int idx;
-        if (lim1 > count / 2) idx = lim1; else if (lim2 < count / 2) idx = lim2; else idx = count / 2;
-
-        // tight child boxes along the cut dimension (:878-882): divlow = max over left, divhigh = min over right
-        float m3n[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, m3x[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int i0 = tid; i0 < count; i0 += 4 * NT) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = Sf[4 * (size_t)min(i0 + u * NT, count - 1) + cf];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * NT;
-                if (i < idx) m3x[0] = fmaxf(m3x[0], v[u]); else if (i < count) m3n[0] = fminf(m3n[0], v[u]);
-            }
-        }
-        block_minmax3<NT>(m3n, m3x, s_mm);
-
+        block_minmax3<TREE_NT>(mn, mx, L.mm);
         if (tid == 0) {
-            int c = f.ntrees + 2 * (left + idx);
-            if (c + 2 > f.node_cap) { atomicOr(&f.ctr[CTR_STATUS], ST_NODE_OVF); c = -1; }
-            s_child = c;
-            s_reach[0] = s_reach[1] = cut_to_balls ? 0 : 1;
+            for (int d = 0; d < 3; ++d) { f.desc[t].lo[d] = mn[d]; f.desc[t].hi[d] = mx[d]; f.node_box[6 * t + d] = mn[d]; f.node_box[6 * t + 3 + d] = mx[d]; }
+            f.desc[t].root = t;
+            f.node_a[2 * (size_t)(t)] = make_int4(voff, voff + n, -1, -1);
+            f.node_b[2 * (size_t)(t)] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f.node_tree[t] = t;
+            s_head = 0; s_tail = 0;
+            if (n > SMALL_MAX) { s_q[0] = t; s_lv[0] = 0; s_tail = 1; }
+            else if (n > LEAF_MAX) { int q = atomicAdd(&f.ctr[CTR_SQ], 1); if (q < 2 * f.queue_cap) f.squeue[q] = t; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF); }
         }
+        __syncthreads();      // (the sorted records are this workgroup's own global stores: visible to its later loads after the barrier)
+    }
+    int maxlevel = -1;
+    for (;;) {
+        const int head = s_head, tail = s_tail;
+        if (head == tail) break;
+        const int node = s_q[head % TREE_Q], level = s_lv[head % TREE_Q];
         __syncthreads();
-        if (cut_to_balls) {
-            // does a ball of this tree reach the child's box?  (the box the walk prices it with: the node's box, tight along the cut)
-            int r0 = 0, r1 = 0;
-            for (int i = tid; i < nballs; i += NT) {
-                if (f.balls.tree[i] != tree) continue;
-                const float4 b = f.balls.q[i];
-                const float q[3] = {b.x, b.y, b.z};
-                float lb0 = 0.f, lb1 = 0.f;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const float h0 = d == cf ? m3x[0] : hi[d], l1 = d == cf ? m3n[0] : lo[d];
-                    const float g0 = fmaxf(fmaxf(lo[d] - q[d], q[d] - h0), 0.f), g1 = fmaxf(fmaxf(l1 - q[d], q[d] - hi[d]), 0.f);
-                    lb0 += g0 * g0; lb1 += g1 * g1;
-                }
-                r0 |= lb0 <= b.w; r1 |= lb1 <= b.w;
-            }
-            if (r0) atomicOr(&s_reach[0], 1);
-            if (r1) atomicOr(&s_reach[1], 1);
-            __syncthreads();
-        }
-        const int c1 = s_child;
-        if (c1 >= 0 && tid < 2) {
-            const int c = c1 + tid;
-            const int cl = tid == 0 ? left : left + idx, cr = tid == 0 ? left + idx : left + count;
-            f.node_a[2 * (size_t)(c)] = make_int4(cl, cr, -1, -1);
-            f.node_b[2 * (size_t)(c)] = make_float4(0.f, 0.f, 0.f, 0.f);
-            f.node_tree[c] = tree;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                f.node_box[6 * (size_t)c + d] = (tid == 1 && d == cf) ? cut : lo[d];
-                f.node_box[6 * (size_t)c + 3 + d] = (tid == 0 && d == cf) ? cut : hi[d];
-            }
-            if (cr - cl > LEAF_MAX && !s_reach[tid]) f.node_a[2 * (size_t)(c)] = make_int4(cl, cr, CLOSED, CLOSED);
-            else if (cr - cl > SMALL_MAX) {
-                if (level + 1 >= BIG_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
-                int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
-                if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
-            } else if (cr - cl > LEAF_MAX) {
-                f.node_b[2 * (size_t)(c)] = make_float4(0.f, 0.f, 0.f, __int_as_float(level + 1));      // depth of this small root
-                int q = atomicAdd(&f.ctr[CTR_SQ], 1);
-                if (q < 2 * f.queue_cap) f.squeue[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
-            }
-        }
-        if (c1 >= 0 && tid == 0) {
-            f.node_a[2 * (size_t)(node)] = make_int4(na.x, na.y, c1, c1 + 1);
-            f.node_b[2 * (size_t)(node)] = make_float4(m3x[0], m3n[0], __int_as_float(cf), 0.f);
-        }
-        __syncthreads();
+        if (tid == 0) s_head = head + 1;
+        maxlevel = max(maxlevel, level);
+        kd_split_node<TREE_NT>(f, L, node, level, cut_to_balls, nballs, [&](int c) {
+            const int q = atomicAdd(&s_tail, 1);               // (both children may be pushed, by two threads)
+            if (q - s_head >= TREE_Q) atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+            s_q[q % TREE_Q] = c; s_lv[q % TREE_Q] = (unsigned char)(level + 1);
+        });
+    }
+    if (tid == 0 && maxlevel >= 0) {
+        atomicMax(&f.ctr[CTR_DEPTH], maxlevel + 1);
+        if (maxlevel + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
     }
 }
 
@@ -686,7 +752,17 @@ ForestPtrs ptrs(const KdForest& f) {
 }  // namespace
 
 // init + one launch per level + the small subtrees, for the trees p.need flags (all without flags)
-static int launch_build(const KdForest& f, const ForestPtrs& p, hipStream_t s) {
+static int launch_build(const KdForest& f, const ForestPtrs& p, hipStream_t s, bool per_tree = false) {
+    if (per_tree && p.need && f.max_n <= 64 * (TREE_Q / 4)) {
+        // one workgroup per flagged tree instead of a launch per level: the complete re-build behind the hand-over, whose flags are almost
+        // always all clear (26 launches that find nothing to do cost 0.13 ms of stream time; this one costs a launch).  A flagged tree is built
+        // by its one workgroup node after node — measured 2x slower than the level-wide launches for the first, ball-cut build (its one to
+        // three open nodes per level run side by side there), which therefore keeps them.
+        hipLaunchKernelGGL(kd_tree_kernel, dim3(f.ntrees), dim3(TREE_NT), 0, s, p);
+        hipLaunchKernelGGL(kd_small_subtree_kernel, dim3(std::max(1, std::min(f.queue_cap / 2 + 1, ctx().num_cu * 16))), dim3(BS), 0, s, p);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     hipLaunchKernelGGL(kd_init_kernel, dim3(f.ntrees), dim3(INIT_NT), 0, s, p);
     const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
     // nodes above 64 points: one workgroup each, level by level; deeper than BIG_LEVELS a node that large means a
@@ -738,7 +814,7 @@ int kd_rebuild(KdForest& f, const int* d_need, hipStream_t s) {
     // the queues start empty again; status and depth of the first build stay
     SSDR_HIP(hipMemsetAsync(f.counters.as<int>() + CTR_SQ, 0, 4 * (CTR_TOTAL - CTR_SQ), s));
     ForestPtrs p = ptrs(f); p.need = d_need;
-    return launch_build(f, p, s);
+    return launch_build(f, p, s, true);
 }
 
 int kd_search(const KdForest& f, int tree0, int ntrees, const float* d_queries, size_t q_stride, int nq, int K,
