@@ -270,6 +270,13 @@ int ssdr_propagate_batch_dev(const double* d_adj, const int32_t* d_coff, const i
 /* One hop of sum_i A^i V on a block (fps_gcn_cpu.py:162-167): vout[rows] = adj * vin[rows]; comb[rows] += vout[rows] */
 int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, const double* d_vin, int feat_dim, double* d_vout,
                        double* d_comb, void* stream);
+/* gcn.create_adj (S3/gcn.py:116-191): the adjacency of the trained-GCN branch (what GCN_sampling feeds its graph convolutions, gcn.py:193-263),
+ * torch float32 in the reference: rows of d_feat [N,F] L2-normalised (eps 1e-12) -> d_out_v, cosine matrix times exp(-(ED + CD)) inside a
+ * cloud's block and 0 between clouds, minus I, columns scaled by the inverse column sums, plus I -> d_out_adj [N,N].  The clouds' bbox centres
+ * and directed chamfer means are those of ssdr_cloud_graph_batch_dev (same d_coff / d_boff); d_rows [N] gives, cloud by cloud, the row of
+ * every member in the result (the reference's ref_idx: unlabelled candidates first, then the labelled regions).  N <= 32767. */
+int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_centres, const double* d_cd_dir, const int32_t* d_coff, const int64_t* d_boff,
+                        size_t num_clouds, size_t n_max, const int32_t* d_rows, float* d_out_v, float* d_out_adj, void* stream);
 /* farthest_features_sample (fps_gcn_cpu.py:119-147); `start` is the reference's np.random.randint draw */
 int ssdr_fps_dev(const double* d_feat, size_t n, int feat_dim, int start, size_t count, int32_t* d_out, void* stream);
 /* farthest_superpoint_sample (sampler2.py:49-80, "edcd" branch) over one cloud's superpoints, from the centres and

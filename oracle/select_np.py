@@ -125,6 +125,30 @@ def block_adjacency(centres, cd):
     return adj * dinv[None, :] + np.eye(len(adj))
 
 
+def create_adj(features, centres_blocks, cd_blocks, block_rows):
+    """gcn.create_adj (gcn.py:116-191), the adjacency of the trained-GCN branch, restated in NumPy float32 (the reference runs it as torch
+    float32): rows L2-normalised (torch.nn.functional.normalize, eps 1e-12), cosine matrix, times exp(-(ED + CD)) — both float64 matrices
+    cast to float32 first, 1e10 between clouds so those entries are exactly 0 —, minus I, columns scaled by the inverse column sums, plus I.
+    centres_blocks / cd_blocks: per cloud the bbox centres [n_c,3] (float64) and chamfer matrix [n_c,n_c] (float64, create_cd);
+    block_rows: per cloud the row of every member in the [N, N] result."""
+    f = np.asarray(features, np.float32)
+    nrm = np.sqrt(np.sum(f * f, axis=1, dtype=np.float32)).astype(np.float32)
+    V = (f / np.maximum(nrm, np.float32(1e-12))[:, None]).astype(np.float32)
+    N = len(V)
+    a_ed = np.ones((N, N)) * 1e10; a_cd = np.ones((N, N)) * 1e10
+    for cen, cd, rows in zip(centres_blocks, cd_blocks, block_rows):
+        d = cen[:, None, :] - cen[None, :, :]
+        a_ed[np.ix_(rows, rows)] = np.sqrt(np.sum(np.multiply(d, d), axis=-1))
+        a_cd[np.ix_(rows, rows)] = cd
+    lat = (V @ V.T).astype(np.float32)
+    adj = (lat * np.exp(-(a_ed.astype(np.float32) + a_cd.astype(np.float32)))).astype(np.float32)
+    adj = adj - np.eye(N, dtype=np.float32)
+    diag = adj.sum(0, dtype=np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        adj = (adj * (np.float32(1.0) / diag)[None, :]).astype(np.float32)
+    return V, adj + np.eye(N, dtype=np.float32)
+
+
 def keep_top(adj, gcn_top):
     """The keep-top mask of GCN_FPS_sampling (fps_gcn_cpu.py:153-160) on one cloud's block: every row keeps its gcn_top largest
     entries.  The reference sorts whole rows of the global matrix; entries outside the block are exactly 0 and block entries are

@@ -838,6 +838,87 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
     }
 }
 
+// FPS / k-center over more candidates than one workgroup sweeps per pick (n > 16384): ONE launch of G co-resident workgroups instead of a
+// launch per pick (the reference's AL rounds pick 10 000 of ~2 x 10^4 regions, ssdr_main_S3DIS2.py:134: 10^4 dependent launches).  Every
+// workgroup keeps the running min-distance of its points in registers; per pick it publishes its partial arg-max with write-through (sc1)
+// stores, drains them, adds to a counter; all workgroups poll that counter and read the G partials with sc1 loads (the fence-free hand-off
+// of MI355X_MICROARCH.md, "Valid forms": 9.3 us per pick with __threadfence on both sides, measured), and each reduces them itself.  Partials and counters alternate between two
+// sets by the parity of the pick, so a workgroup that runs ahead never overwrites what a slower one still reads.
+constexpr int FC_NT = 256, FC_PPT = 8;
+struct FpsCoopArgs { const double* f; int n, D, from_partials, start, use_sqrt; const Part* pin; int npart; const double* mind; int count; int* out; Part* part; int* sync; int G; };
+#ifndef HIPEMU
+__global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
+    __shared__ double s_v[FC_NT / 64]; __shared__ int s_i[FC_NT / 64]; __shared__ int s_c; __shared__ double s_fc[128];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G;
+    auto block_argmax = [&](double v, int i, double& ov, int& oi) {
+        wave_argmax(v, i);
+        if (lane == 0) { s_v[wid] = v; s_i[wid] = i; }
+        __syncthreads();
+        ov = s_v[0]; oi = s_i[0];
+#pragma unroll
+        for (int w = 1; w < FC_NT / 64; ++w) if (better(s_v[w], s_i[w], ov, oi)) { ov = s_v[w]; oi = s_i[w]; }
+        __syncthreads();
+    };
+    // this workgroup's points: i = (k * G + g) * FC_NT + tid
+    double rmin[FC_PPT];
+#pragma unroll
+    for (int k = 0; k < FC_PPT; ++k) { const long i = ((long)k * G + g) * FC_NT + tid; rmin[k] = i < a.n ? a.mind[i] : -1.0; }
+    int c;
+    if (!a.from_partials) c = a.start;
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < a.npart; k += FC_NT) if (better(a.pin[k].v, a.pin[k].i, v, i)) { v = a.pin[k].v; i = a.pin[k].i; }
+        double ov; block_argmax(v, i, ov, c);
+    }
+    for (int it = 0; it < a.count; ++it) {
+        if (g == 0 && tid == 0) a.out[it] = c;
+        if (it + 1 == a.count) break;
+        const double* fc = a.f + (size_t)c * a.D;
+        if (a.D <= 128) { if (tid < a.D) s_fc[tid] = fc[tid]; __syncthreads(); }
+        double bv = -1.0; int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < FC_PPT; ++k) {
+            const long i = ((long)k * G + g) * FC_NT + tid;
+            if (i < a.n) {
+                const double* fi = a.f + (size_t)i * a.D;
+                double dist;
+                if (a.D == 32) dist = np_pairwise_fixed<32>([&](int q) { const double d = fi[q] - s_fc[q]; return d * d; });
+                else if (a.D <= 128) dist = np_pairwise<double>([&](int q) { const double d = fi[q] - s_fc[q]; return d * d; }, a.D);
+                else dist = np_pairwise<double>([&](int q) { const double d = fi[q] - fc[q]; return d * d; }, a.D);
+                if (a.use_sqrt) dist = sqrt(dist);
+                if (dist < rmin[k]) rmin[k] = dist;
+                if (better(rmin[k], (int)i, bv, bi)) { bv = rmin[k]; bi = (int)i; }
+            }
+        }
+        double wv; int wi;
+        block_argmax(bv, bi, wv, wi);
+        const int par = it & 1;
+        Part* P = a.part + (size_t)par * G;
+        if (tid == 0) {
+            // write-through (sc1) stores of the partial, drained, then the arrival: no cache write-back / invalidate on either side
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&P[g].v), (unsigned long long)__double_as_longlong(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&P[g].i, wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&a.sync[par], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int want = G * (it / 2 + 1);
+            long spins = 0;
+            while (__hip_atomic_load(&a.sync[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1L << 26)) { atomicOr(&a.sync[2], 1); break; }       // a workgroup never arrived (not co-resident?): flagged, not hung
+            }
+        }
+        __syncthreads();
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < G; k += FC_NT) {
+            const double pv = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&P[k].v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int pi = __hip_atomic_load(&P[k].i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (better(pv, pi, v, i)) { v = pv; i = pi; }
+        }
+        double ov; block_argmax(v, i, ov, c);
+    }
+}
+#endif
+
 // farthest_superpoint_sample (sampler2.py:49-80, the "edcd" branch): FPS over one cloud's superpoints with the
 // distance |centre_i - centre_c|^2 + CD(i, c), CD = dir + dir^T from sel_chamfer_dir.  One workgroup, n <= a few thousand.
 __global__ __launch_bounds__(256) void fps_superpoint(const double* __restrict__ centres, const double* __restrict__ dir, int n, int start, int count, int* out) {
@@ -905,6 +986,51 @@ __global__ __launch_bounds__(256) void kc_init(const double* __restrict__ f, int
     if (tid == 0) {
         for (int w = 1; w < 4; ++w) if (better(s_p[w].v, s_p[w].i, b.v, b.i)) b = s_p[w];
         pout[blockIdx.x] = b;
+    }
+}
+
+// ---- gcn.create_adj (gcn.py:116-191): the adjacency of the trained-GCN branch, torch float32 in the reference ---------------------------
+// rows of V: features / max(|features|_2, 1e-12) (torch.nn.functional.normalize)
+__global__ __launch_bounds__(256) void ca_normalize(const float* __restrict__ f, int n, int F, float* V) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        float ss = 0.f;
+        for (int k = lane; k < F; k += 64) { const float v = f[(size_t)i * F + k]; ss += v * v; }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        for (int k = lane; k < F; k += 64) V[(size_t)i * F + k] = f[(size_t)i * F + k] * inv;
+    }
+}
+// one cloud's block: adj[rows[i]][rows[j]] = <V_i, V_j> * exp(-((float)ED + (float)CD)), minus 1 on the diagonal.  Entries between clouds are
+// <V_i, V_j> * exp(-2e10) = +-0 in the reference: the matrix is cleared beforehand.
+__global__ __launch_bounds__(256) void ca_block(const float* __restrict__ V, int F, const double* __restrict__ centres, const double* __restrict__ dir,
+                                                const int* __restrict__ coff, const long long* __restrict__ boff, const int* __restrict__ rows, int N, float* adj) {
+    const int c = blockIdx.z, r0 = coff[c], nc = coff[c + 1] - r0;
+    const double* D = dir + boff[c];
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)nc * nc; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / nc), j = (int)(e % nc);
+        const int gi = rows[r0 + i], gj = rows[r0 + j];
+        const double dx = centres[3 * (size_t)(r0 + i)] - centres[3 * (size_t)(r0 + j)], dy = centres[3 * (size_t)(r0 + i) + 1] - centres[3 * (size_t)(r0 + j) + 1],
+                     dz = centres[3 * (size_t)(r0 + i) + 2] - centres[3 * (size_t)(r0 + j) + 2];
+        const double ed = sqrt((dx * dx + dy * dy) + dz * dz);
+        const double cd = i == j ? 0.0 : D[(size_t)i * nc + j] + D[(size_t)j * nc + i];
+        float lat = 0.f;
+        for (int k = 0; k < F; ++k) lat += V[(size_t)gi * F + k] * V[(size_t)gj * F + k];
+        adj[(size_t)gi * N + gj] = lat * expf(-((float)ed + (float)cd)) - (gi == gj ? 1.0f : 0.0f);
+    }
+}
+// column sums (torch.sum(adj, dim=0)), then adj[:, j] *= 1 / sum_j, plus I
+__global__ __launch_bounds__(256) void ca_colsum(const float* __restrict__ adj, int N, float* colsum) {
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) {
+        float s = 0.f;
+        for (int i = 0; i < N; ++i) s += adj[(size_t)i * N + j];
+        colsum[j] = s;
+    }
+}
+__global__ __launch_bounds__(256) void ca_scale(float* adj, int N, const float* __restrict__ colsum) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)N * N; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / N), j = (int)(e % N);
+        adj[e] = adj[e] * (1.0f / colsum[j]) + (i == j ? 1.0f : 0.0f);
     }
 }
 
@@ -1153,6 +1279,18 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
     }
+#ifndef HIPEMU
+    if (n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) {          // one launch: co-resident workgroups meeting at a counter per pick
+        const int G = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
+        SSDR_TRY(Q.vtmp.reserve(sizeof(Part) * 2 * (size_t)G + 64));
+        Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(part + 2 * G);
+        SSDR_HIP(hipMemsetAsync(sync, 0, 16, s));
+        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G};
+        hipLaunchKernelGGL(fps_coop, dim3(G), dim3(FC_NT), 0, s, a);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
+#endif
     for (size_t it = 0; it < count; ++it) {
         Part* pin = (it & 1) ? p0 : p1; Part* pout = (it & 1) ? p1 : p0;
         const bool last = it + 1 == count;
@@ -1161,6 +1299,25 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
                            last ? (Part*)nullptr : pout, Q.mind.as<double>(), d_out + it);
         (void)pin;
     }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+/* gcn.create_adj (gcn.py:116-191): the adjacency the trained-GCN branch feeds its graph convolutions and the k-center step, torch float32 in the
+ * reference.  d_feat [N,F] float32 = concatenate(unlabelled candidates, labelled regions) (gcn.py:199); the clouds' bbox centres and directed
+ * chamfer means come from ssdr_cloud_graph_batch_dev (same d_coff / d_boff), d_rows [N] gives, cloud by cloud, the row of every member in the
+ * result.  Outputs: d_out_v [N,F] (the normalised features the function returns) and d_out_adj [N,N] = (cos * exp(-(ED + CD)) - I) D^-1 + I. */
+int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_centres, const double* d_cd_dir, const int32_t* d_coff, const int64_t* d_boff,
+                        size_t num_clouds, size_t n_max, const int32_t* d_rows, float* d_out_v, float* d_out_adj, void* stream) {
+    if (!d_feat || !d_centres || !d_cd_dir || !d_coff || !d_boff || !d_rows || !d_out_v || !d_out_adj || N == 0 || F < 1 || num_clouds == 0 || N > 0x7fff) { set_error("create_adj: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    SSDR_TRY(Q.rowsum.reserve(8 * N));
+    SSDR_HIP(hipMemsetAsync(d_out_adj, 0, 4 * N * N, s));
+    hipLaunchKernelGGL(ca_normalize, dim3(grid_for((long)N * 64)), dim3(256), 0, s, d_feat, (int)N, F, d_out_v);
+    hipLaunchKernelGGL(ca_block, dim3(grid_for((long)n_max * n_max, 256), 1, (unsigned)num_clouds), dim3(256), 0, s, d_out_v, F, d_centres, d_cd_dir, d_coff, (const long long*)d_boff, d_rows, (int)N, d_out_adj);
+    hipLaunchKernelGGL(ca_colsum, dim3(grid_for((long)N)), dim3(256), 0, s, d_out_adj, (int)N, Q.rowsum.as<float>());
+    hipLaunchKernelGGL(ca_scale, dim3(grid_for((long)N * N)), dim3(256), 0, s, d_out_adj, (int)N, Q.rowsum.as<float>());
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

@@ -91,6 +91,7 @@ def lib():
         L.ssdr_cloud_graph_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz, sz, sz, i32, vp, vp, vp, vp]
         L.ssdr_propagate_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp, i32, vp, vp, vp]
         L.ssdr_fps_dev.argtypes = [vp, sz, i32, i32, sz, vp, vp]
+        L.ssdr_create_adj_dev.argtypes = [vp, sz, i32, vp, vp, vp, vp, sz, sz, vp, vp, vp, vp]
         L.ssdr_fps_superpoint_dev.argtypes = [vp, vp, sz, i32, sz, vp, vp]
         L.ssdr_kcenter_dev.argtypes = [vp, sz, i32, vp, sz, sz, vp, vp]
         L.ssdr_tile_select_dev.argtypes = [vp, vp, i32, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp]

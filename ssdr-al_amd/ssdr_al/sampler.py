@@ -144,6 +144,41 @@ def farthest_superpoint_sample(xyz, offsets, points, sel, sample_number, trigger
     return d_out.to_host()
 
 
+def create_adj(featuresV, labeled_select_ref, unlabeled_candidate_ref, clouds):
+    """gcn.create_adj (gcn.py:116-191) with the on-disk inputs replaced by `clouds` {cloud_name: (xyz [n,3] f32, offsets, points)}; refs are
+    lists of {"cloud_name", "sp_idx"} as in the reference, featuresV = concatenate(unlabelled candidates, labelled regions) [N,F] (gcn.py:199).
+    Returns (normalised features [N,F] float32, adjacency [N,N] float32) like the reference (which also returns its run time)."""
+    f = np.ascontiguousarray(featuresV, np.float32)
+    N, F = f.shape
+    total_cloud, order = {}, []                 # gcn.py:122-138
+    for i, r in enumerate(list(unlabeled_candidate_ref) + list(labeled_select_ref)):
+        if r["cloud_name"] not in total_cloud:
+            total_cloud[r["cloud_name"]] = []
+            order.append(r["cloud_name"])
+        total_cloud[r["cloud_name"]].append((r["sp_idx"], i))
+    L = _lib.lib()
+    # every cloud's centres and directed chamfer means by the batched graph call: one concatenated point array, CSR offsets shifted per cloud
+    xyzs, offs, ptss, sel, rows, counts = [], [np.zeros(1, np.int32)], [], [], [], []
+    pbase = sbase = 0
+    for name in order:
+        xyz, off, pts = clouds[name]
+        off = np.ascontiguousarray(off, np.int32)
+        xyzs.append(np.ascontiguousarray(xyz, np.float32)); ptss.append(np.ascontiguousarray(pts, np.int32) + pbase); offs.append(off[1:] + offs[-1][-1])
+        sel += [s + sbase for s, _ in total_cloud[name]]; rows += [i for _, i in total_cloud[name]]; counts.append(len(total_cloud[name]))
+        pbase += len(xyz); sbase += len(off) - 1
+    counts = np.asarray(counts, np.int64)
+    coff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32); boff = np.concatenate([[0], np.cumsum(counts * counts)]).astype(np.int64)
+    d_x = DevArray.from_host(np.concatenate(xyzs)); d_o = DevArray.from_host(np.concatenate(offs).astype(np.int32)); d_p = DevArray.from_host(np.concatenate(ptss))
+    d_s = DevArray.from_host(np.asarray(sel, np.int32)); d_r = DevArray.from_host(np.asarray(rows, np.int32))
+    d_coff = DevArray.from_host(coff); d_boff = DevArray.from_host(boff)
+    d_c = DevArray((N, 3), np.float64); d_dir = DevArray((int(boff[-1]),), np.float64); d_a = DevArray((int(boff[-1]),), np.float64)
+    _lib.check(L.ssdr_cloud_graph_batch_dev(d_x.ptr, d_o.ptr, d_p.ptr, d_s.ptr, d_coff.ptr, d_boff.ptr, len(order), N, int(counts.max()), 0, d_c.ptr, d_dir.ptr, d_a.ptr, None))
+    d_f = DevArray.from_host(f); d_v = DevArray((N, F), np.float32); d_adj = DevArray((N, N), np.float32)
+    _lib.check(L.ssdr_create_adj_dev(d_f.ptr, N, F, d_c.ptr, d_dir.ptr, d_coff.ptr, d_boff.ptr, len(order), int(counts.max()), d_r.ptr, d_v.ptr, d_adj.ptr, None))
+    _lib.sync()
+    return d_v.to_host(), d_adj.to_host()
+
+
 class kCenterGreedy:
     """kcenterGreedy.py:46-128 (the part the AL loop calls: select_batch_ with a non-empty already_selected)."""
 

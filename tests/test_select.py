@@ -215,3 +215,24 @@ def test_selection_fresh_inputs_against_oracle(backend):
     f = rng.normal(0, 1, (m, 32))
     k = 60 if backend == "emu" else 600
     assert np.array_equal(sampler.farthest_features_sample(f, k, 17), O.farthest_features_sample(f, k, 17))
+
+
+def test_create_adj_of_the_gcn_branch(backend, golden):
+    """gcn.create_adj (gcn.py:116-191), torch float32 in the reference: golden from the reference's own function on the 70 + 60 superpoint
+    fixture (tests/golden/make_golden_gcn.py).  Float32 dot products / column sums in another order than torch's: 2e-4 relative to max(|entry|, 1)."""
+    from ssdr_al import sampler
+    g = golden("select_golden.npz"); G = golden("gcn_golden.npz")
+    names = ["cloudC", "cloudD"]
+    clouds = {n: (g["g/%s/xyz" % n], g["g/%s/offsets" % n], g["g/%s/points" % n]) for n in names}
+    unl = [{"cloud_name": names[c], "sp_idx": int(s)} for c, s in zip(g["g/unl_cloud"], g["g/unl_sp"])]
+    lab = [{"cloud_name": names[c], "sp_idx": int(s)} for c, s in zip(g["g/lab_cloud"], g["g/lab_sp"])]
+    V, adj = sampler.create_adj(np.concatenate([g["g/unl_feat"], g["g/lab_feat"]]), lab, unl, clouds)
+    assert V.dtype == np.float32 and adj.dtype == np.float32 and adj.shape == (130, 130)
+    assert np.abs(V - G["featuresV"]).max() < 1e-6
+    # the columns are scaled by 1 / (their float32 sum), and a sum of ~130 entries of both signs can come close to 0: its rounding (which
+    # depends on the order torch adds in) is what remains — relative to the entry, not absolute
+    err = (np.abs(adj - G["adj"]) / np.maximum(np.abs(G["adj"]), 1.0)).max()
+    print("\ncreate_adj on %s: max |adj - reference| / max(|reference|, 1) = %.3g (tolerance 2e-4), |adj| max %.3g" % (backend, err, np.abs(G["adj"]).max()))
+    assert err < 2e-4
+    cross = adj[:55, 55:100]                       # candidates of cloud C against candidates of cloud D: exactly 0
+    assert np.all(cross == 0)

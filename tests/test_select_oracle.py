@@ -108,3 +108,22 @@ def test_fps_and_kcenter_sequences(golden):
     g = _g(golden)
     assert np.array_equal(S.farthest_features_sample(g["fps/feat"], 50, int(g["fps/start"])), g["fps/seq"])
     assert np.array_equal(S.kcenter_greedy(g["kc/feat"], g["kc/already"], 30), g["kc/seq"])
+
+
+def test_oracle_create_adj_matches_reference_golden(golden):
+    """oracle/select_np.py:create_adj against gcn.create_adj's own output (tests/golden/make_golden_gcn.py)."""
+    from oracle import select_np as S
+    g = golden("select_golden.npz"); G = golden("gcn_golden.npz")
+    names = ["cloudC", "cloudD"]
+    refs = [(int(c), int(s)) for c, s in zip(g["g/unl_cloud"], g["g/unl_sp"])] + [(int(c), int(s)) for c, s in zip(g["g/lab_cloud"], g["g/lab_sp"])]
+    cens, cds, rows = [], [], []
+    for ci, n in enumerate(names):
+        xyz, off, pts = g["g/%s/xyz" % n], g["g/%s/offsets" % n], g["g/%s/points" % n]
+        sel = [s for c, s in refs if c == ci]
+        o2 = np.concatenate([[0], np.cumsum([off[s + 1] - off[s] for s in sel])]).astype(np.int64)
+        p2 = np.concatenate([pts[off[s]:off[s + 1]] for s in sel])
+        cen = S.bbox_centres(xyz, o2, p2)
+        cens.append(cen); cds.append(S.create_cd(xyz, o2, p2, cen)); rows.append([i for i, (c, _) in enumerate(refs) if c == ci])
+    V, adj = S.create_adj(np.concatenate([g["g/unl_feat"], g["g/lab_feat"]]), cens, cds, rows)
+    assert np.abs(V - G["featuresV"]).max() < 1e-6
+    assert (np.abs(adj - G["adj"]) / np.maximum(np.abs(G["adj"]), 1.0)).max() < 2e-4      # float32 column sums near 0 (see tests/test_select.py)
