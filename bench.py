@@ -30,7 +30,7 @@ METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_ROUND = "r02"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
+PROFILE_ROUND = "r03"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
 DTYPE = {"f32": "f32 (exact f32-input MFMA)",
          "bf16x3": "bf16x3: split-bf16 MFMA operands (hi*hi + lo*hi + hi*lo), fp32 accumulate, fp32 activations and non-matrix arithmetic",
          "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 activations and non-matrix arithmetic"}
@@ -195,6 +195,7 @@ def main():
     roofline = None
     stage_ms = None
     stage_roofline = None
+    whole_step = None
     if rank == 0 and not args.emu:
         # (b) ... and strictly sequential on rank 0: the kernel with the GPU to itself.  (b) is the roofline figure: it is
         # the kernel's own duration (rocprofv3's per-dispatch duration agrees with it, profiles/rNN_bench_seq_kernel_stats.csv),
@@ -210,17 +211,21 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes of this round (tools/collect_profiles.sh: rocprofv3 --pmc
         # FETCH_SIZE / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes).
         # bench.py cannot collect PMC counters itself: the figure is a constant of that file, labelled with its source and commit.
-        traffic, traffic_source = None, None
+        traffic, traffic_source, mfma_util, step_traffic = None, None, None, None
         try:
             pmcf = os.path.join("profiles", "%s_pmc_summary.json" % PROFILE_ROUND)
             pmc = json.load(open(os.path.join(ROOT, pmcf)))
             traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
+            mfma_util = pmc["kernels"][name].get("mfma_utilisation")
+            step_traffic = pmc.get("step_hbm_bytes")
             traffic_source = "%s (rocprofv3 --pmc passes at commit %s, not measured in this run)" % (pmcf, pmc.get("commit", "?"))
         except Exception:
             pass
         roofline = {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": round(achieved, 3), "peak": peak,
                     "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2), "conditions": "sequential pass, one kernel at a time"}
+                    "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2), "conditions": "sequential pass, one kernel at a time",
+                    "mfma_utilisation": mfma_util, "mfma_utilisation_is": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) of this kernel family in the "
+                                                                          "committed PMC pass (same source as traffic)"}
         if mfma:
             roofline.update({"instruction": mfma_insn,
                              "achieved_is": "ALGORITHMIC FLOPs of the reference's formulation (attention dense d x d on every neighbour row) per second",
@@ -255,6 +260,16 @@ def main():
                     stage_roofline[k] = {"bound": "mfma", "algorithmic_flops": int(w), "achieved_TFLOPs": round(w / t / 1e12, 2), "peak_TFLOPs": mfma_peak,
                                          "frac": round(w / t / 1e12 / mfma_peak, 4), "hbm_bytes": int(63.1e6 * B), "hbm_frac": round(63.1e6 * B / t / 1e9 / PEAK_HBM_GBS, 4)}
             stage_roofline["select"] = {"bound": "latency", "note": "one-workgroup FPS chain (592 dependent picks) + float64 chamfer graph; overlapped with the other stages"}
+            # the whole step against both rooflines: algorithmic bytes and FLOPs of all stages over the measured time per step
+            alg_bytes = sum(w for b, w in stage_work.values() if b == "hbm") + 63.1e6 * B
+            alg_flops = 16.71e9 * B
+            tstep = dt / args.steps
+            whole_step = {"ms_per_step": round(tstep * 1e3, 3), "algorithmic_bytes": int(alg_bytes), "algorithmic_flops": int(alg_flops),
+                          "achieved_GBs": round(alg_bytes / tstep / 1e9, 1), "hbm_frac": round(alg_bytes / tstep / 1e9 / PEAK_HBM_GBS, 4),
+                          "achieved_TFLOPs": round(alg_flops / tstep / 1e12, 2), "mfma_frac": round(alg_flops / tstep / 1e12 / mfma_peak, 4),
+                          "measured_hbm_bytes_per_step": step_traffic,
+                          "traffic_over_algorithmic": round(step_traffic / alg_bytes, 2) if step_traffic else None,
+                          "traffic_source": traffic_source}
             if args.stages:
                 print("stages(ms, sequential):", stage_ms, file=sys.stderr)
 
@@ -305,7 +320,7 @@ def main():
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,
                           "timed_region": "GPU idle at both ends (every stream drained): K launch sequences of every stage and K completed selections, fill and "
                                           "drain of the %d-deep pipe included" % args.pipeline_depth if pipe is not None else "strictly sequential steps"},
-               "stage_ms": stage_ms, "stage_roofline": stage_roofline, "roofline": roofline, "cpu_baseline": cpu}
+               "stage_ms": stage_ms, "stage_roofline": stage_roofline, "whole_step": whole_step, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

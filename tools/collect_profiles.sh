@@ -19,8 +19,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o pf -- python3 bench
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o pw -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/pw.err
 cp $OUT/pf/pf_counter_collection.csv $OUT/${R}_pmc_fetch_size.csv
 cp $OUT/pw/pw_counter_collection.csv $OUT/${R}_pmc_write_size.csv
-# 4. matrix-core utilisation: SQ_VALU_MFMA_BUSY_CYCLES next to SQ_BUSY_CYCLES / SQ_WAVE_CYCLES (own pass, no tracing besides the counters)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/pm -o pm -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/pm.err
+# 4. matrix-core utilisation: SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) next to GRBM_GUI_ACTIVE (the kernel's cycles, summed over the 8 XCDs): own pass, no tracing besides the counters
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pm -o pm -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/pm.err
 cp $OUT/pm/pm_counter_collection.csv $OUT/${R}_pmc_mfma_busy.csv
 # 5. the N > 1 code path (RCCL exchanges on device buffers) on this one GPU, with its kernel stats
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29561 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 SSDR_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline 2> $OUT/rccl.err | grep '^{"metric"' > $OUT/${R}_bench_rccl_world1_line.json

@@ -35,11 +35,12 @@ except Exception:
     commit = "?"
 MFMA = {}
 try:      # optional third pass: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel family (tools/collect_profiles.sh)
-    busy = collections.defaultdict(lambda: [0.0, 0.0])
+    busy = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
     for r in csv.DictReader(open(os.path.join(D, "%s_pmc_mfma_busy.csv" % R))):
         b = busy[family(r["Kernel_Name"])]
         if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES": b[0] += float(r["Counter_Value"])
         elif r["Counter_Name"] == "SQ_BUSY_CYCLES": b[1] += float(r["Counter_Value"])
+        elif r["Counter_Name"] == "GRBM_GUI_ACTIVE": b[2] += float(r["Counter_Value"])
     MFMA = {k: v for k, v in busy.items() if v[0] > 0}
 except FileNotFoundError:
     pass
@@ -52,6 +53,15 @@ for k in sorted(set(f) | set(w), key=lambda k: -(2 * f[k][1] + w[k][1])):
                          "write_size_bytes_per_launch": int(w[k][1] / n), "hbm_bytes_per_launch": int((2 * f[k][1] + w[k][1]) / n)}
     if k in MFMA:      # SQ_VALU_MFMA_BUSY_CYCLES sums over the 4 SIMDs of every CU and over the XCDs' SQ_BUSY_CYCLES samples: report the raw sums and the
         out["kernels"][k]["sq_valu_mfma_busy_cycles"] = int(MFMA[k][0]); out["kernels"][k]["sq_busy_cycles"] = int(MFMA[k][1])      # ratio for relative comparison
-        out["kernels"][k]["mfma_busy_over_sq_busy"] = round(MFMA[k][0] / max(MFMA[k][1], 1.0), 3)
+        # utilisation of the matrix pipes: busy cycles (summed over the chip's 1024 SIMDs) / (1024 x the kernels' cycles); GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), so the kernels' cycles are GRBM_GUI_ACTIVE / 8
+        if MFMA[k][2] > 0:
+            out["kernels"][k]["grbm_gui_active"] = int(MFMA[k][2])
+            out["kernels"][k]["mfma_utilisation"] = round(MFMA[k][0] / (1024.0 * MFMA[k][2] / 8.0), 4)
+# HBM bytes of ONE step: every kernel family's bytes per launch x its launches per step (a step = one selection: the FPS kernel runs once)
+steps = max([v[0] for k, v in f.items() if k.startswith("fps_block") or k.startswith("fps_coop") or k.startswith("fps_step")] + [1])
+out["steps_in_pass"] = steps
+out["step_hbm_bytes"] = int(sum(out["kernels"][k]["hbm_bytes_per_launch"] * max(1, round(out["kernels"][k]["launches"] / steps)) for k in out["kernels"]
+                                if not k.startswith("__amd_rocclr")))
 json.dump(out, open(os.path.join(D, "%s_pmc_summary.json" % R), "w"), indent=1)
 print("wrote", len(out["kernels"]), "kernel families")
