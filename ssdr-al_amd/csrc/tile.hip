@@ -107,105 +107,75 @@ __global__ __launch_bounds__(256) void tile_hist_b(TileTab t, const float* __res
     __syncthreads();
     for (int b = threadIdx.x; b < TS_BINS; b += 256) if (s_h[b]) atomicAdd(&hist[(size_t)r * TS_BINS + b], s_h[b]);
 }
-// one workgroup per room: first bin T whose cumulative count reaches num_points (the last bin when the room is smaller); where every bin <= T
-// starts among the room's candidates (the histogram becomes the bins' write cursors: zero again beyond T); ranges of consecutive bins with
-// at most TS_RCAP candidates each (a bin of its own when it holds more) for the sort
-constexpr int TS_RCAP = 2048, TS_MAXR = TS_BINS;
-__global__ __launch_bounds__(256) void tile_thresh_b(unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand, unsigned* ranges, int* nranges) {
+// one workgroup per room: first bin whose cumulative count reaches num_points (the last bin when the room is smaller); clears the histogram
+__global__ __launch_bounds__(256) void tile_thresh_b(unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand) {
     __shared__ unsigned s_part[256];
-    __shared__ unsigned s_c[TS_BINS];
     const int r = blockIdx.x, tid = threadIdx.x;
     unsigned* h = hist + (size_t)r * TS_BINS;
     constexpr int PER = TS_BINS / 256;
     unsigned c[PER], tot = 0;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { c[k] = h[tid * PER + k]; tot += c[k]; s_c[tid * PER + k] = c[k]; }
+    for (int k = 0; k < PER; ++k) { c[k] = h[tid * PER + k]; tot += c[k]; h[tid * PER + k] = 0u; }
     s_part[tid] = tot;
     __syncthreads();
-    const unsigned want = (unsigned)min(num_points, d_count[r]);
     if (tid == 0) {
+        const unsigned want = (unsigned)min(num_points, d_count[r]);
         unsigned run = 0; int w = 0;
         while (w < 255 && run + s_part[w] < want) { run += s_part[w]; ++w; }
-        int k = w * PER;
-        while (k < w * PER + PER - 1 && run + s_c[k] < want) { run += s_c[k]; ++k; }
-        const int T = k;
-        thr[r] = (unsigned)T;
-        // starts of the bins 0..T, and the ranges
-        unsigned pos = 0; int nr = 0; unsigned rs = 0, rc = 0;
-        unsigned* R = ranges + (size_t)r * 2 * TS_MAXR;
-        for (int b = 0; b <= T; ++b) {
-            const unsigned cb = s_c[b];
-            s_c[b] = pos;
-            if (cb) {
-                if (rc && rc + cb > (unsigned)TS_RCAP) { R[2 * nr] = rs; R[2 * nr + 1] = rc; ++nr; rc = 0; }
-                if (!rc) rs = pos;
-                rc += cb;
-            }
-            pos += cb;
-        }
-        if (rc) { R[2 * nr] = rs; R[2 * nr + 1] = rc; ++nr; }
-        nranges[r] = nr;
-        d_cand[r] = (int)pos;
-        s_part[0] = (unsigned)T;
+        s_part[0] = (unsigned)w; s_part[1] = run;
     }
     __syncthreads();
-    const int T = (int)s_part[0];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { const int b = tid * PER + k; h[b] = b <= T ? s_c[b] : 0u; }
+    if (tid == (int)s_part[0]) {
+        const unsigned want = (unsigned)min(num_points, d_count[r]);
+        unsigned run = s_part[1]; int k = 0;
+        while (k < PER - 1 && run + c[k] < want) { run += c[k]; ++k; }
+        thr[r] = (unsigned)(tid * PER + k);
+        d_cand[r] = 0;
+    }
 }
-// candidates (bin <= T) to their bin's slots: inside a bin in the order the atomics hand out (the sort settles it: the words are unique)
-__global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, unsigned* hist, uint64_t* keys) {
+__global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, uint64_t* keys, int* d_cand) {
+    __shared__ int s_w[2][U][256 / 64];
+    __shared__ int s_base;
     const int r = blockIdx.y, m = d_count[r];
     const float* P = pts + 3 * (size_t)t.off[r];
     const unsigned T = thr[r];
-    unsigned* cur = hist + (size_t)r * TS_BINS;
     uint64_t* K = keys + t.toff[r];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
-        const unsigned bits = __float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r]));
-        const unsigned b = bits >> TS_SHIFT;
-        if (b <= T) K[atomicAdd(&cur[b], 1u)] = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)i;
+    for (int base = blockIdx.x * CHUNK; base < m; base += gridDim.x * CHUNK) {
+        const int hi = min(m, base + CHUNK);
+        // candidates of this chunk: counted first, then written behind one reservation (their order is settled by the sort: keys are unique)
+        int cnt = 0;
+        unsigned bits[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * 256 + threadIdx.x;
+            bits[u] = i < hi ? __float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r])) : 0xffffffffu;
+            cnt += (i < hi && (bits[u] >> TS_SHIFT) <= T) ? 1 : 0;
+        }
+        int zero = 0;
+        block_sum2<256>(cnt, zero, &s_w[0][0][0]);
+        if (threadIdx.x == 0) s_base = cnt ? atomicAdd(&d_cand[r], cnt) : 0;
+        __syncthreads();
+        const int at = s_base;
+        block_compact<256>(base, hi, [&](int i) { const int u = (i - base - (int)threadIdx.x) / 256; return (bits[u] >> TS_SHIFT) <= T; },
+                           [&](int k, int i) { const int u = (i - base - (int)threadIdx.x) / 256; K[at + k] = ((uint64_t)bits[u] << 32) | (uint64_t)(uint32_t)i; }, s_w);
     }
 }
-// clears what tile_compact_b left in the cursors (bins <= T), for the next call's histogram
-__global__ __launch_bounds__(256) void tile_clear_b(unsigned* hist) {
-    for (int b = threadIdx.x; b < TS_BINS; b += 256) hist[(size_t)blockIdx.x * TS_BINS + b] = 0u;
-}
-// one workgroup per range: bitonic sort of its words (distance bits << 32 | index: ascending distance, ties by index) in LDS.  A single bin
-// of more than TS_RCAP candidates (thousands of rows inside 1/16 of a binade of distance) is ranked by counting instead, through `tmp`.
-__global__ __launch_bounds__(256) void tile_binsort_b(TileTab t, const unsigned* __restrict__ ranges, const int* __restrict__ nranges, uint64_t* keys, uint64_t* tmp) {
-    __shared__ uint64_t s_k[TS_RCAP];
-    const int r = blockIdx.y, tid = threadIdx.x;
-    const unsigned* R = ranges + (size_t)r * 2 * TS_MAXR;
-    uint64_t* K = keys + t.toff[r]; uint64_t* Tm = tmp + t.toff[r];
-    for (int q = blockIdx.x; q < nranges[r]; q += gridDim.x) {
-        const unsigned s0 = R[2 * q], n = R[2 * q + 1];
-        if (n <= 1) continue;
-        if (n <= (unsigned)TS_RCAP) {
-            unsigned N = 2; while (N < n) N <<= 1;
-            for (unsigned i = tid; i < N; i += 256) s_k[i] = i < n ? K[s0 + i] : ~0ull;
-            __syncthreads();
-            for (unsigned k = 2; k <= N; k <<= 1)
-                for (unsigned j = k >> 1; j > 0; j >>= 1) {
-                    for (unsigned i = tid; i < N / 2; i += 256) {
-                        const unsigned lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
-                        const bool up = (lo & k) == 0;
-                        const uint64_t a = s_k[lo], b = s_k[hi];
-                        if ((a > b) == up) { s_k[lo] = b; s_k[hi] = a; }
-                    }
-                    __syncthreads();
-                }
-            for (unsigned i = tid; i < n; i += 256) K[s0 + i] = s_k[i];
-            __syncthreads();
-        } else {
-            for (unsigned i = tid; i < n; i += 256) {
-                const uint64_t me = K[s0 + i]; unsigned rank = 0;
-                for (unsigned j = 0; j < n; ++j) rank += K[s0 + j] < me ? 1u : 0u;
-                Tm[s0 + rank] = me;
+
+// The sort orders by distance bits and is stable, but the compacted candidates are not in index order: rows at EQUAL distance (a few pairs
+// per room) are put into index order here — the head of every run of equal distances sorts its run (the full words: index in the low half)
+__global__ __launch_bounds__(256) void tile_fix_ties_b(TileTab t, uint64_t* keys, const int* __restrict__ d_cand) {
+    const int r = blockIdx.y, n = min(d_cand[r], t.off[r + 1] - t.off[r]);
+    uint64_t* K = keys + t.toff[r];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j + 1 < n; j += gridDim.x * 256) {
+        const unsigned d = (unsigned)(K[j] >> 32);
+        if ((j == 0 || (unsigned)(K[j - 1] >> 32) != d) && (unsigned)(K[j + 1] >> 32) == d) {
+            int e = j + 2;
+            while (e < n && (unsigned)(K[e] >> 32) == d) ++e;
+            for (int x = j + 1; x < e; ++x) {
+                const uint64_t kx = K[x]; int y = x - 1;
+                while (y >= j && K[y] > kx) { K[y + 1] = K[y]; --y; }
+                K[y + 1] = kx;
             }
-            __syncthreads();
-            __threadfence();
-            for (unsigned i = tid; i < n; i += 256) K[s0 + i] = Tm[s0 + i];
-            __syncthreads();
         }
     }
 }
@@ -241,7 +211,7 @@ __global__ __launch_bounds__(1024) void possibility_min(const double* __restrict
     if (tid == 0) { *out_min = s_v[0]; *out_arg = s_i[0]; }
 }
 
-struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand, ranges, nranges; bool hist_clear = false; };
+struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand; bool hist_clear = false; };
 TileState& tst(hipStream_t st) { return per_stream<TileState>(st); }
 
 }  // namespace
@@ -301,20 +271,17 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
         toff += ((int)n + RADIX_TILE - 1) / RADIX_TILE * RADIX_TILE;
     }
     t.off[num_clouds] = (int)cloud_offsets[num_clouds]; t.toff[num_clouds] = toff;
-    SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.vals.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
+    SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
     SSDR_TRY(T.hist.reserve(4 * (size_t)TS_BINS * RADIX_MAX_SEG)); SSDR_TRY(T.thr.reserve(4 * RADIX_MAX_SEG)); SSDR_TRY(T.cand.reserve(4 * RADIX_MAX_SEG));
-    SSDR_TRY(T.ranges.reserve(8 * (size_t)TS_MAXR * RADIX_MAX_SEG)); SSDR_TRY(T.nranges.reserve(4 * RADIX_MAX_SEG));
-    if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_clear_b leaves it clear
+    if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_thresh_b leaves it clear
     const unsigned R = (unsigned)num_clouds;
     const int g = std::max(1, std::min((maxn + 255) / 256, 64));
-    // distance histogram -> threshold bin, bin starts, ranges -> candidates into their bins -> every range sorted in LDS (5 launches; the
-    // segmented radix sort of all rows this replaces took 0.3 ms of launch-bound digit passes)
     hipLaunchKernelGGL(tile_hist_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.hist.as<unsigned>(), T.count.as<int>());
-    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>(),
-                       T.ranges.as<unsigned>(), T.nranges.as<int>());
-    hipLaunchKernelGGL(tile_compact_b, dim3(g, R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(), T.hist.as<unsigned>(), T.keys.as<uint64_t>());
-    hipLaunchKernelGGL(tile_clear_b, dim3(R), dim3(256), 0, s, T.hist.as<unsigned>());
-    hipLaunchKernelGGL(tile_binsort_b, dim3(64, R), dim3(256), 0, s, t, T.ranges.as<unsigned>(), T.nranges.as<int>(), T.keys.as<uint64_t>(), reinterpret_cast<uint64_t*>(T.vals.p));
+    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>());
+    const int gc = std::max(1, std::min((maxn + CHUNK - 1) / CHUNK, 64));
+    hipLaunchKernelGGL(tile_compact_b, dim3(gc, R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(), T.keys.as<uint64_t>(), T.cand.as<int>());
+    SSDR_TRY(T.sorter.sort_segments(T.keys.as<uint64_t>(), nullptr, (int)num_clouds, t.toff, n_host.data(), T.cand.as<int>(), s, 32, false, nullptr, 32));      // keys only: distance bits above the index
+    hipLaunchKernelGGL(tile_fix_ties_b, dim3(gc, R), dim3(256), 0, s, t, T.keys.as<uint64_t>(), T.cand.as<int>());
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
     hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, reinterpret_cast<const uint32_t*>(T.keys.as<uint64_t>()), T.count.as<int>(),
                        d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2);
