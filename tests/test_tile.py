@@ -44,3 +44,47 @@ def test_tile_select_and_possibility_update(backend):
     assert np.array_equal(d_idx.to_host(), queried)
     assert np.array_equal(d_poss.to_host(), poss_ref)                             # float64 map, bit-exact
     assert d_min.to_host()[0] == poss_ref.min() and d_arg.to_host()[0] == int(np.argmin(poss_ref))
+
+
+def test_tile_select_batch_ties_and_crowded_distance_bins(backend):
+    """The batch flavour sorts only the rows that can be among the nearest num_points (distance histogram over the top 12 bits of the float
+    pattern, candidates compacted, sorted by distance bits, runs of equal distances put back into index order).  Shapes that leave its
+    common case: rows at EXACTLY equal distances (ties go by index), a shell of thousands of rows inside one histogram bin, a room smaller
+    than the tile."""
+    from ssdr_al import _lib
+    from ssdr_al._lib import DevArray
+    rng = np.random.default_rng(3)
+    N = 1024 if backend == "emu" else 8192
+    clouds, centers = [], []
+    # (a) a lattice around its centre: many equal distances
+    g = np.stack(np.meshgrid(*[np.arange(-12, 13)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.25)
+    clouds.append(g[rng.permutation(len(g))]); centers.append(np.zeros(3, np.float32))
+    # (b) a thin shell: thousands of rows within 1 % of one radius, plus a sparse cloud inside
+    n_shell = 3000 if backend == "emu" else 9000
+    d = rng.normal(size=(n_shell, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    shell = (d * (2.0 + rng.random((n_shell, 1)) * 0.01)).astype(np.float32)
+    inner = (rng.random((200 if backend == "emu" else 2000, 3)) * 2 - 1).astype(np.float32)
+    clouds.append(np.concatenate([inner, shell])[rng.permutation(len(inner) + n_shell)]); centers.append(np.array([0.01, -0.02, 0.005], np.float32))
+    # (c) fewer rows than the tile
+    clouds.append((rng.random((N // 3, 3), dtype=np.float32) * 4).astype(np.float32)); centers.append(np.array([2, 2, 2], np.float32))
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int64)
+    P = np.concatenate(clouds); col = rng.integers(0, 256, (len(P), 3)).astype(np.float32)
+    R = len(clouds)
+    perm = np.stack([rng.permutation(N) for _ in range(R)]).astype(np.int32); dup = rng.random((R, N)).astype(np.float32)
+    d_p, d_c = DevArray.from_host(P), DevArray.from_host(col)
+    d_m = DevArray.from_host(np.array([len(c) for c in clouds] + [0], np.int64))
+    d_perm, d_dup = DevArray.from_host(perm), DevArray.from_host(dup)
+    d_xyz, d_feat, d_idx = DevArray((R, N, 3), np.float32), DevArray((R, N, 6), np.float32), DevArray((R, N), np.int32)
+    cen = np.ascontiguousarray(np.stack(centers), np.float32)
+    _lib.check(_lib.lib().ssdr_tile_select_batch_dev(d_p.ptr, d_c.ptr, 3, d_m.ptr, _lib.ptr(off), R, _lib.ptr(cen), N, d_perm.ptr, d_dup.ptr, 1.0 / 255.0,
+                                                    d_xyz.ptr, d_feat.ptr, d_idx.ptr, None))
+    _lib.sync()
+    got = d_idx.to_host()
+    for r in range(2):                      # full tiles: index for index
+        pts = clouds[r]; dd = pts - cen[r][None]
+        dist = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+        order = np.argsort(dist, kind="stable")[:N]
+        assert np.array_equal(got[r], order[perm[r]]), "cloud %d" % r
+    # the small room: its rows, shuffled, then duplicates of them (data_aug)
+    m = len(clouds[2])
+    assert set(got[2].tolist()) == set(range(m))
