@@ -84,10 +84,12 @@ __global__ __launch_bounds__(256) void tile_gather_b(TileTab t, const float* __r
 }
 
 // ---- batch flavour: only the rows that can be among the num_points nearest are sorted ------------------------------------------
-// A room holds ~4 x num_points rows; sorting all of them by distance was a third of the front end.  Non-negative float distances order like
-// their bit patterns, so a histogram over the top TS_BITS bits of the pattern finds the first bin T whose cumulative count reaches
-// num_points; rows with bin <= T (all num_points nearest and the rest of bin T, ties included) are compacted and sorted as before.
-constexpr int TS_BITS = 12, TS_BINS = 1 << TS_BITS, TS_SHIFT = 31 - TS_BITS;       // bit 31 (sign) is clear: 8 exponent + 4 mantissa bits
+// A room holds ~4 x num_points rows; sorting all of them by distance (a segmented radix sort: a dozen launch-bound digit passes) was a third
+// of the front end.  Non-negative float distances order like their bit patterns, so a histogram over the top TS_BITS bits of the pattern
+// finds the first bin T whose cumulative count reaches num_points; rows with bin <= T (all num_points nearest and the rest of bin T, ties
+// included) are the candidates.  They are written straight to their bin's slots (the histogram's prefix = cursors), and ranges of about a
+// thousand consecutive candidates, cut at bin boundaries, are sorted in LDS.
+constexpr int TS_BITS = 14, TS_BINS = 1 << TS_BITS, TS_SHIFT = 31 - TS_BITS;       // bit 31 (sign) is clear: 8 exponent + 6 mantissa bits
 
 __device__ __forceinline__ float tile_dist(const float* __restrict__ pts, int i, float cx, float cy, float cz) {
     const float dx = pts[3 * (size_t)i] - cx, dy = pts[3 * (size_t)i + 1] - cy, dz = pts[3 * (size_t)i + 2] - cz;
@@ -107,76 +109,106 @@ __global__ __launch_bounds__(256) void tile_hist_b(TileTab t, const float* __res
     __syncthreads();
     for (int b = threadIdx.x; b < TS_BINS; b += 256) if (s_h[b]) atomicAdd(&hist[(size_t)r * TS_BINS + b], s_h[b]);
 }
-// one workgroup per room: first bin whose cumulative count reaches num_points (the last bin when the room is smaller); clears the histogram
-__global__ __launch_bounds__(256) void tile_thresh_b(unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand) {
+// one workgroup per room: first bin T whose cumulative count reaches num_points (the last non-empty bin when the room is smaller); the start
+// of every bin <= T among the room's candidates (the histogram becomes the bins' write cursors; bins beyond T are cleared); the ranges the
+// sort works on: range k = the bins that START in [k TS_RSTEP, (k + 1) TS_RSTEP)
+constexpr int TS_RCAP = 2048, TS_RSTEP = 1024;
+__global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand, unsigned* rstart, int rstride) {
     __shared__ unsigned s_part[256];
+    __shared__ unsigned s_T, s_total;
     const int r = blockIdx.x, tid = threadIdx.x;
     unsigned* h = hist + (size_t)r * TS_BINS;
+    unsigned* RS = rstart + (size_t)r * rstride;
     constexpr int PER = TS_BINS / 256;
-    unsigned c[PER], tot = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { c[k] = h[tid * PER + k]; tot += c[k]; h[tid * PER + k] = 0u; }
+    const unsigned want = (unsigned)min(num_points, d_count[r]);
+    unsigned tot = 0;
+    for (int k = 0; k < PER; ++k) tot += h[tid * PER + k];
     s_part[tid] = tot;
+    for (int k = tid; k < rstride; k += 256) RS[k] = 0xffffffffu;
     __syncthreads();
-    if (tid == 0) {
-        const unsigned want = (unsigned)min(num_points, d_count[r]);
-        unsigned run = 0; int w = 0;
-        while (w < 255 && run + s_part[w] < want) { run += s_part[w]; ++w; }
-        s_part[0] = (unsigned)w; s_part[1] = run;
+    // exclusive prefix of the per-thread totals (256 entries: Hillis-Steele in LDS)
+    unsigned incl = tot;
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned y = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        incl += y; s_part[tid] = incl;
+        __syncthreads();
     }
+    const unsigned before = incl - tot;
+    if (tid == 255) s_total = incl;
+    if (want > 0 && before < want && incl >= want) {          // the bin where the cumulative count reaches `want` lies in this thread's stretch
+        unsigned run = before; int k = 0;
+        while (k < PER - 1 && run + h[tid * PER + k] < want) { run += h[tid * PER + k]; ++k; }
+        s_T = (unsigned)(tid * PER + k);
+    }
+    if (want == 0 && tid == 0) s_T = 0;
     __syncthreads();
-    if (tid == (int)s_part[0]) {
-        const unsigned want = (unsigned)min(num_points, d_count[r]);
-        unsigned run = s_part[1]; int k = 0;
-        while (k < PER - 1 && run + c[k] < want) { run += c[k]; ++k; }
-        thr[r] = (unsigned)(tid * PER + k);
-        d_cand[r] = 0;
+    const unsigned T = s_T;
+    unsigned pos = before, ncand = 0;
+    for (int k = 0; k < PER; ++k) {
+        const int b = tid * PER + k;
+        const unsigned cb = h[b];
+        if ((unsigned)b <= T) {
+            h[b] = pos;
+            if (cb) atomicMin(&RS[pos / TS_RSTEP], pos);
+            pos += cb; ncand = pos;
+        } else h[b] = 0u;
     }
+    if ((unsigned)(tid * PER) <= T && (unsigned)(tid * PER + PER - 1) >= T) { thr[r] = T; d_cand[r] = (int)ncand; }
 }
-__global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, uint64_t* keys, int* d_cand) {
-    __shared__ int s_w[2][U][256 / 64];
-    __shared__ int s_base;
+// candidates (bin <= T) to their bin's slots: inside a bin in the order the atomics hand out (the sort settles it: the words are unique)
+__global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, unsigned* hist, uint64_t* keys) {
     const int r = blockIdx.y, m = d_count[r];
     const float* P = pts + 3 * (size_t)t.off[r];
     const unsigned T = thr[r];
+    unsigned* cur = hist + (size_t)r * TS_BINS;
     uint64_t* K = keys + t.toff[r];
-    for (int base = blockIdx.x * CHUNK; base < m; base += gridDim.x * CHUNK) {
-        const int hi = min(m, base + CHUNK);
-        // candidates of this chunk: counted first, then written behind one reservation (their order is settled by the sort: keys are unique)
-        int cnt = 0;
-        unsigned bits[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * 256 + threadIdx.x;
-            bits[u] = i < hi ? __float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r])) : 0xffffffffu;
-            cnt += (i < hi && (bits[u] >> TS_SHIFT) <= T) ? 1 : 0;
-        }
-        int zero = 0;
-        block_sum2<256>(cnt, zero, &s_w[0][0][0]);
-        if (threadIdx.x == 0) s_base = cnt ? atomicAdd(&d_cand[r], cnt) : 0;
-        __syncthreads();
-        const int at = s_base;
-        block_compact<256>(base, hi, [&](int i) { const int u = (i - base - (int)threadIdx.x) / 256; return (bits[u] >> TS_SHIFT) <= T; },
-                           [&](int k, int i) { const int u = (i - base - (int)threadIdx.x) / 256; K[at + k] = ((uint64_t)bits[u] << 32) | (uint64_t)(uint32_t)i; }, s_w);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        const unsigned bits = __float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r]));
+        const unsigned b = bits >> TS_SHIFT;
+        if (b <= T) K[atomicAdd(&cur[b], 1u)] = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)i;
     }
 }
-
-// The sort orders by distance bits and is stable, but the compacted candidates are not in index order: rows at EQUAL distance (a few pairs
-// per room) are put into index order here — the head of every run of equal distances sorts its run (the full words: index in the low half)
-__global__ __launch_bounds__(256) void tile_fix_ties_b(TileTab t, uint64_t* keys, const int* __restrict__ d_cand) {
-    const int r = blockIdx.y, n = min(d_cand[r], t.off[r + 1] - t.off[r]);
+// clears what tile_compact_b left in the cursors (bins <= T), for the next call's histogram
+__global__ __launch_bounds__(256) void tile_clear_b(unsigned* hist) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < TS_BINS; b += gridDim.x * 256) hist[(size_t)blockIdx.y * TS_BINS + b] = 0u;
+}
+// one workgroup per range: bitonic sort of its words (distance bits << 32 | index: ascending distance, ties by index).  A range of at most
+// TS_RCAP words is sorted in LDS; a larger one (a single bin of more than TS_RSTEP candidates: rows crowded into 1/64 of a binade of
+// distance) in place in global memory.
+__global__ __launch_bounds__(256) void tile_binsort_b(TileTab t, const unsigned* __restrict__ rstart, int rstride, const int* __restrict__ d_cand, uint64_t* keys) {
+    __shared__ uint64_t s_k[TS_RCAP];
+    const int r = blockIdx.y, tid = threadIdx.x;
+    const unsigned* RS = rstart + (size_t)r * rstride;
     uint64_t* K = keys + t.toff[r];
-    for (int j = blockIdx.x * 256 + threadIdx.x; j + 1 < n; j += gridDim.x * 256) {
-        const unsigned d = (unsigned)(K[j] >> 32);
-        if ((j == 0 || (unsigned)(K[j - 1] >> 32) != d) && (unsigned)(K[j + 1] >> 32) == d) {
-            int e = j + 2;
-            while (e < n && (unsigned)(K[e] >> 32) == d) ++e;
-            for (int x = j + 1; x < e; ++x) {
-                const uint64_t kx = K[x]; int y = x - 1;
-                while (y >= j && K[y] > kx) { K[y + 1] = K[y]; --y; }
-                K[y + 1] = kx;
+    const unsigned cand = (unsigned)d_cand[r];
+    const int nk = (int)((cand + TS_RSTEP - 1) / TS_RSTEP);
+    for (int q = blockIdx.x; q < nk; q += gridDim.x) {
+        const unsigned s0 = RS[q];
+        if (s0 == 0xffffffffu) continue;                         // no bin starts here (it lies inside the previous range's last bin)
+        unsigned e0 = cand;
+        for (int q2 = q + 1; q2 < nk; ++q2) if (RS[q2] != 0xffffffffu) { e0 = RS[q2]; break; }
+        const unsigned n = e0 - s0;
+        if (n <= 1) continue;
+        unsigned N = 2; while (N < n) N <<= 1;
+        // bitonic network with ascending comparators only (the first step of every merge pairs i with its mirror image in the block): positions
+        // >= n then simply count as +infinity and are never touched, so n need not be a power of two and nothing is padded
+        const bool lds = n <= (unsigned)TS_RCAP;
+        uint64_t* A = lds ? s_k : K + s0;
+        if (lds) { for (unsigned i = tid; i < n; i += 256) s_k[i] = K[s0 + i]; __syncthreads(); }
+        for (unsigned k = 2; k <= N; k <<= 1) {
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                for (unsigned i = tid; i < N / 2; i += 256) {
+                    unsigned lo, hi;
+                    if (j == (k >> 1)) { const unsigned blk = i / j, off = i % j; lo = blk * k + off; hi = blk * k + (k - 1 - off); }
+                    else { lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)); hi = lo | j; }
+                    if (hi < n) { const uint64_t a = A[lo], b = A[hi]; if (a > b) { A[lo] = b; A[hi] = a; } }
+                }
+                if (!lds) __threadfence_block();
+                __syncthreads();
             }
         }
+        if (lds) { for (unsigned i = tid; i < n; i += 256) K[s0 + i] = s_k[i]; __syncthreads(); }
     }
 }
 
@@ -211,7 +243,7 @@ __global__ __launch_bounds__(1024) void possibility_min(const double* __restrict
     if (tid == 0) { *out_min = s_v[0]; *out_arg = s_i[0]; }
 }
 
-struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand; bool hist_clear = false; };
+struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand, rstart; bool hist_clear = false; };
 TileState& tst(hipStream_t st) { return per_stream<TileState>(st); }
 
 }  // namespace
@@ -272,16 +304,17 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
     }
     t.off[num_clouds] = (int)cloud_offsets[num_clouds]; t.toff[num_clouds] = toff;
     SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
+    const int rstride = (maxn + TS_RSTEP - 1) / TS_RSTEP + 1;
     SSDR_TRY(T.hist.reserve(4 * (size_t)TS_BINS * RADIX_MAX_SEG)); SSDR_TRY(T.thr.reserve(4 * RADIX_MAX_SEG)); SSDR_TRY(T.cand.reserve(4 * RADIX_MAX_SEG));
-    if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_thresh_b leaves it clear
+    SSDR_TRY(T.rstart.reserve(4 * (size_t)rstride * num_clouds));
+    if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_clear_b leaves it clear
     const unsigned R = (unsigned)num_clouds;
     const int g = std::max(1, std::min((maxn + 255) / 256, 64));
     hipLaunchKernelGGL(tile_hist_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.hist.as<unsigned>(), T.count.as<int>());
-    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>());
-    const int gc = std::max(1, std::min((maxn + CHUNK - 1) / CHUNK, 64));
-    hipLaunchKernelGGL(tile_compact_b, dim3(gc, R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(), T.keys.as<uint64_t>(), T.cand.as<int>());
-    SSDR_TRY(T.sorter.sort_segments(T.keys.as<uint64_t>(), nullptr, (int)num_clouds, t.toff, n_host.data(), T.cand.as<int>(), s, 32, false, nullptr, 32));      // keys only: distance bits above the index
-    hipLaunchKernelGGL(tile_fix_ties_b, dim3(gc, R), dim3(256), 0, s, t, T.keys.as<uint64_t>(), T.cand.as<int>());
+    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, t, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>(), T.rstart.as<unsigned>(), rstride);
+    hipLaunchKernelGGL(tile_compact_b, dim3(g, R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(), T.hist.as<unsigned>(), T.keys.as<uint64_t>());
+    hipLaunchKernelGGL(tile_clear_b, dim3(8, R), dim3(256), 0, s, T.hist.as<unsigned>());
+    hipLaunchKernelGGL(tile_binsort_b, dim3(std::min(rstride, 64), R), dim3(256), 0, s, t, T.rstart.as<unsigned>(), rstride, T.cand.as<int>(), T.keys.as<uint64_t>());
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
     hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, reinterpret_cast<const uint32_t*>(T.keys.as<uint64_t>()), T.count.as<int>(),
                        d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2);

@@ -195,6 +195,7 @@ template <class T> static inline T atomicAnd(T* p, T v) { return hipemu_rmw(p, [
 template <class T> static inline T atomicExch(T* p, T v) { return hipemu_rmw(p, [v](T) { return v; }); }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = c; __atomic_compare_exchange(p, &o, &v, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED); return o; }
 static inline void __threadfence() {}
+static inline void __threadfence_block() {}
 
 // f32-in MFMA 16x16x4 (v_mfma_f32_16x16x4_f32): lane l holds A[l&15][l>>4], B[l>>4][l&15]; C/D col = l&15,
 // rows (l>>4)*4 + r.  Result is a k-ordered fmaf chain (cdna_hip_programming.md section 3).
