@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void sel_rank_keys(const double* __restrict__ 
 // ---- U3: compute_features (sampler2.py:333,339): float32 row-sequential mean over the dominant-class members ----
 __global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict__ feat, int D, const int* __restrict__ cls, const int* __restrict__ dom,
                                                         const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                        const int* __restrict__ sel, int nsel, float* out) {
+                                                        const int* __restrict__ sel, int nsel, float* out, const int* __restrict__ dn = nullptr,
+                                                        double* y0 = nullptr, double* y1 = nullptr) {
+    if (dn) nsel = min(nsel, *dn);               // the row count is the device's (candidate rule on the device)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < nsel * D; e += gridDim.x * 256) {
         const int q = e / D, c = e % D, s = sel ? sel[q] : q;
         const int lo = sp_off[s], hi = sp_off[s + 1], d = dom[s];
@@ -229,14 +231,17 @@ __global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict_
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (j0 + u < hi && k[u] == d) { sum = sum + v[u]; ++cnt; }
         }
-        out[(size_t)q * D + c] = cnt ? sum / (float)cnt : 0.f;
+        const float mean = cnt ? sum / (float)cnt : 0.f;
+        if (out) out[(size_t)q * D + c] = mean;
+        if (y0) { y0[(size_t)q * D + c] = (double)mean; y1[(size_t)q * D + c] = (double)mean; }      // float32 -> float64 as np.concatenate / np.matmul promote it
     }
 }
 
 // ---- F1/F2: bbox centres, chamfer, adjacency, propagation for the superpoints `sel` of ONE cloud ----------------
 __global__ __launch_bounds__(256) void sel_centres(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                   const int* __restrict__ sel, int nsel, double* centres) {
+                                                   const int* __restrict__ sel, int nsel, double* centres, const int* __restrict__ dn = nullptr) {
     const int lane = threadIdx.x & 63;
+    if (dn) nsel = min(nsel, *dn);
     for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nsel; q += gridDim.x * 4) {      // one wave per superpoint
         const int s = sel[q], lo = sp_off[s], hi = sp_off[s + 1];
         float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -669,8 +674,9 @@ __device__ __forceinline__ void wave_argmax(double& v, int& i) {
 // One step: (1) every block reduces the previous step's partial maxima to learn the current centre,
 // (2) updates the running min-distance of its points, (3) publishes its own partial maximum.
 __global__ __launch_bounds__(256) void fps_step(const double* __restrict__ f, int n, int D, int from_partials, int start, int use_sqrt,
-                                                const Part* __restrict__ pin, int npart, Part* pout, double* mind, int* out) {
+                                                const Part* __restrict__ pin, int npart, Part* pout, double* mind, int* out, const int* __restrict__ dn = nullptr) {
     __shared__ Part s_p[256];
+    if (dn) n = min(n, *dn);
     __shared__ int s_c;
     const int tid = threadIdx.x;
     if (!from_partials) { if (tid == 0) s_c = start; }
@@ -709,7 +715,8 @@ __global__ __launch_bounds__(256) void fps_step(const double* __restrict__ f, in
 // shuffle + LDS reduction.
 template <int DF>
 __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, int n, int D, int from_partials, int start, int use_sqrt,
-                                                  const Part* __restrict__ pin, int npart, double* mind, int count, int* out) {
+                                                  const Part* __restrict__ pin, int npart, double* mind, int count, int* out, const int* __restrict__ dn = nullptr) {
+    if (dn) n = min(n, *dn);
     __shared__ double s_v[16];
     __shared__ int s_i[16];
     __shared__ int s_c;
@@ -783,7 +790,9 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
 // the owning thread, so the loop touches global memory only to store the selected index.
 template <int DF, int PPT>
 __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ f, int n, int from_partials, int start, int use_sqrt,
-                                                     const Part* __restrict__ pin, int npart, const double* __restrict__ mind, int count, int* out) {
+                                                     const Part* __restrict__ pin, int npart, const double* __restrict__ mind, int count, int* out,
+                                                     const int* __restrict__ dn = nullptr) {
+    if (dn) n = min(n, *dn);
     __shared__ double s_v[2][8];
     __shared__ int s_i[2][8];
     __shared__ double s_fc[2][DF];
@@ -1034,7 +1043,118 @@ __global__ __launch_bounds__(256) void ca_scale(float* adj, int N, const float* 
     }
 }
 
-struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int; };
+// ---- the candidate rule on the device (sampler2.py:533-552 create_file_top_and_all, :745-753 GCN_FPS_sampling's caller) -----------------------
+// order[] ranks the regions by descending uncertainty.  cand = the unlabelled ones in that order; the first min(batch, S) of them are "top";
+// a cloud offers its first 2 x (its number of top regions) candidates.  The superpoints of cloud c are sp_base[c] .. sp_base[c+1]-1.
+// Results: the candidates cloud by cloud (descending uncertainty inside a cloud) followed by the labelled regions (refs), the same rows grouped
+// cloud by cloud (candidates then labelled of the cloud: the block structure of the graph), and the counts downstream kernels read instead of
+// host-side sizes.  counts[]: 0 n_unl, 1 n_lab, 2 ntot, 3 nmax, 4 sampling_batch, 5 status (1: more rows, 2: more block elements than the
+// caller's capacity), 6-7 the block elements as int64.
+constexpr int CR_NT = 1024;
+__global__ __launch_bounds__(CR_NT) void cand_rank(const int* __restrict__ order, int S, const unsigned char* __restrict__ labelled, int* rankpos, int* cploc, int* chunkcnt) {
+    __shared__ int s_w[CR_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = blockIdx.x * CR_NT + tid;
+    int sp = -1, v = 0;
+    if (r < S) { sp = order[r]; v = labelled[sp] ? 0 : 1; }
+    const unsigned long long m = __ballot(v);
+    if (lane == 0) s_w[wid] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < CR_NT / 64; ++w) { const int c = s_w[w]; if (w < wid) base += c; tot += c; }
+    if (sp >= 0) { rankpos[sp] = r; cploc[sp] = base + __popcll(m & ((1ull << lane) - 1ull)); }
+    if (tid == 0) chunkcnt[blockIdx.x] = tot;
+}
+// exclusive prefix of n ints in place by one workgroup of 256: every thread owns a contiguous piece
+__device__ void block_exscan_inplace(int* a, int n, int* s_part /* [257] */) {
+    const int tid = threadIdx.x, per = (n + 255) / 256, lo = min(n, tid * per), hi = min(n, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += a[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int v = s_part[t]; s_part[t] = run; run += v; } s_part[256] = run; }
+    __syncthreads();
+    int run = s_part[tid];
+    for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void cand_chunkscan(int* chunkcnt, int nchunks) {
+    __shared__ int s_part[257];
+    block_exscan_inplace(chunkcnt, nchunks, s_part);
+}
+constexpr int CC_TILE = 2048;
+__global__ __launch_bounds__(256) void cand_cloud(const int* __restrict__ rankpos, const int* __restrict__ cploc, const int* __restrict__ chunkoff,
+                                                  const unsigned char* __restrict__ labelled, const int* __restrict__ sp_base, int S, int batch_size,
+                                                  int* stage, int* ncand, int* ntop) {
+    __shared__ int s_tile[CC_TILE];
+    __shared__ int s_red[8];
+    const int tid = threadIdx.x, c = blockIdx.x, lo = sp_base[c], n = sp_base[c + 1] - lo;
+    const int lim = min(batch_size, S);
+    int nv = 0, nt = 0;
+    for (int j = tid; j < n; j += 256)
+        if (!labelled[lo + j]) { ++nv; const int r = rankpos[lo + j]; nt += (chunkoff[r / CR_NT] + cploc[lo + j]) < lim; }
+    block_sum2<256>(nv, nt, s_red);
+    const int take = min(2 * nt, nv);
+    if (tid == 0) { ncand[c] = take; ntop[c] = nt; }
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        const bool live = j < n && !labelled[lo + j];
+        const int rj = live ? rankpos[lo + j] : 0x7fffffff;
+        int pos = 0;
+        for (int t0 = 0; t0 < n; t0 += CC_TILE) {
+            const int m = min(CC_TILE, n - t0);
+            __syncthreads();
+            for (int k = tid; k < m; k += 256) s_tile[k] = labelled[lo + t0 + k] ? 0x7fffffff : rankpos[lo + t0 + k];
+            __syncthreads();
+            if (live) for (int k = 0; k < m; ++k) pos += s_tile[k] < rj;
+        }
+        if (live && pos < take) stage[lo + pos] = lo + j;
+    }
+}
+__global__ __launch_bounds__(256) void cand_layout(const int* __restrict__ ncand, const int* __restrict__ ntop, const int* __restrict__ lab_off, int B,
+                                                   long long cap_rows, long long cap_sq, int* uoff, int* coff, long long* boff, int* counts) {
+    __shared__ long long s_p[3][257];
+    __shared__ int s_mx[256];
+    const int tid = threadIdx.x, per = (B + 255) / 256, lo = min(B, tid * per), hi = min(B, lo + per);
+    long long su = 0, sc = 0, sb = 0; int mx = 0, st = 0;
+    for (int c = lo; c < hi; ++c) { const long long a = ncand[c] + (lab_off[c + 1] - lab_off[c]); su += ncand[c]; sc += a; sb += a * a; mx = max(mx, (int)a); st += ntop[c]; }
+    s_p[0][tid] = su; s_p[1][tid] = sc; s_p[2][tid] = sb; s_mx[tid] = mx;
+    __syncthreads();
+    // sampling_batch: the tops of all clouds
+    __shared__ int s_st[256];
+    s_st[tid] = st;
+    __syncthreads();
+    if (tid == 0) {
+        long long r0 = 0, r1 = 0, r2 = 0; int m = 0, t = 0;
+        for (int k = 0; k < 256; ++k) { const long long a = s_p[0][k], b = s_p[1][k], q = s_p[2][k]; s_p[0][k] = r0; s_p[1][k] = r1; s_p[2][k] = r2; r0 += a; r1 += b; r2 += q; m = max(m, s_mx[k]); t += s_st[k]; }
+        int status = 0;
+        if (r1 > cap_rows) status |= 1;
+        if (r2 > cap_sq) status |= 2;
+        counts[0] = status ? 0 : (int)r0; counts[1] = lab_off[B]; counts[2] = status ? 0 : (int)r1; counts[3] = m; counts[4] = t; counts[5] = status;
+        counts[6] = (int)(r2 & 0xffffffffll); counts[7] = (int)(r2 >> 32);
+        s_p[0][256] = status;
+    }
+    __syncthreads();
+    const bool bad = s_p[0][256] != 0;           // over capacity: every block is empty, nothing downstream runs; the caller reads the status
+    long long u = s_p[0][tid], k = s_p[1][tid], q = s_p[2][tid];
+    for (int c = lo; c < hi; ++c) {
+        const long long a = ncand[c] + (lab_off[c + 1] - lab_off[c]);
+        uoff[c] = (int)u; coff[c] = bad ? 0 : (int)k; boff[c] = bad ? 0 : q;
+        u += ncand[c]; k += a; q += a * a;
+    }
+    if (hi == B && lo < B) { uoff[B] = (int)u; coff[B] = bad ? 0 : (int)k; boff[B] = bad ? 0 : q; }
+    if (B == 0 && tid == 0) { uoff[0] = 0; coff[0] = 0; boff[0] = 0; }
+}
+__global__ __launch_bounds__(256) void cand_fill(const int* __restrict__ stage, const int* __restrict__ sp_base, const int* __restrict__ ncand, const int* __restrict__ uoff,
+                                                 const int* __restrict__ coff, const int* __restrict__ lab_off, const int* __restrict__ lab_sp, const int* __restrict__ counts,
+                                                 int* sel, int* gsel, int* rows) {
+    if (counts[5]) return;
+    const int c = blockIdx.x, nc = ncand[c], u0 = uoff[c], g0 = coff[c], l0 = lab_off[c], nl = lab_off[c + 1] - l0, n_unl = counts[0], lo = sp_base[c];
+    for (int k = threadIdx.x; k < nc; k += 256) { const int sp = stage[lo + k]; sel[u0 + k] = sp; gsel[g0 + k] = sp; rows[g0 + k] = u0 + k; }
+    for (int k = threadIdx.x; k < nl; k += 256) { const int sp = lab_sp[l0 + k]; sel[n_unl + l0 + k] = sp; gsel[g0 + nc + k] = sp; rows[g0 + nc + k] = n_unl + l0 + k; }
+}
+
+struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f; };
 
 // scratch of the chamfer packer for nrows superpoints in nclouds clouds
 int chamfer_pack_buffers(SelState& Q, size_t nrows, size_t nclouds, ChamferPack& P) {
@@ -1254,7 +1374,9 @@ int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, con
     return SSDR_OK;
 }
 
-static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_already, size_t na, int start, size_t count, int use_sqrt, int32_t* d_out, hipStream_t s) {
+// d_n (optional): the row count on the device; n is then the bound the launch shapes are chosen by
+static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_already, size_t na, int start, size_t count, int use_sqrt, int32_t* d_out, hipStream_t s,
+                    const int* d_n = nullptr) {
     SelState& Q = sst(s);
     int nb = grid_for((long)n, ctx().num_cu * 2);
     // seeded single-workgroup paths: kc_init takes a wave per row and its partial maxima are read once — as many workgroups as give every
@@ -1267,20 +1389,20 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     const bool seeded = d_already && na;
     if (D == 32 && n <= 1536) {   // register-resident single workgroup
         const int fp = seeded ? 1 : 0;
-        if (n <= 512) hipLaunchKernelGGL((fps_block_reg<32, 1>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
-        else if (n <= 1024) hipLaunchKernelGGL((fps_block_reg<32, 2>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
-        else hipLaunchKernelGGL((fps_block_reg<32, 3>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        if (n <= 512) hipLaunchKernelGGL((fps_block_reg<32, 1>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
+        else if (n <= 1024) hipLaunchKernelGGL((fps_block_reg<32, 2>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
+        else hipLaunchKernelGGL((fps_block_reg<32, 3>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
     }
     if (n <= 16384) {     // one CU sweeps the candidates faster than a launch per iteration costs
-        if (D == 32) hipLaunchKernelGGL((fps_block<32>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
-        else hipLaunchKernelGGL((fps_block<0>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out);
+        if (D == 32) hipLaunchKernelGGL((fps_block<32>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
+        else hipLaunchKernelGGL((fps_block<0>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
     }
 #ifndef HIPEMU
-    if (n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) {          // one launch: co-resident workgroups meeting at a counter per pick
+    if (!d_n && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) {          // one launch: co-resident workgroups meeting at a counter per pick
         const int G = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
         SSDR_TRY(Q.vtmp.reserve(sizeof(Part) * 2 * (size_t)G + 64));
         Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(part + 2 * G);
@@ -1296,7 +1418,7 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         const bool last = it + 1 == count;
         // k-center starts from the arg-max of the seeded distances; FPS from `start`
         hipLaunchKernelGGL(fps_step, dim3(last ? 1 : nb), dim3(256), 0, s, d_feat, (int)n, D, (seeded || it > 0) ? 1 : 0, start, use_sqrt, pin, nb,
-                           last ? (Part*)nullptr : pout, Q.mind.as<double>(), d_out + it);
+                           last ? (Part*)nullptr : pout, Q.mind.as<double>(), d_out + it, d_n);
         (void)pin;
     }
     SSDR_HIP(hipGetLastError());
@@ -1320,6 +1442,62 @@ int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_ce
     hipLaunchKernelGGL(ca_scale, dim3(grid_for((long)N * N)), dim3(256), 0, s, d_out_adj, (int)N, Q.rowsum.as<float>());
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
+}
+
+/* GCN_FPS_sampling (sampler2.py:313-342, :736-781) behind the candidate rule of its caller (sampler2.py:533-552, :745-753), with no host decision in
+ * between: ranking in, selected candidates out.  The candidate rule runs as four small kernels (cand_*); the row counts it finds stay on the device and
+ * every kernel behind it (features, bbox centres, chamfer packer, chamfer, adjacency, keep-top mask, propagation hops, FPS) reads them there, its launch
+ * shape chosen by the caller's capacities.  d_result: [0..7] counts (n_unl, n_lab, ntot, nmax, sampling_batch, status, block elements as int64),
+ * [8 .. 8+max_select) the selected candidates (indices into the candidate list), [8+max_select .. +cap_rows) the candidate list followed by the labelled
+ * regions (superpoint ids; the first n_unl are the candidates, cloud by cloud, descending uncertainty inside a cloud). */
+int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
+                              const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
+                              const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t batch_size, int gcn_number, int gcn_top, int start,
+                              size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream) {
+    if (!d_feat || !d_cls || !d_dom || !d_xyz || !d_sp_off || !d_sp_pts || !d_order || !d_labelled || !d_sp_base || !d_lab_off || !d_result || feat_dim != 32 ||
+        num_clouds == 0 || num_clouds > 65535 || S == 0 || S > 0x7ffffff0 || cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || cap_unl == 0 || cap_unl > 16384 || gcn_number < 0 || start < 0) {
+        set_error("gcn_fps_sampling: bad arguments (feat_dim == 32, at most 16384 candidates, at most 65535 clouds)"); return SSDR_ERR_INVALID;
+    }
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    const int B = (int)num_clouds, nchunks = (int)((S + CR_NT - 1) / CR_NT), D = feat_dim;
+    // ints: rankpos S, cploc S, stage S, chunk nchunks, ncand B, ntop B, uoff B+1, coff B+1, gsel cap, rows cap | int64: boff B+1
+    const size_t ni = 3 * S + (size_t)nchunks + 4 * (size_t)B + 2 + 2 * cap_rows + 16;
+    SSDR_TRY(Q.cand_i.reserve(4 * ni + 8 * ((size_t)B + 2)));
+    int* rankpos = Q.cand_i.as<int>(); int* cploc = rankpos + S; int* stage = cploc + S; int* chunk = stage + S; int* ncand = chunk + nchunks; int* ntop = ncand + B;
+    int* uoff = ntop + B; int* coff = uoff + B + 1; int* gsel = coff + B + 1; int* rows = gsel + cap_rows;
+    long long* boff = reinterpret_cast<long long*>(Q.cand_i.as<char>() + ((4 * ni + 7) & ~(size_t)7));
+    // doubles: V, comb, tmp0, tmp1 [cap_rows, D]; centres [cap_rows, 3]; dir, adj [cap_sq]
+    SSDR_TRY(Q.cand_f.reserve(8 * (4 * cap_rows * D + 3 * cap_rows + 2 * cap_sq)));
+    double* V = Q.cand_f.as<double>(); double* comb = V + cap_rows * D; double* tmp0 = comb + cap_rows * D; double* tmp1 = tmp0 + cap_rows * D;
+    double* cen = tmp1 + cap_rows * D; double* dir = cen + 3 * cap_rows; double* adj = dir + cap_sq;
+    int* counts = d_result; int* out = d_result + 8; int* sel = out + max_select;
+    hipLaunchKernelGGL(cand_rank, dim3(nchunks), dim3(CR_NT), 0, s, d_order, (int)S, d_labelled, rankpos, cploc, chunk);
+    hipLaunchKernelGGL(cand_chunkscan, dim3(1), dim3(256), 0, s, chunk, nchunks);
+    hipLaunchKernelGGL(cand_cloud, dim3(B), dim3(256), 0, s, rankpos, cploc, chunk, d_labelled, d_sp_base, (int)S, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
+    hipLaunchKernelGGL(cand_layout, dim3(1), dim3(256), 0, s, ncand, ntop, d_lab_off, B, (long long)cap_rows, (long long)cap_sq, uoff, coff, boff, counts);
+    hipLaunchKernelGGL(cand_fill, dim3(B), dim3(256), 0, s, stage, d_sp_base, ncand, uoff, coff, d_lab_off, d_lab_sp, counts, sel, gsel, rows);
+    const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
+    // compute_features (sampler2.py:333,339) of the refs, widened; bbox centres of the grouped rows
+    hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, counts + 2, V, comb);
+    SSDR_TRY(Q.rowsum.reserve(8 * cap_rows));
+    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, counts + 2);
+    ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
+    SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
+    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
+                       coff, boff, cen, dir, P);
+    hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
+    hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), coff, boff, adj);
+    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(std::max(1, std::min((nm + 3) / 4, 1024)), 1, nc), dim3(256), 0, s, adj, coff, boff, gcn_top);
+    const double* src = V;
+    for (int hop = 0; hop < gcn_number; ++hop) {
+        double* dst = (hop & 1) ? tmp1 : tmp0;
+        hipLaunchKernelGGL(sel_propagate_batch, dim3(grid_for((long)nm * D, 256), 1, nc), dim3(256), 0, s, adj, coff, boff, rows, src, D, dst, comb);
+        src = dst;
+    }
+    SSDR_HIP(hipGetLastError());
+    if (max_select == 0) return SSDR_OK;
+    return fps_like(comb, cap_unl, D, nullptr, 0, start, max_select, 0, out, s, counts);
 }
 
 int ssdr_fps_superpoint_dev(const double* d_centres, const double* d_cd_dir, size_t n, int start, size_t count, int32_t* d_out, void* stream) {

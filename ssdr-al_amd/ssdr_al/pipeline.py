@@ -119,7 +119,35 @@ class HotPath:
         for b in self.labeled:
             self.labeled_mask[list(self.labeled[b])] = True
         self.sp_size_h = np.diff(self.sp_off_h)
+        self._select_static()
         return self
+
+    def _select_static(self):
+        """Static tables and capacities of the device-side candidate rule (ssdr_gcn_fps_sampling_dev): which regions are labelled, where a
+        cloud's superpoints start, its labelled regions, and upper bounds of what the rule can produce (the counts themselves are the
+        ranking's and stay on the device)."""
+        B, S = self.B, self.S
+        base = np.concatenate([np.asarray(self.sp_base, np.int64), [S]])
+        lab = [sorted(self.labeled.get(b, ())) for b in range(B)]
+        lab_off = np.concatenate([[0], np.cumsum([len(l) for l in lab])]).astype(np.int32)
+        lab_sp = np.array([s for l in lab for s in l] + [0], np.int32)
+        nvalid = np.array([int((~self.labeled_mask[base[b]:base[b + 1]]).sum()) for b in range(B)], np.int64)
+        nlab = np.diff(lab_off).astype(np.int64)
+        batch = self.select_per_tile * B
+        picks = int(min(batch, nvalid.sum()))
+        cap_unl = int(min(2 * picks, nvalid.sum()))
+        share = np.minimum(2 * picks, nvalid)                    # a cloud offers at most 2 x (its top regions) <= 2 x picks, and what it has
+        cap_rows = cap_unl + int(nlab.sum())
+        # the largest sum of squared cloud shares: fill the roomiest clouds first
+        left, sq = cap_unl, 0
+        for i in np.argsort(-(share + nlab), kind="stable"):
+            a = int(min(share[i], left)); left -= a
+            sq += (a + int(nlab[i])) ** 2
+        self._sel_static = dict(
+            d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)), d_base=DevArray.from_host(base.astype(np.int32)),
+            d_lab_off=DevArray.from_host(lab_off), d_lab_sp=DevArray.from_host(lab_sp), batch=batch, picks=picks, cap_unl=max(cap_unl, 1),
+            cap_rows=max(cap_rows, 1), cap_nmax=max(int((share + nlab).max()) if B else 1, 1), cap_sq=max(int(sq), 1),
+            d_result=DevArray((8 + picks + max(cap_rows, 1),), np.int32))
 
     # ---- stages ------------------------------------------------------------------------------------------------
     def _front_end(self):
@@ -232,6 +260,16 @@ class HotPath:
         """everything of the selection up to the enqueued FPS chain (the host decisions and uploads happen here)"""
         L = _lib.lib()
         st = self.sel_stream          # None: the library stream; a stream of its own lets the selections of consecutive batches overlap
+        T = self._sel_static
+        if (self.global_order is None and self.selector != "kcenter" and T["cap_unl"] <= 16384 and T["picks"] > 0
+                and not os.environ.get("SSDR_SELECT_HOST_RULE")):
+            # candidate rule + GCN_FPS_sampling enqueued as one chain: the host decides nothing and uploads nothing (the result is read in _select_collect)
+            _lib.check(L.ssdr_gcn_fps_sampling_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
+                                                   self.sorted_inds.ptr, self.S, T["d_lab"].ptr, T["d_base"].ptr, self.B, T["d_lab_off"].ptr, T["d_lab_sp"].ptr,
+                                                   T["batch"], int(self.gcn_number), int(self.gcn_top), 0, T["cap_rows"], T["cap_nmax"], T["cap_sq"],
+                                                   T["cap_unl"], T["picks"], T["d_result"].ptr, st))
+            self._pending = ("device", None)
+            return
         if self.global_order is None:          # (the D2H below runs on the selection stream, which already waits for the scoring stream's work)
             cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(st), ~self.labeled_mask, self.sp_cloud_h, self.select_per_tile * self.B)
             unl = [(int(b), int(s)) for b, s in zip(ccloud, cand)]
@@ -331,7 +369,19 @@ class HotPath:
         """wait for the FPS chain of _select_issue and read the selection back"""
         d_out, unl = self._pending
         self._pending = None
-        sel = d_out.to_host(self.sel_stream)                 # waits for the selection stream alone
+        if isinstance(d_out, str):                           # the device-side rule: counts, picks and the candidate list in one read-back
+            T = self._sel_static
+            res = T["d_result"].to_host(self.sel_stream)     # waits for the selection stream alone
+            if res[5]:
+                raise RuntimeError("gcn_fps_sampling: the candidate rule produced more rows than the capacities allow (status %d)" % int(res[5]))
+            n_unl, picks = int(res[0]), int(res[4])
+            sel = res[8:8 + picks].copy()
+            cand = res[8 + T["picks"]: 8 + T["picks"] + n_unl].astype(np.int64)
+            ccloud = self.sp_cloud_h[cand]
+            unl = [(int(b), int(s)) for b, s in zip(ccloud, cand)]
+            self.unl_cloud_ids = np.asarray(self.room_ids, np.int64)[ccloud]; self.unl_sp = cand - np.asarray(self.sp_base, np.int64)[ccloud]
+        else:
+            sel = d_out.to_host(self.sel_stream)             # waits for the selection stream alone
         # the device-flavour KNN calls cannot report what their kernels found (overflowed kd queue / node table / level limit, hand-over
         # list): ask once per batch, here where the host waits anyway — without waiting for the pyramids of the LATER batches that the
         # KNN stream already holds (the finished calls' tickets are looked at; Pipelined.finish / the sequential step wait for all)

@@ -133,3 +133,43 @@ def test_semantic3d_configuration_matches_oracle(backend):
     assert gp.shape[1] == 8 and np.abs(gp - ref["probs"]).max() < 1e-3 and np.abs(gf - ref["f32"]).max() < 1e-3     # north_star tolerance (fp32)
     ref2 = pipeline_np.run(hp, rooms, W, threads=2, net_outputs=(gp, gf))                # selection: exact given the same network outputs
     assert np.array_equal(hp.sorted_inds.to_host(), ref2["sorted_inds"]) and unl == ref2["unl"] and np.array_equal(sel, ref2["selected"])
+
+
+@pytest.mark.parametrize("case", ["plain", "cloud_all_labelled", "batch_exceeds_regions"])
+def test_candidate_rule_on_device_equals_host_rule(backend, case, monkeypatch):
+    """sampler2.py:533-552, :745-753 as device kernels (ssdr_gcn_fps_sampling_dev: counts stay on the device) against the vectorised host rule +
+    the separate entry points: same candidates, same picks — also when a cloud has no region left to offer and when the batch asks for
+    more regions than are unlabelled."""
+    if backend == "emu":
+        hp, rooms, W = _setup(2048, 3, 150.0, 6, 3)
+    else:
+        hp, rooms, W = _setup(40960, 3, 2500.0, 37, 15)
+    if case == "cloud_all_labelled":
+        hp.labeled[1] = set(np.flatnonzero(hp.sp_cloud_h == 1).tolist())
+    if case == "batch_exceeds_regions":
+        hp.select_per_tile = hp.S
+    hp.labeled_mask[:] = False
+    for b in hp.labeled:
+        hp.labeled_mask[list(hp.labeled[b])] = True
+    hp._select_static()
+    monkeypatch.setenv("SSDR_SELECT_HOST_RULE", "1")
+    sel_h, unl_h = hp.step()
+    picked_h = list(hp.selected)
+    monkeypatch.delenv("SSDR_SELECT_HOST_RULE")
+    sel_d, unl_d = hp.step()
+    assert hp._sel_static["d_result"].to_host()[5] == 0
+    assert unl_d == unl_h
+    assert np.array_equal(sel_d, sel_h)
+    assert hp.selected == picked_h
+    if case == "cloud_all_labelled":
+        assert all(b != 1 for b, _ in unl_d)
+    if case == "batch_exceeds_regions":
+        assert len(sel_d) == int((~hp.labeled_mask).sum()) == len(unl_d)
+
+
+def test_candidate_rule_reports_capacity_overflow(backend):
+    """capacities below what the rule produces: nothing is selected and the status says so (no write past the caller's buffers)"""
+    hp, rooms, W = _setup(2048, 2, 150.0, 6, 3) if backend == "emu" else _setup(40960, 2, 2500.0, 37, 15)
+    hp._sel_static["cap_sq"] = 4
+    with pytest.raises(RuntimeError, match="capacities"):
+        hp.step()

@@ -10,8 +10,8 @@ import csv, statistics
 rows=list(csv.DictReader(open("$OUT/kt/kt_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 def short(n): return n.replace("(anonymous namespace)::","").replace("void ","").replace("ssdr::","").split("(")[0]
-# steps are delimited by the first kernel of the front end (gs_minmax_partial_b)
-starts=[i for i,r in enumerate(rows) if "gs_minmax_partial_b" in r["Kernel_Name"]]
+# steps are delimited by the first kernel of the front end (fe_minmax_partial)
+starts=[i for i,r in enumerate(rows) if "fe_minmax_partial" in r["Kernel_Name"]]
 steps=[rows[a:b] for a,b in zip(starts[:-1], starts[1:])]
 steps=[s for s in steps if len(s)==len(steps[-1])]
 print("steps with identical launch counts:", len(steps), "launches per step:", len(steps[-1]))
