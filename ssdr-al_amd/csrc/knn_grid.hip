@@ -204,72 +204,11 @@ __device__ __forceinline__ bool grid_settled(const GridDesc& d, float qx, float 
     return gs > 0.f && rs.worst() <= gs * gs;
 }
 
-template <int K>
-__device__ __forceinline__ void grid_scan_range(const float4* __restrict__ S, int s, int e, float qx, float qy, float qz, RegSet<K + 1>& rs) {
-    for (int i = s; i < e; ++i) {
-        const float4 p = S[i];
-        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
-        if (dist < rs.worst()) rs.add(dist, __float_as_int(p.w));
-    }
-}
-
-// One query against the block of (2R+1)^3 cells around its cell.  Returns true when the K + 1 best found are final.
-template <int K>
-__device__ __forceinline__ bool grid_scan(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
-                                          int cx, int cy, int cz, int R, RegSet<K + 1>& rs) {
-    rs.init();
-    const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1), y0 = max(cy - R, 0), y1 = min(cy + R, d.ny - 1), z0 = max(cz - R, 0), z1 = min(cz + R, d.nz - 1);
-    for (int z = z0; z <= z1; ++z)
-        for (int y = y0; y <= y1; ++y) {
-            const int row = (z * d.ny + y) * d.nx;      // x is the fastest cell dimension: the cells x0..x1 of a row are one contiguous range
-            grid_scan_range<K>(S, cell[row + x0], cell[row + x1 + 1], qx, qy, qz, rs);
-        }
-    return grid_settled<K>(d, qx, qy, qz, x0, x1, y0, y1, z0, z1, rs);
-}
-
 // distance from q to the slab of cell index i along one axis, shortened by the margin (cell boundaries are rounded fp32 products and
 // a point's cell comes from a rounded quotient: the margin is far above both)
 __device__ __forceinline__ float slab_gap(float q, float lo, float c, int i, int ci, float mg) {
     const float gap = i == ci ? 0.f : (i > ci ? (lo + (float)i * c) - q : q - (lo + (float)(i + 1) * c));
     return fmaxf(gap - mg, 0.f);
-}
-
-// Widens a scanned block of radius R - 1 (its K + 1 best are in rs) to radius R: only the cells of the new shell that the ball of
-// the current (K+1)-th distance around the query reaches are read — anything outside that ball cannot enter the set, so the result
-// is that of the full block scan.
-template <int K>
-__device__ __forceinline__ bool grid_scan_shell(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
-                                                int cx, int cy, int cz, int R, RegSet<K + 1>& rs) {
-    const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1), y0 = max(cy - R, 0), y1 = min(cy + R, d.ny - 1), z0 = max(cz - R, 0), z1 = min(cz + R, d.nz - 1);
-    const float mg = d.c * 1.0e-3f + 1.0e-6f * fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
-    const float r = sqrtf(rs.worst()) * 1.00001f + mg;      // fewer than K + 1 found so far: worst is FLT_MAX and the ball is everything
-    const float r2 = r * r;
-    const int zs = max(z0, cell_of(qz - r, d.lo[2], d.inv_c, d.nz)), ze = min(z1, cell_of(qz + r, d.lo[2], d.inv_c, d.nz));
-    const int ix0 = cx - (R - 1), ix1 = cx + (R - 1);
-    for (int z = zs; z <= ze; ++z) {
-        const float gz = slab_gap(qz, d.lo[2], d.c, z, cz, mg);
-        const float remz = r2 - gz * gz;
-        if (!(remz > 0.f)) continue;
-        const float hy = sqrtf(remz);
-        const int ys = max(y0, cell_of(qy - hy, d.lo[1], d.inv_c, d.ny)), ye = min(y1, cell_of(qy + hy, d.lo[1], d.inv_c, d.ny));
-        for (int y = ys; y <= ye; ++y) {
-            const float gy = slab_gap(qy, d.lo[1], d.c, y, cy, mg);
-            const float rem = remz - gy * gy;
-            if (!(rem > 0.f)) continue;
-            const float h = sqrtf(rem);
-            const int xs = max(x0, cell_of(qx - h, d.lo[0], d.inv_c, d.nx)), xe = min(x1, cell_of(qx + h, d.lo[0], d.inv_c, d.nx));
-            if (xs > xe) continue;
-            const int row = (z * d.ny + y) * d.nx;
-            const bool inner = abs(z - cz) < R && abs(y - cy) < R;      // this row of cells crosses the block already scanned
-            if (!inner) grid_scan_range<K>(S, cell[row + xs], cell[row + xe + 1], qx, qy, qz, rs);
-            else {
-                if (xs < ix0) grid_scan_range<K>(S, cell[row + xs], cell[row + min(xe + 1, ix0)], qx, qy, qz, rs);
-                if (xe > ix1) grid_scan_range<K>(S, cell[row + max(xs, ix1 + 1)], cell[row + xe + 1], qx, qy, qz, rs);
-            }
-        }
-    }
-    return grid_settled<K>(d, qx, qy, qz, x0, x1, y0, y1, z0, z1, rs);
 }
 
 // rows whose answer depends on the tree (ties, a near-tie at the K-th boundary, too few support points, no settled block) go to the
@@ -426,24 +365,113 @@ __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
 }
 
 // second pass over the rows the first one left (compacted: a lane that needs a larger block no longer holds its wave): 3^3
-// (3^3 for the rows the masks could not hold and for K = 1 rows on their own grid), 5^3, 7^3 with the streaming insertion
+// (for the rows the masks could not hold and for K = 1 rows on their own grid), then the 5^3 and 7^3 shells cut to the ball of the current
+// (K+1)-th distance.  The rows are few (2-4 % of the queries: a few hundred waves at a lane per row) and each waits on a chain of dependent
+// loads (cell table, then the records of one row of cells after the other), so a row is spread over RL lanes: lane l of a row's group takes
+// the rows of cells l, l + RL, ... of the block or shell, four records in flight, and appends the candidates closer than the row's current
+// (K+1)-th distance to the group's list in LDS; the group's first lane alone runs the sorted insertion over that list (drained when it
+// may overflow and at the end of a block / shell).  Which of several equal candidates enters depends on the order of the appends, but a
+// row with equal distances among its K + 1 best is handed to the tree anyway (grid_finish) and a tie behind them does not change the
+// answer, so the results are those of the lane-per-row scan.
+constexpr int RL = 8, RCB = 64;          // lanes per row; candidates a group's list holds (a scan step appends at most 4 per lane)
 template <int K, typename OutT>
 __global__ __launch_bounds__(64) void grid_retry_kernel(GridSearchArgs a) {
+    constexpr int RPW = 64 / RL;
+    __shared__ float c_d[RPW][RCB];
+    __shared__ int c_i[RPW][RCB];
+    __shared__ int c_n[RPW];
+    __shared__ float s_gw[RPW];
+    __shared__ int s_set[RPW];
+    const int lane = threadIdx.x, sub = lane % RL, grp = lane / RL;
     const int n = min(*a.retry_count, a.work_cap);
-    for (int e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
+    for (int e0 = blockIdx.x * RPW; e0 < n; e0 += gridDim.x * RPW) {          // uniform over the wave
+        const bool live = e0 + grp < n;
+        const int e = min(e0 + grp, n - 1);
         const int tag = a.retry[2 * (size_t)e], q = a.retry[2 * (size_t)e + 1];
         const int jid = tag & ~RETRY_FROM_R1;
         const GridJob job = a.jobs[jid];
         const GridDesc d = a.desc[job.sup];
+        const int* __restrict__ cell = a.cell + d.cell_off;
+        const float4* __restrict__ S = a.sorted + d.pt_off;
         const float qx = job.qpts[3 * (size_t)q], qy = job.qpts[3 * (size_t)q + 1], qz = job.qpts[3 * (size_t)q + 2];
         const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
-        RegSet<K + 1> rs;
-        bool settled = false;
-        // the 3^3 block again with the streaming insertion (its K + 1 best bound the ball the wider shells are cut to), then the
-        // shells of 5^3 and 7^3.  (Marking the 5^3 block in masks as well was measured slower: 25 masks + 25 range starts per lane.)
-        settled = grid_scan<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, 1, rs);
-        for (int R = 2; R <= GS_RMAX && !settled; ++R) settled = grid_scan_shell<K>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, cx, cy, cz, R, rs);
-        grid_finish<K, OutT>(a, job, jid, q, settled, rs);
+        RegSet<K + 1> G;                        // the row's set: kept by the first lane of the group
+        G.init();
+        float gw = FLT_MAX; bool settled = false;
+        const float mg = d.c * 1.0e-3f + 1.0e-6f * fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+        if (sub == 0) c_n[grp] = 0;
+        auto drain = [&]() {                    // wave-uniform: the first lanes insert their group's list, everyone learns the new (K+1)-th distance
+            wave_sync();
+            if (sub == 0) {
+                const int m = c_n[grp];
+                for (int j = 0; j < m; ++j) { const float dist = c_d[grp][j]; if (dist < G.worst()) G.add(dist, c_i[grp][j]); }
+                c_n[grp] = 0; s_gw[grp] = G.worst();
+            }
+            wave_sync();
+            gw = s_gw[grp];
+        };
+        for (int R = 1; R <= GS_RMAX; ++R) {
+            const int x0 = max(cx - R, 0), x1 = min(cx + R, d.nx - 1), y0 = max(cy - R, 0), y1 = min(cy + R, d.ny - 1), z0 = max(cz - R, 0), z1 = min(cz + R, d.nz - 1);
+            // only the cells of the block (R = 1) or of the new shell that the ball of the current (K+1)-th distance reaches (fewer than K + 1 found so
+            // far: everything)
+            const int W = 2 * R + 1;
+            const float r = sqrtf(gw) * 1.00001f + mg;
+            const float r2 = r * r;
+            const int zs = max(z0, cell_of(qz - r, d.lo[2], d.inv_c, d.nz)), ze = min(z1, cell_of(qz + r, d.lo[2], d.inv_c, d.nz));
+            const int ix0 = cx - (R - 1), ix1 = cx + (R - 1);
+            for (int t0 = 0; t0 < W * W; t0 += RL) {                           // uniform: the lanes' rows of cells advance together
+                const int t = t0 + sub;
+                int cs[2] = {1, 1}, ce[2] = {0, 0}, row = 0;
+                if (!settled && t < W * W) {
+                    const int z = cz - R + t / W, y = cy - R + t % W;
+                    const float gz = slab_gap(qz, d.lo[2], d.c, z, cz, mg);
+                    const float remz = r2 - gz * gz;
+                    if (z >= zs && z <= ze && remz > 0.f) {
+                        const float hy = sqrtf(remz);
+                        const int ys = max(y0, cell_of(qy - hy, d.lo[1], d.inv_c, d.ny)), ye = min(y1, cell_of(qy + hy, d.lo[1], d.inv_c, d.ny));
+                        const float gy = slab_gap(qy, d.lo[1], d.c, y, cy, mg);
+                        const float rem = remz - gy * gy;
+                        if (y >= ys && y <= ye && rem > 0.f) {
+                            const float h = sqrtf(rem);
+                            const int xs = max(x0, cell_of(qx - h, d.lo[0], d.inv_c, d.nx)), xe = min(x1, cell_of(qx + h, d.lo[0], d.inv_c, d.nx));
+                            row = (z * d.ny + y) * d.nx;
+                            const bool inner = R > 1 && abs(z - cz) < R && abs(y - cy) < R;      // this row of cells crosses the block already scanned
+                            // up to two pieces of the row: left and right of the scanned block (or the whole reach)
+                            cs[0] = xs; ce[0] = inner ? min(xe + 1, ix0) : xe + 1;
+                            if (inner) { cs[1] = max(xs, ix1 + 1); ce[1] = xe + 1; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int i = 0, e1 = 0;
+                    if (cs[u] < ce[u]) { i = cell[row + cs[u]]; e1 = cell[row + ce[u]]; }
+                    while (__ballot(i < e1)) {
+                        wave_sync();
+                        if (__ballot(c_n[grp] > RCB - 4 * RL)) drain();
+                        if (i < e1) {
+                            float4 p[4];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) p[v] = S[min(i + v, e1 - 1)];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float dx = qx - p[v].x, dy = qy - p[v].y, dz = qz - p[v].z;
+                                float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
+                                if (i + v < e1 && dist < gw) { const int pos = atomicAdd(&c_n[grp], 1); c_d[grp][pos] = dist; c_i[grp][pos] = __float_as_int(p[v].w); }
+                            }
+                            i += 4;
+                        }
+                    }
+                }
+            }
+            drain();
+            if (sub == 0 && !settled) s_set[grp] = grid_settled<K>(d, qx, qy, qz, x0, x1, y0, y1, z0, z1, G) ? 1 : 0;
+            wave_sync();
+            if (!settled) settled = s_set[grp] != 0;
+            wave_sync();                        // s_set is rewritten by the next shell
+            if (__ballot(!settled) == 0ull) break;
+        }
+        if (sub == 0 && live) grid_finish<K, OutT>(a, job, jid, q, settled, G);
     }
 }
 
