@@ -112,19 +112,23 @@ __global__ __launch_bounds__(256) void tile_hist_b(TileTab t, const float* __res
 // one workgroup per room: first bin T whose cumulative count reaches num_points (the last non-empty bin when the room is smaller); the start
 // of every bin <= T among the room's candidates (the histogram becomes the bins' write cursors; bins beyond T are cleared); the ranges the
 // sort works on: range k = the bins that START in [k TS_RSTEP, (k + 1) TS_RSTEP)
-constexpr int TS_RCAP = 2048, TS_RSTEP = 1024;
+constexpr int TS_RCAP = 4096, TS_RSTEP = 1024;
 __global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand, unsigned* rstart, int rstride) {
+    __shared__ unsigned s_h[TS_BINS + TS_BINS / 32];          // the room's histogram (coalesced in, coalesced out); one pad word per 32 bins: a thread's stretch starts in its own bank pair
     __shared__ unsigned s_part[256];
-    __shared__ unsigned s_T, s_total;
+    __shared__ unsigned s_T;
     const int r = blockIdx.x, tid = threadIdx.x;
     unsigned* h = hist + (size_t)r * TS_BINS;
     unsigned* RS = rstart + (size_t)r * rstride;
     constexpr int PER = TS_BINS / 256;
+    auto at = [](int b) { return b + (b >> 5); };
     const unsigned want = (unsigned)min(num_points, d_count[r]);
-    unsigned tot = 0;
-    for (int k = 0; k < PER; ++k) tot += h[tid * PER + k];
-    s_part[tid] = tot;
+    for (int b = tid; b < TS_BINS; b += 256) s_h[at(b)] = h[b];
     for (int k = tid; k < rstride; k += 256) RS[k] = 0xffffffffu;
+    __syncthreads();
+    unsigned tot = 0;
+    for (int k = 0; k < PER; ++k) tot += s_h[at(tid * PER + k)];
+    s_part[tid] = tot;
     __syncthreads();
     // exclusive prefix of the per-thread totals (256 entries: Hillis-Steele in LDS)
     unsigned incl = tot;
@@ -135,10 +139,9 @@ __global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, 
         __syncthreads();
     }
     const unsigned before = incl - tot;
-    if (tid == 255) s_total = incl;
     if (want > 0 && before < want && incl >= want) {          // the bin where the cumulative count reaches `want` lies in this thread's stretch
         unsigned run = before; int k = 0;
-        while (k < PER - 1 && run + h[tid * PER + k] < want) { run += h[tid * PER + k]; ++k; }
+        while (k < PER - 1 && run + s_h[at(tid * PER + k)] < want) { run += s_h[at(tid * PER + k)]; ++k; }
         s_T = (unsigned)(tid * PER + k);
     }
     if (want == 0 && tid == 0) s_T = 0;
@@ -147,14 +150,16 @@ __global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, 
     unsigned pos = before, ncand = 0;
     for (int k = 0; k < PER; ++k) {
         const int b = tid * PER + k;
-        const unsigned cb = h[b];
+        const unsigned cb = s_h[at(b)];
         if ((unsigned)b <= T) {
-            h[b] = pos;
+            s_h[at(b)] = pos;
             if (cb) atomicMin(&RS[pos / TS_RSTEP], pos);
             pos += cb; ncand = pos;
-        } else h[b] = 0u;
+        } else s_h[at(b)] = 0u;
     }
     if ((unsigned)(tid * PER) <= T && (unsigned)(tid * PER + PER - 1) >= T) { thr[r] = T; d_cand[r] = (int)ncand; }
+    __syncthreads();
+    for (int b = tid; b < TS_BINS; b += 256) h[b] = s_h[at(b)];
 }
 // candidates (bin <= T) to their bin's slots: inside a bin in the order the atomics hand out (the sort settles it: the words are unique)
 __global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, unsigned* hist, uint64_t* keys) {
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
         const unsigned bits = __float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r]));
         const unsigned b = bits >> TS_SHIFT;
-        if (b <= T) K[atomicAdd(&cur[b], 1u)] = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)i;
+        if (b <= T) K[atomicAdd(&cur[b], 1u)] = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)i;      // (one atomic per bin and wave for rows that share a bin: measured slower, the rows of a wave rarely do)
     }
 }
 // clears what tile_compact_b left in the cursors (bins <= T), for the next call's histogram
