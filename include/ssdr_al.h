@@ -282,15 +282,16 @@ int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_ce
  * candidates come out, and no host decision sits in between — the row counts the rule finds stay on the device and every kernel behind it reads them
  * there.  d_order [S] = the regions by descending uncertainty (ssdr_rank_regions_dev); d_labelled [S] != 0: the region is labelled and never competes;
  * the superpoints of cloud c are d_sp_base[c] .. d_sp_base[c+1]-1; d_lab_off [num_clouds+1] / d_lab_sp: the labelled regions cloud by cloud
- * (ascending superpoint id).  batch_size = sampling_batch.  Capacities the caller sizes the run by (upper bounds, computable from the static tables):
+ * (ascending superpoint id), n_lab of them in all.  batch_size = sampling_batch.  selector 0: farthest_features_sample from candidate `start`
+ * (fps_gcn_cpu.py:119-147); 1: kCenterGreedy over candidates + labelled rows seeded with the labelled ones (kcenterGreedy.py:84-128).  Capacities the caller sizes the run by (upper bounds, computable from the static tables):
  * cap_rows >= candidates + labelled regions, cap_nmax >= the largest cloud's share of them, cap_sq >= the sum over clouds of its share squared,
- * cap_unl >= candidates (<= 16384), max_select = min(batch_size, unlabelled regions) = the number of picks.
+ * cap_unl >= candidates (cap_rows <= 16384), max_select = min(batch_size, unlabelled regions) = the number of picks.
  * d_result (int32): [0..7] n_unl, n_lab, rows, largest block, picks, status (bit 0: rows > cap_rows, bit 1: blocks > cap_sq: nothing was selected),
  * block elements (int64 in two words); [8 .. 8+max_select) the picks (indices into the candidate list); then [cap_rows] the candidate list
  * (superpoint ids, cloud by cloud, descending uncertainty inside a cloud) followed by the labelled regions.  feat_dim = 32. */
 int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
                               const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
-                              const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t batch_size, int gcn_number, int gcn_top, int start,
+                              const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t batch_size, int gcn_number, int gcn_top, int selector, int start,
                               size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream);
 /* farthest_features_sample (fps_gcn_cpu.py:119-147); `start` is the reference's np.random.randint draw */
 int ssdr_fps_dev(const double* d_feat, size_t n, int feat_dim, int start, size_t count, int32_t* d_out, void* stream);

@@ -857,7 +857,7 @@ constexpr int FC_NT = 256, FC_PPT = 8;
 struct FpsCoopArgs { const double* f; int n, D, from_partials, start, use_sqrt; const Part* pin; int npart; const double* mind; int count; int* out; Part* part; int* sync; int G; };
 #ifndef HIPEMU
 __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
-    __shared__ double s_v[FC_NT / 64]; __shared__ int s_i[FC_NT / 64]; __shared__ int s_c; __shared__ double s_fc[128];
+    __shared__ double s_v[FC_NT / 64]; __shared__ int s_i[FC_NT / 64]; __shared__ double s_fc[128];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G;
     auto block_argmax = [&](double v, int i, double& ov, int& oi) {
         wave_argmax(v, i);
@@ -969,8 +969,10 @@ __global__ __launch_bounds__(256) void fill_double(double* p, int n, double v) {
 // min_distances against the already-selected centres (kcenterGreedy.py:72-82); also the first partial maxima.  One wave per row, one lane
 // per centre (each distance is summed in NumPy's pairwise order by its lane, the minimum over the centres is order-free): a thread per
 // row walked the centres one after the other, 0.59 ms for 1400 rows x 240 centres.
-__global__ __launch_bounds__(256) void kc_init(const double* __restrict__ f, int n, int D, const int* __restrict__ already, int na, double* mind, Part* pout) {
+__global__ __launch_bounds__(256) void kc_init(const double* __restrict__ f, int n, int D, const int* __restrict__ already, int na, double* mind, Part* pout,
+                                               const int* __restrict__ dn = nullptr) {
     __shared__ Part s_p[4];
+    if (dn) n = min(n, *dn);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     Part b; b.v = -1.0; b.i = 0x7fffffff;
     for (int i = blockIdx.x * 4 + wid; i < n; i += gridDim.x * 4) {
@@ -1147,11 +1149,11 @@ __global__ __launch_bounds__(256) void cand_layout(const int* __restrict__ ncand
 }
 __global__ __launch_bounds__(256) void cand_fill(const int* __restrict__ stage, const int* __restrict__ sp_base, const int* __restrict__ ncand, const int* __restrict__ uoff,
                                                  const int* __restrict__ coff, const int* __restrict__ lab_off, const int* __restrict__ lab_sp, const int* __restrict__ counts,
-                                                 int* sel, int* gsel, int* rows) {
+                                                 int* sel, int* gsel, int* rows, int* already) {
     if (counts[5]) return;
     const int c = blockIdx.x, nc = ncand[c], u0 = uoff[c], g0 = coff[c], l0 = lab_off[c], nl = lab_off[c + 1] - l0, n_unl = counts[0], lo = sp_base[c];
     for (int k = threadIdx.x; k < nc; k += 256) { const int sp = stage[lo + k]; sel[u0 + k] = sp; gsel[g0 + k] = sp; rows[g0 + k] = u0 + k; }
-    for (int k = threadIdx.x; k < nl; k += 256) { const int sp = lab_sp[l0 + k]; sel[n_unl + l0 + k] = sp; gsel[g0 + nc + k] = sp; rows[g0 + nc + k] = n_unl + l0 + k; }
+    for (int k = threadIdx.x; k < nl; k += 256) { const int sp = lab_sp[l0 + k]; sel[n_unl + l0 + k] = sp; gsel[g0 + nc + k] = sp; rows[g0 + nc + k] = n_unl + l0 + k; already[l0 + k] = n_unl + l0 + k; }
 }
 
 struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f; };
@@ -1384,7 +1386,7 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     if (d_already && na && n <= 16384) nb = std::max(nb, (int)std::min<size_t>((n + 15) / 16, 2048));
     SSDR_TRY(Q.part.reserve(sizeof(Part) * 2 * (size_t)nb)); SSDR_TRY(Q.mind.reserve(8 * n));
     Part* p0 = Q.part.as<Part>(); Part* p1 = p0 + nb;
-    if (d_already && na) hipLaunchKernelGGL(kc_init, dim3(nb), dim3(256), 0, s, d_feat, (int)n, D, d_already, (int)na, Q.mind.as<double>(), p1);
+    if (d_already && na) hipLaunchKernelGGL(kc_init, dim3(nb), dim3(256), 0, s, d_feat, (int)n, D, d_already, (int)na, Q.mind.as<double>(), p1, d_n);
     else hipLaunchKernelGGL(fill_double, dim3(grid_for((long)n)), dim3(256), 0, s, Q.mind.as<double>(), (int)n, 1.0e10);   // fps_gcn_cpu.py:135
     const bool seeded = d_already && na;
     if (D == 32 && n <= 1536) {   // register-resident single workgroup
@@ -1452,20 +1454,20 @@ int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_ce
  * regions (superpoint ids; the first n_unl are the candidates, cloud by cloud, descending uncertainty inside a cloud). */
 int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
                               const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
-                              const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t batch_size, int gcn_number, int gcn_top, int start,
+                              const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t batch_size, int gcn_number, int gcn_top, int selector, int start,
                               size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream) {
     if (!d_feat || !d_cls || !d_dom || !d_xyz || !d_sp_off || !d_sp_pts || !d_order || !d_labelled || !d_sp_base || !d_lab_off || !d_result || feat_dim != 32 ||
-        num_clouds == 0 || num_clouds > 65535 || S == 0 || S > 0x7ffffff0 || cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || cap_unl == 0 || cap_unl > 16384 || gcn_number < 0 || start < 0) {
-        set_error("gcn_fps_sampling: bad arguments (feat_dim == 32, at most 16384 candidates, at most 65535 clouds)"); return SSDR_ERR_INVALID;
+        num_clouds == 0 || num_clouds > 65535 || S == 0 || S > 0x7ffffff0 || cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || cap_unl == 0 || cap_rows > 16384 || gcn_number < 0 || start < 0 || selector < 0 || selector > 1 || (selector == 1 && n_lab == 0) || (n_lab && !d_lab_sp)) {
+        set_error("gcn_fps_sampling: bad arguments (feat_dim == 32, at most 16384 candidate + labelled rows, at most 65535 clouds, k-center needs labelled regions)"); return SSDR_ERR_INVALID;
     }
     SSDR_TRY(ensure_init());
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     const int B = (int)num_clouds, nchunks = (int)((S + CR_NT - 1) / CR_NT), D = feat_dim;
     // ints: rankpos S, cploc S, stage S, chunk nchunks, ncand B, ntop B, uoff B+1, coff B+1, gsel cap, rows cap | int64: boff B+1
-    const size_t ni = 3 * S + (size_t)nchunks + 4 * (size_t)B + 2 + 2 * cap_rows + 16;
+    const size_t ni = 3 * S + (size_t)nchunks + 4 * (size_t)B + 2 + 2 * cap_rows + n_lab + 16;
     SSDR_TRY(Q.cand_i.reserve(4 * ni + 8 * ((size_t)B + 2)));
     int* rankpos = Q.cand_i.as<int>(); int* cploc = rankpos + S; int* stage = cploc + S; int* chunk = stage + S; int* ncand = chunk + nchunks; int* ntop = ncand + B;
-    int* uoff = ntop + B; int* coff = uoff + B + 1; int* gsel = coff + B + 1; int* rows = gsel + cap_rows;
+    int* uoff = ntop + B; int* coff = uoff + B + 1; int* gsel = coff + B + 1; int* rows = gsel + cap_rows; int* already = rows + cap_rows;
     long long* boff = reinterpret_cast<long long*>(Q.cand_i.as<char>() + ((4 * ni + 7) & ~(size_t)7));
     // doubles: V, comb, tmp0, tmp1 [cap_rows, D]; centres [cap_rows, 3]; dir, adj [cap_sq]
     SSDR_TRY(Q.cand_f.reserve(8 * (4 * cap_rows * D + 3 * cap_rows + 2 * cap_sq)));
@@ -1476,7 +1478,7 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     hipLaunchKernelGGL(cand_chunkscan, dim3(1), dim3(256), 0, s, chunk, nchunks);
     hipLaunchKernelGGL(cand_cloud, dim3(B), dim3(256), 0, s, rankpos, cploc, chunk, d_labelled, d_sp_base, (int)S, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
     hipLaunchKernelGGL(cand_layout, dim3(1), dim3(256), 0, s, ncand, ntop, d_lab_off, B, (long long)cap_rows, (long long)cap_sq, uoff, coff, boff, counts);
-    hipLaunchKernelGGL(cand_fill, dim3(B), dim3(256), 0, s, stage, d_sp_base, ncand, uoff, coff, d_lab_off, d_lab_sp, counts, sel, gsel, rows);
+    hipLaunchKernelGGL(cand_fill, dim3(B), dim3(256), 0, s, stage, d_sp_base, ncand, uoff, coff, d_lab_off, d_lab_sp, counts, sel, gsel, rows, already);
     const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
     // compute_features (sampler2.py:333,339) of the refs, widened; bbox centres of the grouped rows
     hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, counts + 2, V, comb);
@@ -1497,6 +1499,8 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     }
     SSDR_HIP(hipGetLastError());
     if (max_select == 0) return SSDR_OK;
+    // selector 1: kCenterGreedy over candidates + labelled rows, seeded with the labelled ones (kcenterGreedy.py:84-128; sampler2.py's "kcenter" branch)
+    if (selector == 1) return fps_like(comb, cap_rows, D, already, n_lab, 0, max_select, 1, out, s, counts + 2);
     return fps_like(comb, cap_unl, D, nullptr, 0, start, max_select, 0, out, s, counts);
 }
 

@@ -145,7 +145,7 @@ class HotPath:
             sq += (a + int(nlab[i])) ** 2
         self._sel_static = dict(
             d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)), d_base=DevArray.from_host(base.astype(np.int32)),
-            d_lab_off=DevArray.from_host(lab_off), d_lab_sp=DevArray.from_host(lab_sp), batch=batch, picks=picks, cap_unl=max(cap_unl, 1),
+            d_lab_off=DevArray.from_host(lab_off), d_lab_sp=DevArray.from_host(lab_sp), n_lab=int(nlab.sum()), batch=batch, picks=picks, cap_unl=max(cap_unl, 1),
             cap_rows=max(cap_rows, 1), cap_nmax=max(int((share + nlab).max()) if B else 1, 1), cap_sq=max(int(sq), 1),
             d_result=DevArray((8 + picks + max(cap_rows, 1),), np.int32))
 
@@ -261,12 +261,13 @@ class HotPath:
         L = _lib.lib()
         st = self.sel_stream          # None: the library stream; a stream of its own lets the selections of consecutive batches overlap
         T = self._sel_static
-        if (self.global_order is None and self.selector != "kcenter" and T["cap_unl"] <= 16384 and T["picks"] > 0
+        kc = self.selector == "kcenter"
+        if (self.global_order is None and T["cap_rows"] <= 16384 and T["picks"] > 0 and (not kc or T["n_lab"] > 0)
                 and not os.environ.get("SSDR_SELECT_HOST_RULE")):
             # candidate rule + GCN_FPS_sampling enqueued as one chain: the host decides nothing and uploads nothing (the result is read in _select_collect)
             _lib.check(L.ssdr_gcn_fps_sampling_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
                                                    self.sorted_inds.ptr, self.S, T["d_lab"].ptr, T["d_base"].ptr, self.B, T["d_lab_off"].ptr, T["d_lab_sp"].ptr,
-                                                   T["batch"], int(self.gcn_number), int(self.gcn_top), 0, T["cap_rows"], T["cap_nmax"], T["cap_sq"],
+                                                   T["n_lab"], T["batch"], int(self.gcn_number), int(self.gcn_top), 1 if kc else 0, 0, T["cap_rows"], T["cap_nmax"], T["cap_sq"],
                                                    T["cap_unl"], T["picks"], T["d_result"].ptr, st))
             self._pending = ("device", None)
             return

@@ -135,7 +135,7 @@ def test_semantic3d_configuration_matches_oracle(backend):
     assert np.array_equal(hp.sorted_inds.to_host(), ref2["sorted_inds"]) and unl == ref2["unl"] and np.array_equal(sel, ref2["selected"])
 
 
-@pytest.mark.parametrize("case", ["plain", "cloud_all_labelled", "batch_exceeds_regions"])
+@pytest.mark.parametrize("case", ["plain", "cloud_all_labelled", "batch_exceeds_regions", "kcenter"])
 def test_candidate_rule_on_device_equals_host_rule(backend, case, monkeypatch):
     """sampler2.py:533-552, :745-753 as device kernels (ssdr_gcn_fps_sampling_dev: counts stay on the device) against the vectorised host rule +
     the separate entry points: same candidates, same picks — also when a cloud has no region left to offer and when the batch asks for
@@ -148,6 +148,8 @@ def test_candidate_rule_on_device_equals_host_rule(backend, case, monkeypatch):
         hp.labeled[1] = set(np.flatnonzero(hp.sp_cloud_h == 1).tolist())
     if case == "batch_exceeds_regions":
         hp.select_per_tile = hp.S
+    if case == "kcenter":
+        hp.selector = "kcenter"          # kCenterGreedy over candidates + labelled rows, seeded with the labelled ones
     hp.labeled_mask[:] = False
     for b in hp.labeled:
         hp.labeled_mask[list(hp.labeled[b])] = True
