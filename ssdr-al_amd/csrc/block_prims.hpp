@@ -51,6 +51,20 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 #endif
 
+// Launches whose grid is (blocks of one tile) x (tiles) and whose blocks gather rows of their tile's tables at random: blocks are dealt
+// round-robin over the 8 XCDs in linear order (MI355X_MICROARCH.md, Workgroup dispatch), so with the plain mapping every XCD works on every
+// tile and each of the eight L2s fetches every tile's table (measured: the LFA kernels read 8 x their gathered tables from beyond L2).  This
+// mapping gives the blocks of a tile to ONE XCD (blocks b and b + 8 share an XCD): a tile's table (<= 4 MB) is fetched into one L2, once.
+// Placement is a speed matter only.  Needs the tile count to be a multiple of 8; otherwise the identity.
+__device__ __forceinline__ void xcd_tile_map(int& bx, int& tile) {
+    const int gx = (int)gridDim.x, nb = (int)gridDim.y;
+    bx = (int)blockIdx.x; tile = (int)blockIdx.y;
+    if ((nb & 7) == 0) {
+        const int lin = tile * gx + bx, xcd = lin & 7, j = lin >> 3;
+        tile = xcd + 8 * (j / gx); bx = j % gx;
+    }
+}
+
 // Orders the LDS traffic of the lanes of ONE wave (waves of a workgroup that take different trip counts cannot use the workgroup barrier):
 // everything the wave's lanes wrote before is visible to its lanes after.
 __device__ __forceinline__ void wave_sync() {

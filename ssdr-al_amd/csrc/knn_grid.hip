@@ -328,9 +328,10 @@ __device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __
 // lies inside the guaranteed radius and clear of the runner-up; otherwise that job's own (coarser) grid answers the row in its retry pass.
 template <int K, typename OutT>
 __global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
-    const int jid = a.job0 + blockIdx.y;
+    int bx, by; xcd_tile_map(bx, by);          // a job's support set (one tile's records and cell table) into one XCD's L2
+    const int jid = a.job0 + by;
     const GridJob job = a.jobs[jid];
-    const int qi = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int qi = bx * 256 + (int)threadIdx.x;
     if (qi >= job.nq) return;
     const GridDesc d = a.desc[job.sup];
     int q = qi; float qx, qy, qz;

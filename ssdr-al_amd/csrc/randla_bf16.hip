@@ -208,7 +208,8 @@ __global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lc = lane & 15, lg = lane >> 4;
     const int cg = w % NCG, p0 = (w / NCG) * PW;   // this wave's column group and first point
-    const int b = blockIdx.y, pt0 = blockIdx.x * PTS;
+    int bx_, b; xcd_tile_map(bx_, b);
+    const int pt0 = bx_ * PTS;
     const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
     const int* neigh = a.neigh + (size_t)b * a.n * 16;
 
@@ -453,7 +454,13 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float
         for (int q = 0; q < 4; ++q) { unsigned h, l; split_bf16(v[2 * q], v[2 * q + 1], h, l); f[0][q] = h; f[1][q] = l; }
     };
     const int ntiles = (M + 15) / 16;
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    // PRE gathers rows of the coarser level's table of the row's batch element: give a batch element's tiles to one XCD (block_prims.hpp,
+    // xcd_tile_map: blocks b and b + 8 share an XCD) when the shapes allow, so that table is fetched into one L2 instead of eight
+    int tpb = 0, nbe = 0;
+    if (PRE && pre.m_per_batch % 16 == 0 && M % pre.m_per_batch == 0 && (gridDim.x & 7) == 0) { tpb = pre.m_per_batch / 16; nbe = M / pre.m_per_batch; if (nbe & 7) tpb = 0; }
+    const int lw = ((int)blockIdx.x >> 3) * 4 + ((int)threadIdx.x >> 6), lnw = nwaves >> 3, lnt = tpb ? (nbe >> 3) * tpb : 0;
+    for (int it = tpb ? lw : wave; it < (tpb ? lnt : ntiles); it += tpb ? lnw : nwaves) {
+        const int tile = tpb ? (((int)blockIdx.x & 7) + 8 * (it / tpb)) * tpb + it % tpb : it;
         const int row = tile * 16 + lc;
         auto load8 = [&](const float* p, float (&v)[8]) {
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;

@@ -6,8 +6,10 @@
 // f32-input MFMA per instruction slot; three products => 5.3x).  Plain bf16 keeps only a_hi*b_hi.
 #pragma once
 #include "ssdr_internal.hpp"
+#include "block_prims.hpp"
 
 namespace ssdr {
+
 
 #ifndef HIPEMU
 typedef float f32x4 __attribute__((ext_vector_type(4)));

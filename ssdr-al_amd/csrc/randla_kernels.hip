@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
     float* REL = smem + (size_t)ROWS * LD;        // [ROWS][10]
     int* NBR = reinterpret_cast<int*>(REL + (size_t)ROWS * 10);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y, pt0 = blockIdx.x * PTS;
+    int bx_, b; xcd_tile_map(bx_, b);
+    const int pt0 = bx_ * PTS;
     const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
     const int* neigh = a.neigh + (size_t)b * a.n * 16;
 
@@ -492,12 +493,12 @@ __global__ __launch_bounds__(256) void lfa_att_kernel(LfaArgs a) {
 // ---- random_sample (:537-548) --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict__ f, const int* __restrict__ idx, int n_in, int n_out,
                                                          int idx_rows, int C, float* __restrict__ out) {
-    const int b = blockIdx.y;
+    int bx, b; xcd_tile_map(bx, b);
     const float* fb = f + (size_t)b * n_in * C;
     const int* ib = idx + (size_t)b * idx_rows * 16;
     float* ob = out + (size_t)b * n_out * C;
     const size_t total = (size_t)n_out * C;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    for (size_t e = (size_t)bx * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int m = (int)(e / C), c = (int)(e % C);
         float v = -3.402823466e+38f;
 #pragma unroll

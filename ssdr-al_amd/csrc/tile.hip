@@ -34,10 +34,10 @@ __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, 
                                                    const uint32_t* __restrict__ sorted, const int* __restrict__ d_count,
                                                    const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
                                                    float cx, float cy, float cz, float color_scale,
-                                                   float* out_xyz, float* out_feat, int* out_idx, int stride = 1) {
+                                                   float* out_xyz, float* out_feat, int* out_idx, int stride = 1, int bx = -1) {
     const int m = *d_count;
     const int avail = min(m, num_points);
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < num_points; r += gridDim.x * 256) {
+    for (int r = (bx < 0 ? (int)blockIdx.x : bx) * 256 + threadIdx.x; r < num_points; r += gridDim.x * 256) {
         int pos;
         if (avail == num_points) pos = perm[r];
         else {
@@ -78,9 +78,10 @@ __global__ __launch_bounds__(256) void tile_keys_b(TileTab t, const float* __res
 __global__ __launch_bounds__(256) void tile_gather_b(TileTab t, const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted,
                                                      const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
                                                      float color_scale, float* out_xyz, float* out_feat, int* out_idx, int stride) {
-    const int r = blockIdx.y; const size_t o = (size_t)t.off[r], q = (size_t)r * num_points;
+    int bx, r; xcd_tile_map(bx, r);            // the rows of a room are gathered at random: one room per XCD's L2
+    const size_t o = (size_t)t.off[r], q = (size_t)r * num_points;
     tile_gather_body(pts + 3 * o, colors ? colors + o * cdim : nullptr, cdim, sorted + (size_t)t.toff[r] * stride, d_count + r, perm + q, dup_u + q, num_points, t.cx[r], t.cy[r], t.cz[r],
-                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, stride);
+                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, stride, bx);
 }
 
 // ---- batch flavour: only the rows that can be among the num_points nearest are sorted ------------------------------------------
