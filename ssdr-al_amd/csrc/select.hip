@@ -210,6 +210,41 @@ __global__ __launch_bounds__(256) void sel_rank_keys(const double* __restrict__ 
     }
 }
 
+// Ranking of up to RANK_SMALL regions by COUNTING, spread over the chip: the rank of region i is the number of regions whose (key, index) pair is
+// smaller — descending uncertainty, equal values by ascending index: the order the stable radix sort of (key, index) pairs gives.  Every workgroup
+// stages all keys in LDS and ranks 32 regions, eight lanes per region (S^2 / 8 comparisons per lane group: 51 M in all for the bench's 7149 regions).
+// The segmented radix sorter takes ~14 launch-bound launches for a few thousand keys (0.17 ms in front of every selection), a bitonic network in one
+// workgroup 0.1 ms (one CU's vector rate); this is one launch of ~10 us.
+constexpr int RANK_SMALL = 8192;
+__global__ __launch_bounds__(256) void sel_rank_count(const double* __restrict__ u, int S, int* __restrict__ sorted_inds) {
+    __shared__ unsigned long long s_k[RANK_SMALL];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S; i += 256) {
+        unsigned long long b = (unsigned long long)__double_as_longlong(-u[i]);
+        s_k[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);          // order-preserving map of IEEE doubles to u64 (as sel_rank_keys)
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 32 + (tid >> 3), part = tid & 7;
+    const bool live = i < S;
+    const unsigned long long ki = s_k[live ? i : 0];
+    int cnt = 0;
+    if (live) {
+        // (kj, j) < (ki, i)  <=>  kj < ki + (j < i): one 64-bit add and compare per pair (ki + 1 does not wrap: only a NaN maps to all ones); eight
+        // LDS reads in flight
+        int j = part;
+        for (; j + 56 < S; j += 64) {
+            unsigned long long kj[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) kj[t] = s_k[j + 8 * t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cnt += kj[t] < ki + (unsigned long long)(j + 8 * t < i);
+        }
+        for (; j < S; j += 8) cnt += s_k[j] < ki + (unsigned long long)(j < i);
+    }
+    cnt += __shfl_xor(cnt, 1); cnt += __shfl_xor(cnt, 2); cnt += __shfl_xor(cnt, 4);
+    if (live && part == 0) sorted_inds[cnt] = i;
+}
+
 // ---- U3: compute_features (sampler2.py:333,339): float32 row-sequential mean over the dominant-class members ----
 __global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict__ feat, int D, const int* __restrict__ cls, const int* __restrict__ dom,
                                                         const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
@@ -303,16 +338,34 @@ __device__ void chamfer_plan_body(const int* __restrict__ sp_off, const int* __r
     }
     for (int i = tid; i < n; i += 256) { const int sp = sel[i]; s_n[i] = sp_off[sp + 1] - sp_off[sp]; }
     __syncthreads();
+    // the lay-out rule is sequential (first fit into 256-slot items, in order), but only `cur` is carried: one lane runs the short recurrence over the
+    // sizes in LDS and leaves every superpoint's start (and whether it opens an item) there; the tables are then written by all threads
+    __shared__ int s_start[PACK_MAX];
     if (tid == 0) {
-        int cur = 0, nitems = 0, nbig = 0;
+        int cur = 0;
         for (int i = 0; i < n; ++i) {
             const int ni = s_n[i];
-            if (ni == 0 || ni > ITEM) { P.start[i] = -1; P.big[nbig++] = i; continue; }
+            if (ni == 0 || ni > ITEM) { s_start[i] = -1; continue; }
             if ((cur & (ITEM - 1)) + ni > ITEM) cur = (cur + ITEM - 1) & ~(ITEM - 1);
-            if ((cur & (ITEM - 1)) == 0) P.item_slot[nitems++] = cur;
-            P.start[i] = cur; cur += ni;
+            s_start[i] = cur; cur += ni;
         }
-        counts[0] = nitems; counts[1] = nbig;
+    }
+    __syncthreads();
+    // ranks of the item openers and of the pair-by-pair superpoints: counted per thread over a contiguous piece, then offset by the pieces before
+    __shared__ int s_ci[257], s_cb[257];
+    const int per = (n + 255) / 256, lo = min(n, tid * per), hi = min(n, lo + per);
+    int ci = 0, cb = 0;
+    for (int i = lo; i < hi; ++i) { const int st = s_start[i]; if (st < 0) ++cb; else if ((st & (ITEM - 1)) == 0) ++ci; }
+    s_ci[tid] = ci; s_cb[tid] = cb;
+    __syncthreads();
+    if (tid == 0) { int a = 0, b = 0; for (int t = 0; t < 256; ++t) { const int x = s_ci[t], y = s_cb[t]; s_ci[t] = a; s_cb[t] = b; a += x; b += y; } counts[0] = a; counts[1] = b; }
+    __syncthreads();
+    ci = s_ci[tid]; cb = s_cb[tid];
+    for (int i = lo; i < hi; ++i) {
+        const int st = s_start[i];
+        P.start[i] = st;
+        if (st < 0) P.big[cb++] = i;
+        else if ((st & (ITEM - 1)) == 0) P.item_slot[ci++] = st;
     }
 }
 // ... and its slots: one wave per superpoint (seg / cnt of the padding slots were preset by the launcher: -1 / 0)
@@ -608,7 +661,17 @@ __device__ void propagate_body(const double* __restrict__ adj, int n, const int*
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n * D; e += gridDim.x * 256) {
         const int i = e / D, c = e % D;
         double acc = 0.0;
-        for (int j = 0; j < n; ++j) acc += adj[(size_t)i * n + j] * vin[(size_t)rows[j] * D + c];
+        // eight terms' dependent loads (row index, then the feature) in flight; the additions stay in column order (np.matmul's row-times-column sum
+        // is compared at 1e-12, and the selection downstream must not depend on the unrolling)
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            int rj[8]; double a[8], v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rj[t] = rows[min(j0 + t, n - 1)];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { a[t] = adj[(size_t)i * n + min(j0 + t, n - 1)]; v[t] = vin[(size_t)rj[t] * D + c]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (j0 + t < n) acc += a[t] * v[t];
+        }
         vout[(size_t)rows[i] * D + c] = acc;
         comb[(size_t)rows[i] * D + c] += acc;
     }
@@ -1088,7 +1151,7 @@ constexpr int CC_TILE = 2048;
 __global__ __launch_bounds__(256) void cand_cloud(const int* __restrict__ rankpos, const int* __restrict__ cploc, const int* __restrict__ chunkoff,
                                                   const unsigned char* __restrict__ labelled, const int* __restrict__ sp_base, int S, int batch_size,
                                                   int* stage, int* ncand, int* ntop) {
-    __shared__ int s_tile[CC_TILE];
+    __shared__ __attribute__((aligned(16))) int s_tile[CC_TILE];
     __shared__ int s_red[8];
     const int tid = threadIdx.x, c = blockIdx.x, lo = sp_base[c], n = sp_base[c + 1] - lo;
     const int lim = min(batch_size, S);
@@ -1106,9 +1169,12 @@ __global__ __launch_bounds__(256) void cand_cloud(const int* __restrict__ rankpo
         for (int t0 = 0; t0 < n; t0 += CC_TILE) {
             const int m = min(CC_TILE, n - t0);
             __syncthreads();
-            for (int k = tid; k < m; k += 256) s_tile[k] = labelled[lo + t0 + k] ? 0x7fffffff : rankpos[lo + t0 + k];
+            for (int k = tid; k < ((m + 3) & ~3); k += 256) s_tile[k] = (k >= m || labelled[lo + t0 + k]) ? 0x7fffffff : rankpos[lo + t0 + k];
             __syncthreads();
-            if (live) for (int k = 0; k < m; ++k) pos += s_tile[k] < rj;
+            if (live) {          // four rank positions per LDS read (the tile is padded with +infinity to a multiple of four)
+                const int4* t4 = reinterpret_cast<const int4*>(s_tile);
+                for (int k = 0; k < (m + 3) / 4; ++k) { const int4 v = t4[k]; pos += (v.x < rj) + (v.y < rj) + (v.z < rj) + (v.w < rj); }
+            }
         }
         if (live && pos < take) stage[lo + pos] = lo + j;
     }
@@ -1257,6 +1323,11 @@ int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorte
     SSDR_TRY(ensure_init());
     if (S == 0) return SSDR_OK;
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    if (S <= (size_t)RANK_SMALL) {
+        hipLaunchKernelGGL(sel_rank_count, dim3((unsigned)((S + 31) / 32)), dim3(256), 0, s, d_region_unc, (int)S, d_sorted_inds);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     SSDR_TRY(Q.keys.reserve(8 * S)); SSDR_TRY(Q.vals.reserve(4 * S));
     hipLaunchKernelGGL(sel_rank_keys, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_unc, (int)S, Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>());
     SSDR_TRY(Q.sorter.sort(Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>(), (int)S, nullptr, s));

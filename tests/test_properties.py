@@ -58,14 +58,15 @@ def test_grid_subsample_invariants_at_room_size(backend):
 def test_ranking_and_fps_invariants(backend):
     from ssdr_al import sampler
     rng = np.random.default_rng(47)
-    S = 5000 if backend == "emu" else 800000
-    u = rng.normal(0, 1, S); u[rng.integers(0, S, S // 10)] = 0.25          # plenty of exact ties
-    order = sampler.rank_regions(u)
-    assert np.array_equal(np.sort(order), np.arange(S))                      # a permutation
-    su = u[order]
-    assert (np.diff(su) <= 0).all()                                          # descending uncertainty
-    tie = np.diff(su) == 0
-    assert (np.diff(order)[tie] > 0).all()                                   # equal values keep ascending index (argsort(-u), stable)
+    for S in ((12000, 8192, 3001, 2) if backend == "emu" else (800000, 8192, 7149)):      # above 8192: segmented radix sort; up to 8192: one workgroup, in LDS
+        u = rng.normal(0, 1, S); u[rng.integers(0, S, S // 10 + 1)] = 0.25  # plenty of exact ties
+        order = sampler.rank_regions(u)
+        assert np.array_equal(np.sort(order), np.arange(S))                  # a permutation
+        su = u[order]
+        assert (np.diff(su) <= 0).all()                                      # descending uncertainty
+        tie = np.diff(su) == 0
+        assert (np.diff(order)[tie] > 0).all()                               # equal values keep ascending index (argsort(-u), stable)
+        assert np.array_equal(order, np.argsort(-u, kind="stable"))
     n, m = (600, 200) if backend == "emu" else (12000, 3000)
     f = rng.normal(0, 1, (n, 32))
     sel = sampler.farthest_features_sample(f, m, 5)
