@@ -69,6 +69,26 @@ __device__ __forceinline__ double np_pairwise_fixed(Get get) {
     return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
 }
 
+// The same order for one block of 8 <= n <= 128 terms with the eight accumulators on eight lanes of a wave (every lane of the wave calls it with uniform
+// n; result on lane 0): lane k sums the terms k, k + 8, ... of the multiple-of-eight part, the accumulators are combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+// through lane exchanges (fp addition is commutative, so lane 0's a + b is the reference's), the leftover terms are added by lane 0 in order.
+template <class T, class Get>
+__device__ __forceinline__ T np_pairwise_w8(Get get, int n, int lane) {
+    const int n8 = n - (n % 8);
+    T r = T(0);
+    if (lane < 8) { r = get(lane); for (int i = 8; i < n8; i += 8) r += get(i + lane); }
+    auto xchg = [&](T v, int m) -> T {
+        if constexpr (sizeof(T) == 8) {
+            const long long b = __double_as_longlong((double)v);
+            const unsigned lo = __shfl_xor((unsigned)b, m), hi = __shfl_xor((unsigned)(b >> 32), m);
+            return (T)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        } else return (T)__shfl_xor((float)v, m);
+    };
+    r = r + xchg(r, 1); r = r + xchg(r, 2); r = r + xchg(r, 4);
+    if (lane == 0) for (int i = n8; i < n; ++i) r += get(i);
+    return r;
+}
+
 // ---- U1: compute_point_uncertainty (sampler2.py:28-47) + argmax class (:602) ------------------------------
 __global__ __launch_bounds__(256) void sel_point_unc(const float* __restrict__ prob, int n, int C, int mode, float* unc, int* cls) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -144,26 +164,32 @@ __global__ __launch_bounds__(256) void sel_region_stats_w(const float* __restric
             if (c >= 0 && c < 32) atomicAdd(&s_h[w][c], 1);
         }
         wave_sync();
-        if (lane == 0) {
-            const int* h = s_h[w];
-            int d = 0;
-            for (int c = 1; c < C; ++c) if (h[c] > h[d]) d = c;           // np.argmax: first maximum
-            dom[s] = d; dom_cnt[s] = h[d];
-            auto U = [&](int j) { return staged ? s_u[w][j] : unc[sp_pts[lo + j]]; };
-            auto K = [&](int j) { return staged ? s_c[w][j] : cls[sp_pts[lo + j]]; };
-            double r;
-            if (mode == 0) {
-                const float sum = np_pairwise<float>([&](int j) { return U(j); }, n);
-                r = (double)(float)((double)sum / (double)n);
-            } else if (mode == 1) {                                      // weights_percentage (:92-100) * uncertainty
-                r = np_pairwise<double>([&](int j) { return ((double)h[K(j)] / (double)n) * (double)U(j); }, n);
-            } else {                                                     // WetSU (:19-26)
-                const double a = np_pairwise<double>([&](int j) { return (double)U(j) * (K(j) == d ? 1.0 : 0.0); }, n);
-                const double b = np_pairwise<double>([&](int j) { return (double)U(j) * (1.0 - (K(j) == d ? 1.0 : 0.0)); }, n);
-                r = a - b;
-            }
-            region_unc[s] = r;
+        const int* h = s_h[w];
+        int d = 0;
+        for (int c = 1; c < C; ++c) if (h[c] > h[d]) d = c;           // np.argmax: first maximum (every lane: uniform)
+        if (lane == 0) { dom[s] = d; dom_cnt[s] = h[d]; }
+        auto U = [&](int j) { return staged ? s_u[w][j] : unc[sp_pts[lo + j]]; };
+        auto K = [&](int j) { return staged ? s_c[w][j] : cls[sp_pts[lo + j]]; };
+        const bool w8 = staged && n >= 8 && n <= 128;                 // one block of NumPy's pairwise sum: its eight accumulators on eight lanes
+        double r = 0.0;
+        if (mode == 0) {
+            float sum = 0.f;
+            if (w8) sum = np_pairwise_w8<float>([&](int j) { return U(j); }, n, lane);
+            else if (lane == 0) sum = np_pairwise<float>([&](int j) { return U(j); }, n);
+            r = (double)(float)((double)sum / (double)n);
+        } else if (mode == 1) {                                      // weights_percentage (:92-100) * uncertainty
+            auto term = [&](int j) { return ((double)h[K(j)] / (double)n) * (double)U(j); };
+            if (w8) r = np_pairwise_w8<double>(term, n, lane);
+            else if (lane == 0) r = np_pairwise<double>(term, n);
+        } else {                                                     // WetSU (:19-26)
+            auto ta = [&](int j) { return (double)U(j) * (K(j) == d ? 1.0 : 0.0); };
+            auto tb = [&](int j) { return (double)U(j) * (1.0 - (K(j) == d ? 1.0 : 0.0)); };
+            double a = 0.0, b = 0.0;
+            if (w8) { a = np_pairwise_w8<double>(ta, n, lane); b = np_pairwise_w8<double>(tb, n, lane); }
+            else if (lane == 0) { a = np_pairwise<double>(ta, n); b = np_pairwise<double>(tb, n); }
+            r = a - b;
         }
+        if (lane == 0) region_unc[s] = r;
         wave_sync();
     }
 }
