@@ -45,7 +45,15 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t As[TERMS][TM * KS];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[TERMS][64 * KS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int row0 = blockIdx.x * TM, col0 = blockIdx.y * 64;
+    int bxr = (int)blockIdx.x, byc = (int)blockIdx.y;
+    if (a.idx2 && a.m_per_batch % TM == 0 && a.M % a.m_per_batch == 0 && ((a.M / a.m_per_batch) & 7) == 0) {
+        // decoder layers gather rows of the coarser level's table of the row's batch element: a batch element's row blocks (all their column
+        // blocks) to one XCD (block_prims.hpp, xcd_tile_map: blocks b and b + 8 share an XCD), so the table is fetched into one L2 instead of eight
+        const int gy = (int)gridDim.y, rpb = a.m_per_batch / TM;
+        const int lin = byc * (int)gridDim.x + bxr, xcd = lin & 7, j = lin >> 3, rb = j / gy;
+        byc = j % gy; bxr = (xcd + 8 * (rb / rpb)) * rpb + rb % rpb;
+    }
+    const int row0 = bxr * TM, col0 = byc * 64;
     const int K = a.k1 + a.k2;
     const int sr = tid / TPR, sk = (tid % TPR) * 8;
     const float* x1r[APASS]; const float* x2r[APASS];
