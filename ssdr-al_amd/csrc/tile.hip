@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void tile_hist_b(TileTab t, const float* __res
 // of every bin <= T among the room's candidates (the histogram becomes the bins' write cursors; bins beyond T are cleared); the ranges the
 // sort works on: range k = the bins that START in [k TS_RSTEP, (k + 1) TS_RSTEP)
 constexpr int TS_RCAP = 4096, TS_RSTEP = 1024;
-__global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand, unsigned* rstart, int rstride) {
+__global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand, unsigned* rstart, unsigned* rcur, int rstride) {
     __shared__ unsigned s_h[TS_BINS + TS_BINS / 32];          // the room's histogram (coalesced in, coalesced out); one pad word per 32 bins: a thread's stretch starts in its own bank pair
     __shared__ unsigned s_part[256];
     __shared__ unsigned s_T;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, 
     auto at = [](int b) { return b + (b >> 5); };
     const unsigned want = (unsigned)min(num_points, d_count[r]);
     for (int b = tid; b < TS_BINS; b += 256) s_h[at(b)] = h[b];
-    for (int k = tid; k < rstride; k += 256) RS[k] = 0xffffffffu;
+    for (int k = tid; k < rstride; k += 256) { RS[k] = 0xffffffffu; rcur[(size_t)r * rstride + k] = 0u; }
     __syncthreads();
     unsigned tot = 0;
     for (int k = 0; k < PER; ++k) tot += s_h[at(tid * PER + k)];
@@ -162,8 +162,46 @@ __global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, 
     __syncthreads();
     for (int b = tid; b < TS_BINS; b += 256) h[b] = s_h[at(b)];
 }
-// candidates (bin <= T) to their bin's slots: inside a bin in the order the atomics hand out (the sort settles it: the words are unique)
-__global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, unsigned* hist, uint64_t* keys) {
+// candidates (bin <= T) to their RANGE's slots (the sort orders a range completely, so the order inside it is free): a workgroup counts its
+// candidates per range in LDS (the range of bin b is (start of b) / TS_RSTEP: the histogram now holds the starts), reserves each range's share
+// with ONE global atomic and writes.  A global atomic per candidate (0.66 M per step on ~130 k cursors) was the cost of this kernel.
+constexpr int TS_CPT = 12;            // rows per thread (held in registers between the two passes)
+constexpr int TS_RMAX = 2048;         // ranges a workgroup keeps counters for; beyond: the per-bin cursors (tile_compact_bins_b)
+__global__ __launch_bounds__(256) void tile_compact_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr,
+                                                      const unsigned* __restrict__ hist, const unsigned* __restrict__ rstart, unsigned* rcur, int rstride, uint64_t* keys) {
+    __shared__ unsigned s_cnt[TS_RMAX], s_base[TS_RMAX];
+    const int r = blockIdx.y, m = d_count[r], tid = threadIdx.x;
+    const float* P = pts + 3 * (size_t)t.off[r];
+    const unsigned T = thr[r];
+    const unsigned* h = hist + (size_t)r * TS_BINS;
+    const unsigned* RS = rstart + (size_t)r * rstride;
+    unsigned* RC = rcur + (size_t)r * rstride;
+    uint64_t* K = keys + t.toff[r];
+    for (int i0 = blockIdx.x * 256 * TS_CPT; i0 < m; i0 += gridDim.x * 256 * TS_CPT) {          // uniform over the workgroup
+        for (int k = tid; k < rstride; k += 256) s_cnt[k] = 0u;
+        __syncthreads();
+        unsigned bits[TS_CPT], loc[TS_CPT]; int rid[TS_CPT];
+#pragma unroll
+        for (int u = 0; u < TS_CPT; ++u) {
+            const int i = i0 + u * 256 + tid;
+            rid[u] = -1; bits[u] = 0u; loc[u] = 0u;
+            if (i < m) {
+                bits[u] = __float_as_uint(tile_dist(P, i, t.cx[r], t.cy[r], t.cz[r]));
+                const unsigned b = bits[u] >> TS_SHIFT;
+                if (b <= T) { rid[u] = (int)(h[b] / TS_RSTEP); loc[u] = atomicAdd(&s_cnt[rid[u]], 1u); }
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < rstride; k += 256) { const unsigned c = s_cnt[k]; if (c) s_base[k] = RS[k] + atomicAdd(&RC[k], c); }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TS_CPT; ++u)
+            if (rid[u] >= 0) K[s_base[rid[u]] + loc[u]] = ((uint64_t)bits[u] << 32) | (uint64_t)(uint32_t)(i0 + u * 256 + tid);
+        __syncthreads();
+    }
+}
+// the same with one global atomic per candidate on its bin's cursor (rooms of more than TS_RMAX ranges)
+__global__ __launch_bounds__(256) void tile_compact_bins_b(TileTab t, const float* __restrict__ pts, const int* __restrict__ d_count, const unsigned* __restrict__ thr, unsigned* hist, uint64_t* keys) {
     const int r = blockIdx.y, m = d_count[r];
     const float* P = pts + 3 * (size_t)t.off[r];
     const unsigned T = thr[r];
@@ -249,7 +287,7 @@ __global__ __launch_bounds__(1024) void possibility_min(const double* __restrict
     if (tid == 0) { *out_min = s_v[0]; *out_arg = s_i[0]; }
 }
 
-struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand, rstart; bool hist_clear = false; };
+struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand, rstart, rcur; bool hist_clear = false; };
 TileState& tst(hipStream_t st) { return per_stream<TileState>(st); }
 
 }  // namespace
@@ -312,13 +350,16 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
     SSDR_TRY(T.keys.reserve(8 * (size_t)toff + 16)); SSDR_TRY(T.count.reserve(4 * num_clouds + 16));
     const int rstride = (maxn + TS_RSTEP - 1) / TS_RSTEP + 1;
     SSDR_TRY(T.hist.reserve(4 * (size_t)TS_BINS * RADIX_MAX_SEG)); SSDR_TRY(T.thr.reserve(4 * RADIX_MAX_SEG)); SSDR_TRY(T.cand.reserve(4 * RADIX_MAX_SEG));
-    SSDR_TRY(T.rstart.reserve(4 * (size_t)rstride * num_clouds));
+    SSDR_TRY(T.rstart.reserve(4 * (size_t)rstride * num_clouds)); SSDR_TRY(T.rcur.reserve(4 * (size_t)rstride * num_clouds));
     if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_clear_b leaves it clear
     const unsigned R = (unsigned)num_clouds;
     const int g = std::max(1, std::min((maxn + 255) / 256, 64));
     hipLaunchKernelGGL(tile_hist_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.hist.as<unsigned>(), T.count.as<int>());
-    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, t, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>(), T.rstart.as<unsigned>(), rstride);
-    hipLaunchKernelGGL(tile_compact_b, dim3(g, R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(), T.hist.as<unsigned>(), T.keys.as<uint64_t>());
+    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, t, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>(), T.rstart.as<unsigned>(), T.rcur.as<unsigned>(), rstride);
+    if (rstride <= TS_RMAX)
+        hipLaunchKernelGGL(tile_compact_b, dim3(std::max(1, std::min((maxn + 256 * TS_CPT - 1) / (256 * TS_CPT), 256)), R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(),
+                           T.hist.as<unsigned>(), T.rstart.as<unsigned>(), T.rcur.as<unsigned>(), rstride, T.keys.as<uint64_t>());
+    else hipLaunchKernelGGL(tile_compact_bins_b, dim3(g, R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(), T.hist.as<unsigned>(), T.keys.as<uint64_t>());
     hipLaunchKernelGGL(tile_clear_b, dim3(8, R), dim3(256), 0, s, T.hist.as<unsigned>());
     hipLaunchKernelGGL(tile_binsort_b, dim3(std::min(rstride, 64), R), dim3(256), 0, s, t, T.rstart.as<unsigned>(), rstride, T.cand.as<int>(), T.keys.as<uint64_t>());
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
