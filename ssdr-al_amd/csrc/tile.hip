@@ -239,6 +239,55 @@ __global__ __launch_bounds__(256) void tile_binsort_b(TileTab t, const unsigned*
         // >= n then simply count as +infinity and are never touched, so n need not be a power of two and nothing is padded
         const bool lds = n <= (unsigned)TS_RCAP;
         uint64_t* A = lds ? s_k : K + s0;
+        if (N <= 2048u && N >= 16u) {
+            // the usual case (~1000-1450 words), eight consecutive words per thread: the steps with partners less than eight apart run in registers
+            // (no index arithmetic, no LDS, no barrier: 30 of the 66 steps of a 2048-word network), the others through LDS four comparators per thread;
+            // the words beyond n are +infinity here (a plain network on N words)
+            for (unsigned i = tid; i < N; i += 256) s_k[i] = i < n ? K[s0 + i] : ~0ull;
+            __syncthreads();
+            const bool act = (unsigned)tid < N / 8;
+            uint64_t v[8];
+            auto ce = [&](int a, int b) { const uint64_t x = v[a], y = v[b]; const bool sw = x > y; v[a] = sw ? y : x; v[b] = sw ? x : y; };
+            auto ld8 = [&]() {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = s_k[8 * tid + e];
+            };
+            auto st8 = [&]() {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_k[8 * tid + e] = v[e];
+            };
+            auto tail3 = [&]() { ce(0, 4); ce(1, 5); ce(2, 6); ce(3, 7); ce(0, 2); ce(1, 3); ce(4, 6); ce(5, 7); ce(0, 1); ce(2, 3); ce(4, 5); ce(6, 7); };
+            if (act) {
+                ld8();
+                ce(0, 1); ce(2, 3); ce(4, 5); ce(6, 7);                                        // k = 2
+                ce(0, 3); ce(1, 2); ce(4, 7); ce(5, 6); ce(0, 1); ce(2, 3); ce(4, 5); ce(6, 7);        // k = 4: mirror step, then 1
+                ce(0, 7); ce(1, 6); ce(2, 5); ce(3, 4); ce(0, 2); ce(1, 3); ce(4, 6); ce(5, 7); ce(0, 1); ce(2, 3); ce(4, 5); ce(6, 7);      // k = 8
+                st8();
+            }
+            __syncthreads();
+            for (unsigned k = 16; k <= N; k <<= 1) {
+                for (unsigned j = k >> 1; j >= 8; j >>= 1) {
+                    const int lj = __ffsll((long long)j) - 1;
+                    if (act) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const unsigned i = 4u * tid + c;
+                            unsigned lo, hi;
+                            if (j == (k >> 1)) { const unsigned blk = i >> lj, off = i & (j - 1); lo = blk * k + off; hi = blk * k + (k - 1 - off); }
+                            else { lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)); hi = lo | j; }
+                            const uint64_t a = s_k[lo], b = s_k[hi];
+                            if (a > b) { s_k[lo] = b; s_k[hi] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (act) { ld8(); tail3(); st8(); }
+                __syncthreads();
+            }
+            for (unsigned i = tid; i < n; i += 256) K[s0 + i] = s_k[i];
+            __syncthreads();
+            continue;
+        }
         if (lds) { for (unsigned i = tid; i < n; i += 256) s_k[i] = K[s0 + i]; __syncthreads(); }
         for (unsigned k = 2; k <= N; k <<= 1) {
             for (unsigned j = k >> 1; j > 0; j >>= 1) {
