@@ -45,6 +45,9 @@ int  ssdr_stream_sync(void* stream);     /* NULL = library stream */
 /* Extra streams for callers that overlap independent work (e.g. the per-room front end); every *_dev entry point
  * keeps its workspaces per stream, so calls on different streams may run concurrently. */
 int  ssdr_stream_create(void** out_stream);
+/* priority > 0: the device's highest stream priority, < 0: its lowest, 0: the default (hipStreamCreateWithPriority, non-blocking).  Streams of
+ * another priority live on hardware queues of their own: short dependent launches are not held behind the other streams' chip-filling kernels. */
+int  ssdr_stream_create_priority(void** out_stream, int priority);
 int  ssdr_stream_destroy(void* stream);
 int  ssdr_main_stream(void** out_stream);            /* the library's own stream (what stream == NULL means) */
 int  ssdr_stream_wait(void* waiter, void* waited);   /* waiter continues after what is enqueued on waited so far */

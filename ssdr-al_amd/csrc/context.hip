@@ -145,6 +145,18 @@ int ssdr_stream_create(void** out_stream) {
     *out_stream = s;
     return SSDR_OK;
 }
+/* priority: 0 = the default, > 0 = the highest priority the device offers, < 0 = the lowest.  Streams of another priority live on hardware queues of
+ * their own: short dependent launches on a high-priority stream are not held behind the chip-filling kernels of the other streams. */
+int ssdr_stream_create_priority(void** out_stream, int priority) {
+    if (!out_stream) { ssdr::set_error("stream_create_priority: NULL"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ssdr::ensure_init());
+    int least = 0, greatest = 0;
+    SSDR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));          // numerically lower = higher priority
+    hipStream_t s = nullptr;
+    SSDR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority > 0 ? greatest : (priority < 0 ? least : 0)));
+    *out_stream = s;
+    return SSDR_OK;
+}
 /* the library's own stream (what stream == NULL means everywhere), e.g. to wrap it as a framework's external stream */
 int ssdr_main_stream(void** out_stream) {
     if (!out_stream) { ssdr::set_error("main_stream: NULL"); return SSDR_ERR_INVALID; }

@@ -53,6 +53,7 @@ def lib():
         L.ssdr_init.argtypes = [i32]
         L.ssdr_stream_sync.argtypes = [vp]
         L.ssdr_stream_create.argtypes = [C.POINTER(vp)]
+        L.ssdr_stream_create_priority.argtypes = [C.POINTER(vp), i32]
         L.ssdr_stream_destroy.argtypes = [vp]
         L.ssdr_stream_wait.argtypes = [vp, vp]
         L.ssdr_knn.argtypes = [vp, sz, sz, vp, sz, sz, vp]

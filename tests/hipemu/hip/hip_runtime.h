@@ -265,6 +265,8 @@ static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; retur
 static inline hipError_t hipStreamCreate(hipStream_t* s) { static uintptr_t next = 0; *s = (void*)__atomic_add_fetch(&next, 16, __ATOMIC_SEQ_CST); return hipSuccess; }
 #define hipStreamNonBlocking 1
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
