@@ -36,7 +36,9 @@ namespace {
 constexpr int FE_NBMAX = 16384;      // buckets per cloud: the count / scatter kernels keep one LDS word per bucket (64 KiB)
 constexpr int FE_CH = 32768;         // points per chunk of the count / scatter kernels
 constexpr int FE_NT = 1024;          // their workgroup size
-constexpr int FE_PPT = 4;            // points per thread and step of the scatter (their loads are issued together)
+constexpr int FE_PPT = 12, FE_SNT = 1024;      // points per thread and step of the scatter, its workgroup size: 12288 points per step leave ~12 records = three
+                                              // whole lines in a bucket at a time, and one workgroup per CU halves the lines the L2 has open (PPT 4: 0.51 ms, 8: 0.44, 12: 0.36;
+                                              // 512 threads x 24 the same, x 32 = the whole chunk in one step spills: 0.37)
 constexpr int FE_LR = 64;            // local rows (y, z) of a bucket: 8 x 8
 constexpr int FE_VMAX = 1024;        // voxels per bucket (sx <= 4)
 constexpr int FE_RNT = 256;          // workgroup size of the reduction
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(FE_NT) void fe_bscan(FeTab t, const FeGeom* __restr
 }
 
 // second read of the points: packed records behind the LDS cursors of this chunk, FE_PPT points per thread and step (their loads issued
-// together).  The kernel runs at the rate the memory system takes scattered 32-byte writes (~1 TB/s of them): issuing a step's loads ahead
-// of the previous step's stores changed nothing.  FD / LD >= 0: row layout known at compile time (straight-line loads).
+// together).  The kernel runs at the rate the memory system takes scattered 32-byte writes: what helps is more records per bucket and step (lines
+// complete before the L2 drops them); issuing a step's loads ahead of the previous step's stores changed nothing.  FD / LD >= 0: row layout known at compile time (straight-line loads).
 struct FePoint { float x, y, z; uint32_t w[4]; };
 template <int FD, int LD>
 __device__ __forceinline__ FePoint fe_load_point(const float* __restrict__ Pr, const float* __restrict__ Fr, const int* __restrict__ Cr, int fdim, int ldim, int i) {
@@ -217,7 +219,7 @@ __device__ __forceinline__ FePoint fe_load_point(const float* __restrict__ Pr, c
     return pt;
 }
 template <int FD, int LD>
-__global__ __launch_bounds__(FE_NT) void fe_scatter(FeTab t, const float* __restrict__ P, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim,
+__global__ __launch_bounds__(FE_SNT) void fe_scatter(FeTab t, const float* __restrict__ P, const float* __restrict__ F, int fdim, const int* __restrict__ cls, int ldim,
                                                     const FeGeom* __restrict__ geom, const unsigned* __restrict__ cntm, const unsigned* __restrict__ boff, uint4* rec) {
     __shared__ unsigned s_cur[FE_NBMAX];
     const int r = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(FE_NT) void fe_scatter(FeTab t, const float* __rest
     if (!g.ok || c * FE_CH >= g.n) return;
     const unsigned* row = cntm + ((size_t)r * t.chunks_max + c) * FE_NBMAX;
     const unsigned* bo = boff + (size_t)r * (FE_NBMAX + 1);
-    for (int b = tid; b < g.nb; b += FE_NT) s_cur[b] = bo[b] + row[b];
+    for (int b = tid; b < g.nb; b += FE_SNT) s_cur[b] = bo[b] + row[b];
     __syncthreads();
     const size_t o = (size_t)t.off[r];
     const float* Pr = P + 3 * o;
@@ -233,13 +235,13 @@ __global__ __launch_bounds__(FE_NT) void fe_scatter(FeTab t, const float* __rest
     const int* Cr = cls ? cls + o * ldim : nullptr;
     uint4* R = rec + 2 * o;
     const int lo = c * FE_CH, hi = min(g.n, (c + 1) * FE_CH);
-    for (int i0 = lo; i0 < hi; i0 += FE_NT * FE_PPT) {
+    for (int i0 = lo; i0 < hi; i0 += FE_SNT * FE_PPT) {
         FePoint cur[FE_PPT];
 #pragma unroll
-        for (int k = 0; k < FE_PPT; ++k) cur[k] = fe_load_point<FD, LD>(Pr, Fr, Cr, fdim, ldim, min(i0 + k * FE_NT + tid, hi - 1));
+        for (int k = 0; k < FE_PPT; ++k) cur[k] = fe_load_point<FD, LD>(Pr, Fr, Cr, fdim, ldim, min(i0 + k * FE_SNT + tid, hi - 1));
 #pragma unroll
         for (int k = 0; k < FE_PPT; ++k) {
-            const int i = i0 + k * FE_NT + tid;
+            const int i = i0 + k * FE_SNT + tid;
             int ix, iy, iz;
             if (i < hi && fe_voxel(g, cur[k].x, cur[k].y, cur[k].z, ix, iy, iz)) {
                 const unsigned slot = atomicAdd(&s_cur[fe_bucket(g, ix, iy, iz)], 1u);
@@ -685,10 +687,10 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     hipLaunchKernelGGL(fe_colscan, dim3(FE_NBMAX / BS, R), dim3(BS), 0, s, t, geom, S.cntm.as<unsigned>(), S.tot.as<unsigned>());
     hipLaunchKernelGGL(fe_bscan, dim3(R), dim3(FE_NT), 0, s, t, geom, S.tot.as<unsigned>(), S.boff.as<unsigned>(), items, counters);
     if (fdim == 3 && ldim == 1)
-        hipLaunchKernelGGL((fe_scatter<3, 1>), dim3(t.chunks_max, R), dim3(FE_NT), 0, s, t, d_p, d_f, (int)fdim, (const int*)d_c, (int)ldim, geom, S.cntm.as<unsigned>(), S.boff.as<unsigned>(),
+        hipLaunchKernelGGL((fe_scatter<3, 1>), dim3(t.chunks_max, R), dim3(FE_SNT), 0, s, t, d_p, d_f, (int)fdim, (const int*)d_c, (int)ldim, geom, S.cntm.as<unsigned>(), S.boff.as<unsigned>(),
                            S.rec.as<uint4>());
     else
-        hipLaunchKernelGGL((fe_scatter<-1, -1>), dim3(t.chunks_max, R), dim3(FE_NT), 0, s, t, d_p, d_f, (int)fdim, (const int*)d_c, (int)ldim, geom, S.cntm.as<unsigned>(), S.boff.as<unsigned>(),
+        hipLaunchKernelGGL((fe_scatter<-1, -1>), dim3(t.chunks_max, R), dim3(FE_SNT), 0, s, t, d_p, d_f, (int)fdim, (const int*)d_c, (int)ldim, geom, S.cntm.as<unsigned>(), S.boff.as<unsigned>(),
                            S.rec.as<uint4>());
     FeRedArgs ra; ra.t = t; ra.items = items; ra.prm = prm; ra.counters = counters; ra.rcp = S.rcp.as<float>(); ra.rec = S.rec.as<uint4>();
     ra.nocc = S.nocc.as<unsigned>(); ra.trow = S.trow.as<unsigned>(); ra.lrc = S.lrc.as<unsigned char>(); ra.fdim = (int)fdim; ra.ldim = (int)ldim;
