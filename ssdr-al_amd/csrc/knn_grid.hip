@@ -327,7 +327,7 @@ __device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __
 // job.job1 >= 0 (pyramid): the K = 1 job over the first n1 support points is answered in the same scan when its nearest prefix point
 // lies inside the guaranteed radius and clear of the runner-up; otherwise that job's own (coarser) grid answers the row in its retry pass.
 template <int K, typename OutT>
-__global__ __launch_bounds__(256) void grid_search_kernel(GridSearchArgs a) {
+__global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(5) void grid_search_kernel(GridSearchArgs a) {      // 94 registers instead of 106: five waves per SIMD, no spills (six spill: slower)
     int bx, by; xcd_tile_map(bx, by);          // a job's support set (one tile's records and cell table) into one XCD's L2
     const int jid = a.job0 + by;
     const GridJob job = a.jobs[jid];

@@ -15,6 +15,13 @@
 #define SSDR_DYN_SHARED(type, name) extern __shared__ type name[]
 #endif
 
+// register budget of a kernel: at least n waves per SIMD (the allocator's own choice is sometimes one short of the next occupancy step)
+#ifndef HIPEMU
+#define SSDR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#else
+#define SSDR_WAVES_PER_EU(n)
+#endif
+
 namespace ssdr {
 
 void set_error(const char* fmt, ...);
