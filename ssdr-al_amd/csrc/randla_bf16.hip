@@ -206,7 +206,7 @@ template <int IMM> static inline float buf_load(rsrc_t r, unsigned voff) { retur
 #endif
 
 template <int D, bool SECOND, int TERMS>
-__global__ __launch_bounds__(LfaBf16Cfg<D>::NT) void lfa_bf16_kernel(LfaArgs a) {
+__global__ __launch_bounds__(LfaBf16Cfg<D>::NT) SSDR_WAVES_PER_EU((D == 256 && !SECOND) ? 4 : 1) void lfa_bf16_kernel(LfaArgs a) {      // (d = 256, first half: 127 registers instead of 166, 4 waves per SIMD: 90 -> 74 us)
     using C = LfaBf16Cfg<D>;
     constexpr int H = C::H, PTS = C::PTS, ROWS = C::ROWS, LDX = C::LDX, NT = C::NT, NCG = C::NCG, PW = C::PW, NCH = C::NCH, NCT1 = C::NCT1;
     SSDR_DYN_SHARED(float, smem);

@@ -330,7 +330,7 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 #endif
 }
 
-constexpr int CH_TILE = 1536;   // target points staged per step (36 KiB of float64 coordinates)
+constexpr int CH_TILE = 768;    // target points staged per step (18 KiB of float64 coordinates)
 constexpr int PACK_MAX = 4096;  // superpoints of one cloud the packer lays out (two int tables in LDS)
 constexpr int ITEM = 256;       // source points one wave takes against a target
 constexpr int NV = ITEM / 64;   // ... per lane
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__
 }
 // all clouds of a batch in one launch: blockIdx.z = cloud, coff[c] = first row of cloud c in sel / centres, boff[c] = first
 // element of its n_c x n_c blocks in dir / adj
-__global__ __launch_bounds__(256) void sel_chamfer_dir_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+__global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(5) void sel_chamfer_dir_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                              const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
                                                              const double* __restrict__ centres, double* dir, ChamferPack P) {
     __shared__ double tb[CH_TILE * 3];
