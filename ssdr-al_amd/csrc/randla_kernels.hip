@@ -213,7 +213,7 @@ template <int D> struct LfaCfg {
     static constexpr int H = D / 2;
     // points per workgroup: small enough that 3-5 workgroups share a CU's LDS at the low levels (their phases are
     // latency-bound gathers), large enough at d >= 256 that a W element fetched from L2 serves several points
-    static constexpr int PTS = D == 16 ? 16 : (D == 64 ? 8 : (D == 128 ? 4 : (D == 256 ? 4 : 2)));      // re-measured after the gather fix: 8/4/2/2 variants within 2 %
+    static constexpr int PTS = D == 16 ? 8 : (D == 64 ? 8 : (D == 128 ? 4 : (D == 256 ? 4 : 2)));      // re-measured after the gather fix: 8/4/2/2 variants within 2 %
     static constexpr int ROWS = PTS * 16;
     static constexpr bool WIDE = D >= 64;                              // 16-byte operand fetches in the attention GEMM
     static constexpr int LD = WIDE ? D + 4 : D + 2;                    // LDS row stride: 16-byte aligned rows (WIDE) / == 2 (mod 32): conflict-free 4-byte A reads
