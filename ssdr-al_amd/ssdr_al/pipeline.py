@@ -144,6 +144,7 @@ class HotPath:
             a = int(min(share[i], left)); left -= a
             sq += (a + int(nlab[i])) ** 2
         self._sel_static = dict(
+            lab_cloud=np.repeat(np.arange(B, dtype=np.int64), nlab), lab_sp_h=lab_sp[:-1].astype(np.int64),
             d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)), d_base=DevArray.from_host(base.astype(np.int32)),
             d_lab_off=DevArray.from_host(lab_off), d_lab_sp=DevArray.from_host(lab_sp), n_lab=int(nlab.sum()), batch=batch, picks=picks, cap_unl=max(cap_unl, 1),
             cap_rows=max(cap_rows, 1), cap_nmax=max(int((share + nlab).max()) if B else 1, 1), cap_sq=max(int(sq), 1),
@@ -241,13 +242,15 @@ class HotPath:
         The order is canonical: the reference's own depends on a shuffled DataLoader (sampler2.py:323) and carries no meaning."""
         order = np.asarray(order, np.int64)
         cand = order[valid[order]]                            # labelled regions never compete
-        in_top = np.arange(len(cand)) < min(batch_size, len(order))
         c = cloud[cand]
-        grp = np.argsort(c, kind="stable")                    # cloud ascending, descending uncertainty inside a cloud
-        cand, in_top, c = cand[grp], in_top[grp], c[grp]
         nc = int(cloud.max()) + 1 if len(cloud) else 0
-        ntop = np.bincount(c[in_top], minlength=nc)           # selected_num per cloud (len(file_list_top[cloud]))
-        first = np.searchsorted(c, np.arange(nc))
+        ntop = np.bincount(c[: min(batch_size, len(order))], minlength=nc)      # selected_num per cloud (len(file_list_top[cloud])): the first batch_size candidates are "top"
+        # cloud ascending, descending uncertainty inside a cloud (a stable sort of 16-bit keys is a radix sort in NumPy: the sharded run ranks
+        # the regions of ALL ranks here, 8 x as many on 8 GPUs)
+        grp = np.argsort(c.astype(np.uint16) if nc <= 65536 else c, kind="stable")
+        cand, c = cand[grp], c[grp]
+        counts = np.bincount(c, minlength=nc)
+        first = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64) if nc else np.zeros(0, np.int64)
         pos = np.arange(len(cand)) - first[c]
         take = pos < 2 * ntop[c]                              # candidates = first 2 x selected_num of the cloud (:748)
         return cand[take], c[take], int(ntop.sum())
@@ -273,7 +276,7 @@ class HotPath:
             return
         if self.global_order is None:          # (the D2H below runs on the selection stream, which already waits for the scoring stream's work)
             cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(st), ~self.labeled_mask, self.sp_cloud_h, self.select_per_tile * self.B)
-            unl = [(int(b), int(s)) for b, s in zip(ccloud, cand)]
+            unl_c, unl_s = np.asarray(ccloud, np.int64), np.asarray(cand, np.int64)
             gl_room = np.asarray(self.room_ids, np.int64)[ccloud]; gl_sp = cand - np.asarray(self.sp_base, np.int64)[ccloud]
             counts_r = None
         else:       # every rank derives the global candidate list from the global ranking, then keeps its own rows
@@ -282,20 +285,20 @@ class HotPath:
             r_of = gcand // D["Smax"]
             counts_r = np.bincount(r_of, minlength=comm.world)
             mine = r_of == comm.rank
-            unl = [(int(b), int(s)) for b, s in zip(gcloud[mine] - comm.rank * D["Bmax"], gcand[mine] - comm.rank * D["Smax"])]
+            unl_c, unl_s = (gcloud[mine] - comm.rank * D["Bmax"]).astype(np.int64), (gcand[mine] - comm.rank * D["Smax"]).astype(np.int64)
             gl_room, gl_sp = D["room"][gcand], D["spin"][gcand]
-        lab = [(b, s) for b in sorted(self.labeled) for s in sorted(self.labeled[b])]
-        refs = unl + lab
-        sel = np.array([s for _, s in refs], np.int32)
+        unl = list(zip(unl_c.tolist(), unl_s.tolist()))          # (cloud, superpoint) of this rank's candidates
+        lab_c, lab_s = T["lab_cloud"], T["lab_sp_h"]              # the labelled regions, cloud by cloud, ascending superpoint id (static)
+        sel = np.concatenate([unl_s, lab_s]).astype(np.int32)
         # every cloud's chamfer graph and propagation hop in one batched call (rows grouped cloud by cloud)
-        ref_cloud = np.fromiter((c for c, _ in refs), np.int64, len(refs))
+        ref_cloud = np.concatenate([unl_c, lab_c])
         order = np.argsort(ref_cloud, kind="stable").astype(np.int32)
         clouds, counts = np.unique(ref_cloud, return_counts=True)
         counts = counts.astype(np.int64)
         coff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         boff = np.concatenate([[0], np.cumsum(counts * counts)]).astype(np.int64)
         ntot, nmax, nsq = int(coff[-1]), int(counts.max()), int(boff[-1])
-        n_unl = len(unl)
+        n_unl = len(unl_s)
         src = np.zeros(0, np.int32)
         if counts_r is not None:     # exchange 3 is padded to nu_max rows per rank: positions of the real rows in the gathered array
             src = np.concatenate([r * self.global_order["nu_max"] + np.arange(c) for r, c in enumerate(counts_r)]).astype(np.int32)
@@ -324,7 +327,7 @@ class HotPath:
             src_v = dst
         keep = [d_pack, d_cen, d_dir, d_adj, d_v, d_tmp, d_mf, d_comb]
         self.unl_cloud_ids, self.unl_sp = gl_room, gl_sp          # (room id, superpoint inside its room) of every candidate, global order
-        n_lab = len(lab)
+        n_lab = len(lab_s)
         if comm is not None:                                 # exchange 3: the candidates' propagated features, on the selection stream
             D = self.global_order
             kc = self.selector == "kcenter"                  # k-center also needs the labelled regions' rows of every rank
