@@ -1494,7 +1494,12 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
     }
-    if (n <= 16384) {     // one CU sweeps the candidates faster than a launch per iteration costs
+#ifndef HIPEMU
+    const bool coop_ok = !d_n && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2);
+#else
+    const bool coop_ok = false;
+#endif
+    if (n <= 16384 && !coop_ok) {     // one CU sweeps the candidates faster than a launch per iteration costs
         if (D == 32) hipLaunchKernelGGL((fps_block<32>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
         else hipLaunchKernelGGL((fps_block<0>), dim3(1), dim3(1024), 0, s, d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
         SSDR_HIP(hipGetLastError());

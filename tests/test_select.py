@@ -151,6 +151,19 @@ def test_fps_and_kcenter_golden(backend, golden):
     assert kc.select_batch_(g["kc/already"], 30) == list(g["kc/seq"])
 
 
+@pytest.mark.parametrize("n,count", [(1537, 300), (4736, 600)])
+def test_fps_mid_sizes_against_the_oracle(backend, n, count):
+    """Candidate sets between the register-resident single workgroup (n <= 1536) and 16384 rows — the sharded run's replicated global FPS
+    (2 / 4 / 8 ranks: 2368 / 4736 / 9472 candidates) — take the cooperative multi-workgroup kernel on the GPU (the single-workgroup sweep
+    on the CPU logic build): the sequence is the oracle's, index for index."""
+    from ssdr_al import sampler
+    if backend == "emu":
+        n, count = min(n, 1800), min(count, 40)
+    f = np.random.default_rng(n).normal(size=(n, 32))
+    f[n // 3] = f[n // 5]                                   # an exact duplicate: a tie the arg-max settles by index
+    assert np.array_equal(sampler.farthest_features_sample(f, count, 7), O.farthest_features_sample(f, count, 7))
+
+
 def test_compute_features_mean_golden(backend, golden):
     """np.mean(last_second_features[dominant_point_ids], axis=0) (sampler2.py:333, :339) with the reference's own _dominant_2 ids."""
     from ssdr_al import sampler
