@@ -1017,6 +1017,102 @@ __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
 }
 #endif
 
+// The same chain for 32-d features with every workgroup's rows IN REGISTERS (two rows per thread, 512 per workgroup) and partials that carry the candidate's
+// features: a pick costs one publish (the owner's row through LDS, one 272-byte write-through store by 34 lanes, drained, counter) and ONE round of loads
+// (every workgroup reads all G partials, features included, into LDS and finds the winner there) instead of three dependent rounds (partials, the winner's
+// row from the feature table, every row's features from L2).  This is the replicated global FPS of the sharded run (2 / 4 / 8 ranks: 2368 / 4736 / 9472 rows).
+#ifndef HIPEMU
+constexpr int FR_NT = 256, FR_RPT = 2, FR_ROWS = FR_NT * FR_RPT, FR_REC = 34;        // record: v, (i, pad), f[32] as 34 doubles
+__global__ __launch_bounds__(FR_NT) void fps_coop_reg(FpsCoopArgs a) {
+    extern __shared__ double s_all[];                      // [G][FR_REC]: the partials of a pick, as read
+    __shared__ double s_v[FR_NT / 64]; __shared__ int s_i[FR_NT / 64]; __shared__ double s_fc[32]; __shared__ double s_pub[FR_REC];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G;
+    double reg[FR_RPT][32], rmin[FR_RPT];
+#pragma unroll
+    for (int q = 0; q < FR_RPT; ++q) {
+        const long i = (long)g * FR_ROWS + q * FR_NT + tid;
+        rmin[q] = i < a.n ? a.mind[i] : -1.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) reg[q][k] = i < a.n ? a.f[(size_t)i * 32 + k] : 0.0;
+    }
+    auto block_argmax = [&](double v, int i, double& ov, int& oi) {
+        wave_argmax(v, i);
+        if (lane == 0) { s_v[wid] = v; s_i[wid] = i; }
+        __syncthreads();
+        ov = s_v[0]; oi = s_i[0];
+#pragma unroll
+        for (int w = 1; w < FR_NT / 64; ++w) if (better(s_v[w], s_i[w], ov, oi)) { ov = s_v[w]; oi = s_i[w]; }
+        __syncthreads();
+    };
+    int c;
+    if (!a.from_partials) c = a.start;
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < a.npart; k += FR_NT) if (better(a.pin[k].v, a.pin[k].i, v, i)) { v = a.pin[k].v; i = a.pin[k].i; }
+        double ov; block_argmax(v, i, ov, c);
+    }
+    if (tid < 32) s_fc[tid] = a.f[(size_t)c * 32 + tid];    // the first centre's row comes from the table
+    __syncthreads();
+    double* recs = reinterpret_cast<double*>(a.part);      // [2][G][FR_REC]
+    for (int it = 0; it < a.count; ++it) {
+        if (g == 0 && tid == 0) a.out[it] = c;
+        if (it + 1 == a.count) break;
+        double bv = -1.0; int bi = 0x7fffffff, bq = 0;
+#pragma unroll
+        for (int q = 0; q < FR_RPT; ++q) {
+            const int i = g * FR_ROWS + q * FR_NT + tid;
+            if (i < a.n) {
+                double dist = np_pairwise_fixed<32>([&](int k) { const double d = reg[q][k] - s_fc[k]; return d * d; });
+                if (a.use_sqrt) dist = sqrt(dist);
+                if (dist < rmin[q]) rmin[q] = dist;
+                if (better(rmin[q], i, bv, bi)) { bv = rmin[q]; bi = i; bq = q; }
+            }
+        }
+        double wv; int wi;
+        block_argmax(bv, bi, wv, wi);
+        // the owner of the workgroup's best row lays the record out in LDS ...
+        if (wi == bi && bi != 0x7fffffff) {
+            s_pub[0] = wv; s_pub[1] = __longlong_as_double((long long)(unsigned)wi);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s_pub[2 + k] = bq == 0 ? reg[0][k] : reg[1][k];
+        } else if (wi == 0x7fffffff && tid == 0) { s_pub[0] = -1.0; s_pub[1] = __longlong_as_double(0x7fffffffll); }      // a workgroup of padding rows only
+        __syncthreads();
+        const int par = it & 1;
+        double* mine = recs + ((size_t)par * G + g) * FR_REC;
+        if (tid < 64) {
+            // ... and one wave writes it through (sc1), drains, then arrives: no cache write-back / invalidate on either side
+            if (tid < FR_REC) __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + tid), (unsigned long long)__double_as_longlong(s_pub[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&a.sync[par], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int want = G * (it / 2 + 1);
+                long spins = 0;
+                while (__hip_atomic_load(&a.sync[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1L << 26)) { atomicOr(&a.sync[2], 1); break; }       // a workgroup never arrived (not co-resident?): flagged, not hung
+                }
+            }
+        }
+        __syncthreads();
+        // every partial, features included, in ONE round of loads
+        const double* all = recs + (size_t)par * G * FR_REC;
+        for (int k = tid; k < G * FR_REC; k += FR_NT)
+            s_all[k] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(all + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < G; k += FR_NT) {
+            const double pv = s_all[(size_t)k * FR_REC]; const int pi = (int)(unsigned)__double_as_longlong(s_all[(size_t)k * FR_REC + 1]);
+            if (better(pv, pi, v, i)) { v = pv; i = pi; }
+        }
+        double ov; block_argmax(v, i, ov, c);
+        // the winner's row: the record of the workgroup that owns row c
+        const int wg = c / FR_ROWS;
+        if (tid < 32) s_fc[tid] = s_all[(size_t)wg * FR_REC + 2 + tid];
+        __syncthreads();
+    }
+}
+#endif
+
 // farthest_superpoint_sample (sampler2.py:49-80, the "edcd" branch): FPS over one cloud's superpoints with the
 // distance |centre_i - centre_c|^2 + CD(i, c), CD = dir + dir^T from sel_chamfer_dir.  One workgroup, n <= a few thousand.
 __global__ __launch_bounds__(256) void fps_superpoint(const double* __restrict__ centres, const double* __restrict__ dir, int n, int start, int count, int* out) {
@@ -1506,6 +1602,18 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         return SSDR_OK;
     }
 #ifndef HIPEMU
+    if (!d_n && D == 32 && n <= (size_t)FR_ROWS * (size_t)(ctx().num_cu / 2)) {       // rows in registers, partials that carry the candidate's features
+        const int G = (int)((n + FR_ROWS - 1) / FR_ROWS);
+        SSDR_TRY(Q.vtmp.reserve(8 * 2 * (size_t)G * FR_REC + 64));
+        Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(Q.vtmp.as<char>() + 8 * 2 * (size_t)G * FR_REC);
+        SSDR_HIP(hipMemsetAsync(sync, 0, 16, s));
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * FR_REC * 128); });
+        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G};
+        hipLaunchKernelGGL(fps_coop_reg, dim3(G), dim3(FR_NT), 8 * (size_t)G * FR_REC, s, a);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     if (!d_n && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) {          // one launch: co-resident workgroups meeting at a counter per pick
         const int G = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
         SSDR_TRY(Q.vtmp.reserve(sizeof(Part) * 2 * (size_t)G + 64));
