@@ -353,6 +353,16 @@ class HotPath:
             keep += [d_gath, d_glob]
             d_comb = d_glob
             self._comb_dev, self._comb_n = d_glob, n_rows
+        emu = int(os.environ.get("SSDR_EMULATE_WORLD", "0"))
+        if emu > 1 and comm is not None and self.selector != "kcenter":
+            # development: the FPS LOAD of `emu` ranks on one GPU (the replicated global chain is N^2: N x the rows, N x the picks) — the rows are
+            # repeated, the picks beyond the real ones are ties; only the timing means anything (tools/gpu_emulate_world.sh)
+            idx = np.tile(np.arange(n_unl, dtype=np.int32), emu)
+            d_idx = DevArray.from_host(idx, st); d_big = DevArray((emu * n_unl, 32), np.float64)
+            _lib.check(L.ssdr_gather_rows_dev(d_comb.ptr, d_idx.ptr, emu * n_unl, 32 * 8, d_big.ptr, st))
+            keep += [d_idx, d_big]
+            d_comb, n_unl, sampling_batch = d_big, emu * n_unl, emu * sampling_batch
+            self._emu_mod = len(idx) // emu
         d_out = DevArray((sampling_batch,), np.int32)
         if self.selector == "kcenter":
             d_already = DevArray.from_host((n_unl + np.arange(n_lab)).astype(np.int32), st); keep.append(d_already)
@@ -393,6 +403,8 @@ class HotPath:
         _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream, wait=not self.pipelined)
         if not self.pipelined:                               # sequential use: the front end of this batch has finished, ask it too
             _lib.check(_lib.lib().ssdr_grid_subsample_status(self.front_stream if self.front_stream is not None else self.stream, None))
+        if getattr(self, "_emu_mod", 0):                    # (SSDR_EMULATE_WORLD: the picks index the repeated rows)
+            sel = sel % self._emu_mod
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
         return sel, unl
 
