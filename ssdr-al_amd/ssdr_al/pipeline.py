@@ -449,7 +449,7 @@ class Pipelined:
     STAGES = ("front", "knn", "infer", "score")
     GROUPS = {2: (0, 0, 0, 0), 3: (0, 1, 1, 1), 4: (0, 0, 1, 2), 5: (0, 1, 2, 3)}     # stage -> stream group
 
-    def __init__(self, make_hot_path, depth=5, groups=None, overlap_select=True):
+    def __init__(self, make_hot_path, depth=5, groups=None, overlap_select=True, sel_lag=1):
         """groups: optional stage -> stream-group tuple for (front, knn, infer, score), non-decreasing from 0; depth = last group + 2"""
         if groups is not None:
             depth = groups[-1] + 2
@@ -472,11 +472,18 @@ class Pipelined:
         self.sel_streams = [None]                            # selections alternate between the library stream and one of their own
         if overlap_select:
             self.sel_streams.append(mkstream())
+        # sel_lag: how many selections behind the newest the host waits for (1: the previous batch's).  The sharded run's replicated global FPS
+        # grows with the square of the rank count: from 4 ranks on a chain is longer than two steps, and sel_lag = 2 keeps
+        # three chains in flight on three streams, with one more buffer set so that no stage overwrites what a running selection reads
+        self.sel_lag = max(1, int(sel_lag)) if overlap_select else 1
+        for _ in range(self.sel_lag - 1):
+            self.sel_streams.append(mkstream())
         self._uncollected = None
+        self._issued = []                                    # selections enqueued, not collected yet (oldest first)
         self.lead = {n: depth - 1 - g for n, g in self.group.items()}      # batches ahead of the selection
         # one buffer set per batch in flight (a spare set, so that no stage has to wait for the previous selection's buffers, was
         # measured slower: 127 vs 137 Mpoints/s — a sixth working set in the caches costs more than the deferred front end)
-        self.slots = depth
+        self.slots = depth + self.sel_lag - 1
         self.hp = [make_hot_path() for _ in range(self.slots)]
         for h in self.hp:
             h.pipelined = True
@@ -517,7 +524,7 @@ class Pipelined:
         k0 = self._k if steady else 0
         last = None if steady else steps                     # batches >= last are never issued
         if k0 == 0:
-            self._uncollected = None
+            self._uncollected = None; self._issued = []
             for b in range(first if steady else min(steps, first)):      # prologue: fill the pipe
                 for name in self.STAGES:
                     if b < lead[name]:
@@ -533,32 +540,37 @@ class Pipelined:
                     break
                 for name in self.STAGES:
                     if b == k + lead[name]:
-                        if self.overlap_select and b - k == self.slots - 1:
-                            deferred.append((name, b))       # writes the buffer set of batch k - 1, whose selection may still run
+                        if self.overlap_select and b - k == self.slots - self.sel_lag:
+                            deferred.append((name, b))       # writes the buffer set of batch k - sel_lag, whose selection may still run
                         else:
                             self._stage(name, b)             # the buffer set of batch b was last read by select(b - depth), done
             if self.overlap_select:
-                if self._uncollected is not None:
-                    out = self.hp[self._uncollected % self.slots]._select_collect()
-                self._uncollected = k
+                self._issued.append(k)
+                while len(self._issued) > self.sel_lag:
+                    out = self.hp[self._issued.pop(0) % self.slots]._select_collect()
+                self._uncollected = self._issued[0] if self._issued else None
                 for name, b in deferred:
                     self._stage(name, b)
             else:
                 out = hk._select_collect()                   # ... and only then the host waits for the selection
         if steady:
             self._k = k0 + steps
-            if out is None and self._uncollected is not None:      # a one-step call right after the fill: nothing older to hand back
-                out = self.hp[self._uncollected % self.slots]._select_collect(); self._uncollected = None
+            if out is None and self._issued:                       # a short call right after the fill: nothing older to hand back
+                while self._issued:
+                    out = self.hp[self._issued.pop(0) % self.slots]._select_collect()
+                self._uncollected = None
         else:
-            if self.overlap_select and self._uncollected is not None:
-                out = self.hp[self._uncollected % self.slots]._select_collect(); self._uncollected = None
+            while self.overlap_select and self._issued:
+                out = self.hp[self._issued.pop(0) % self.slots]._select_collect()
+            self._uncollected = None
             self._drain()
         return out
 
     def finish(self):
         """end a steady run: wait for everything issued and forget the partially processed batches"""
-        if getattr(self, "_uncollected", None) is not None:
-            self.hp[self._uncollected % self.slots]._select_collect(); self._uncollected = None
+        while getattr(self, "_issued", None):
+            self.hp[self._issued.pop(0) % self.slots]._select_collect()
+        self._uncollected = None
         self._drain()
         from . import knn as _knn
         _knn.knn_status(self.streams[self.group["knn"]])     # everything has finished: the blocking checks

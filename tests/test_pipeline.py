@@ -109,6 +109,13 @@ def test_overlapped_batches_give_the_same_selection(backend, depth):
     for k in ((depth + 1,) if backend == "emu" else (1, 2, 5)):       # the emulator is slow: one run that fills and drains the pipe
         sel, _ = pipe.run(k)
         assert np.array_equal(sel, one)
+    if backend != "emu" and depth == 5:          # two selections behind the newest in flight (three selection streams, one more buffer set)
+        pipe2 = pipeline.Pipelined(make, depth, sel_lag=2)
+        for k in (1, 3, 8):
+            sel, _ = pipe2.run(k)
+            assert np.array_equal(sel, one)
+        pipe2.run(4, steady=True); sel, _ = pipe2.run(3, steady=True); pipe2.finish()
+        assert np.array_equal(sel, one)
 
 
 def test_semantic3d_configuration_matches_oracle(backend):
