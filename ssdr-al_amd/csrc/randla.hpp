@@ -32,6 +32,18 @@ struct LfaArgs {
     const uint16_t* l2_hi; const uint16_t* l2_lo; int kp2;
 };
 
+struct Lfa32Args {        // randla_lfa32.hip: the same operation on 32 x 32 tiles, softmax inside the lane
+    const float* xyz; size_t xyz_batch_stride;
+    const int* neigh;                 // [B][n][16]
+    const float* fin;                 // [B][n][H]  features gathered from the neighbours
+    const float* g;                   // [B][n][D]  fin W[0:H] (x log2 e)
+    float* out;                       // [B][n][D]
+    int n;
+    const uint16_t* w1p; const float* b1;                       // LocSE operand fragments [H][2][16] (7 reformulated inputs, hi | lo slots), bias
+    const uint16_t *w2_hi, *w2_lo; const float* b2;             // LFAmlp2 [H out][H k, permuted inside 16-blocks]
+    const uint16_t *fc_hi, *fc_lo;                              // attention, position half [D cols][H k, permuted], x log2 e
+};
+
 // arithmetic of the matrix products (ssdr_randla_set_precision)
 constexpr int PREC_F32 = 0;       // exact f32-input MFMA (v_mfma_f32_16x16x4_f32)
 constexpr int PREC_BF16X3 = 1;    // split bf16: hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16, fp32 accumulate
@@ -53,6 +65,7 @@ int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s);      // SSDR_E
 // randla_bf16.hip: the same two operations on the bf16 matrix cores (prec = PREC_BF16X3 / PREC_BF16)
 int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s);
 int launch_lfa_bf16(int D, const LfaArgs& a, bool second, int B, int prec, hipStream_t s);
+int launch_lfa32(int D, const Lfa32Args& a, bool second, int B, int prec, hipStream_t s);        // SSDR_ERR_UNSUPPORTED (no error text) for a D it has no instantiation for
 int launch_gather_max(const float* f, const int* idx, int n_in, int n_out, int idx_rows, int C, float* out, int B, hipStream_t s);
 int launch_tail(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
                 int M, int C, float* feat32, float* probs, hipStream_t s);

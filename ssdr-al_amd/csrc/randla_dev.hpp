@@ -39,12 +39,20 @@ template <class Op> __device__ __forceinline__ float combine_xor32(float v, Op o
     return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 #define SSDR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// 32x32x16 bf16: lane l (r = l&31, h = l>>5) holds A[row r][k = 8h+j], B[k = 8h+j][col r], j = 0..7; C/D col = l&31,
+// row = (reg&3) + 8(reg>>2) + 4h: the 16 registers of a lane are 16 rows of ONE column (reductions over rows stay inside the lane)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 #else
 typedef hipemu_f32x4 f32x4;
 typedef hipemu_u32x4 u32x4;
 typedef hipemu_u32x2 u32x2;
 static inline f32x4 mfma16(float a, float b, f32x4 c) { return hipemu_mfma_f32_16x16x4f32(a, b, c); }
 static inline f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) { return hipemu_mfma_f32_16x16x32_bf16(a, b, c); }
+typedef hipemu_f32x16 f32x16;
+static inline f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) { return hipemu_mfma_f32_32x32x16_bf16(a, b, c); }
 static inline unsigned pack_bf16(float a, float b) { return hipemu_bf16_rn(a) | (hipemu_bf16_rn(b) << 16); }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_exp2(float x) { return exp2f(x); }

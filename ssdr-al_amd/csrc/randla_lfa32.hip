@@ -1,0 +1,471 @@
+// The K-expanded half of RandLA-Net's building_block (RandLANet.py:514-527, :529-535, :572-585) on v_mfma_f32_32x32x16_bf16,
+// laid out so that everything that reduces over the 16 neighbours of a point stays inside one lane.
+//
+// A 32 x 32 accumulator tile holds its 16 registers of a lane in ONE column and 16 ROWS.  Rows are numbered so that the rows of a
+// lane are the 16 neighbours of one point: row r of a tile = (point (r >> 2) & 1, neighbour (r & 3) + 4 (r >> 3)) of a pair of
+// points, and register q of lane (column c, half h) is then (point h, neighbour q, channel c): softmax over the neighbours and the
+// weighted sum (att_pooling, :578-581) are 16-term loops over a lane's own registers — no lane exchanges, all 64 lanes store.
+//
+// The chain  rel -> LocSE conv -> (LFAmlp2) -> attention scores  never leaves the registers either: a product computed TRANSPOSED,
+// T = W^T X^T (A = weights, B = activations), leaves the 32 neighbour rows on the lanes and the channels in the registers, which is
+// the operand shape of the next product in either role (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's
+// operand"): as B it continues the transposed chain (T2 = W2^T T1), as A it gives the plain orientation (X2 = T1^T W2, scores =
+// T^T Wfc) with the channel back on the lane.  The k order inside a 16-wide step is permuted by that reuse (slot (h, j) is row
+// 8 (j >> 2) + 4 h + (j & 3)); the weights are stored in that order by the host (randla_model.hip, permuted_pieces).
+//
+// relative_pos_encoding (:529-535) enters as 7 inputs instead of 10: [|d|, d, p, p_nbr] W = |d| w0 + d (w1..3 - w7..9) + p (w4..6 + w7..9)
+// since p_nbr = p - d; hi and lo bf16 pieces of the 7 inputs fill the 16 k slots of ONE MFMA step, so the four products
+// (hi + lo)(Whi + Wlo) of the LocSE conv are two instructions.
+//
+// Weights: the position half of the attention matrix (rows H..D of W, x log2 e) and LFAmlp2 are staged through LDS in chunks of
+// <= 32 KB shared by the four waves of a workgroup (double buffered, one barrier per chunk); each wave owns one pair of points and
+// all D output columns.  The neighbour half of the scores arrives as gathered rows of G = f W[0:H] (one dense launch per point).
+#include "ssdr_internal.hpp"
+#include "randla.hpp"
+#include "randla_dev.hpp"
+#include <cmath>
+
+namespace ssdr {
+
+#ifndef HIPEMU
+typedef __amdgpu_buffer_rsrc_t rsrc32_t;
+__device__ __forceinline__ rsrc32_t make_rsrc32(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); }
+// per-lane byte offset + wave-uniform byte offset (an SGPR): one instruction, no address arithmetic per column tile
+__device__ __forceinline__ float buf_load_s(rsrc32_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0)); }
+#else
+struct rsrc32_t { const char* p; unsigned bytes; };
+static inline rsrc32_t make_rsrc32(const void* p, unsigned bytes) { return rsrc32_t{reinterpret_cast<const char*>(p), bytes}; }
+static inline float buf_load_s(rsrc32_t r, unsigned voff, unsigned soff) {      // out-of-range raw buffer loads return 0, as on the hardware
+    const unsigned long long o = (unsigned long long)voff + soff;
+    return o + 4 <= r.bytes ? *reinterpret_cast<const float*>(r.p + o) : 0.f;
+}
+#endif
+
+__device__ __forceinline__ u32x4 ld128g(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st128s(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+template <int D> struct Lfa32Cfg {
+    static constexpr int H = D / 2;
+    static constexpr int KS = H / 16;                                  // k steps of the products over H channels
+    static constexpr int HT = H / 32;                                  // 32-channel tiles per half
+    static constexpr int CT = D / 32;                                  // column tiles of the scores
+    static constexpr int CCF = D < 8192 / H ? D : 8192 / H;            // attention columns per staged chunk
+    static constexpr int CC2 = H < 8192 / H ? H : 8192 / H;            // LFAmlp2 output channels per staged chunk
+    static constexpr int NF = D / CCF, N2 = H / CC2;
+    static constexpr int RS = 2 * H + 16;                              // bytes per staged row: 16-byte slots rotate through the banks
+    static constexpr int NT = 256;
+    static constexpr size_t buf_bytes(int terms) { return (size_t)terms * CCF * RS; }
+    static constexpr size_t lds_bytes(int terms, bool second) { return buf_bytes(terms) * ((second ? N2 : 0) + NF > 1 ? 2 : 1); }
+    static constexpr int maxp(int terms) { return (terms * CCF * (H / 8) + NT - 1) / NT; }
+};
+
+template <int TERMS> __device__ __forceinline__ f32x16 mma32_split(const u32x4 (&a)[TERMS], const u32x4 (&b)[TERMS], f32x16 c) {
+    c = mfma32_bf16(a[0], b[0], c);
+    if constexpr (TERMS == 2) { c = mfma32_bf16(a[1], b[0], c); c = mfma32_bf16(a[0], b[1], c); }
+    return c;
+}
+
+// lrelu + bf16 pieces of an accumulator tile whose rows are channels: registers 8 s2 .. 8 s2 + 7 are the fragment of k step s2
+template <int TERMS> __device__ __forceinline__ void acc_to_frags(const f32x16& v, u32x4 (&f0)[TERMS], u32x4 (&f1)[TERMS]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        unsigned h, l;
+        split_bf16(lrelu(v[2 * jj]), lrelu(v[2 * jj + 1]), h, l); f0[0][jj] = h; if constexpr (TERMS == 2) f0[1][jj] = l;
+        split_bf16(lrelu(v[8 + 2 * jj]), lrelu(v[8 + 2 * jj + 1]), h, l); f1[0][jj] = h; if constexpr (TERMS == 2) f1[1][jj] = l;
+    }
+}
+
+// bias of 32 output channels ch0.. in the two accumulator layouts
+__device__ __forceinline__ f32x16 bias_rows(const float* b, int ch0, int lh) {       // channel = the register's row
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(b + ch0 + 8 * g + 4 * lh);
+        v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+    }
+    return v;
+}
+__device__ __forceinline__ f32x16 bias_cols(const float* b, int ch0, int lr) {       // channel = the lane's column
+    const float t = b[ch0 + lr];
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = t;
+    return v;
+}
+
+// the seven inputs of the reformulated position encoding of this lane's (point, neighbour) row as one operand fragment:
+// k slots [hi0..hi6, lo0 | lo1..lo6, 0, 0]
+template <int TERMS> __device__ __forceinline__ u32x4 rel_fragment(const float* xyz, int p, int j, int lh) {
+    const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
+    const float qx = xyz[3 * (size_t)j], qy = xyz[3 * (size_t)j + 1], qz = xyz[3 * (size_t)j + 2];
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    const float x[7] = {sqrtf(dx * dx + dy * dy + dz * dz), dx, dy, dz, px, py, pz};
+    const unsigned p01 = pack_bf16(x[0], x[1]), p23 = pack_bf16(x[2], x[3]), p45 = pack_bf16(x[4], x[5]);
+    u32x4 f;
+    if constexpr (TERMS == 2) {
+        const float r0 = x[0] - bf16_lo_f32(p01), r1 = x[1] - bf16_hi_f32(p01), r2 = x[2] - bf16_lo_f32(p23), r3 = x[3] - bf16_hi_f32(p23);
+        const float r4 = x[4] - bf16_lo_f32(p45), r5 = x[5] - bf16_hi_f32(p45);
+        const unsigned p6 = pack_bf16(x[6], r0);
+        const float r6 = x[6] - bf16_lo_f32(p6);
+        f[0] = lh ? pack_bf16(r1, r2) : p01; f[1] = lh ? pack_bf16(r3, r4) : p23; f[2] = lh ? pack_bf16(r5, r6) : p45; f[3] = lh ? 0u : p6;
+    } else {
+        f[0] = lh ? 0u : p01; f[1] = lh ? 0u : p23; f[2] = lh ? 0u : p45; f[3] = lh ? 0u : pack_bf16(x[6], 0.f);
+    }
+    return f;
+}
+
+// softmax over the 16 registers (scores in base-2 units) and the weighted sum of f: sum_q f_q 2^(s_q - m) / sum_q 2^(s_q - m)
+__device__ __forceinline__ float softmax_wsum(const f32x16& s, const float (&f)[16]) {
+    float m = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const float e = fast_exp2(s[q] - m); den += e; num = fmaf(f[q], e, num); }
+    return num * fast_rcp(den);
+}
+
+template <int D, bool SECOND, int TERMS>
+__global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
+    using C = Lfa32Cfg<D>;
+    constexpr int H = C::H, KS = C::KS, HT = C::HT, CT = C::CT, CCF = C::CCF, CC2 = C::CC2, NF = C::NF, N2 = SECOND ? C::N2 : 0, RS = C::RS;
+    constexpr int NCH = N2 + NF, MAXP = C::maxp(TERMS);
+    constexpr size_t BUFB = C::buf_bytes(TERMS), TERMB = (size_t)CCF * RS;
+    constexpr bool OFFREG = H <= 64;            // both gather offset tables in registers
+    constexpr bool W1REG = H <= 64;             // LocSE weight fragments in registers
+    SSDR_DYN_SHARED(float, smem);
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    int bx, b; xcd_tile_map(bx, b);
+    const int n = a.n, rt = bx * 4 + w;
+    const bool active = 2 * rt < n;             // wave-uniform: a wave past the end still stages weights and meets the barriers
+    const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
+    const int* neigh = a.neigh + (size_t)b * n * 16;
+
+    // ---- weight chunks through LDS ----------------------------------------------------------------------------------------------
+    u32x4 stg[MAXP];
+    auto stage_load = [&](int i) {
+        const bool is2 = SECOND && i < N2;
+        const int rows = is2 ? CC2 : CCF, per = rows * (H / 8);
+        const size_t base = is2 ? (size_t)i * CC2 * H : (size_t)(i - N2) * CCF * H;
+        const uint16_t* hi = (is2 ? a.w2_hi : a.fc_hi) + base; const uint16_t* lo = (is2 ? a.w2_lo : a.fc_lo) + base;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int e = tid + 256 * p;
+            if (e < TERMS * per) { const int t = e >= per ? 1 : 0; stg[p] = ld128g((t ? lo : hi) + (size_t)(e - t * per) * 8); }
+        }
+    };
+    auto stage_store = [&](int i, char* buf) {
+        const bool is2 = SECOND && i < N2;
+        const int rows = is2 ? CC2 : CCF, per = rows * (H / 8);
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int e = tid + 256 * p;
+            if (e < TERMS * per) { const int t = e >= per ? 1 : 0, r = e - t * per; st128s(buf + t * TERMB + (size_t)(r / (H / 8)) * RS + (r % (H / 8)) * 16, stg[p]); }
+        }
+    };
+    stage_load(0);
+
+    // ---- this lane's row of the position encoding, and its point's neighbour table -----------------------------------------------
+    u32x4 relf = {0u, 0u, 0u, 0u};
+    unsigned goff[16], foff[OFFREG ? 16 : 1];
+    const int pc = min(2 * rt + lh, n - 1);                    // the point whose 16 neighbours this lane's registers hold (column layout)
+    {
+        const int pr = min(2 * rt + ((lr >> 2) & 1), n - 1);   // the point of this lane's row (operand layout)
+        const int j = neigh[(size_t)pr * 16 + (lr & 3) + 4 * (lr >> 3)];
+        relf = rel_fragment<TERMS>(xyz, pr, j, lh);
+        const int4* nb4 = reinterpret_cast<const int4*>(neigh + (size_t)pc * 16);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int4 v = nb4[g4];
+            const int nb[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                goff[4 * g4 + r] = (unsigned)nb[r] * (unsigned)(D * 4) + (unsigned)lr * 4u;
+                if constexpr (OFFREG) foff[4 * g4 + r] = (unsigned)nb[r] * (unsigned)(H * 4) + (unsigned)lr * 4u;
+            }
+        }
+    }
+    const rsrc32_t rG = make_rsrc32(a.g + (size_t)b * n * D, (unsigned)n * D * 4u);
+    const rsrc32_t rF = make_rsrc32(a.fin + (size_t)b * n * H, (unsigned)n * H * 4u);
+    auto f_off = [&](int q) -> unsigned { if constexpr (OFFREG) return foff[q]; else return (goff[q] + (unsigned)lr * 4u) >> 1; };
+
+    // LocSE weights
+    u32x4 w1r[W1REG ? HT : 1][TERMS];
+    auto w1_frag = [&](int t, int term) { return ld128g(a.w1p + ((size_t)(32 * t + lr) * 2 + term) * 16 + 8 * lh); };
+    if constexpr (W1REG) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int term = 0; term < TERMS; ++term) w1r[t][term] = w1_frag(t, term);
+    }
+    auto w1_get = [&](int t, u32x4 (&f)[TERMS]) {
+#pragma unroll
+        for (int term = 0; term < TERMS; ++term) { if constexpr (W1REG) f[term] = w1r[t][term]; else f[term] = w1_frag(t, term); }
+    };
+
+    // ---- T1 = lrelu(W1^T rel^T + b1): channels in the registers, neighbour rows on the lanes (LFAmlp1, :518) ----------------------------
+    u32x4 Tf[KS][TERMS];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        u32x4 wf[TERMS]; w1_get(t, wf);
+        f32x16 acc = bias_rows(a.b1, 32 * t, lh);
+        acc = mfma32_bf16(wf[0], relf, acc);
+        if constexpr (TERMS == 2) acc = mfma32_bf16(wf[1], relf, acc);
+        acc_to_frags<TERMS>(acc, Tf[2 * t], Tf[2 * t + 1]);
+    }
+    auto x1_tile = [&](int t, float (&x)[16]) {               // the same product in the plain orientation: channel on the lane
+        u32x4 wf[TERMS]; w1_get(t, wf);
+        f32x16 acc = bias_cols(a.b1, 32 * t, lr);
+        acc = mfma32_bf16(relf, wf[0], acc);
+        if constexpr (TERMS == 2) acc = mfma32_bf16(relf, wf[1], acc);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = lrelu(acc[q]);
+    };
+
+    stage_store(0, lds);
+    float x2[SECOND ? HT : 1][16];
+    u32x4 T2f[SECOND ? KS : 1][TERMS];
+    auto score_frag = [&](int s) -> const u32x4 (&)[TERMS] { if constexpr (SECOND) return T2f[s]; else return Tf[s]; };
+
+    // first gathered rows of G (in flight across the LFAmlp2 pass)
+    float gn[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gn[q] = buf_load_s(rG, goff[q], 0u);
+
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        char* buf = lds + (size_t)(i & 1) * BUFB;
+        __syncthreads();                                       // chunk i is in place; everybody is done with the other buffer
+        if (i + 1 < NCH) stage_load(i + 1);
+        if (SECOND && i < N2) {
+            // ---- f_xyz <- lrelu(f_xyz W2 + b2) (LFAmlp2, :523) in both orientations from the same staged fragments ---------------------
+            if (active) {
+#pragma unroll
+                for (int tt = 0; tt < CC2 / 32; ++tt) {
+                    const int t2 = i * (CC2 / 32) + tt;
+                    f32x16 accT = bias_rows(a.b2, 32 * t2, lh), accX = bias_cols(a.b2, 32 * t2, lr);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        u32x4 wf[TERMS];
+#pragma unroll
+                        for (int term = 0; term < TERMS; ++term) wf[term] = ld128g(buf + term * TERMB + (size_t)(32 * tt + lr) * RS + (16 * s + 8 * lh) * 2);
+                        accT = mma32_split<TERMS>(wf, Tf[s], accT);
+                        accX = mma32_split<TERMS>(Tf[s], wf, accX);
+                    }
+                    if constexpr (SECOND) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) x2[t2][q] = lrelu(accX[q]);
+                        acc_to_frags<TERMS>(accT, T2f[2 * t2], T2f[2 * t2 + 1]);
+                    }
+                }
+            }
+        } else {
+            // ---- attention scores (:578), softmax over the 16 neighbours (:579), weighted sum (:580-581) ---------------------------------
+            if (active) {
+#pragma unroll
+                for (int uu = 0; uu < CCF / 32; ++uu) {
+                    const int u = (i - N2) * (CCF / 32) + uu;
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[q] = gn[q];
+                    if (u + 1 < CT) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) gn[q] = buf_load_s(rG, goff[q], (unsigned)(u + 1) * 128u);
+                    }
+                    float fv[16];
+                    if (u < HT) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) fv[q] = buf_load_s(rF, f_off(q), (unsigned)u * 128u);
+                    }
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        u32x4 wf[TERMS];
+#pragma unroll
+                        for (int term = 0; term < TERMS; ++term) wf[term] = ld128g(buf + term * TERMB + (size_t)(32 * uu + lr) * RS + (16 * s + 8 * lh) * 2);
+                        acc = mma32_split<TERMS>(score_frag(s), wf, acc);
+                    }
+                    if (u >= HT) {
+                        if constexpr (SECOND) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) fv[q] = x2[u - HT][q];
+                        } else x1_tile(u - HT, fv);
+                    }
+                    const float v = softmax_wsum(acc, fv);
+                    if (2 * rt + lh < n) a.out[((size_t)b * n + (size_t)(2 * rt + lh)) * D + 32 * u + lr] = v;
+                }
+            }
+        }
+        if (i + 1 < NCH) stage_store(i + 1, lds + (size_t)((i + 1) & 1) * BUFB);
+    }
+}
+
+
+// ---- level 0 (d = 16, h = 8): two pairs of points per tile ----------------------------------------------------------------------------
+// With 8 position channels the k dimension of a 16-deep MFMA step holds TWO independent problems: k slots 0..7 (the lanes of half 0)
+// carry the 8 inputs of point pair A, slots 8..15 those of pair B, and the weight operand is block diagonal — columns 0..15 are pair A's 16
+// output channels and see only slots 0..7, columns 16..31 are pair B's.  One 32 x 32 tile is then 4 points x 16 neighbours x 16 channels
+// with every lane busy: lane (column c, half h) register q = (point 2 (c >> 4) + h, neighbour q, channel c & 15).  The operand fragments
+// are lane-dependent constants of the layer, tabulated by the host (randla_model.hip, level0_tables): [fragment][64 lanes][8 bf16].
+// LocSE slot 7 carries the constant 1 against the bias row; the neighbour-feature columns (c & 15 < 8) of the "plain" product have zero
+// weights and start from the gathered feature, so one accumulator holds [f_nbr | f_xyz] in the layout of the weighted sum.
+constexpr int L0_TPW = 8;          // tiles (of 4 points) per wave
+
+template <bool SECOND, int TERMS>
+__global__ __launch_bounds__(256) void lfa32_l0_kernel(Lfa32Args a) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5, cc = lr & 15, sg = lr >> 4;
+    int bx, b; xcd_tile_map(bx, b);
+    const int n = a.n;
+    const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
+    const int* neigh = a.neigh + (size_t)b * n * 16;
+    auto tab = [&](const uint16_t* t, int f) { return ld128g(t + ((size_t)f * 64 + lane) * 8); };
+    u32x4 locT[TERMS], locX[TERMS], w2T[SECOND ? TERMS : 1], w2X[SECOND ? TERMS : 1], fcB[TERMS];
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) {
+        locT[t] = tab(a.w1p, t); locX[t] = tab(a.w1p, 2 + t);
+        fcB[t] = tab(t ? a.fc_lo : a.fc_hi, 0);
+        if constexpr (SECOND) { w2T[t] = tab(t ? a.w2_lo : a.w2_hi, 0); w2X[t] = tab(t ? a.w2_lo : a.w2_hi, 1); }
+    }
+    u32x4 onesA = {0u, 0u, 0u, 0u}, biasB = {0u, 0u, 0u, 0u};      // SECOND: the plain product's bias as a fourth product (1, 1 | hi, lo)
+    float b2r[8];
+    if constexpr (SECOND) {
+        if (lh == 0) { onesA[0] = 0x3f803f80u; if (cc >= 8) { const float bv = a.b2[cc - 8]; unsigned h, l; split_bf16(bv, 0.f, h, l); biasB[0] = (h & 0xffffu) | (TERMS == 2 ? (l << 16) : 0u); } }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b2r[q] = a.b2[q];
+    }
+    const float slope = cc < 8 ? 1.f : 0.2f;
+    const rsrc32_t rG = make_rsrc32(a.g + (size_t)b * n * 16, (unsigned)n * 64u);
+    const rsrc32_t rF = make_rsrc32(a.fin + (size_t)b * n * 8, (unsigned)n * 32u);
+    const unsigned fl = cc < 8 ? (unsigned)cc * 4u : 0x80000000u;      // position columns read out of range: 0
+    float* out = a.out + (size_t)b * n * 16;
+    const int g0 = ((int)bx * 4 + w) * L0_TPW;
+    for (int it = 0; it < L0_TPW; ++it) {
+        const int P0 = 4 * (g0 + it);
+        if (P0 >= n) break;                                            // wave-uniform
+        // this lane's (point, neighbour) row of the position encoding: hi pieces [x0..x6, 1], lo pieces [.., 0]
+        u32x4 rel[TERMS];
+        {
+            const int pr = min(P0 + 2 * lh + ((lr >> 2) & 1), n - 1);
+            const int j = neigh[(size_t)pr * 16 + (lr & 3) + 4 * (lr >> 3)];
+            const float px = xyz[3 * (size_t)pr], py = xyz[3 * (size_t)pr + 1], pz = xyz[3 * (size_t)pr + 2];
+            const float qx = xyz[3 * (size_t)j], qy = xyz[3 * (size_t)j + 1], qz = xyz[3 * (size_t)j + 2];
+            const float dx = px - qx, dy = py - qy, dz = pz - qz;
+            const float x[8] = {sqrtf(dx * dx + dy * dy + dz * dz), dx, dy, dz, px, py, pz, 1.f};
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                unsigned h, l; split_bf16(x[2 * k2], x[2 * k2 + 1], h, l);
+                rel[0][k2] = h; if constexpr (TERMS == 2) rel[1][k2] = l;
+            }
+        }
+        // the 16 neighbours of this lane's column point
+        const int pcu = P0 + 2 * sg + lh, pc = min(pcu, n - 1);
+        unsigned goff[16], foff[16];
+        {
+            const int4* nb4 = reinterpret_cast<const int4*>(neigh + (size_t)pc * 16);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int4 v = nb4[g4];
+                const int nb[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { goff[4 * g4 + r] = (unsigned)nb[r] * 64u + (unsigned)cc * 4u; foff[4 * g4 + r] = (unsigned)nb[r] * 32u + fl; }
+            }
+        }
+        f32x16 accS, accX;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { accS[q] = buf_load_s(rG, goff[q], 0u); accX[q] = buf_load_s(rF, foff[q], 0u); }
+        // T1 = lrelu(W1^T rel^T) (bias through slot 7): rows 0..15 = (pair, channel), the rest of the tile is idle
+        f32x16 accT;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accT[q] = 0.f;
+        accT = mma32_split<TERMS>(locT, rel, accT);
+        u32x4 Tf[TERMS];
+        auto to_frag = [&](const f32x16& v, u32x4 (&f)[TERMS]) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { unsigned h, l; split_bf16(lrelu(v[2 * jj]), lrelu(v[2 * jj + 1]), h, l); f[0][jj] = h; if constexpr (TERMS == 2) f[1][jj] = l; }
+        };
+        to_frag(accT, Tf);
+        if constexpr (SECOND) {
+            // f_xyz <- lrelu(f_xyz W2 + b2) (LFAmlp2, :523) in both orientations
+            f32x16 acc2;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc2[q] = q < 8 ? b2r[q] : 0.f;
+            acc2 = mma32_split<TERMS>(w2T, Tf, acc2);
+            accX = mfma32_bf16(onesA, biasB, accX);
+            accX = mma32_split<TERMS>(Tf, w2X, accX);
+            to_frag(acc2, Tf);
+        } else {
+            accX = mma32_split<TERMS>(rel, locX, accX);
+        }
+        float fv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) fv[q] = fmaxf(accX[q], accX[q] * slope);
+        accS = mma32_split<TERMS>(Tf, fcB, accS);
+        const float v = softmax_wsum(accS, fv);
+        if (pcu < n) out[(size_t)pcu * 16 + cc] = v;
+    }
+}
+
+static int launch_lfa32_l0(const Lfa32Args& a, bool second, int B, int prec, hipStream_t s) {
+    dim3 grid((unsigned)((a.n + 16 * L0_TPW - 1) / (16 * L0_TPW)), (unsigned)B);
+    const int terms = prec == PREC_BF16X3 ? 2 : 1;
+    const double rows = (double)B * (double)a.n * 16.0, np = terms == 2 ? 3.0 : 1.0;
+    // executed: every product is a 32 x 32 x 16 tile for 4 points (LocSE in both orientations, LFAmlp2 in both + its bias product, the scores)
+    const double exec = (double)B * std::ceil(a.n / 4.0) * 2.0 * 32 * 32 * 16 * (np * (second ? 4.0 : 3.0) + (second ? 1.0 : 0.0));
+    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * 8 + (second ? 2.0 * 8 * 8 : 0.0) + 2.0 * 16 * 16 + 2.0 * 16), exec);
+    if (terms == 2) {
+        if (second) hipLaunchKernelGGL((lfa32_l0_kernel<true, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((lfa32_l0_kernel<false, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        if (second) hipLaunchKernelGGL((lfa32_l0_kernel<true, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((lfa32_l0_kernel<false, 1>), grid, dim3(256), 0, s, a);
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+template <int D> static int launch_lfa32_d(const Lfa32Args& a, bool second, int B, int prec, hipStream_t s) {
+    using C = Lfa32Cfg<D>;
+    dim3 grid((unsigned)((a.n + 7) / 8), (unsigned)B);
+    const int terms = prec == PREC_BF16X3 ? 2 : 1;
+    const size_t lds = C::lds_bytes(terms, second);
+    static std::once_flag attr_once;
+    hipError_t ae = hipSuccess;
+    std::call_once(attr_once, [&] {
+        ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2, true));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2, false));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1, true));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1, false));
+    });
+    SSDR_HIP(ae);
+    const double rows = (double)B * (double)a.n * 16.0;       // algorithmic FLOPs of the reference's formulation (as lfa_att_kernel)
+    // executed on the matrix cores: LocSE with K padded to 16 in both orientations (two instructions carry the four products),
+    // LFAmlp2 in both orientations and the position half of the attention product (one or three bf16 products)
+    const double np = terms == 2 ? 3.0 : 1.0;
+    const double exec = rows * (2.0 * 2.0 * 16 * C::H * terms + (second ? 2.0 * 2.0 * C::H * C::H * np : 0.0) + 2.0 * C::H * D * np);
+    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
+    if (terms == 2) {
+        if (second) hipLaunchKernelGGL((lfa32_kernel<D, true, 2>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((lfa32_kernel<D, false, 2>), grid, dim3(256), lds, s, a);
+    } else {
+        if (second) hipLaunchKernelGGL((lfa32_kernel<D, true, 1>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((lfa32_kernel<D, false, 1>), grid, dim3(256), lds, s, a);
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int launch_lfa32(int D, const Lfa32Args& a, bool second, int B, int prec, hipStream_t s) {
+    if (a.n <= 0 || B <= 0) return SSDR_OK;
+    if (!a.g || !a.fc_hi || !a.w1p || (second && !a.w2_hi)) { set_error("lfa32: missing G rows or permuted weight pieces"); return SSDR_ERR_INVALID; }
+    switch (D) {
+        case 16: return launch_lfa32_l0(a, second, B, prec, s);
+        case 64: return launch_lfa32_d<64>(a, second, B, prec, s);
+        case 128: return launch_lfa32_d<128>(a, second, B, prec, s);
+        case 256: return launch_lfa32_d<256>(a, second, B, prec, s);
+        case 512: return launch_lfa32_d<512>(a, second, B, prec, s);
+        default: return SSDR_ERR_UNSUPPORTED;       // no error text: the caller falls back to lfa_bf16_kernel
+    }
+}
+
+}  // namespace ssdr

@@ -18,6 +18,7 @@ namespace {
 struct Layer {
     int in = 0, out = 0; bool has_b = true; DevBuf W, b, Wt; bool set = false;     // Wt: [out][in] copy for the attention layers
     DevBuf Wh, Wl; int kp = 0;        // bf16 pieces of W, transposed [out][kp] (kp = in rounded up to 64, zero padded): hi = bf16(w), lo = bf16(w - hi)
+    DevBuf Ph, Pl, P1;                // operands of lfa32_kernel (randla_lfa32.hip): k-permuted pieces [out][K] / LocSE fragments [out][2][16]
 };
 
 struct Model {
@@ -59,6 +60,100 @@ DenseArgs dense(const float* x1, int k1, const Layer& ly, float* y, int M, int a
 // round-to-nearest-even bf16 of a finite float
 uint16_t bf16_rn(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
 float bf16_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// slot (h, j) of a 16-wide k step that reuses an accumulator tile as an operand holds row 8 (j >> 2) + 4 h + (j & 3) of the tile
+// (cdna_hip_programming.md section 3): position pos = 8 h + j of the stored block <- k offset
+int kperm_src(int pos) { const int h = pos >> 3, j = pos & 7; return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// rows k0 .. k0 + K of W [in][out] as bf16 pieces [out][K] in that k order, scaled
+int permuted_pieces(Layer& ly, const float* W, int k0, int K, double scale) {
+    std::vector<uint16_t> hi((size_t)ly.out * K), lo((size_t)ly.out * K);
+    for (int x = 0; x < ly.out; ++x)
+        for (int kb = 0; kb < K; kb += 16)
+            for (int pos = 0; pos < 16; ++pos) {
+                const float v = (float)((double)W[(size_t)(k0 + kb + kperm_src(pos)) * ly.out + x] * scale);
+                const uint16_t h = bf16_rn(v);
+                hi[(size_t)x * K + kb + pos] = h; lo[(size_t)x * K + kb + pos] = bf16_rn(v - bf16_f32(h));
+            }
+    SSDR_TRY(ly.Ph.reserve(2 * hi.size())); SSDR_TRY(ly.Pl.reserve(2 * lo.size()));
+    SSDR_HIP(hipMemcpy(ly.Ph.p, hi.data(), 2 * hi.size(), hipMemcpyHostToDevice));
+    SSDR_HIP(hipMemcpy(ly.Pl.p, lo.data(), 2 * lo.size(), hipMemcpyHostToDevice));
+    return SSDR_OK;
+}
+
+// LFAmlp1 (10 -> h) for lfa32_kernel: the position encoding [|d|, d, p, p_nbr] enters as the 7 inputs [|d|, d, p] (p_nbr = p - d), whose hi and
+// lo pieces share the 16 k slots of one MFMA step [hi0..hi6, lo0 | lo1..lo6, 0, 0]; the weights repeat to match: fragment a carries
+// the hi pieces of the 7 folded rows in the slots of BOTH input pieces, fragment b the lo pieces
+int locse_fragments(Layer& ly, const float* W) {
+    std::vector<uint16_t> f((size_t)ly.out * 32, 0);
+    for (int c = 0; c < ly.out; ++c) {
+        double w7[7];
+        w7[0] = W[c];
+        for (int a = 0; a < 3; ++a) { w7[1 + a] = (double)W[(size_t)(1 + a) * ly.out + c] - (double)W[(size_t)(7 + a) * ly.out + c]; w7[4 + a] = (double)W[(size_t)(4 + a) * ly.out + c] + (double)W[(size_t)(7 + a) * ly.out + c]; }
+        for (int i = 0; i < 7; ++i) {
+            const float v = (float)w7[i];
+            const uint16_t h = bf16_rn(v), l = bf16_rn(v - bf16_f32(h));
+            const int s0 = i, s1 = i == 0 ? 7 : 7 + i;       // slot of the input's hi piece, slot of its lo piece
+            f[(size_t)c * 32 + s0] = h; f[(size_t)c * 32 + s1] = h;
+            f[(size_t)c * 32 + 16 + s0] = l; f[(size_t)c * 32 + 16 + s1] = l;
+        }
+    }
+    SSDR_TRY(ly.P1.reserve(2 * f.size()));
+    SSDR_HIP(hipMemcpy(ly.P1.p, f.data(), 2 * f.size(), hipMemcpyHostToDevice));
+    return SSDR_OK;
+}
+
+bool use_lfa32() { static const bool on = [] { const char* e = getenv("SSDR_LFA32"); return !e || e[0] != '0'; }(); return on; }
+
+// Level 0 (d = 16, h = 8) of lfa32_kernel: two pairs of points share one 32 x 32 x 16 tile through block-diagonal weight operands, so the operand
+// fragments are lane-dependent constants: table [fragment][64 lanes][8 bf16].  Lane l = (r = l & 31, half hh = l >> 5) holds k slots 8 hh + j, i.e.
+// input j of point pair hh.  "T" fragments are the A operand of a transposed product (row r = (pair (r >> 2) & 1, channel (r & 3) + 4 (r >> 3)) for r < 16),
+// "X" fragments the B operand of a plain one (column r = (pair r >> 4, channel r & 15); only the position channels 8..15 have weights).
+template <class F> void level0_fragment(std::vector<uint16_t>& hi, std::vector<uint16_t>& lo, bool transposed, bool pos_only, F&& weight /* (input j, channel) */) {
+    for (int l = 0; l < 64; ++l) {
+        const int r = l & 31, hh = l >> 5;
+        int pair, ch; bool used;
+        if (transposed) { pair = (r >> 2) & 1; ch = (r & 3) + 4 * (r >> 3); used = r < 16; }
+        else { pair = r >> 4; ch = r & 15; used = !pos_only || ch >= 8; if (pos_only) ch -= 8; }
+        for (int j = 0; j < 8; ++j) {
+            uint16_t h = 0, lw = 0;
+            if (used && pair == hh) { const float v = weight(j, ch); h = bf16_rn(v); lw = bf16_rn(v - bf16_f32(h)); }
+            hi.push_back(h); lo.push_back(lw);
+        }
+    }
+}
+int upload16(DevBuf& d, const std::vector<uint16_t>& v) {
+    SSDR_TRY(d.reserve(2 * v.size()));
+    SSDR_HIP(hipMemcpy(d.p, v.data(), 2 * v.size(), hipMemcpyHostToDevice));
+    return SSDR_OK;
+}
+int level0_tables(Layer& ly, int role, const float* W, const float* b) {
+    std::vector<uint16_t> hi, lo;
+    if (role == 1) {            // LFAmlp1 10 -> 8: inputs [|d|, d, p, 1] (p_nbr = p - d folded into the rows, the bias rides on the constant 1)
+        auto w8 = [&](int j, int c) -> float {
+            if (j == 0) return W[c];
+            if (j < 4) return (float)((double)W[(size_t)j * 8 + c] - (double)W[(size_t)(6 + j) * 8 + c]);
+            if (j < 7) return (float)((double)W[(size_t)j * 8 + c] + (double)W[(size_t)(3 + j) * 8 + c]);
+            return b[c];
+        };
+        std::vector<uint16_t> th, tl, xh, xl;
+        level0_fragment(th, tl, true, false, w8); level0_fragment(xh, xl, false, true, w8);
+        std::vector<uint16_t> all; all.insert(all.end(), th.begin(), th.end()); all.insert(all.end(), tl.begin(), tl.end());
+        all.insert(all.end(), xh.begin(), xh.end()); all.insert(all.end(), xl.begin(), xl.end());
+        return upload16(ly.P1, all);                    // fragments: T hi, T lo, X hi, X lo
+    }
+    if (role == 4) {            // LFAmlp2 8 -> 8
+        auto w = [&](int j, int c) -> float { return W[(size_t)j * 8 + c]; };
+        std::vector<uint16_t> xh, xl;
+        level0_fragment(hi, lo, true, false, w); level0_fragment(xh, xl, false, true, w);
+        hi.insert(hi.end(), xh.begin(), xh.end()); lo.insert(lo.end(), xl.begin(), xl.end());      // fragments: T, X
+    } else {                    // attention 16 -> 16: rows 8..15 (the position half), x log2 e
+        auto w = [&](int j, int c) -> float { return (float)((double)W[(size_t)(8 + j) * 16 + c] * 1.4426950408889634); };
+        level0_fragment(hi, lo, false, false, w);
+    }
+    SSDR_TRY(upload16(ly.Ph, hi));
+    return upload16(ly.Pl, lo);
+}
 
 int run_dense(const Model& m, const DenseArgs& a, hipStream_t s) { return m.prec == PREC_F32 ? launch_dense(a, s) : launch_dense_bf16(a, m.prec, s); }
 
@@ -125,6 +220,13 @@ int ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* 
         SSDR_HIP(hipMemcpy(ly.Wh.p, hi.data(), 2 * hi.size(), hipMemcpyHostToDevice));
         SSDR_HIP(hipMemcpy(ly.Wl.p, lo.data(), 2 * lo.size(), hipMemcpyHostToDevice));
     }
+    if (layer >= 1 && layer < 1 + 8 * m->L) {       // operands of lfa32_kernel
+        const int r = (layer - 1) % 8;
+        if (m->d_out[(layer - 1) / 8] == 16 && (r == 1 || r == 2 || r == 4 || r == 5)) SSDR_TRY(level0_tables(ly, r == 5 ? 2 : r, W, b));
+        else if (r == 1 && ly.in == 10) SSDR_TRY(locse_fragments(ly, W));
+        else if (r == 4 && ly.in % 16 == 0) SSDR_TRY(permuted_pieces(ly, W, 0, ly.in, 1.0));
+        else if ((r == 2 || r == 5) && ly.in % 32 == 0) SSDR_TRY(permuted_pieces(ly, W, ly.in / 2, ly.in / 2, 1.4426950408889634));
+    }
     ly.set = true;
     return SSDR_OK;
 }
@@ -139,7 +241,7 @@ int ssdr_randla_set_precision(void* handle, int mode) {
 void ssdr_randla_destroy(void* handle) {
     Model* m = static_cast<Model*>(handle);
     if (!m) return;
-    for (auto& l : m->layers) { l.W.release(); l.b.release(); l.Wt.release(); l.Wh.release(); l.Wl.release(); }
+    for (auto& l : m->layers) { l.W.release(); l.b.release(); l.Wt.release(); l.Wh.release(); l.Wl.release(); l.Ph.release(); l.Pl.release(); l.P1.release(); }
     for (auto& w : m->ws) w.release();
     delete m;
 }
@@ -181,16 +283,29 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         la.fin = f_pc; la.w_fc = m->layers[base + 2].W.as<float>(); la.w_fc_t = m->layers[base + 2].Wt.as<float>(); la.out = agg;
         la.fc_hi = m->layers[base + 2].Wh.as<uint16_t>(); la.fc_lo = m->layers[base + 2].Wl.as<uint16_t>();
         la.l2_hi = m->layers[base + 4].Wh.as<uint16_t>(); la.l2_lo = m->layers[base + 4].Wl.as<uint16_t>(); la.kp2 = m->layers[base + 4].kp;
-        const bool lfa16 = m->prec != PREC_F32 && d >= 64;      // d = 16: exact-f32 kernel in every mode
+        const bool use32 = m->prec != PREC_F32 && use_lfa32();    // 32 x 32-tile formulation (randla_lfa32.hip), every level
+        const bool lfa16 = m->prec != PREC_F32 && d >= 64;         // the 16 x 16-tile bf16 kernels; their d = 16 level runs on the exact-f32 kernel in every mode
         float* gbuf = nullptr;
-        if (d >= 64) {      // neighbour half of the attention product once per point: G = f_pc * W[0:h]  (rows 0..h-1 of the [d][d] weights)
+        if (d >= 64 || use32) {      // neighbour half of the attention product once per point: G = f_pc * W[0:h]  (rows 0..h-1 of the [d][d] weights)
             gbuf = buf(idxs(i, 5), rows * d); if (!gbuf) return SSDR_ERR_HIP;
             DenseArgs ga{}; ga.x1 = f_pc; ga.k1 = h; ga.W = la.w_fc; ga.b = nullptr; ga.y = gbuf; ga.M = (int)rows; ga.N = d; ga.act = 0; ga.m_per_batch = 1;
             ga.wt_hi = la.fc_hi; ga.wt_lo = la.fc_lo; ga.kp = m->layers[base + 2].kp;
             SSDR_TRY(run_dense(*m, ga, s));
         }
         la.g = gbuf;
-        SSDR_TRY(lfa16 ? launch_lfa_bf16(d, la, false, Bi, m->prec, s) : launch_lfa(d, la, false, Bi, s));                                                          // LocSE + att pool 1
+        // 32 x 32-tile formulation (randla_lfa32.hip) where it has an instantiation; SSDR_LFA32=0 keeps the 16 x 16-tile kernels (A/B timing)
+        Lfa32Args l32{}; l32.xyz = d_xyz; l32.xyz_batch_stride = n0 * 3; l32.neigh = d_neigh_idx[i]; l32.n = n; l32.g = gbuf; l32.out = agg;
+        l32.w1p = m->layers[base + 1].P1.as<uint16_t>(); l32.b1 = la.b_l1;
+        l32.w2_hi = m->layers[base + 4].Ph.as<uint16_t>(); l32.w2_lo = m->layers[base + 4].Pl.as<uint16_t>(); l32.b2 = la.b_l2;
+        auto run_lfa = [&](bool second, const float* fin, const Layer& fc) -> int {
+            if (use32) {
+                l32.fin = fin; l32.fc_hi = fc.Ph.as<uint16_t>(); l32.fc_lo = fc.Pl.as<uint16_t>();
+                const int rc = launch_lfa32(d, l32, second, Bi, m->prec, s);
+                if (rc != SSDR_ERR_UNSUPPORTED) return rc;
+            }
+            return lfa16 ? launch_lfa_bf16(d, la, second, Bi, m->prec, s) : launch_lfa(d, la, second, Bi, s);
+        };
+        SSDR_TRY(run_lfa(false, f_pc, m->layers[base + 2]));                                                 // LocSE + att pool 1
         SSDR_TRY(run_dense(*m, dense(agg, d, m->layers[base + 3], aggm, (int)rows, 1), s));                   // att1 mlp d->h
         la.fin = aggm; la.w_fc = m->layers[base + 5].W.as<float>(); la.w_fc_t = m->layers[base + 5].Wt.as<float>(); la.out = agg;
         la.fc_hi = m->layers[base + 5].Wh.as<uint16_t>(); la.fc_lo = m->layers[base + 5].Wl.as<uint16_t>();
@@ -199,7 +314,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
             ga.wt_hi = la.fc_hi; ga.wt_lo = la.fc_lo; ga.kp = m->layers[base + 5].kp;
             SSDR_TRY(run_dense(*m, ga, s));
         }
-        SSDR_TRY(lfa16 ? launch_lfa_bf16(d, la, true, Bi, m->prec, s) : launch_lfa(d, la, true, Bi, s));                                                           // LocSE2 + att pool 2
+        SSDR_TRY(run_lfa(true, aggm, m->layers[base + 5]));                                                  // LocSE2 + att pool 2
         SSDR_TRY(run_dense(*m, dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
         DenseArgs r = dense(aggm, d, m->layers[base + 7], out, (int)rows, 1);                               // lrelu(mlp2 + shortcut)
         r.x2 = f; r.k2 = d_in;

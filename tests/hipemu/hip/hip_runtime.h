@@ -255,6 +255,36 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_u32x4 a, hipemu_
     return d;
 }
 
+// 32x32x16 bf16 MFMA (v_mfma_f32_32x32x16_bf16): lane l (r = l&31, h = l>>5) holds A[row r][k = 8h+j] and B[k = 8h+j][col r],
+// j = 0..7; C/D col = l&31, row = (reg&3) + 8(reg>>2) + 4(l>>5), reg = 0..15 (cdna_hip_programming.md section 3).
+struct hipemu_f32x16 { float v[16]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x16 c) {
+    auto* f = hipemu::g_bs->cur; auto& w = hipemu::g_bs->waves[f->wave];
+    const int col = f->lane & 31, hh = f->lane >> 5;
+    unsigned Al[16][2][4], Bv[2][4];          // A[reg's row][k half][dword], B[k half][dword]
+    for (int half = 0; half < 4; ++half) {
+        const hipemu_u32x4& v = half < 2 ? a : b; const int d0 = (half & 1) * 2;
+        hipemu::wave_op((uint64_t)v[d0] | ((uint64_t)v[d0 + 1] << 32), 8 + half);
+        for (int g = 0; g < 2; ++g) {
+            if (half < 2) for (int q = 0; q < 16; ++q) { const uint64_t s = w.snap[(q & 3) + 8 * (q >> 2) + 4 * hh + 32 * g]; Al[q][g][d0] = (unsigned)s; Al[q][g][d0 + 1] = (unsigned)(s >> 32); }
+            else { const uint64_t s = w.snap[col + 32 * g]; Bv[g][d0] = (unsigned)s; Bv[g][d0 + 1] = (unsigned)(s >> 32); }
+        }
+    }
+    hipemu_f32x16 d = c;
+    for (int q = 0; q < 16; ++q) {
+        double acc = c[q];
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 8; ++j) {
+                const unsigned ad = Al[q][g][j >> 1], bd = Bv[g][j >> 1];
+                const float av = __uint_as_float((j & 1) ? (ad & 0xffff0000u) : (ad << 16));
+                const float bv = __uint_as_float((j & 1) ? (bd & 0xffff0000u) : (bd << 16));
+                acc += (double)av * (double)bv;
+            }
+        d[q] = (float)acc;
+    }
+    return d;
+}
+
 // ---- runtime API (host memory stands in for device memory) --------------------------------------
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
