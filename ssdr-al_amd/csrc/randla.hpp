@@ -12,6 +12,8 @@ struct DenseArgs {        // y[M,N] = act( [x1 | x2(gathered)] [M,k1+k2] * W[k1+
     int x2_rows_per_batch;
     const float* W; const float* b;
     float* y; int M, N; int act;
+    int ldy;              // row stride of y in floats (0: N) — the thin level-0 layers write into the 16-float rows of the gather table [x y z 0 | f0..f7 | -]
+    const float* xyz; size_t xyz_batch_stride; int xyz_rows_per_batch;      // optional: also write the row's coordinates to y[row * ldy - 4 .. - 1]
     // bf16 modes: the weights once more as bf16 pieces, transposed [N][kp] (k contiguous, kp = K rounded up to 64, zero padded)
     const uint16_t* wt_hi; const uint16_t* wt_lo; int kp;
 };
@@ -50,6 +52,7 @@ constexpr int PREC_BF16X3 = 1;    // split bf16: hi*hi + lo*hi + hi*lo on v_mfma
 constexpr int PREC_BF16 = 2;      // plain bf16 operands, fp32 accumulate
 
 int launch_dense(const DenseArgs& a, hipStream_t s);
+int launch_xyz_fill(const DenseArgs& a, hipStream_t s);
 int launch_lfa(int D, const LfaArgs& a, bool second, int B, hipStream_t s);
 struct TailArgs {         // fc1 + fc2 + fc + softmax on the bf16 cores
     const float* x; int M, C;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(TM == 128 ? 4 : 5) void dens
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = row0 + rbase + r * 16 + (lane >> 4) * 4 + q;
-                if (row < a.M) { float v = acc[r][c][q] + bias; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
+                if (row < a.M) { float v = acc[r][c][q] + bias; a.y[(size_t)row * (a.ldy ? a.ldy : a.N) + col] = a.act ? lrelu(v) : v; }
             }
     }
 }
@@ -556,6 +556,7 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
     if (a.N == 8 && a.k2 == 0 && a.k1 <= 16) return launch_dense(a, s);      // thin layers: HBM streams on fp32 FMAs in every mode
     if (!a.wt_hi || (prec == PREC_BF16X3 && !a.wt_lo)) { set_error("dense (bf16): the layer has no bf16 weight pieces"); return SSDR_ERR_INVALID; }
+    if (a.xyz) SSDR_TRY(launch_xyz_fill(a, s));
     // executed: rows / columns padded to the tile, K to the chunk, one or three bf16 products
     const bool small = a.M <= 16384;
     const double tm = small ? 32.0 : 128.0, kc = small ? 64.0 : 32.0;

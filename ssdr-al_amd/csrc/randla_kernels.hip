@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = row0 + w * 32 + r * 16 + (lane >> 4) * 4 + q;
-                if (row < a.M) { float v = acc[r][c][q] + bias; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
+                if (row < a.M) { float v = acc[r][c][q] + bias; a.y[(size_t)row * (a.ldy ? a.ldy : a.N) + col] = a.act ? lrelu(v) : v; }
             }
     }
 }
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = row0 + r * 16 + (lane >> 4) * 4 + q;
-                if (row < a.M) { float v = acc[r][q] + bias; a.y[(size_t)row * a.N + col] = a.act ? lrelu(v) : v; }
+                if (row < a.M) { float v = acc[r][q] + bias; a.y[(size_t)row * (a.ldy ? a.ldy : a.N) + col] = a.act ? lrelu(v) : v; }
             }
     }
 }
@@ -570,7 +570,12 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(DenseArgs a) {
             for (int n = 0; n < N; ++n) acc[n] = fmaf(x[k], Ws[k * N + n], acc[n]);
             SSDR_SCHED_FENCE();
         }
-        float4* yo = reinterpret_cast<float4*>(a.y + (size_t)row * N);
+        float4* yo = reinterpret_cast<float4*>(a.y + (size_t)row * (a.ldy ? a.ldy : N));
+        if (a.xyz) {      // the row's coordinates in front of its features: one 64-byte row of the level-0 gather table
+            const int be = row / a.xyz_rows_per_batch, i = row - be * a.xyz_rows_per_batch;
+            const float* c = a.xyz + (size_t)be * a.xyz_batch_stride + 3 * (size_t)i;
+            yo[-1] = make_float4(c[0], c[1], c[2], 0.f);
+        }
 #pragma unroll
         for (int q = 0; q < N / 4; ++q) {
             float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -640,6 +645,20 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
     }
 }
 
+__global__ __launch_bounds__(256) void xyz_fill_kernel(DenseArgs a) {      // the coordinate columns of the gather table when the fused thin-layer kernel did not run
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.M) return;
+    const int be = row / a.xyz_rows_per_batch, i = row - be * a.xyz_rows_per_batch;
+    const float* c = a.xyz + (size_t)be * a.xyz_batch_stride + 3 * (size_t)i;
+    float* yo = a.y + (size_t)row * (a.ldy ? a.ldy : a.N) - 4;
+    yo[0] = c[0]; yo[1] = c[1]; yo[2] = c[2]; yo[3] = 0.f;
+}
+int launch_xyz_fill(const DenseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(xyz_fill_kernel, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 int launch_dense(const DenseArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
@@ -653,6 +672,7 @@ int launch_dense(const DenseArgs& a, hipStream_t s) {
         SSDR_ROWS(6, 0, 8) SSDR_ROWS(8, 0, 8) SSDR_ROWS(16, 0, 8)      // wider outputs: register allocation degrades, the MFMA tile wins
 #undef SSDR_ROWS
     }
+    if (a.xyz) SSDR_TRY(launch_xyz_fill(a, s));
     if (vec && a.M <= 16384) {      // too few 128-row tiles to fill the chip
         dim3 gs((unsigned)((a.M + STM - 1) / STM), (unsigned)((a.N + DTN - 1) / DTN));
         hipLaunchKernelGGL(dense_small_kernel, gs, dim3(256), 0, s, a);

@@ -95,9 +95,7 @@ __device__ __forceinline__ f32x16 bias_cols(const float* b, int ch0, int lr) {  
 
 // the seven inputs of the reformulated position encoding of this lane's (point, neighbour) row as one operand fragment:
 // k slots [hi0..hi6, lo0 | lo1..lo6, 0, 0]
-template <int TERMS> __device__ __forceinline__ u32x4 rel_fragment(const float* xyz, int p, int j, int lh) {
-    const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
-    const float qx = xyz[3 * (size_t)j], qy = xyz[3 * (size_t)j + 1], qz = xyz[3 * (size_t)j + 2];
+template <int TERMS> __device__ __forceinline__ u32x4 rel_fragment_x(float px, float py, float pz, float qx, float qy, float qz, int lh) {
     const float dx = px - qx, dy = py - qy, dz = pz - qz;
     const float x[7] = {sqrtf(dx * dx + dy * dy + dz * dz), dx, dy, dz, px, py, pz};
     const unsigned p01 = pack_bf16(x[0], x[1]), p23 = pack_bf16(x[2], x[3]), p45 = pack_bf16(x[4], x[5]);
@@ -112,6 +110,9 @@ template <int TERMS> __device__ __forceinline__ u32x4 rel_fragment(const float* 
         f[0] = lh ? 0u : p01; f[1] = lh ? 0u : p23; f[2] = lh ? 0u : p45; f[3] = lh ? 0u : pack_bf16(x[6], 0.f);
     }
     return f;
+}
+template <int TERMS> __device__ __forceinline__ u32x4 rel_fragment(const float* xyz, int p, int j, int lh) {
+    return rel_fragment_x<TERMS>(xyz[3 * (size_t)p], xyz[3 * (size_t)p + 1], xyz[3 * (size_t)p + 2], xyz[3 * (size_t)j], xyz[3 * (size_t)j + 1], xyz[3 * (size_t)j + 2], lh);
 }
 
 // softmax over the 16 registers (scores in base-2 units) and the weighted sum of f: sum_q f_q 2^(s_q - m) / sum_q 2^(s_q - m)
@@ -301,6 +302,149 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
 }
 
 
+// ---- levels whose weights fit in LDS whole (d = 64, 128): no G table ----------------------------------------------------------------------------
+// What bounds the gathering levels is the vector-memory return path: a gather-type load costs the CU ~10 cycles per dword of a wave instruction
+// (PMC: TD busy 80-98 % of these kernels' time, the same with a third of the arithmetic), i.e. ~25-30 bytes per clock from L2 — the rate
+// MI355X_MICROARCH.md quotes for row gathers.  So the kernel fetches each neighbour row ONCE, in the operand layout: lane (row r, half h) reads
+// the 8 features of k step s of ITS neighbour straight into the A fragment of the neighbour half of the scores (multiplied here: no G rows to
+// gather, no G launch), and the same registers go through a wave-private LDS image [32 rows][H] from which the weighted sum reads them back in
+// the accumulator layout (channel on the lane, neighbour in the register).  Per pair of points: 1 + 6 + H / 2 dwords per lane instead of
+// 23 + 24 (H / 16).
+template <int D> struct Lfa32ResCfg {
+    static constexpr int H = D / 2, RS = 2 * H + 16;
+    static constexpr int NW = 4;                                       // waves per workgroup (they share the staged weights)
+    static constexpr int RPW = 8;                                      // pairs of points per wave
+    static constexpr int FRS = H * 4 + 16;                             // bytes per row of the feature image
+    static constexpr size_t w_bytes(int terms, bool second) { return (size_t)terms * ((second ? H : 0) + 2 * D) * RS; }
+    static constexpr size_t lds_bytes(int terms, bool second) { return w_bytes(terms, second) + (size_t)NW * 32 * FRS; }
+};
+
+template <int D, bool SECOND, int TERMS>
+__global__ __launch_bounds__(Lfa32ResCfg<D>::NW * 64) void lfa32_res_kernel(Lfa32Args a) {
+    using C = Lfa32ResCfg<D>;
+    constexpr int H = C::H, KS = H / 16, HT = H / 32, CT = D / 32, RS = C::RS, RPW = C::RPW, NW = C::NW, FRS = C::FRS;
+    SSDR_DYN_SHARED(float, smem);
+    char* lds = reinterpret_cast<char*>(smem);
+    char* const img2 = lds;                                                    // LFAmlp2         [TERMS][H rows][RS], k permuted
+    char* const imgp = lds + (SECOND ? (size_t)TERMS * H * RS : 0);            // attention, position half [TERMS][D rows][RS], k permuted
+    char* const imgn = imgp + (size_t)TERMS * D * RS;                          // attention, neighbour half [TERMS][D rows][RS], natural k
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    char* const fimg = lds + C::w_bytes(TERMS, SECOND) + (size_t)w * 32 * FRS; // this wave's gathered features [32 rows][H] f32
+    const int lr = lane & 31, lh = lane >> 5;
+    int bx, b; xcd_tile_map(bx, b);
+    const int n = a.n;
+    const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
+    const int* neigh = a.neigh + (size_t)b * n * 16;
+    const float* finb = a.fin + (size_t)b * n * H;
+    {   // weights -> LDS (16-byte pieces; rows of H bf16 are contiguous in the source: fc = [position half [D][H] | neighbour half [D][H]])
+        constexpr int P8 = H / 8, N2P = SECOND ? TERMS * H * P8 : 0, NFP = TERMS * 2 * D * P8;
+        for (int e = tid; e < N2P + NFP; e += NW * 64) {
+            const bool is2 = e < N2P;
+            const int r = is2 ? e : e - N2P, rows = is2 ? H : 2 * D, per = rows * P8, t = r >= per ? 1 : 0, q = r - t * per;
+            const uint16_t* src = (is2 ? (t ? a.w2_lo : a.w2_hi) : (t ? a.fc_lo : a.fc_hi)) + (size_t)q * 8;
+            const int row = q / P8;
+            char* dst = is2 ? img2 + (size_t)t * H * RS + (size_t)row * RS : (row < D ? imgp + (size_t)t * D * RS + (size_t)row * RS : imgn + (size_t)t * D * RS + (size_t)(row - D) * RS);
+            st128s(dst + (q % P8) * 16, ld128g(src));
+        }
+    }
+    u32x4 w1r[HT][TERMS];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int term = 0; term < TERMS; ++term) w1r[t][term] = ld128g(a.w1p + ((size_t)(32 * t + lr) * 2 + term) * 16 + 8 * lh);
+    const int nbrrow = (lr & 3) + 4 * (lr >> 3), prow = (lr >> 2) & 1;
+    __syncthreads();                                     // the weights are in place (no workgroup barrier below: waves run at their own pace)
+
+    const int rt0 = ((int)bx * NW + w) * RPW;
+    for (int it = 0; it < RPW; ++it) {
+        const int rt = rt0 + it;
+        if (2 * rt >= n) break;                          // wave-uniform
+        // this lane's (point, neighbour) row: index, coordinates, and its share of the neighbour's features (k = 16 s + 8 h ..)
+        const int pr = min(2 * rt + prow, n - 1);
+        const int j = neigh[(size_t)pr * 16 + nbrrow];
+        const float* fj = finb + (size_t)j * H + 8 * lh;
+        float4 fa[KS][2];
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) { fa[s2][0] = *reinterpret_cast<const float4*>(fj + 16 * s2); fa[s2][1] = *reinterpret_cast<const float4*>(fj + 16 * s2 + 4); }
+        const u32x4 relf = rel_fragment<TERMS>(xyz, pr, j, lh);
+        u32x4 fnf[KS][TERMS];
+        wave_sync();                                     // the previous pair's reads of the feature image are done
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            float4* dst = reinterpret_cast<float4*>(fimg + (size_t)lr * FRS + (16 * s2 + 8 * lh) * 4);
+            dst[0] = fa[s2][0]; dst[1] = fa[s2][1];
+            const float f[8] = {fa[s2][0].x, fa[s2][0].y, fa[s2][0].z, fa[s2][0].w, fa[s2][1].x, fa[s2][1].y, fa[s2][1].z, fa[s2][1].w};
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) { unsigned hh, ll; split_bf16(f[2 * k2], f[2 * k2 + 1], hh, ll); fnf[s2][0][k2] = hh; if constexpr (TERMS == 2) fnf[s2][1][k2] = ll; }
+        }
+        wave_sync();
+        u32x4 Tf[KS][TERMS];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {                   // T1 = lrelu(W1^T rel^T + b1) (LFAmlp1, :518)
+            f32x16 acc = bias_rows(a.b1, 32 * t, lh);
+            acc = mfma32_bf16(w1r[t][0], relf, acc);
+            if constexpr (TERMS == 2) acc = mfma32_bf16(w1r[t][1], relf, acc);
+            acc_to_frags<TERMS>(acc, Tf[2 * t], Tf[2 * t + 1]);
+        }
+        float x2[SECOND ? HT : 1][16];
+        if constexpr (SECOND) {                          // f_xyz <- lrelu(f_xyz W2 + b2) (LFAmlp2, :523), both orientations
+            u32x4 T2f[KS][TERMS];
+#pragma unroll
+            for (int t2 = 0; t2 < HT; ++t2) {
+                f32x16 accT = bias_rows(a.b2, 32 * t2, lh), accX = bias_cols(a.b2, 32 * t2, lr);
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2) {
+                    u32x4 wf[TERMS];
+#pragma unroll
+                    for (int term = 0; term < TERMS; ++term) wf[term] = ld128g(img2 + (size_t)term * H * RS + (size_t)(32 * t2 + lr) * RS + (16 * s2 + 8 * lh) * 2);
+                    accT = mma32_split<TERMS>(wf, Tf[s2], accT);
+                    accX = mma32_split<TERMS>(Tf[s2], wf, accX);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) x2[t2][q] = lrelu(accX[q]);
+                acc_to_frags<TERMS>(accT, T2f[2 * t2], T2f[2 * t2 + 1]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+                for (int term = 0; term < TERMS; ++term) Tf[s2][term] = T2f[s2][term];
+        }
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {                   // scores (:578), softmax over the neighbours (:579), weighted sum (:580-581)
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                u32x4 wn[TERMS], wp[TERMS];
+#pragma unroll
+                for (int term = 0; term < TERMS; ++term) {
+                    wn[term] = ld128g(imgn + (size_t)term * D * RS + (size_t)(32 * u + lr) * RS + (16 * s2 + 8 * lh) * 2);
+                    wp[term] = ld128g(imgp + (size_t)term * D * RS + (size_t)(32 * u + lr) * RS + (16 * s2 + 8 * lh) * 2);
+                }
+                acc = mma32_split<TERMS>(fnf[s2], wn, acc);
+                acc = mma32_split<TERMS>(Tf[s2], wp, acc);
+            }
+            float fv[16];
+            if (u < HT) {                                // the gathered features back in the accumulator layout: row (half lh, neighbour q), channel 32 u + lr
+#pragma unroll
+                for (int q = 0; q < 16; ++q) fv[q] = *reinterpret_cast<const float*>(fimg + (size_t)((q & 3) + 8 * (q >> 2) + 4 * lh) * FRS + (32 * u + lr) * 4);
+            } else if constexpr (SECOND) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) fv[q] = x2[u - HT][q];
+            } else {
+                f32x16 ax = bias_cols(a.b1, 32 * (u - HT), lr);
+                ax = mfma32_bf16(relf, w1r[u - HT][0], ax);
+                if constexpr (TERMS == 2) ax = mfma32_bf16(relf, w1r[u - HT][1], ax);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) fv[q] = lrelu(ax[q]);
+            }
+            const float v = softmax_wsum(acc, fv);
+            if (2 * rt + lh < n) a.out[((size_t)b * n + (size_t)(2 * rt + lh)) * D + 32 * u + lr] = v;
+        }
+    }
+}
+
 // ---- level 0 (d = 16, h = 8): two pairs of points per tile ----------------------------------------------------------------------------
 // With 8 position channels the k dimension of a 16-deep MFMA step holds TWO independent problems: k slots 0..7 (the lanes of half 0)
 // carry the 8 inputs of point pair A, slots 8..15 those of pair B, and the weight operand is block diagonal — columns 0..15 are pair A's 16
@@ -308,23 +452,31 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
 // with every lane busy: lane (column c, half h) register q = (point 2 (c >> 4) + h, neighbour q, channel c & 15).  The operand fragments
 // are lane-dependent constants of the layer, tabulated by the host (randla_model.hip, level0_tables): [fragment][64 lanes][8 bf16].
 // LocSE slot 7 carries the constant 1 against the bias row; the neighbour-feature columns (c & 15 < 8) of the "plain" product have zero
-// weights and start from the gathered feature, so one accumulator holds [f_nbr | f_xyz] in the layout of the weighted sum.
+// weights and start from the neighbour's feature, so one accumulator holds [f_nbr | f_xyz] in the layout of the weighted sum.
+// As above the neighbour half of the scores is multiplied here and every neighbour row is fetched once, by the lane that owns the row: the level
+// keeps ONE gather table with a point's coordinates and features in the same 64-byte row [x y z 0 | f0..f7 | -] (written by the thin layers that
+// produce the features, randla_kernels.hip), a lane reads 48 bytes of its neighbour's row, and the accumulator layout of the features comes
+// back out of a wave-private LDS image (64 rows of 32 bytes; the position columns read a block of zeros).
 constexpr int L0_TPW = 8;          // tiles (of 4 points) per wave
+constexpr int L0_IMG = 64 * 32 + 32, L0_ZERO = 1024, L0_WAVE = L0_IMG + L0_ZERO;      // bytes of LDS per wave
 
 template <bool SECOND, int TERMS>
 __global__ __launch_bounds__(256) void lfa32_l0_kernel(Lfa32Args a) {
+    __shared__ __attribute__((aligned(16))) char l0lds[4 * L0_WAVE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5, cc = lr & 15, sg = lr >> 4;
     int bx, b; xcd_tile_map(bx, b);
     const int n = a.n;
-    const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
     const int* neigh = a.neigh + (size_t)b * n * 16;
+    const float* tabb = a.fin + (size_t)b * n * 16;                    // gather table: one 64-byte row per point, [x y z 0 | f0..f7 | -]
+    char* const img = l0lds + w * L0_WAVE;
+    for (int i = lane; i < L0_ZERO / 4; i += 64) reinterpret_cast<float*>(img + L0_IMG)[i] = 0.f;
     auto tab = [&](const uint16_t* t, int f) { return ld128g(t + ((size_t)f * 64 + lane) * 8); };
-    u32x4 locT[TERMS], locX[TERMS], w2T[SECOND ? TERMS : 1], w2X[SECOND ? TERMS : 1], fcB[TERMS];
+    u32x4 locT[TERMS], locX[TERMS], w2T[SECOND ? TERMS : 1], w2X[SECOND ? TERMS : 1], fcB[TERMS], fcN[TERMS];
 #pragma unroll
     for (int t = 0; t < TERMS; ++t) {
         locT[t] = tab(a.w1p, t); locX[t] = tab(a.w1p, 2 + t);
-        fcB[t] = tab(t ? a.fc_lo : a.fc_hi, 0);
+        fcB[t] = tab(t ? a.fc_lo : a.fc_hi, 0); fcN[t] = tab(t ? a.fc_lo : a.fc_hi, 1);
         if constexpr (SECOND) { w2T[t] = tab(t ? a.w2_lo : a.w2_hi, 0); w2X[t] = tab(t ? a.w2_lo : a.w2_hi, 1); }
     }
     u32x4 onesA = {0u, 0u, 0u, 0u}, biasB = {0u, 0u, 0u, 0u};      // SECOND: the plain product's bias as a fourth product (1, 1 | hi, lo)
@@ -335,49 +487,45 @@ __global__ __launch_bounds__(256) void lfa32_l0_kernel(Lfa32Args a) {
         for (int q = 0; q < 8; ++q) b2r[q] = a.b2[q];
     }
     const float slope = cc < 8 ? 1.f : 0.2f;
-    const rsrc32_t rG = make_rsrc32(a.g + (size_t)b * n * 16, (unsigned)n * 64u);
-    const rsrc32_t rF = make_rsrc32(a.fin + (size_t)b * n * 8, (unsigned)n * 32u);
-    const unsigned fl = cc < 8 ? (unsigned)cc * 4u : 0x80000000u;      // position columns read out of range: 0
     float* out = a.out + (size_t)b * n * 16;
     const int g0 = ((int)bx * 4 + w) * L0_TPW;
+    const int nbrrow = (lr & 3) + 4 * (lr >> 3), prow = 2 * lh + ((lr >> 2) & 1), pcol = 2 * sg + lh;
+    // the image row of lane L sits at 32 L + 32 (L >> 5): the two halves of the wave on different banks
+    char* const wrow = img + lane * 32 + lh * 32;
+    // accumulator layout: register q of this lane = (point pcol, neighbour q) = the row owned by lane 32 (pcol >> 1) + 4 (pcol & 1) + (q & 3) + 8 (q >> 2)
+    const char* const rbase = cc < 8 ? img + (32 * (pcol >> 1) + 4 * (pcol & 1)) * 32 + (pcol >> 1) * 32 + cc * 4 : img + L0_IMG;
     for (int it = 0; it < L0_TPW; ++it) {
-        const int P0 = 4 * (g0 + it);
-        if (P0 >= n) break;                                            // wave-uniform
-        // this lane's (point, neighbour) row of the position encoding: hi pieces [x0..x6, 1], lo pieces [.., 0]
-        u32x4 rel[TERMS];
+        const int t = g0 + it;
+        if (4 * t >= n) break;                                         // wave-uniform
+        const int pr = min(4 * t + prow, n - 1);
+        const int j = neigh[(size_t)pr * 16 + nbrrow];
+        const float4 pp = *reinterpret_cast<const float4*>(tabb + (size_t)pr * 16);
+        const float4* rowj = reinterpret_cast<const float4*>(tabb + (size_t)j * 16);
+        const float4 qq = rowj[0], fa0 = rowj[1], fa1 = rowj[2];
+        wave_sync();                                                   // the previous tile's reads of the image are done
+        reinterpret_cast<float4*>(wrow)[0] = fa0; reinterpret_cast<float4*>(wrow)[1] = fa1;
+        // this lane's (point, neighbour) row: position encoding [x0..x6, 1] and the neighbour's features, as hi / lo operand fragments
+        u32x4 rel[TERMS], fnA[TERMS];
         {
-            const int pr = min(P0 + 2 * lh + ((lr >> 2) & 1), n - 1);
-            const int j = neigh[(size_t)pr * 16 + (lr & 3) + 4 * (lr >> 3)];
-            const float px = xyz[3 * (size_t)pr], py = xyz[3 * (size_t)pr + 1], pz = xyz[3 * (size_t)pr + 2];
-            const float qx = xyz[3 * (size_t)j], qy = xyz[3 * (size_t)j + 1], qz = xyz[3 * (size_t)j + 2];
-            const float dx = px - qx, dy = py - qy, dz = pz - qz;
-            const float x[8] = {sqrtf(dx * dx + dy * dy + dz * dz), dx, dy, dz, px, py, pz, 1.f};
+            const float dx = pp.x - qq.x, dy = pp.y - qq.y, dz = pp.z - qq.z;
+            const float v[8] = {sqrtf(dx * dx + dy * dy + dz * dz), dx, dy, dz, pp.x, pp.y, pp.z, 1.f};
+            const float f[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2) {
-                unsigned h, l; split_bf16(x[2 * k2], x[2 * k2 + 1], h, l);
-                rel[0][k2] = h; if constexpr (TERMS == 2) rel[1][k2] = l;
+                unsigned h, l;
+                split_bf16(v[2 * k2], v[2 * k2 + 1], h, l); rel[0][k2] = h; if constexpr (TERMS == 2) rel[1][k2] = l;
+                split_bf16(f[2 * k2], f[2 * k2 + 1], h, l); fnA[0][k2] = h; if constexpr (TERMS == 2) fnA[1][k2] = l;
             }
         }
-        // the 16 neighbours of this lane's column point
-        const int pcu = P0 + 2 * sg + lh, pc = min(pcu, n - 1);
-        unsigned goff[16], foff[16];
-        {
-            const int4* nb4 = reinterpret_cast<const int4*>(neigh + (size_t)pc * 16);
+        wave_sync();
+        f32x16 accX;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int4 v = nb4[g4];
-                const int nb[4] = {v.x, v.y, v.z, v.w};
+        for (int q = 0; q < 16; ++q) accX[q] = *reinterpret_cast<const float*>(rbase + ((q & 3) + 8 * (q >> 2)) * 32);
+        f32x16 accS, accT;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { goff[4 * g4 + r] = (unsigned)nb[r] * 64u + (unsigned)cc * 4u; foff[4 * g4 + r] = (unsigned)nb[r] * 32u + fl; }
-            }
-        }
-        f32x16 accS, accX;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { accS[q] = buf_load_s(rG, goff[q], 0u); accX[q] = buf_load_s(rF, foff[q], 0u); }
+        for (int q = 0; q < 16; ++q) { accS[q] = 0.f; accT[q] = 0.f; }
+        accS = mma32_split<TERMS>(fnA, fcN, accS);                    // neighbour half of the scores
         // T1 = lrelu(W1^T rel^T) (bias through slot 7): rows 0..15 = (pair, channel), the rest of the tile is idle
-        f32x16 accT;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) accT[q] = 0.f;
         accT = mma32_split<TERMS>(locT, rel, accT);
         u32x4 Tf[TERMS];
         auto to_frag = [&](const f32x16& v, u32x4 (&f)[TERMS]) {
@@ -402,6 +550,7 @@ __global__ __launch_bounds__(256) void lfa32_l0_kernel(Lfa32Args a) {
         for (int q = 0; q < 16; ++q) fv[q] = fmaxf(accX[q], accX[q] * slope);
         accS = mma32_split<TERMS>(Tf, fcB, accS);
         const float v = softmax_wsum(accS, fv);
+        const int pcu = 4 * t + pcol;
         if (pcu < n) out[(size_t)pcu * 16 + cc] = v;
     }
 }
@@ -410,8 +559,8 @@ static int launch_lfa32_l0(const Lfa32Args& a, bool second, int B, int prec, hip
     dim3 grid((unsigned)((a.n + 16 * L0_TPW - 1) / (16 * L0_TPW)), (unsigned)B);
     const int terms = prec == PREC_BF16X3 ? 2 : 1;
     const double rows = (double)B * (double)a.n * 16.0, np = terms == 2 ? 3.0 : 1.0;
-    // executed: every product is a 32 x 32 x 16 tile for 4 points (LocSE in both orientations, LFAmlp2 in both + its bias product, the scores)
-    const double exec = (double)B * std::ceil(a.n / 4.0) * 2.0 * 32 * 32 * 16 * (np * (second ? 4.0 : 3.0) + (second ? 1.0 : 0.0));
+    // executed: every product is a 32 x 32 x 16 tile for 4 points (LocSE in both orientations, LFAmlp2 in both + its bias product, the two halves of the scores)
+    const double exec = (double)B * std::ceil(a.n / 4.0) * 2.0 * 32 * 32 * 16 * (np * (second ? 5.0 : 4.0) + (second ? 1.0 : 0.0));
     ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * 8 + (second ? 2.0 * 8 * 8 : 0.0) + 2.0 * 16 * 16 + 2.0 * 16), exec);
     if (terms == 2) {
         if (second) hipLaunchKernelGGL((lfa32_l0_kernel<true, 2>), grid, dim3(256), 0, s, a);
@@ -455,13 +604,43 @@ template <int D> static int launch_lfa32_d(const Lfa32Args& a, bool second, int 
     return SSDR_OK;
 }
 
+template <int D> static int launch_lfa32_res(const Lfa32Args& a, bool second, int B, int prec, hipStream_t s) {
+    using C = Lfa32ResCfg<D>;
+    dim3 grid((unsigned)((a.n + 2 * C::NW * C::RPW - 1) / (2 * C::NW * C::RPW)), (unsigned)B);
+    const int terms = prec == PREC_BF16X3 ? 2 : 1;
+    const size_t lds = C::lds_bytes(terms, second);
+    static std::once_flag attr_once;
+    hipError_t ae = hipSuccess;
+    std::call_once(attr_once, [&] {
+        ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_res_kernel<D, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2, true));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_res_kernel<D, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2, false));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_res_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1, true));
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_res_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1, false));
+    });
+    SSDR_HIP(ae);
+    const double rows = (double)B * (double)a.n * 16.0, np = terms == 2 ? 3.0 : 1.0;
+    // executed: LocSE (K padded to 16, both orientations, two instructions for the four products), LFAmlp2 in both orientations, the whole d x d attention product
+    const double exec = rows * (2.0 * 2.0 * 16 * C::H * terms + (second ? 2.0 * 2.0 * C::H * C::H * np : 0.0) + 2.0 * D * D * np);
+    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
+    const dim3 blk(C::NW * 64);
+    if (terms == 2) {
+        if (second) hipLaunchKernelGGL((lfa32_res_kernel<D, true, 2>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((lfa32_res_kernel<D, false, 2>), grid, blk, lds, s, a);
+    } else {
+        if (second) hipLaunchKernelGGL((lfa32_res_kernel<D, true, 1>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((lfa32_res_kernel<D, false, 1>), grid, blk, lds, s, a);
+    }
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
 int launch_lfa32(int D, const Lfa32Args& a, bool second, int B, int prec, hipStream_t s) {
     if (a.n <= 0 || B <= 0) return SSDR_OK;
-    if (!a.g || !a.fc_hi || !a.w1p || (second && !a.w2_hi)) { set_error("lfa32: missing G rows or permuted weight pieces"); return SSDR_ERR_INVALID; }
+    if ((!a.g && D > 64) || !a.fc_hi || !a.w1p || (second && !a.w2_hi)) { set_error("lfa32: missing G rows or permuted weight pieces"); return SSDR_ERR_INVALID; }
     switch (D) {
         case 16: return launch_lfa32_l0(a, second, B, prec, s);
-        case 64: return launch_lfa32_d<64>(a, second, B, prec, s);
-        case 128: return launch_lfa32_d<128>(a, second, B, prec, s);
+        case 64: return launch_lfa32_res<64>(a, second, B, prec, s);
+        case 128: return launch_lfa32_d<128>(a, second, B, prec, s);      // (the no-G form was measured at this width: 103 / 121 us against 67 / 100 — twice the matrix work, one workgroup per CU)
         case 256: return launch_lfa32_d<256>(a, second, B, prec, s);
         case 512: return launch_lfa32_d<512>(a, second, B, prec, s);
         default: return SSDR_ERR_UNSUPPORTED;       // no error text: the caller falls back to lfa_bf16_kernel

@@ -66,14 +66,22 @@ float bf16_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f,
 int kperm_src(int pos) { const int h = pos >> 3, j = pos & 7; return 8 * (j >> 2) + 4 * h + (j & 3); }
 
 // rows k0 .. k0 + K of W [in][out] as bf16 pieces [out][K] in that k order, scaled
-int permuted_pieces(Layer& ly, const float* W, int k0, int K, double scale) {
-    std::vector<uint16_t> hi((size_t)ly.out * K), lo((size_t)ly.out * K);
+// (with_natural: followed by rows 0 .. K of W in natural k order, [out][K] again — the neighbour half of the attention matrix)
+int permuted_pieces(Layer& ly, const float* W, int k0, int K, double scale, bool with_natural = false) {
+    std::vector<uint16_t> hi((size_t)ly.out * K * (with_natural ? 2 : 1)), lo(hi.size());
     for (int x = 0; x < ly.out; ++x)
         for (int kb = 0; kb < K; kb += 16)
             for (int pos = 0; pos < 16; ++pos) {
                 const float v = (float)((double)W[(size_t)(k0 + kb + kperm_src(pos)) * ly.out + x] * scale);
                 const uint16_t h = bf16_rn(v);
                 hi[(size_t)x * K + kb + pos] = h; lo[(size_t)x * K + kb + pos] = bf16_rn(v - bf16_f32(h));
+            }
+    if (with_natural)
+        for (int x = 0; x < ly.out; ++x)
+            for (int k = 0; k < K; ++k) {
+                const float v = (float)((double)W[(size_t)k * ly.out + x] * scale);
+                const uint16_t h = bf16_rn(v);
+                hi[(size_t)(ly.out + x) * K + k] = h; lo[(size_t)(ly.out + x) * K + k] = bf16_rn(v - bf16_f32(h));
             }
     SSDR_TRY(ly.Ph.reserve(2 * hi.size())); SSDR_TRY(ly.Pl.reserve(2 * lo.size()));
     SSDR_HIP(hipMemcpy(ly.Ph.p, hi.data(), 2 * hi.size(), hipMemcpyHostToDevice));
@@ -147,9 +155,11 @@ int level0_tables(Layer& ly, int role, const float* W, const float* b) {
         std::vector<uint16_t> xh, xl;
         level0_fragment(hi, lo, true, false, w); level0_fragment(xh, xl, false, true, w);
         hi.insert(hi.end(), xh.begin(), xh.end()); lo.insert(lo.end(), xl.begin(), xl.end());      // fragments: T, X
-    } else {                    // attention 16 -> 16: rows 8..15 (the position half), x log2 e
-        auto w = [&](int j, int c) -> float { return (float)((double)W[(size_t)(8 + j) * 16 + c] * 1.4426950408889634); };
-        level0_fragment(hi, lo, false, false, w);
+    } else {                    // attention 16 -> 16, x log2 e: fragment 0 = rows 8..15 (the position half), fragment 1 = rows 0..7 (the neighbour-feature half)
+        for (int half = 1; half >= 0; --half) {
+            auto w = [&](int j, int c) -> float { return (float)((double)W[(size_t)(8 * half + j) * 16 + c] * 1.4426950408889634); };
+            level0_fragment(hi, lo, false, false, w);
+        }
     }
     SSDR_TRY(upload16(ly.Ph, hi));
     return upload16(ly.Pl, lo);
@@ -225,7 +235,7 @@ int ssdr_randla_set_layer(void* handle, int layer, const float* W, const float* 
         if (m->d_out[(layer - 1) / 8] == 16 && (r == 1 || r == 2 || r == 4 || r == 5)) SSDR_TRY(level0_tables(ly, r == 5 ? 2 : r, W, b));
         else if (r == 1 && ly.in == 10) SSDR_TRY(locse_fragments(ly, W));
         else if (r == 4 && ly.in % 16 == 0) SSDR_TRY(permuted_pieces(ly, W, 0, ly.in, 1.0));
-        else if ((r == 2 || r == 5) && ly.in % 32 == 0) SSDR_TRY(permuted_pieces(ly, W, ly.in / 2, ly.in / 2, 1.4426950408889634));
+        else if ((r == 2 || r == 5) && ly.in % 32 == 0) SSDR_TRY(permuted_pieces(ly, W, ly.in / 2, ly.in / 2, 1.4426950408889634, true));
     }
     ly.set = true;
     return SSDR_OK;
@@ -262,7 +272,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
     // workspaces: per level f_pc, agg(d), agg-mlp, out(2d), sampled(2d); decoder ping-pong; fc1/fc2
     size_t need = 0;
     auto idxs = [&](int level, int which) { return level * 6 + which; };
-    if (m->ws.size() < (size_t)(6 * L + 6)) m->ws.resize(6 * L + 6);
+    if (m->ws.size() < (size_t)(6 * L + 7)) m->ws.resize(6 * L + 7);
     auto buf = [&](int slot, size_t floats) -> float* { if (m->ws[slot].reserve(floats * 4) != SSDR_OK) return nullptr; (void)need; return m->ws[slot].as<float>(); };
 
     // fc0
@@ -276,17 +286,25 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         float* f_pc = buf(idxs(i, 0), rows * h); float* agg = buf(idxs(i, 1), rows * d); float* aggm = buf(idxs(i, 2), rows * d);
         float* out = buf(idxs(i, 3), rows * 2 * d); float* samp = buf(idxs(i, 4), B * (size_t)N[i + 1] * 2 * d);
         if (!f_pc || !agg || !aggm || !out || !samp) return SSDR_ERR_HIP;
-        SSDR_TRY(run_dense(*m, dense(f, d_in, m->layers[base + 0], f_pc, (int)rows, 1), s));                 // mlp1
+        const bool use32 = m->prec != PREC_F32 && use_lfa32();    // 32 x 32-tile formulation (randla_lfa32.hip), every level
+        // level 0 of the 32 x 32 formulation gathers from ONE table [x y z 0 | f0..f7 | -] per point (randla_lfa32.hip): mlp1 and the first attention
+        // mlp write their 8 channels into its rows, the first one the coordinates as well
+        float* tab0 = nullptr;
+        if (use32 && d == 16) { tab0 = buf(6 * L + 5, rows * 16); if (!tab0) return SSDR_ERR_HIP; }
+        {
+            DenseArgs a1 = dense(f, d_in, m->layers[base + 0], tab0 ? tab0 + 4 : f_pc, (int)rows, 1);
+            if (tab0) { a1.ldy = 16; a1.xyz = d_xyz; a1.xyz_batch_stride = n0 * 3; a1.xyz_rows_per_batch = n; }
+            SSDR_TRY(run_dense(*m, a1, s));                                                                  // mlp1
+        }
         LfaArgs la{}; la.xyz = d_xyz; la.xyz_batch_stride = n0 * 3; la.neigh = d_neigh_idx[i]; la.n = n;
         la.w_l1 = m->layers[base + 1].W.as<float>(); la.b_l1 = m->layers[base + 1].b.as<float>();
         la.w_l2 = m->layers[base + 4].W.as<float>(); la.b_l2 = m->layers[base + 4].b.as<float>();
         la.fin = f_pc; la.w_fc = m->layers[base + 2].W.as<float>(); la.w_fc_t = m->layers[base + 2].Wt.as<float>(); la.out = agg;
         la.fc_hi = m->layers[base + 2].Wh.as<uint16_t>(); la.fc_lo = m->layers[base + 2].Wl.as<uint16_t>();
         la.l2_hi = m->layers[base + 4].Wh.as<uint16_t>(); la.l2_lo = m->layers[base + 4].Wl.as<uint16_t>(); la.kp2 = m->layers[base + 4].kp;
-        const bool use32 = m->prec != PREC_F32 && use_lfa32();    // 32 x 32-tile formulation (randla_lfa32.hip), every level
         const bool lfa16 = m->prec != PREC_F32 && d >= 64;         // the 16 x 16-tile bf16 kernels; their d = 16 level runs on the exact-f32 kernel in every mode
         float* gbuf = nullptr;
-        if (d >= 64 || use32) {      // neighbour half of the attention product once per point: G = f_pc * W[0:h]  (rows 0..h-1 of the [d][d] weights)
+        if (d >= 64 && !(use32 && d <= 64)) {      // neighbour half of the attention product once per point (the 32 x 32 formulation multiplies it in the kernel up to d = 64): G = f_pc * W[0:h]  (rows 0..h-1 of the [d][d] weights)
             gbuf = buf(idxs(i, 5), rows * d); if (!gbuf) return SSDR_ERR_HIP;
             DenseArgs ga{}; ga.x1 = f_pc; ga.k1 = h; ga.W = la.w_fc; ga.b = nullptr; ga.y = gbuf; ga.M = (int)rows; ga.N = d; ga.act = 0; ga.m_per_batch = 1;
             ga.wt_hi = la.fc_hi; ga.wt_lo = la.fc_lo; ga.kp = m->layers[base + 2].kp;
@@ -305,8 +323,12 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
             }
             return lfa16 ? launch_lfa_bf16(d, la, second, Bi, m->prec, s) : launch_lfa(d, la, second, Bi, s);
         };
-        SSDR_TRY(run_lfa(false, f_pc, m->layers[base + 2]));                                                 // LocSE + att pool 1
-        SSDR_TRY(run_dense(*m, dense(agg, d, m->layers[base + 3], aggm, (int)rows, 1), s));                   // att1 mlp d->h
+        SSDR_TRY(run_lfa(false, tab0 ? tab0 : f_pc, m->layers[base + 2]));                                                 // LocSE + att pool 1
+        {
+            DenseArgs a3 = dense(agg, d, m->layers[base + 3], tab0 ? tab0 + 4 : aggm, (int)rows, 1);     // att1 mlp d->h
+            if (tab0) a3.ldy = 16;
+            SSDR_TRY(run_dense(*m, a3, s));
+        }
         la.fin = aggm; la.w_fc = m->layers[base + 5].W.as<float>(); la.w_fc_t = m->layers[base + 5].Wt.as<float>(); la.out = agg;
         la.fc_hi = m->layers[base + 5].Wh.as<uint16_t>(); la.fc_lo = m->layers[base + 5].Wl.as<uint16_t>();
         if (gbuf) {
@@ -314,7 +336,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
             ga.wt_hi = la.fc_hi; ga.wt_lo = la.fc_lo; ga.kp = m->layers[base + 5].kp;
             SSDR_TRY(run_dense(*m, ga, s));
         }
-        SSDR_TRY(run_lfa(true, aggm, m->layers[base + 5]));                                                  // LocSE2 + att pool 2
+        SSDR_TRY(run_lfa(true, tab0 ? tab0 : aggm, m->layers[base + 5]));                                                  // LocSE2 + att pool 2
         SSDR_TRY(run_dense(*m, dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
         DenseArgs r = dense(aggm, d, m->layers[base + 7], out, (int)rows, 1);                               // lrelu(mlp2 + shortcut)
         r.x2 = f; r.k2 = d_in;
