@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=("f32", "bf16x3", "bf16"),
                     help="arithmetic of the network's matrix products (activations / accumulation are fp32 in every mode); bf16x3 = split bf16, "
                          "inside the 1e-3 feature tolerance of the fp32 path (tests/test_randla.py); bf16 = BASELINE configuration 3")
+    ap.add_argument("--tiles16", action="store_true", help="bf16 modes: the 16 x 16-tile attention kernels of rounds 1-3 instead of the 32 x 32 formulation (A/B timing)")
     ap.add_argument("--selector", default="fps", choices=("fps", "kcenter"),
                     help="final selection over the (gathered) propagated features: FPS (the paper's gcn_fps branch) or the global k-center of BASELINE configuration 4")
     ap.add_argument("--emu", action="store_true",
@@ -121,7 +122,7 @@ def main():
     rooms = [synthetic.make_room(5000 + i, density=density) for i in ids]
 
     def mk():
-        return pipeline.HotPath(weights, Cfg, precision=args.precision, selector=args.selector, **hp_kw).load_rooms(rooms, ids)
+        return pipeline.HotPath(weights, Cfg, precision=args.precision, selector=args.selector, tiles32=not args.tiles16, **hp_kw).load_rooms(rooms, ids)
     hp = mk()
 
     gather = None
@@ -190,7 +191,7 @@ def main():
     NPROF = 3
     mfma_kernels = ("dense_kernel", "lfa_att_kernel")
     mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
-    mfma_insn = "v_mfma_f32_16x16x4_f32" if args.precision == "f32" else "v_mfma_f32_16x16x32_bf16 (LocSE K = 10 and the d = 16 level on v_mfma_f32_16x16x4_f32)"
+    mfma_insn = "v_mfma_f32_16x16x4_f32" if args.precision == "f32" else ("v_mfma_f32_16x16x32_bf16 (LocSE K = 10 and the d = 16 level on v_mfma_f32_16x16x4_f32)" if args.tiles16 else "v_mfma_f32_32x32x16_bf16 (every level; softmax over the neighbours inside the lane)")
     # (a) the way the timed region ran (every rank takes part because of the exchanges) ...
     timed_rows = [] if args.emu else prof_rows((lambda: (pipe.run(NPROF, gather), pipe.finish())) if pipe is not None else (lambda: [hp.step(gather) for _ in range(NPROF)]))
     roofline = None

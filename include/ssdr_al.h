@@ -208,6 +208,10 @@ int  ssdr_randla_set_layer(void* handle, int layer, const float* W, const float*
 #define SSDR_PREC_BF16X3 1
 #define SSDR_PREC_BF16 2
 int  ssdr_randla_set_precision(void* handle, int mode);
+/* formulation of the K-expanded building_block halves in the two bf16 modes: 1 (default) = 32 x 32 MFMA tiles with the softmax over the
+ * neighbours inside the lane (csrc/randla_lfa32.hip, every level), 0 = the 16 x 16-tile kernels of rounds 1-3 (csrc/randla_bf16.hip; their level 0
+ * runs on the exact-f32 kernel).  Same results within the tolerance above; kept selectable for A/B timing and as a second check of either. */
+int  ssdr_randla_set_formulation(void* handle, int tiles32);
 void ssdr_randla_destroy(void* handle);
 int  ssdr_randla_infer_dev(void* handle, size_t batch_size, size_t npts, const float* d_features, const float* d_xyz,
                            const int32_t* ratios, int32_t* const* d_neigh_idx, int32_t* const* d_interp_idx,

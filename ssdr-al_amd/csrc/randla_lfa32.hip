@@ -53,10 +53,10 @@ template <int D> struct Lfa32Cfg {
     static constexpr int CC2 = H < 8192 / H ? H : 8192 / H;            // LFAmlp2 output channels per staged chunk
     static constexpr int NF = D / CCF, N2 = H / CC2;
     static constexpr int RS = 2 * H + 16;                              // bytes per staged row: 16-byte slots rotate through the banks
-    static constexpr int NT = 256;
-    static constexpr size_t buf_bytes(int terms) { return (size_t)terms * CCF * RS; }
-    static constexpr size_t lds_bytes(int terms, bool second) { return buf_bytes(terms) * ((second ? N2 : 0) + NF > 1 ? 2 : 1); }
-    static constexpr int maxp(int terms) { return (terms * CCF * (H / 8) + NT - 1) / NT; }
+    // waves per workgroup: each owns one pair of points and shares the staged chunk; 8 (two per SIMD) where the registers allow two waves per SIMD anyway
+    static constexpr int nw(bool second) { return D >= 256 && !second ? 8 : 4; }
+    static constexpr int SPR = RS / 16;                                // 16-byte slots per staged row (the last one is padding)
+    static constexpr size_t buf_bytes(int terms) { return ((size_t)terms * CCF * RS + 4095) / 4096 * 4096; }      // whole 1 KB DMA blocks, the same number for each of the 4 waves
 };
 
 template <int TERMS> __device__ __forceinline__ f32x16 mma32_split(const u32x4 (&a)[TERMS], const u32x4 (&b)[TERMS], f32x16 c) {
@@ -126,24 +126,28 @@ __device__ __forceinline__ float softmax_wsum(const f32x16& s, const float (&f)[
 }
 
 template <int D, bool SECOND, int TERMS>
-__global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
+__global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D >= 256 && !SECOND) ? 2 : 1) void lfa32_kernel(Lfa32Args a) {
     using C = Lfa32Cfg<D>;
+    constexpr int NW = C::nw(SECOND), NT = NW * 64;
     constexpr int H = C::H, KS = C::KS, HT = C::HT, CT = C::CT, CCF = C::CCF, CC2 = C::CC2, NF = C::NF, N2 = SECOND ? C::N2 : 0, RS = C::RS;
-    constexpr int NCH = N2 + NF, MAXP = C::maxp(TERMS);
-    constexpr size_t BUFB = C::buf_bytes(TERMS), TERMB = (size_t)CCF * RS;
+    constexpr int NCH = N2 + NF;
+    constexpr size_t BUFB = C::buf_bytes(TERMS);
     constexpr bool OFFREG = H <= 64;            // both gather offset tables in registers
     constexpr bool W1REG = H <= 64;             // LocSE weight fragments in registers
-    SSDR_DYN_SHARED(float, smem);
-    char* lds = reinterpret_cast<char*>(smem);
+    __shared__ __attribute__((aligned(16))) char ldsA[BUFB];
+    __shared__ __attribute__((aligned(16))) char ldsB[NCH > 1 ? BUFB : 16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     int bx, b; xcd_tile_map(bx, b);
-    const int n = a.n, rt = bx * 4 + w;
+    const int n = a.n, rt = bx * NW + w;
     const bool active = 2 * rt < n;             // wave-uniform: a wave past the end still stages weights and meets the barriers
     const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
     const int* neigh = a.neigh + (size_t)b * n * 16;
 
-    // ---- weight chunks through LDS ----------------------------------------------------------------------------------------------
+    // ---- weight chunks through LDS: image [term][row][RS].  Fetched into registers while the previous chunk is multiplied, stored behind it.
+    // (LDS DMA — global_load_lds_dwordx4, no staging registers — was built and measured slower: the compiler makes the first LDS read behind
+    // an outstanding DMA wait for vmcnt(0), the chunk in flight and every gather with it, whatever LDS object the DMA writes.)
+    constexpr int MAXP = (TERMS * CCF * (H / 8) + NT - 1) / NT;
     u32x4 stg[MAXP];
     auto stage_load = [&](int i) {
         const bool is2 = SECOND && i < N2;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
         const uint16_t* hi = (is2 ? a.w2_hi : a.fc_hi) + base; const uint16_t* lo = (is2 ? a.w2_lo : a.fc_lo) + base;
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
-            const int e = tid + 256 * p;
+            const int e = tid + NT * p;
             if (e < TERMS * per) { const int t = e >= per ? 1 : 0; stg[p] = ld128g((t ? lo : hi) + (size_t)(e - t * per) * 8); }
         }
     };
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
         const int rows = is2 ? CC2 : CCF, per = rows * (H / 8);
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
-            const int e = tid + 256 * p;
-            if (e < TERMS * per) { const int t = e >= per ? 1 : 0, r = e - t * per; st128s(buf + t * TERMB + (size_t)(r / (H / 8)) * RS + (r % (H / 8)) * 16, stg[p]); }
+            const int e = tid + NT * p;
+            if (e < TERMS * per) { const int t = e >= per ? 1 : 0, r = e - t * per; st128s(buf + (size_t)t * rows * RS + (size_t)(r / (H / 8)) * RS + (r % (H / 8)) * 16, stg[p]); }
         }
     };
     stage_load(0);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
         for (int q = 0; q < 16; ++q) x[q] = lrelu(acc[q]);
     };
 
-    stage_store(0, lds);
+    stage_store(0, ldsA);
     float x2[SECOND ? HT : 1][16];
     u32x4 T2f[SECOND ? KS : 1][TERMS];
     auto score_frag = [&](int s) -> const u32x4 (&)[TERMS] { if constexpr (SECOND) return T2f[s]; else return Tf[s]; };
@@ -234,9 +238,16 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) gn[q] = buf_load_s(rG, goff[q], 0u);
 
+    // weight fragments out of a staged image, two k steps ahead of the products that use them (an LDS read issued right in front of its
+    // product exposes its ~100 cycles on every k step: the compiler's own schedule, half the matrix rate)
+    auto wfrag = [&](const char* img, int rows, int tile, int s, u32x4 (&f)[TERMS]) {
+#pragma unroll
+        for (int term = 0; term < TERMS; ++term) f[term] = ld128g(img + (size_t)term * rows * RS + (size_t)(32 * tile + lr) * RS + (16 * s + 8 * lh) * 2);
+    };
+
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        char* buf = lds + (size_t)(i & 1) * BUFB;
+        char* buf = (i & 1) ? ldsB : ldsA;
         __syncthreads();                                       // chunk i is in place; everybody is done with the other buffer
         if (i + 1 < NCH) stage_load(i + 1);
         if (SECOND && i < N2) {
@@ -246,13 +257,20 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
                 for (int tt = 0; tt < CC2 / 32; ++tt) {
                     const int t2 = i * (CC2 / 32) + tt;
                     f32x16 accT = bias_rows(a.b2, 32 * t2, lh), accX = bias_cols(a.b2, 32 * t2, lr);
+                    u32x4 wa[TERMS], wb[TERMS];
+                    wfrag(buf, CC2, tt, 0, wa);
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        u32x4 wf[TERMS];
-#pragma unroll
-                        for (int term = 0; term < TERMS; ++term) wf[term] = ld128g(buf + term * TERMB + (size_t)(32 * tt + lr) * RS + (16 * s + 8 * lh) * 2);
-                        accT = mma32_split<TERMS>(wf, Tf[s], accT);
-                        accX = mma32_split<TERMS>(Tf[s], wf, accX);
+                    for (int s = 0; s < KS; s += 2) {              // (the scheduler sinks an LDS read to its first use: fences keep the next step's reads ahead of this step's products)
+                        wfrag(buf, CC2, tt, s + 1, wb);
+                        SSDR_SCHED_FENCE();
+                        accT = mma32_split<TERMS>(wa, Tf[s], accT);
+                        accX = mma32_split<TERMS>(Tf[s], wa, accX);
+                        SSDR_SCHED_FENCE();
+                        if (s + 2 < KS) wfrag(buf, CC2, tt, s + 2, wa);
+                        SSDR_SCHED_FENCE();
+                        accT = mma32_split<TERMS>(wb, Tf[s + 1], accT);
+                        accX = mma32_split<TERMS>(Tf[s + 1], wb, accX);
+                        SSDR_SCHED_FENCE();
                     }
                     if constexpr (SECOND) {
 #pragma unroll
@@ -267,6 +285,8 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
 #pragma unroll
                 for (int uu = 0; uu < CCF / 32; ++uu) {
                     const int u = (i - N2) * (CCF / 32) + uu;
+                    u32x4 wa[TERMS], wb[TERMS];
+                    wfrag(buf, CCF, uu, 0, wa);
                     f32x16 acc;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[q] = gn[q];
@@ -279,12 +299,18 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
 #pragma unroll
                         for (int q = 0; q < 16; ++q) fv[q] = buf_load_s(rF, f_off(q), (unsigned)u * 128u);
                     }
+                    static_assert(KS % 2 == 0, "k steps in pairs");
+                    SSDR_SCHED_FENCE();                            // the gathers above stay above: sunk to their use they cost a trip to L2 per column tile
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        u32x4 wf[TERMS];
-#pragma unroll
-                        for (int term = 0; term < TERMS; ++term) wf[term] = ld128g(buf + term * TERMB + (size_t)(32 * uu + lr) * RS + (16 * s + 8 * lh) * 2);
-                        acc = mma32_split<TERMS>(score_frag(s), wf, acc);
+                    for (int s = 0; s < KS; s += 2) {              // the fragments of the next k step are requested before this step's products
+                        wfrag(buf, CCF, uu, s + 1, wb);
+                        SSDR_SCHED_FENCE();
+                        acc = mma32_split<TERMS>(score_frag(s), wa, acc);
+                        SSDR_SCHED_FENCE();
+                        if (s + 2 < KS) wfrag(buf, CCF, uu, s + 2, wa);
+                        SSDR_SCHED_FENCE();
+                        acc = mma32_split<TERMS>(score_frag(s + 1), wb, acc);
+                        SSDR_SCHED_FENCE();
                     }
                     if (u >= HT) {
                         if constexpr (SECOND) {
@@ -297,10 +323,9 @@ __global__ __launch_bounds__(256) void lfa32_kernel(Lfa32Args a) {
                 }
             }
         }
-        if (i + 1 < NCH) stage_store(i + 1, lds + (size_t)((i + 1) & 1) * BUFB);
+        if (i + 1 < NCH) stage_store(i + 1, (i & 1) ? ldsA : ldsB);
     }
 }
-
 
 // ---- levels whose weights fit in LDS whole (d = 64, 128): no G table ----------------------------------------------------------------------------
 // What bounds the gathering levels is the vector-memory return path: a gather-type load costs the CU ~10 cycles per dword of a wave instruction
@@ -392,13 +417,20 @@ __global__ __launch_bounds__(Lfa32ResCfg<D>::NW * 64) void lfa32_res_kernel(Lfa3
 #pragma unroll
             for (int t2 = 0; t2 < HT; ++t2) {
                 f32x16 accT = bias_rows(a.b2, 32 * t2, lh), accX = bias_cols(a.b2, 32 * t2, lr);
+                u32x4 wa[TERMS], wb[TERMS];
+                auto w2f = [&](int s2, u32x4 (&f)[TERMS]) {
 #pragma unroll
-                for (int s2 = 0; s2 < KS; ++s2) {
-                    u32x4 wf[TERMS];
+                    for (int term = 0; term < TERMS; ++term) f[term] = ld128g(img2 + (size_t)term * H * RS + (size_t)(32 * t2 + lr) * RS + (16 * s2 + 8 * lh) * 2);
+                };
+                w2f(0, wa);
 #pragma unroll
-                    for (int term = 0; term < TERMS; ++term) wf[term] = ld128g(img2 + (size_t)term * H * RS + (size_t)(32 * t2 + lr) * RS + (16 * s2 + 8 * lh) * 2);
-                    accT = mma32_split<TERMS>(wf, Tf[s2], accT);
-                    accX = mma32_split<TERMS>(Tf[s2], wf, accX);
+                for (int s2 = 0; s2 < KS; s2 += 2) {
+                    w2f(s2 + 1, wb);
+                    accT = mma32_split<TERMS>(wa, Tf[s2], accT);
+                    accX = mma32_split<TERMS>(Tf[s2], wa, accX);
+                    if (s2 + 2 < KS) w2f(s2 + 2, wa);
+                    accT = mma32_split<TERMS>(wb, Tf[s2 + 1], accT);
+                    accX = mma32_split<TERMS>(Tf[s2 + 1], wb, accX);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) x2[t2][q] = lrelu(accX[q]);
@@ -414,21 +446,30 @@ __global__ __launch_bounds__(Lfa32ResCfg<D>::NW * 64) void lfa32_res_kernel(Lfa3
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2) {
-                u32x4 wn[TERMS], wp[TERMS];
-#pragma unroll
-                for (int term = 0; term < TERMS; ++term) {
-                    wn[term] = ld128g(imgn + (size_t)term * D * RS + (size_t)(32 * u + lr) * RS + (16 * s2 + 8 * lh) * 2);
-                    wp[term] = ld128g(imgp + (size_t)term * D * RS + (size_t)(32 * u + lr) * RS + (16 * s2 + 8 * lh) * 2);
-                }
-                acc = mma32_split<TERMS>(fnf[s2], wn, acc);
-                acc = mma32_split<TERMS>(Tf[s2], wp, acc);
-            }
             float fv[16];
             if (u < HT) {                                // the gathered features back in the accumulator layout: row (half lh, neighbour q), channel 32 u + lr
 #pragma unroll
                 for (int q = 0; q < 16; ++q) fv[q] = *reinterpret_cast<const float*>(fimg + (size_t)((q & 3) + 8 * (q >> 2) + 4 * lh) * FRS + (32 * u + lr) * 4);
+            }
+            u32x4 wa[2][TERMS], wb[2][TERMS];            // [neighbour half, position half]
+            auto wsf = [&](int s2, u32x4 (&f)[2][TERMS]) {
+#pragma unroll
+                for (int term = 0; term < TERMS; ++term) {
+                    f[0][term] = ld128g(imgn + (size_t)term * D * RS + (size_t)(32 * u + lr) * RS + (16 * s2 + 8 * lh) * 2);
+                    f[1][term] = ld128g(imgp + (size_t)term * D * RS + (size_t)(32 * u + lr) * RS + (16 * s2 + 8 * lh) * 2);
+                }
+            };
+            wsf(0, wa);
+#pragma unroll
+            for (int s2 = 0; s2 < KS; s2 += 2) {         // (fences that keep the next k step's LDS reads ahead of this step's products were measured slower here: 134 / 152 us against 117 / 141)
+                wsf(s2 + 1, wb);
+                acc = mma32_split<TERMS>(fnf[s2], wa[0], acc);
+                acc = mma32_split<TERMS>(Tf[s2], wa[1], acc);
+                if (s2 + 2 < KS) wsf(s2 + 2, wa);
+                acc = mma32_split<TERMS>(fnf[s2 + 1], wb[0], acc);
+                acc = mma32_split<TERMS>(Tf[s2 + 1], wb[1], acc);
+            }
+            if (u < HT) {
             } else if constexpr (SECOND) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) fv[q] = x2[u - HT][q];
@@ -575,18 +616,9 @@ static int launch_lfa32_l0(const Lfa32Args& a, bool second, int B, int prec, hip
 
 template <int D> static int launch_lfa32_d(const Lfa32Args& a, bool second, int B, int prec, hipStream_t s) {
     using C = Lfa32Cfg<D>;
-    dim3 grid((unsigned)((a.n + 7) / 8), (unsigned)B);
+    const int nw = C::nw(second);
+    dim3 grid((unsigned)((a.n + 2 * nw - 1) / (2 * nw)), (unsigned)B);
     const int terms = prec == PREC_BF16X3 ? 2 : 1;
-    const size_t lds = C::lds_bytes(terms, second);
-    static std::once_flag attr_once;
-    hipError_t ae = hipSuccess;
-    std::call_once(attr_once, [&] {
-        ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2, true));
-        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(2, false));
-        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1, true));
-        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&lfa32_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes(1, false));
-    });
-    SSDR_HIP(ae);
     const double rows = (double)B * (double)a.n * 16.0;       // algorithmic FLOPs of the reference's formulation (as lfa_att_kernel)
     // executed on the matrix cores: LocSE with K padded to 16 in both orientations (two instructions carry the four products),
     // LFAmlp2 in both orientations and the position half of the attention product (one or three bf16 products)
@@ -594,11 +626,11 @@ template <int D> static int launch_lfa32_d(const Lfa32Args& a, bool second, int 
     const double exec = rows * (2.0 * 2.0 * 16 * C::H * terms + (second ? 2.0 * 2.0 * C::H * C::H * np : 0.0) + 2.0 * C::H * D * np);
     ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
     if (terms == 2) {
-        if (second) hipLaunchKernelGGL((lfa32_kernel<D, true, 2>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((lfa32_kernel<D, false, 2>), grid, dim3(256), lds, s, a);
+        if (second) hipLaunchKernelGGL((lfa32_kernel<D, true, 2>), grid, dim3(nw * 64), 0, s, a);
+        else hipLaunchKernelGGL((lfa32_kernel<D, false, 2>), grid, dim3(nw * 64), 0, s, a);
     } else {
-        if (second) hipLaunchKernelGGL((lfa32_kernel<D, true, 1>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((lfa32_kernel<D, false, 1>), grid, dim3(256), lds, s, a);
+        if (second) hipLaunchKernelGGL((lfa32_kernel<D, true, 1>), grid, dim3(nw * 64), 0, s, a);
+        else hipLaunchKernelGGL((lfa32_kernel<D, false, 1>), grid, dim3(nw * 64), 0, s, a);
     }
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;

@@ -24,6 +24,7 @@ struct Layer {
 struct Model {
     int L = 5, K = 16, C = 13, in_dim = 6;
     int prec = PREC_F32;
+    int tiles32 = 1;             // lfa32 formulation in the bf16 modes (ssdr_randla_set_formulation)
     int d_out[8] = {16, 64, 128, 256, 512, 0, 0, 0};
     std::vector<Layer> layers;
     std::vector<DevBuf> ws;      // activation workspaces
@@ -110,8 +111,6 @@ int locse_fragments(Layer& ly, const float* W) {
     SSDR_HIP(hipMemcpy(ly.P1.p, f.data(), 2 * f.size(), hipMemcpyHostToDevice));
     return SSDR_OK;
 }
-
-bool use_lfa32() { static const bool on = [] { const char* e = getenv("SSDR_LFA32"); return !e || e[0] != '0'; }(); return on; }
 
 // Level 0 (d = 16, h = 8) of lfa32_kernel: two pairs of points share one 32 x 32 x 16 tile through block-diagonal weight operands, so the operand
 // fragments are lane-dependent constants: table [fragment][64 lanes][8 bf16].  Lane l = (r = l & 31, half hh = l >> 5) holds k slots 8 hh + j, i.e.
@@ -248,6 +247,13 @@ int ssdr_randla_set_precision(void* handle, int mode) {
     return SSDR_OK;
 }
 
+int ssdr_randla_set_formulation(void* handle, int tiles32) {
+    Model* m = static_cast<Model*>(handle);
+    if (!m) { set_error("randla_set_formulation: bad handle"); return SSDR_ERR_INVALID; }
+    m->tiles32 = tiles32 ? 1 : 0;
+    return SSDR_OK;
+}
+
 void ssdr_randla_destroy(void* handle) {
     Model* m = static_cast<Model*>(handle);
     if (!m) return;
@@ -286,7 +292,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         float* f_pc = buf(idxs(i, 0), rows * h); float* agg = buf(idxs(i, 1), rows * d); float* aggm = buf(idxs(i, 2), rows * d);
         float* out = buf(idxs(i, 3), rows * 2 * d); float* samp = buf(idxs(i, 4), B * (size_t)N[i + 1] * 2 * d);
         if (!f_pc || !agg || !aggm || !out || !samp) return SSDR_ERR_HIP;
-        const bool use32 = m->prec != PREC_F32 && use_lfa32();    // 32 x 32-tile formulation (randla_lfa32.hip), every level
+        const bool use32 = m->prec != PREC_F32 && m->tiles32 != 0;    // 32 x 32-tile formulation (randla_lfa32.hip), every level
         // level 0 of the 32 x 32 formulation gathers from ONE table [x y z 0 | f0..f7 | -] per point (randla_lfa32.hip): mlp1 and the first attention
         // mlp write their 8 channels into its rows, the first one the coordinates as well
         float* tab0 = nullptr;
@@ -311,7 +317,7 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
             SSDR_TRY(run_dense(*m, ga, s));
         }
         la.g = gbuf;
-        // 32 x 32-tile formulation (randla_lfa32.hip) where it has an instantiation; SSDR_LFA32=0 keeps the 16 x 16-tile kernels (A/B timing)
+        // 32 x 32-tile formulation (randla_lfa32.hip) where it has an instantiation; ssdr_randla_set_formulation(0) keeps the 16 x 16-tile kernels
         Lfa32Args l32{}; l32.xyz = d_xyz; l32.xyz_batch_stride = n0 * 3; l32.neigh = d_neigh_idx[i]; l32.n = n; l32.g = gbuf; l32.out = agg;
         l32.w1p = m->layers[base + 1].P1.as<uint16_t>(); l32.b1 = la.b_l1;
         l32.w2_hi = m->layers[base + 4].Ph.as<uint16_t>(); l32.w2_lo = m->layers[base + 4].Pl.as<uint16_t>(); l32.b2 = la.b_l2;

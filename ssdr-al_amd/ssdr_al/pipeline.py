@@ -17,9 +17,9 @@ from .helper_tool import ConfigS3DIS
 
 class HotPath:
     def __init__(self, weights, config=ConfigS3DIS, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=1, gcn_top=0,
-                 select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32", selector="fps"):
+                 select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32", selector="fps", tiles32=True):
         self.cfg = config
-        self.net = randlanet.Network(config).load(weights).set_precision(precision)
+        self.net = randlanet.Network(config).load(weights).set_precision(precision).set_formulation(tiles32)
         self.sampler_args = list(sampler_args)
         self.gcn_number, self.gcn_top = gcn_number, gcn_top
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile

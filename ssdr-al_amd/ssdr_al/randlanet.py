@@ -58,6 +58,11 @@ class Network:
         self.precision = mode
         return self
 
+    def set_formulation(self, tiles32=True):
+        """bf16 modes: 32 x 32 MFMA tiles with the softmax inside the lane (default) or the 16 x 16-tile kernels (A/B timing, cross-check)."""
+        _lib.check(_lib.lib().ssdr_randla_set_formulation(self._h, 1 if tiles32 else 0))
+        return self
+
     def layer_table(self, weights):
         """Reference-named weights -> the ABI's ordered (W, b) list (csrc/randla_model.hip header)."""
         L = self.config.num_layers

@@ -154,6 +154,23 @@ def test_randla_bf16_modes_against_fp32_oracle(backend, mode):
         assert np.abs(gp.sum(1) - 1).max() < 1e-5
 
 
+def test_randla_both_tile_formulations_against_fp32_oracle(backend):
+    """The bf16 modes have two formulations of the K-expanded halves (ssdr_randla_set_formulation): 32 x 32 MFMA tiles with the softmax inside
+    the lane (the default, csrc/randla_lfa32.hip: LocSE from 7 reformulated inputs, no G table up to d = 64, level 0 as two point pairs per tile)
+    and the 16 x 16-tile kernels.  Both must sit inside the 1e-3 bar; odd level sizes exercise the tails of the pair / tile loops."""
+    from oracle import randla_np as R
+    from ssdr_al import randlanet
+    B, N = (1, 1016) if backend == "emu" else (2, 8136)
+    W = R.init_weights(2)
+    xyz0, feat, (xyz, neigh, sub, interp) = _inputs(B, N, seed=3)
+    p, f = R.forward(W, feat, xyz, neigh, sub, interp, dtype=np.float32)
+    for tiles32 in (True, False):
+        gp, gf = randlanet.Network().load(W).set_precision("bf16x3").set_formulation(tiles32).infer(feat, xyz0)
+        ep, ef = np.abs(gp - p).max(), np.abs(gf - f).max()
+        print("\nbf16x3, %s tiles on %s: max |probs - oracle| = %.3g, max |feat32 - oracle| = %.3g" % ("32 x 32" if tiles32 else "16 x 16", backend, ep, ef))
+        assert ep < TOL and ef < TOL, (tiles32, ep, ef)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
 def test_randla_full_size_batch16_properties(mode):
