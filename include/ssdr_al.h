@@ -300,6 +300,10 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
                               const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
                               const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t batch_size, int gcn_number, int gcn_top, int selector, int start,
                               size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream);
+/* What the enqueue-only selection calls issued on `stream` found and could not return (bit 0: a cooperative multi-workgroup FPS / k-center
+ * launch — ssdr_fps_dev / ssdr_kcenter_dev above 1536 / 4096 rows — was not co-resident: a workgroup waited for one that never arrived, the chain
+ * stopped and its remaining picks read -1).  Waits for the stream; SSDR_ERR_INTERNAL when a bit is set; clears the word. */
+int ssdr_select_status(void* stream, int32_t* out_status);
 /* farthest_features_sample (fps_gcn_cpu.py:119-147); `start` is the reference's np.random.randint draw */
 int ssdr_fps_dev(const double* d_feat, size_t n, int feat_dim, int start, size_t count, int32_t* d_out, void* stream);
 /* farthest_superpoint_sample (sampler2.py:49-80, "edcd" branch) over one cloud's superpoints, from the centres and

@@ -943,7 +943,11 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
 // of MI355X_MICROARCH.md, "Valid forms": 9.3 us per pick with __threadfence on both sides, measured), and each reduces them itself.  Partials and counters alternate between two
 // sets by the parity of the pick, so a workgroup that runs ahead never overwrites what a slower one still reads.
 constexpr int FC_NT = 256, FC_PPT = 8;
-struct FpsCoopArgs { const double* f; int n, D, from_partials, start, use_sqrt; const Part* pin; int npart; const double* mind; int count; int* out; Part* part; int* sync; int G; };
+struct FpsCoopArgs { const double* f; int n, D, from_partials, start, use_sqrt; const Part* pin; int npart; const double* mind; int count; int* out; Part* part; int* sync; int G; int* status; };
+constexpr long FPS_COOP_SPINS = 1L << 22;      // ~0.3 s of polling: a pick among co-resident workgroups takes microseconds
+// sync[0], sync[1]: arrival counters by pick parity; sync[2]: abort — a workgroup waited FPS_COOP_SPINS polls for one that never arrived (the launch was
+// not co-resident).  It is checked at every pick by every workgroup, which then leaves (the picks from there on read -1), and the stream's selection
+// status word takes bit 0: ssdr_select_status turns it into an error.  Without it a non-resident launch returned a wrong selection silently.
 #ifndef HIPEMU
 __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
     __shared__ double s_v[FC_NT / 64]; __shared__ int s_i[FC_NT / 64]; __shared__ double s_fc[128];
@@ -968,7 +972,11 @@ __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
         for (int k = tid; k < a.npart; k += FC_NT) if (better(a.pin[k].v, a.pin[k].i, v, i)) { v = a.pin[k].v; i = a.pin[k].i; }
         double ov; block_argmax(v, i, ov, c);
     }
+    __shared__ int s_abort;
     for (int it = 0; it < a.count; ++it) {
+        if (tid == 0) s_abort = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_abort) { if (g == 0) for (int k = it + tid; k < a.count; k += FC_NT) a.out[k] = -1; return; }
         if (g == 0 && tid == 0) a.out[it] = c;
         if (it + 1 == a.count) break;
         const double* fc = a.f + (size_t)c * a.D;
@@ -1002,7 +1010,7 @@ __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
             long spins = 0;
             while (__hip_atomic_load(&a.sync[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1L << 26)) { atomicOr(&a.sync[2], 1); break; }       // a workgroup never arrived (not co-resident?): flagged, not hung
+                if (++spins > FPS_COOP_SPINS || __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); break; }
             }
         }
         __syncthreads();
@@ -1054,7 +1062,11 @@ __global__ __launch_bounds__(FR_NT) void fps_coop_reg(FpsCoopArgs a) {
     if (tid < 32) s_fc[tid] = a.f[(size_t)c * 32 + tid];    // the first centre's row comes from the table
     __syncthreads();
     double* recs = reinterpret_cast<double*>(a.part);      // [2][G][FR_REC]
+    __shared__ int s_abort;
     for (int it = 0; it < a.count; ++it) {
+        if (tid == 0) s_abort = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_abort) { if (g == 0) for (int k = it + tid; k < a.count; k += FR_NT) a.out[k] = -1; return; }
         if (g == 0 && tid == 0) a.out[it] = c;
         if (it + 1 == a.count) break;
         double bv = -1.0; int bi = 0x7fffffff, bq = 0;
@@ -1089,7 +1101,7 @@ __global__ __launch_bounds__(FR_NT) void fps_coop_reg(FpsCoopArgs a) {
                 long spins = 0;
                 while (__hip_atomic_load(&a.sync[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1L << 26)) { atomicOr(&a.sync[2], 1); break; }       // a workgroup never arrived (not co-resident?): flagged, not hung
+                    if (++spins > FPS_COOP_SPINS || __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); break; }
                 }
             }
         }
@@ -1344,7 +1356,7 @@ __global__ __launch_bounds__(256) void cand_fill(const int* __restrict__ stage, 
     for (int k = threadIdx.x; k < nl; k += 256) { const int sp = lab_sp[l0 + k]; sel[n_unl + l0 + k] = sp; gsel[g0 + nc + k] = sp; rows[g0 + nc + k] = n_unl + l0 + k; already[l0 + k] = n_unl + l0 + k; }
 }
 
-struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f; };
+struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f, status; bool status_init = false; };
 
 // scratch of the chamfer packer for nrows superpoints in nclouds clouds
 int chamfer_pack_buffers(SelState& Q, size_t nrows, size_t nclouds, ChamferPack& P) {
@@ -1591,7 +1603,25 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         return SSDR_OK;
     }
 #ifndef HIPEMU
-    const bool coop_ok = !d_n && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2);
+    // cooperative kernels (G workgroups that meet at a counter per pick): only above the sizes one workgroup sweeps well (the 160 x 129 / 1000 x 129
+    // k-center shapes keep the 1024-thread fps_block), and only with G workgroups the occupancy query says are resident together — checked, not assumed
+    int coop_g = 0; bool coop_reg = false;
+    if (!d_n && D == 32 && n > 1536 && n <= (size_t)FR_ROWS * (size_t)(ctx().num_cu / 2)) { coop_g = (int)((n + FR_ROWS - 1) / FR_ROWS); coop_reg = true; }
+    else if (!d_n && n > 4096 && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) coop_g = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
+    if (coop_g) {
+        static const int force_g = [] { const char* e = getenv("SSDR_FPS_COOP_G"); return e ? atoi(e) : 0; }();      // tests: a grid above residency must be reported, not believed
+        if (force_g > 0 && coop_g > 0) coop_g = force_g;
+        else {
+            int per_cu = 0;
+            const hipError_t oe = coop_reg ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_reg, FR_NT, 8 * (size_t)coop_g * FR_REC)
+                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop, FC_NT, 0);
+            // half of what the query admits: the query is known to answer one block per CU high at some register counts (MI355X_MICROARCH.md), and
+            // other chains / stage kernels share the CUs
+            if (oe != hipSuccess || (long)per_cu * ctx().num_cu / 2 < coop_g) coop_g = 0;
+        }
+    }
+    const bool coop_ok = coop_g > 0;
+    if (coop_ok && !Q.status_init) { SSDR_TRY(Q.status.reserve(64)); SSDR_HIP(hipMemsetAsync(Q.status.p, 0, 64, s)); Q.status_init = true; }
 #else
     const bool coop_ok = false;
 #endif
@@ -1602,24 +1632,25 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         return SSDR_OK;
     }
 #ifndef HIPEMU
-    if (!d_n && D == 32 && n <= (size_t)FR_ROWS * (size_t)(ctx().num_cu / 2)) {       // rows in registers, partials that carry the candidate's features
-        const int G = (int)((n + FR_ROWS - 1) / FR_ROWS);
+    if (coop_ok && coop_reg) {       // rows in registers, partials that carry the candidate's features
+        const int G = coop_g;
         SSDR_TRY(Q.vtmp.reserve(8 * 2 * (size_t)G * FR_REC + 64));
         Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(Q.vtmp.as<char>() + 8 * 2 * (size_t)G * FR_REC);
         SSDR_HIP(hipMemsetAsync(sync, 0, 16, s));
         static std::once_flag once;
         std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * FR_REC * 128); });
-        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G};
+        if (8 * (size_t)G * FR_REC > 8 * (size_t)FR_REC * 128) { set_error("fps: %d cooperative workgroups exceed the record table of the kernel (128)", G); return SSDR_ERR_INVALID; }
+        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>()};
         hipLaunchKernelGGL(fps_coop_reg, dim3(G), dim3(FR_NT), 8 * (size_t)G * FR_REC, s, a);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
     }
-    if (!d_n && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) {          // one launch: co-resident workgroups meeting at a counter per pick
-        const int G = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
+    if (coop_ok) {          // one launch: co-resident workgroups meeting at a counter per pick
+        const int G = coop_g;
         SSDR_TRY(Q.vtmp.reserve(sizeof(Part) * 2 * (size_t)G + 64));
         Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(part + 2 * G);
         SSDR_HIP(hipMemsetAsync(sync, 0, 16, s));
-        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G};
+        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>()};
         hipLaunchKernelGGL(fps_coop, dim3(G), dim3(FC_NT), 0, s, a);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
@@ -1712,6 +1743,22 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     // selector 1: kCenterGreedy over candidates + labelled rows, seeded with the labelled ones (kcenterGreedy.py:84-128; sampler2.py's "kcenter" branch)
     if (selector == 1) return fps_like(comb, cap_rows, D, already, n_lab, 0, max_select, 1, out, s, counts + 2);
     return fps_like(comb, cap_unl, D, nullptr, 0, start, max_select, 0, out, s, counts);
+}
+
+/* What the enqueue-only selection calls on `stream` found and could not return: bit 0 = a cooperative FPS / k-center launch was not co-resident (a
+ * workgroup waited for one that never arrived): its picks are invalid (-1 from the abort on).  Waits for the stream, clears the word. */
+int ssdr_select_status(void* stream, int32_t* out_status) {
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    int st = 0;
+    if (Q.status_init) {
+        SSDR_HIP(hipMemcpyAsync(&st, Q.status.p, 4, hipMemcpyDeviceToHost, s));
+        SSDR_HIP(hipStreamSynchronize(s));
+        if (st) SSDR_HIP(hipMemsetAsync(Q.status.p, 0, 4, s));
+    } else SSDR_HIP(hipStreamSynchronize(s));
+    if (out_status) *out_status = st;
+    if (st & 1) { set_error("selection: a cooperative FPS / k-center launch was not co-resident (a workgroup never arrived); its picks are invalid"); return SSDR_ERR_INTERNAL; }
+    return SSDR_OK;
 }
 
 int ssdr_fps_superpoint_dev(const double* d_centres, const double* d_cd_dir, size_t n, int start, size_t count, int32_t* d_out, void* stream) {

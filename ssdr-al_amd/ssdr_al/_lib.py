@@ -71,6 +71,7 @@ def lib():
         L.ssdr_randla_layer_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.ssdr_randla_set_layer.argtypes = [vp, i32, vp, vp]
         L.ssdr_randla_set_precision.argtypes = [vp, i32]
+        L.ssdr_select_status.argtypes = [vp, C.POINTER(i32)]
         L.ssdr_randla_set_formulation.argtypes = [vp, i32]
         L.ssdr_randla_destroy.argtypes = [vp]
         L.ssdr_randla_destroy.restype = None

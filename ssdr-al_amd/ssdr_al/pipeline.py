@@ -396,6 +396,8 @@ class HotPath:
             self.unl_cloud_ids = np.asarray(self.room_ids, np.int64)[ccloud]; self.unl_sp = cand - np.asarray(self.sp_base, np.int64)[ccloud]
         else:
             sel = d_out.to_host(self.sel_stream)             # waits for the selection stream alone
+            # a cooperative (multi-workgroup) FPS / k-center launch that was not co-resident reports it here instead of returning a wrong selection
+            _lib.check(_lib.lib().ssdr_select_status(self.sel_stream, None))
         # the device-flavour KNN calls cannot report what their kernels found (overflowed kd queue / node table / level limit, hand-over
         # list): ask once per batch, here where the host waits anyway — without waiting for the pyramids of the LATER batches that the
         # KNN stream already holds (the finished calls' tickets are looked at; Pipelined.finish / the sequential step wait for all)

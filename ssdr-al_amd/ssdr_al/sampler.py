@@ -124,6 +124,7 @@ def farthest_features_sample(feature_list, sample_number, start):
     f = np.ascontiguousarray(feature_list, np.float64)
     d_f = DevArray.from_host(f); d_o = DevArray((sample_number,), np.int32)
     _lib.check(_lib.lib().ssdr_fps_dev(d_f.ptr, f.shape[0], f.shape[1], int(start), sample_number, d_o.ptr, None))
+    _lib.check(_lib.lib().ssdr_select_status(None, None))      # (a cooperative launch that was not co-resident is an error, not a result)
     _lib.sync()
     return d_o.to_host()
 
@@ -190,6 +191,7 @@ class kCenterGreedy:
         a = np.ascontiguousarray(already_selected, np.int32)
         d_f = DevArray.from_host(self.features); d_a = DevArray.from_host(a); d_o = DevArray((N,), np.int32)
         _lib.check(_lib.lib().ssdr_kcenter_dev(d_f.ptr, self.features.shape[0], self.features.shape[1], d_a.ptr, len(a), N, d_o.ptr, None))
+        _lib.check(_lib.lib().ssdr_select_status(None, None))
         _lib.sync()
         return list(d_o.to_host())
 
@@ -235,6 +237,7 @@ def GCN_FPS_sampling(labeled_select_features, labeled_select_ref, unlabeled_cand
         src = dst
     d_out = DevArray((sampling_batch,), np.int32)
     _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, D, int(start), sampling_batch, d_out.ptr, None))   # FPS over comb[:n_unl] (:169-170)
+    _lib.check(L.ssdr_select_status(None, None))
     _lib.sync()
     file_list = {}
     for i in d_out.to_host():

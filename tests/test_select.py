@@ -249,3 +249,27 @@ def test_create_adj_of_the_gcn_branch(backend, golden):
     assert err < 2e-4
     cross = adj[:55, 55:100]                       # candidates of cloud C against candidates of cloud D: exactly 0
     assert np.all(cross == 0)
+
+
+@pytest.mark.gpu
+def test_cooperative_fps_reports_a_launch_that_is_not_co_resident():
+    """fps_coop / fps_coop_reg are G workgroups that meet at a counter per pick: they need all G resident together.  The grid is now taken
+    from the occupancy query (and refused otherwise), a workgroup that waits too long raises an abort flag every workgroup tests at every pick,
+    and the stream's selection status carries it to the host (ssdr_select_status -> SSDR_ERR_INTERNAL).  SSDR_FPS_COOP_G forces a grid above
+    residency (4096 workgroups of 256 threads on 256 CUs x 8): the call must report the failure, with the picks behind the abort reading -1 —
+    and the same problem without the override must give the reference's sequence."""
+    from conftest import GPU_LIB, _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "_fps_coop_worker.py")
+    env = dict(os.environ); env.pop("SSDR_FPS_COOP_G", None)
+    ok = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    assert "RC 0 STATUS 0 MINUS 0" in ok.stdout and "MATCH 1" in ok.stdout, ok.stdout
+    env["SSDR_FPS_COOP_G"] = "4096"
+    bad = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert bad.returncode == 0, bad.stderr[-2000:]
+    line = [l for l in bad.stdout.splitlines() if l.startswith("RC")][0].split()
+    assert int(line[1]) != 0 and int(line[3]) & 1 and int(line[5]) > 0, bad.stdout
