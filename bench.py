@@ -105,6 +105,13 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=not os.environ.get("SSDR_NCCL_NORMAL_PRIO"))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
+    ranks_seen = 1
+    if use_dist:        # what the communicator itself saw: an all-reduce of ones (a SCALE record with n_gpus = N must also show N here)
+        import torch
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if args.emu else torch.device("cuda", local_rank))
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+
     from ssdr_al import _lib, pipeline, synthetic
     from ssdr_al.helper_tool import ConfigS3DIS
     Cfg, tiles_per_gpu, density, hp_kw = ConfigS3DIS, TILES_PER_GPU, RAW_DENSITY, {}
@@ -311,7 +318,7 @@ def main():
 
     if rank == 0:
         assert world == args.gpus or os.environ.get("SSDR_BENCH_FORCE_DIST"), "n_gpus must be what --gpus asked for"
-        out = {"metric": METRIC, "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        out = {"metric": METRIC, "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": DTYPE[args.precision], "data": "synthetic" if not args.emu else "synthetic (TEST MODE: CPU logic build, tiny workload - not a measurement)",
                "config": {"workload": "S3DIS-like rooms (synthetic, Area_5 seeds), %d rooms/tiles of 40960 points per GPU per step: grid-subsample "
@@ -319,6 +326,8 @@ def main():
                                       "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, %s)" % (tiles_per_gpu, args.precision, "FPS start fixed to candidate 0" if args.selector == "fps" else "global k-center over candidates + labelled regions"),
                           "tiles_per_gpu": tiles_per_gpu, "tile_points": Cfg.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
                           "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * tiles_per_gpu * world), "sharding": "tiles",
+                          "selection_rule": getattr(hp, "rule_path", None) or (getattr(pipe.hp[0], "rule_path", None) if pipe is not None else None),
+                          **({"emulated_world": int(os.environ["SSDR_EMULATE_WORLD"])} if os.environ.get("SSDR_EMULATE_WORLD") else {}),
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,
                           "timed_region": "GPU idle at both ends (every stream drained): K launch sequences of every stage and K completed selections, fill and "
                                           "drain of the %d-deep pipe included" % args.pipeline_depth if pipe is not None else "strictly sequential steps"},

@@ -943,13 +943,14 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
 // of MI355X_MICROARCH.md, "Valid forms": 9.3 us per pick with __threadfence on both sides, measured), and each reduces them itself.  Partials and counters alternate between two
 // sets by the parity of the pick, so a workgroup that runs ahead never overwrites what a slower one still reads.
 constexpr int FC_NT = 256, FC_PPT = 8;
-struct FpsCoopArgs { const double* f; int n, D, from_partials, start, use_sqrt; const Part* pin; int npart; const double* mind; int count; int* out; Part* part; int* sync; int G; int* status; };
+struct FpsCoopArgs { const double* f; int n, D, from_partials, start, use_sqrt; const Part* pin; int npart; const double* mind; int count; int* out; Part* part; int* sync; int G; int* status; const int* dn; };
 constexpr long FPS_COOP_SPINS = 1L << 22;      // ~0.3 s of polling: a pick among co-resident workgroups takes microseconds
 // sync[0], sync[1]: arrival counters by pick parity; sync[2]: abort — a workgroup waited FPS_COOP_SPINS polls for one that never arrived (the launch was
 // not co-resident).  It is checked at every pick by every workgroup, which then leaves (the picks from there on read -1), and the stream's selection
 // status word takes bit 0: ssdr_select_status turns it into an error.  Without it a non-resident launch returned a wrong selection silently.
 #ifndef HIPEMU
 __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
+    if (a.dn) a.n = min(a.n, *a.dn);
     __shared__ double s_v[FC_NT / 64]; __shared__ int s_i[FC_NT / 64]; __shared__ double s_fc[128];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G;
     auto block_argmax = [&](double v, int i, double& ov, int& oi) {
@@ -1032,6 +1033,7 @@ __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
 #ifndef HIPEMU
 constexpr int FR_NT = 256, FR_RPT = 2, FR_ROWS = FR_NT * FR_RPT, FR_REC = 34;        // record: v, (i, pad), f[32] as 34 doubles
 __global__ __launch_bounds__(FR_NT) void fps_coop_reg(FpsCoopArgs a) {
+    if (a.dn) a.n = min(a.n, *a.dn);
     extern __shared__ double s_all[];                      // [G][FR_REC]: the partials of a pick, as read
     __shared__ double s_v[FR_NT / 64]; __shared__ int s_i[FR_NT / 64]; __shared__ double s_fc[32]; __shared__ double s_pub[FR_REC];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G;
@@ -1121,6 +1123,101 @@ __global__ __launch_bounds__(FR_NT) void fps_coop_reg(FpsCoopArgs a) {
         const int wg = c / FR_ROWS;
         if (tid < 32) s_fc[tid] = s_all[(size_t)wg * FR_REC + 2 + tid];
         __syncthreads();
+    }
+}
+
+// The same chain with the hand-off in self-validating granules (MI355X_MICROARCH.md, price list: handoff-1to1 against handoff-flag): a record travels as 68
+// 8-byte words {32 bits of data, pick number}, each written by ONE write-through store and polled directly by its reader — no drain, no counter, no second
+// round trip.  Records alternate between two sets by the parity of the pick (a workgroup is at most one pick ahead of the slowest), the winner is found by
+// every wave for itself out of the LDS copy (no barrier), and the distance loop reads the winner's features straight from that copy.  Four barriers per pick.
+constexpr int FT_WORDS = 2 * FR_REC;         // 68 granules per record
+__global__ __launch_bounds__(FR_NT) void fps_coop_tag(FpsCoopArgs a) {
+    if (a.dn) a.n = min(a.n, *a.dn);
+    extern __shared__ unsigned s_rec[];                    // [2][G][FT_WORDS]: the records of a pick, as read (data words)
+    __shared__ double s_v[2][FR_NT / 64]; __shared__ int s_i[2][FR_NT / 64]; __shared__ unsigned s_pub[FT_WORDS]; __shared__ int s_abort; __shared__ double s_f0[32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G;
+    double reg[FR_RPT][32], rmin[FR_RPT];
+#pragma unroll
+    for (int q = 0; q < FR_RPT; ++q) {
+        const long i = (long)g * FR_ROWS + q * FR_NT + tid;
+        rmin[q] = i < a.n ? a.mind[i] : -1.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) reg[q][k] = i < a.n ? a.f[(size_t)i * 32 + k] : 0.0;
+    }
+    int c;
+    if (!a.from_partials) c = a.start;
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < a.npart; k += FR_NT) if (better(a.pin[k].v, a.pin[k].i, v, i)) { v = a.pin[k].v; i = a.pin[k].i; }
+        wave_argmax(v, i);
+        if (lane == 0) { s_v[0][wid] = v; s_i[0][wid] = i; }
+        __syncthreads();
+        v = s_v[0][0]; c = s_i[0][0];
+        for (int w = 1; w < FR_NT / 64; ++w) if (better(s_v[0][w], s_i[0][w], v, c)) { v = s_v[0][w]; c = s_i[0][w]; }
+        __syncthreads();
+    }
+    if (tid < 32) s_f0[tid] = a.f[(size_t)c * 32 + tid];    // the first centre's row comes from the table
+    __syncthreads();
+    const double* fc = s_f0;
+    unsigned long long* recs = reinterpret_cast<unsigned long long*>(a.part);      // [2][G][FT_WORDS]
+    for (int it = 0; it < a.count; ++it) {
+        if (g == 0 && tid == 0) a.out[it] = c;
+        if (it + 1 == a.count) break;
+        const int par = it & 1;
+        double bv = -1.0; int bi = 0x7fffffff, bq = 0;
+#pragma unroll
+        for (int q = 0; q < FR_RPT; ++q) {
+            const int i = g * FR_ROWS + q * FR_NT + tid;
+            if (i < a.n) {
+                double dist = np_pairwise_fixed<32>([&](int k) { const double d = reg[q][k] - fc[k]; return d * d; });
+                if (a.use_sqrt) dist = sqrt(dist);
+                if (dist < rmin[q]) rmin[q] = dist;
+                if (better(rmin[q], i, bv, bi)) { bv = rmin[q]; bi = i; bq = q; }
+            }
+        }
+        double wv = bv; int wi = bi;
+        wave_argmax(wv, wi);
+        if (lane == 0) { s_v[par][wid] = wv; s_i[par][wid] = wi; }
+        if (tid == 0) s_abort = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                   // (1)
+        if (s_abort) { if (g == 0) for (int k = it + 1 + tid; k < a.count; k += FR_NT) a.out[k] = -1; return; }
+        wv = s_v[par][0]; wi = s_i[par][0];
+#pragma unroll
+        for (int w = 1; w < FR_NT / 64; ++w) if (better(s_v[par][w], s_i[par][w], wv, wi)) { wv = s_v[par][w]; wi = s_i[par][w]; }
+        // the owner of the workgroup's best row lays the record out in LDS ...
+        if (wi == bi && bi != 0x7fffffff) {
+            double* pub = reinterpret_cast<double*>(s_pub);
+            pub[0] = wv; pub[1] = __longlong_as_double((long long)(unsigned)wi);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) pub[2 + k] = bq == 0 ? reg[0][k] : reg[1][k];
+        } else if (wi == 0x7fffffff && tid == 0) { double* pub = reinterpret_cast<double*>(s_pub); pub[0] = -1.0; pub[1] = __longlong_as_double(0x7fffffffll); }      // padding rows only
+        __syncthreads();                                   // (2)
+        // ... and 68 lanes write it through, one self-validating granule each
+        const unsigned tag = (unsigned)it + 1u;
+        if (tid < FT_WORDS) __hip_atomic_store(recs + ((size_t)par * G + g) * FT_WORDS + tid, ((unsigned long long)tag << 32) | s_pub[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every record of the pick, polled granule by granule
+        unsigned* mine = s_rec + (size_t)par * G * FT_WORDS;
+        const unsigned long long* all = recs + (size_t)par * G * FT_WORDS;
+        bool gave_up = false;
+        for (int k = tid; k < G * FT_WORDS; k += FR_NT) {
+            unsigned long long v; long spins = 0;
+            while (((v = __hip_atomic_load(all + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) {
+                if (++spins > FPS_COOP_SPINS / 16 || (spins % 4096 == 0 && __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { gave_up = true; break; }
+            }
+            mine[k] = (unsigned)v;
+        }
+        if (gave_up) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); }
+        __syncthreads();                                   // (3)
+        // the winner: every wave finds it for itself (G <= 128 records, two per lane)
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = lane; k < G; k += 64) {
+            const double* r = reinterpret_cast<const double*>(mine + (size_t)k * FT_WORDS);
+            const double pv = r[0]; const int pi = (int)(unsigned)__double_as_longlong(r[1]);
+            if (better(pv, pi, v, i)) { v = pv; i = pi; }
+        }
+        wave_argmax(v, i);
+        c = i;
+        fc = reinterpret_cast<const double*>(mine + (size_t)(c / FR_ROWS) * FT_WORDS) + 2;      // the winner's row: the record of the workgroup that owns row c
     }
 }
 #endif
@@ -1356,6 +1453,68 @@ __global__ __launch_bounds__(256) void cand_fill(const int* __restrict__ stage, 
     for (int k = threadIdx.x; k < nl; k += 256) { const int sp = lab_sp[l0 + k]; sel[n_unl + l0 + k] = sp; gsel[g0 + nc + k] = sp; rows[g0 + nc + k] = n_unl + l0 + k; already[l0 + k] = n_unl + l0 + k; }
 }
 
+
+// ---- the candidate rule of the SHARDED run on the device ------------------------------------------------------------------------------------------------
+// Every rank holds the global ranking (regions of all ranks, global id = rank * Smax + local id, padding counted as labelled) and runs the rule over all
+// clouds of all ranks (cloud rank * Bmax + b): what it keeps for its own graph are its own clouds; what it needs of the others are their candidate COUNTS
+// (where each rank's rows sit in the padded all-gather of the propagated features) and, for the read-back, the global candidate list.
+// plan[]: 0 n_unl (this rank), 1 n_lab, 2 rows, 3 largest block, 4 sampling_batch (all ranks), 5 status, 6-7 block elements, 8 n_unl of all ranks,
+// 9 bit 0: a rank offers more than nu_max candidates; [16 .. 16 + W) candidates per rank; then [W * nu_max] the rows of the gathered array in
+// candidate order, then [W * nu_max] the global candidate list (global region ids).
+__global__ __launch_bounds__(256) void cand_global(const int* __restrict__ ncand, const int* __restrict__ ntop, int W, int Bmax, int nu_max, int* guoff, int* plan) {
+    __shared__ int s_cnt[64], s_off[65], s_top[256];
+    const int tid = threadIdx.x, Bg = W * Bmax;
+    int t = 0;
+    for (int c = tid; c < Bg; c += 256) t += ntop[c];
+    s_top[tid] = t;
+    if (tid < W) { int n = 0; for (int b = 0; b < Bmax; ++b) n += ncand[tid * Bmax + b]; s_cnt[tid] = n; }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, bad = 0, tot = 0;
+        for (int r = 0; r < W; ++r) { s_off[r] = run; run += s_cnt[r]; bad |= s_cnt[r] > nu_max; plan[16 + r] = s_cnt[r]; }
+        s_off[W] = run;
+        for (int k = 0; k < 256; ++k) tot += s_top[k];
+        plan[4] = tot; plan[8] = bad ? 0 : run; plan[9] = bad;
+    }
+    __syncthreads();
+    // candidate offsets of the global clouds, rank-major (a rank's clouds are consecutive)
+    if (tid < W) { int run = s_off[tid]; for (int b = 0; b < Bmax; ++b) { guoff[tid * Bmax + b] = run; run += ncand[tid * Bmax + b]; } }
+    if (tid == 0) guoff[Bg] = s_off[W];
+    int* src = plan + 16 + W;
+    for (int r = 0; r < W; ++r) for (int p = tid; p < min(s_cnt[r], nu_max); p += 256) src[s_off[r] + p] = r * nu_max + p;
+}
+__global__ __launch_bounds__(256) void cand_fill_global(const int* __restrict__ stage, const int* __restrict__ gbase, const int* __restrict__ ncand, const int* __restrict__ guoff,
+                                                        const int* __restrict__ plan, int* glist) {
+    if (plan[9]) return;
+    const int c = blockIdx.x, nc = ncand[c], u0 = guoff[c], lo = gbase[c];
+    for (int k = threadIdx.x; k < nc; k += 256) glist[u0 + k] = stage[lo + k];
+}
+// cand_fill for one rank's clouds: stage holds global region ids, the local tables want local ones
+__global__ __launch_bounds__(256) void cand_fill_local(const int* __restrict__ stage, const int* __restrict__ gbase, const int* __restrict__ ncand, const int* __restrict__ uoff,
+                                                       const int* __restrict__ coff, const int* __restrict__ lab_off, const int* __restrict__ lab_sp, const int* __restrict__ counts,
+                                                       int sub, int* sel, int* gsel, int* rows) {
+    if (counts[5]) return;
+    const int c = blockIdx.x, nc = ncand[c], u0 = uoff[c], g0 = coff[c], l0 = lab_off[c], nl = lab_off[c + 1] - l0, n_unl = counts[0], lo = gbase[c];
+    for (int k = threadIdx.x; k < nc; k += 256) { const int sp = stage[lo + k] - sub; sel[u0 + k] = sp; gsel[g0 + k] = sp; rows[g0 + k] = u0 + k; }
+    for (int k = threadIdx.x; k < nl; k += 256) { const int sp = lab_sp[l0 + k]; sel[n_unl + l0 + k] = sp; gsel[g0 + nc + k] = sp; rows[g0 + nc + k] = n_unl + l0 + k; }
+}
+// rows [0, n) of src -> dst, n on the device
+// rows idx[k % n] of in -> row k of out for k < repeat * n (n on the device); nrep receives repeat * n
+__global__ __launch_bounds__(256) void sel_gather_rows_rep(const uint32_t* __restrict__ in, const int* __restrict__ idx, int cap, int row_words, uint32_t* __restrict__ out,
+                                                           const int* __restrict__ dn, int repeat, int* nrep) {
+    const int n = *dn, tot = min(cap, n * repeat);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nrep = tot;
+    const long total = (long)tot * row_words;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int r = (int)(e / row_words), c = (int)(e % row_words);
+        out[e] = in[(size_t)idx[r % n] * row_words + c];
+    }
+}
+__global__ __launch_bounds__(256) void copy_rows_dn(const double* __restrict__ src, double* __restrict__ dst, int row_len, int cap, const int* __restrict__ dn) {
+    const long total = (long)min(cap, *dn) * row_len;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) dst[e] = src[e];
+}
+
 struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f, status; bool status_init = false; };
 
 // scratch of the chamfer packer for nrows superpoints in nclouds clouds
@@ -1485,7 +1644,9 @@ __global__ __launch_bounds__(256) void sel_mask_regions(const double* __restrict
     for (int i = blockIdx.x * 256 + threadIdx.x; i < Spad; i += gridDim.x * 256)
         out[i] = (i < S && !labelled[i]) ? u[i] : __longlong_as_double((long long)0xfff0000000000000ULL);      // -inf: labelled regions and padding sort last
 }
-__global__ __launch_bounds__(256) void sel_gather_rows(const uint32_t* __restrict__ in, const int* __restrict__ idx, int n, int row_words, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void sel_gather_rows(const uint32_t* __restrict__ in, const int* __restrict__ idx, int n, int row_words, uint32_t* __restrict__ out,
+                                                       const int* __restrict__ dn = nullptr) {
+    if (dn) n = min(n, *dn);
     const long total = (long)n * row_words;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int r = (int)(e / row_words), c = (int)(e % row_words);
@@ -1606,14 +1767,15 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     // cooperative kernels (G workgroups that meet at a counter per pick): only above the sizes one workgroup sweeps well (the 160 x 129 / 1000 x 129
     // k-center shapes keep the 1024-thread fps_block), and only with G workgroups the occupancy query says are resident together — checked, not assumed
     int coop_g = 0; bool coop_reg = false;
-    if (!d_n && D == 32 && n > 1536 && n <= (size_t)FR_ROWS * (size_t)(ctx().num_cu / 2)) { coop_g = (int)((n + FR_ROWS - 1) / FR_ROWS); coop_reg = true; }
-    else if (!d_n && n > 4096 && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) coop_g = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
+    if (D == 32 && n > 1536 && n <= (size_t)FR_ROWS * (size_t)(ctx().num_cu / 2)) { coop_g = (int)((n + FR_ROWS - 1) / FR_ROWS); coop_reg = true; }
+    else if (n > 4096 && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) coop_g = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
     if (coop_g) {
         static const int force_g = [] { const char* e = getenv("SSDR_FPS_COOP_G"); return e ? atoi(e) : 0; }();      // tests: a grid above residency must be reported, not believed
         if (force_g > 0 && coop_g > 0) coop_g = force_g;
         else {
             int per_cu = 0;
-            const hipError_t oe = coop_reg ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_reg, FR_NT, 8 * (size_t)coop_g * FR_REC)
+            const hipError_t oe = coop_reg ? (coop_g > 24 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_reg, FR_NT, 8 * (size_t)coop_g * FR_REC)
+                                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_tag, FR_NT, 4 * 2 * (size_t)coop_g * FT_WORDS))
                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop, FC_NT, 0);
             // half of what the query admits: the query is known to answer one block per CU high at some register counts (MI355X_MICROARCH.md), and
             // other chains / stage kernels share the CUs
@@ -1634,13 +1796,25 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
 #ifndef HIPEMU
     if (coop_ok && coop_reg) {       // rows in registers, partials that carry the candidate's features
         const int G = coop_g;
-        SSDR_TRY(Q.vtmp.reserve(8 * 2 * (size_t)G * FR_REC + 64));
-        Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(Q.vtmp.as<char>() + 8 * 2 * (size_t)G * FR_REC);
+        SSDR_TRY(Q.vtmp.reserve(8 * 2 * (size_t)G * FR_REC * 2 + 64));      // (the granule form: 68 words of 8 bytes per record)
+        Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(Q.vtmp.as<char>() + 8 * 2 * (size_t)G * FR_REC * 2);
         SSDR_HIP(hipMemsetAsync(sync, 0, 16, s));
         static std::once_flag once;
         std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * FR_REC * 128); });
         if (8 * (size_t)G * FR_REC > 8 * (size_t)FR_REC * 128) { set_error("fps: %d cooperative workgroups exceed the record table of the kernel (128)", G); return SSDR_ERR_INVALID; }
-        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>()};
+        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>(), d_n};
+        // two hand-off forms, measured (tools/gpu_fps.sh, us per pick at 2368 / 4736 / 9472 / 20000 rows): self-validating granules 3.46 / 3.92 / 4.71 / 6.30,
+        // drained record + counter 3.90 / 4.14 / 4.77 / 5.74 — the granule form polls 68 words per record and loses from ~24 workgroups on
+        static const int form_env = [] { const char* e = getenv("SSDR_FPS_COOP_COUNTER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        const bool counter_form = form_env >= 0 ? form_env == 1 : G > 24;
+        if (!counter_form) {
+            SSDR_HIP(hipMemsetAsync(part, 0, 8 * 2 * (size_t)G * FR_REC * 2, s));      // tags start at 0: no pick has that number
+            static std::once_flag once2;
+            std::call_once(once2, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_tag), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * FT_WORDS * 128); });
+            hipLaunchKernelGGL(fps_coop_tag, dim3(G), dim3(FR_NT), 4 * 2 * (size_t)G * FT_WORDS, s, a);
+            SSDR_HIP(hipGetLastError());
+            return SSDR_OK;
+        }
         hipLaunchKernelGGL(fps_coop_reg, dim3(G), dim3(FR_NT), 8 * (size_t)G * FR_REC, s, a);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
@@ -1650,7 +1824,7 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         SSDR_TRY(Q.vtmp.reserve(sizeof(Part) * 2 * (size_t)G + 64));
         Part* part = Q.vtmp.as<Part>(); int* sync = reinterpret_cast<int*>(part + 2 * G);
         SSDR_HIP(hipMemsetAsync(sync, 0, 16, s));
-        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>()};
+        FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>(), d_n};
         hipLaunchKernelGGL(fps_coop, dim3(G), dim3(FC_NT), 0, s, a);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
@@ -1759,6 +1933,80 @@ int ssdr_select_status(void* stream, int32_t* out_status) {
     if (out_status) *out_status = st;
     if (st & 1) { set_error("selection: a cooperative FPS / k-center launch was not co-resident (a workgroup never arrived); its picks are invalid"); return SSDR_ERR_INTERNAL; }
     return SSDR_OK;
+}
+
+/* The sharded run's selection without a host decision: two enqueue-only calls around the all-gather of the candidates' propagated features (exchange 3).
+ * ssdr_gcn_fps_sharded_local_dev: the candidate rule over the GLOBAL ranking (d_gorder over Sg = world * Smax padded region ids, d_glabelled != 0 for
+ * labelled regions and padding, global cloud c = rank * Bmax + b spans d_gbase[c] .. d_gbase[c+1]-1), then this rank's share of GCN_FPS_sampling (features,
+ * chamfer graph, adjacency, propagation) for its own clouds.  d_comb_out [nu_max, 32]: its candidates' propagated features in candidate order (what the
+ * all-gather sends); d_plan (int32, 16 + world + 2 * world * nu_max words): counts, candidates per rank, the rows of the gathered array in global candidate
+ * order, the global candidate list.  ssdr_fps_gathered_dev: compacts the gathered array by the plan and runs the replicated global FPS from candidate `start`. */
+int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
+                                   const int32_t* d_sp_pts, const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t num_clouds,
+                                   const int32_t* d_gorder, size_t Sg, const uint8_t* d_glabelled, const int32_t* d_gbase, int rank, int world, size_t Smax, size_t Bmax,
+                                   size_t batch_size, int gcn_number, int gcn_top, size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t nu_max,
+                                   double* d_comb_out, int32_t* d_plan, void* stream) {
+    if (!d_feat || !d_cls || !d_dom || !d_xyz || !d_sp_off || !d_sp_pts || !d_lab_off || !d_gorder || !d_glabelled || !d_gbase || !d_comb_out || !d_plan || feat_dim != 32 ||
+        world < 1 || world > 64 || rank < 0 || rank >= world || num_clouds == 0 || num_clouds > Bmax || Bmax * (size_t)world > 65535 || Sg != Smax * (size_t)world || Sg > 0x7ffffff0 ||
+        cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || nu_max == 0 || gcn_number < 0 || (n_lab && !d_lab_sp)) {
+        set_error("gcn_fps_sharded_local: bad arguments (feat_dim == 32, world <= 64, Sg == world * Smax)"); return SSDR_ERR_INVALID;
+    }
+    SSDR_TRY(ensure_init());
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    const int W = world, Bg = (int)(Bmax * (size_t)world), B = (int)num_clouds, nchunks = (int)((Sg + CR_NT - 1) / CR_NT), D = feat_dim;
+    const size_t ni = 3 * Sg + (size_t)nchunks + 3 * (size_t)Bg + 2 * (size_t)B + 8 + 3 * cap_rows + 16;
+    SSDR_TRY(Q.cand_i.reserve(4 * ni + 8 * ((size_t)B + 2)));
+    int* rankpos = Q.cand_i.as<int>(); int* cploc = rankpos + Sg; int* stage = cploc + Sg; int* chunk = stage + Sg; int* ncand = chunk + nchunks; int* ntop = ncand + Bg;
+    int* guoff = ntop + Bg; int* uoff = guoff + Bg + 1; int* coff = uoff + B + 1; int* gsel = coff + B + 1; int* rows = gsel + cap_rows; int* sel = rows + cap_rows;
+    long long* boff = reinterpret_cast<long long*>(Q.cand_i.as<char>() + ((4 * ni + 7) & ~(size_t)7));
+    SSDR_TRY(Q.cand_f.reserve(8 * (4 * cap_rows * D + 3 * cap_rows + 2 * cap_sq)));
+    double* V = Q.cand_f.as<double>(); double* comb = V + cap_rows * D; double* tmp0 = comb + cap_rows * D; double* tmp1 = tmp0 + cap_rows * D;
+    double* cen = tmp1 + cap_rows * D; double* dir = cen + 3 * cap_rows; double* adj = dir + cap_sq;
+    int* plan = d_plan;
+    hipLaunchKernelGGL(cand_rank, dim3(nchunks), dim3(CR_NT), 0, s, d_gorder, (int)Sg, d_glabelled, rankpos, cploc, chunk);
+    hipLaunchKernelGGL(cand_chunkscan, dim3(1), dim3(256), 0, s, chunk, nchunks);
+    hipLaunchKernelGGL(cand_cloud, dim3(Bg), dim3(256), 0, s, rankpos, cploc, chunk, d_glabelled, d_gbase, (int)Sg, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
+    // this rank's clouds: the layout every kernel below reads (counts in plan[0..7]); then what the other ranks contribute
+    hipLaunchKernelGGL(cand_layout, dim3(1), dim3(256), 0, s, ncand + (size_t)rank * Bmax, ntop + (size_t)rank * Bmax, d_lab_off, B, (long long)cap_rows, (long long)cap_sq, uoff, coff, boff, plan);
+    hipLaunchKernelGGL(cand_global, dim3(1), dim3(256), 0, s, ncand, ntop, W, (int)Bmax, (int)nu_max, guoff, plan);
+    hipLaunchKernelGGL(cand_fill_global, dim3(Bg), dim3(256), 0, s, stage, d_gbase, ncand, guoff, plan, plan + 16 + W + (size_t)W * nu_max);
+    hipLaunchKernelGGL(cand_fill_local, dim3(B), dim3(256), 0, s, stage, d_gbase + (size_t)rank * Bmax, ncand + (size_t)rank * Bmax, uoff, coff, d_lab_off, d_lab_sp, plan,
+                       (int)((size_t)rank * Smax), sel, gsel, rows);
+    const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
+    hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, plan + 2, V, comb);
+    SSDR_TRY(Q.rowsum.reserve(8 * cap_rows));
+    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, plan + 2);
+    ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
+    SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
+    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
+                       coff, boff, cen, dir, P);
+    hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
+    hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), coff, boff, adj);
+    if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(std::max(1, std::min((nm + 3) / 4, 1024)), 1, nc), dim3(256), 0, s, adj, coff, boff, gcn_top);
+    const double* src = V;
+    for (int hop = 0; hop < gcn_number; ++hop) {
+        double* dst = (hop & 1) ? tmp1 : tmp0;
+        hipLaunchKernelGGL(sel_propagate_batch, dim3(grid_for((long)nm * D, 256), 1, nc), dim3(256), 0, s, adj, coff, boff, rows, src, D, dst, comb);
+        src = dst;
+    }
+    // the candidates' rows (the first n_unl of comb) are what the exchange sends
+    hipLaunchKernelGGL(copy_rows_dn, dim3(grid_for((long)nu_max * D)), dim3(256), 0, s, comb, d_comb_out, D, (int)nu_max, plan);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int ssdr_fps_gathered_dev(const double* d_gathered, const int32_t* d_plan, int world, size_t nu_max, size_t cap_rows, int repeat, int start, size_t max_select, double* d_glob,
+                          int32_t* d_out, void* stream) {
+    if (!d_gathered || !d_plan || !d_glob || !d_out || world < 1 || nu_max == 0 || cap_rows == 0 || repeat < 1 || start < 0) { set_error("fps_gathered: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (max_select == 0) return SSDR_OK;
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    SSDR_TRY(Q.hist.reserve(64));
+    int* nrep = Q.hist.as<int>();
+    hipLaunchKernelGGL(sel_gather_rows_rep, dim3(grid_for((long)cap_rows * 64)), dim3(256), 0, s, (const uint32_t*)d_gathered, d_plan + 16 + world, (int)cap_rows, 64, (uint32_t*)d_glob,
+                       d_plan + 8, repeat, nrep);
+    SSDR_HIP(hipGetLastError());
+    return fps_like(d_glob, cap_rows, 32, nullptr, 0, start, max_select, 0, d_out, s, nrep);
 }
 
 int ssdr_fps_superpoint_dev(const double* d_centres, const double* d_cd_dir, size_t n, int start, size_t count, int32_t* d_out, void* stream) {

@@ -195,7 +195,30 @@ class HotPath:
         gcloud = (cloud + (np.arange(W)[:, None] * Bmax)).reshape(-1)                                 # global cloud index, rank-major
         gcloud[cloud.reshape(-1) < 0] = -1
         batch = self.select_per_tile * int(S_all[:, 1].sum())
-        self._dist = dict(comm=comm, Smax=Smax, Bmax=Bmax, valid=lab == 0, gcloud=gcloud, room=room, spin=spin, batch=batch,
+        # the device-side rule of the sharded run (ssdr_gcn_fps_sharded_local_dev): global labelled mask (padding = labelled), where every global cloud's
+        # regions start, and the capacities the static tables bound
+        base_l = np.concatenate([np.asarray(self.sp_base, np.int64), np.full(Bmax + 1 - self.B, self.S, np.int64)])      # local, padded to Bmax + 1 entries
+        gbase = (comm.allgather_host(base_l[:Bmax]) + np.arange(W)[:, None] * Smax).reshape(-1)
+        gbase = np.concatenate([gbase, [W * Smax]]).astype(np.int32)
+        nvalid_c = np.array([int((~self.labeled_mask[base_l[b]:base_l[b + 1]]).sum()) for b in range(self.B)], np.int64)
+        nvalid_all = comm.allgather_host(np.array([int(nvalid_c.sum())], np.int64)).reshape(-1)
+        picks = int(min(batch, nvalid_all.sum()))
+        T = self._sel_static
+        nlab_c = np.diff(T["d_lab_off"].to_host()).astype(np.int64)
+        cap_unl = int(min(2 * picks, nvalid_c.sum()))
+        share = np.minimum(2 * picks, nvalid_c)
+        left, sq = cap_unl, 0
+        for i in np.argsort(-(share + nlab_c), kind="stable"):
+            a = int(min(share[i], left)); left -= a
+            sq += (a + int(nlab_c[i])) ** 2
+        nu_dev = max(int(np.minimum(2 * picks, nvalid_all).max()), 1)
+        rep = max(int(os.environ.get("SSDR_EMULATE_WORLD", "1")), 1)       # development: the FPS load of `rep` x the ranks (tools/gpu_emulate_world.sh)
+        cap_fps = max(rep * int(min(2 * picks, nvalid_all.sum())), 1)
+        dev = dict(picks=picks, cap_rows=max(cap_unl + int(nlab_c.sum()), 1), cap_nmax=max(int((share + nlab_c).max()), 1), cap_sq=max(int(sq), 1), nu_max=nu_dev,
+                   cap_fps=cap_fps, rep=rep, d_glab=DevArray.from_host((lab != 0).astype(np.uint8)), d_gbase=DevArray.from_host(gbase),
+                   d_send=DevArray((nu_dev, 32), np.float64), d_gath=DevArray((W, nu_dev, 32), np.float64), d_glob=DevArray((cap_fps, 32), np.float64),
+                   d_plan=DevArray((16 + W + 2 * W * nu_dev,), np.int32), d_out=DevArray((max(rep * picks, 1),), np.int32))
+        self._dist = dict(dev=dev, comm=comm, Smax=Smax, Bmax=Bmax, valid=lab == 0, gcloud=gcloud, room=room, spin=spin, batch=batch,
                           S_total=int(S_all[:, 0].sum()), nu_max=int(min(2 * batch, Smax)),
                           nlab=comm.allgather_host(np.array([int(self.labeled_mask.sum())], np.int64)).reshape(-1),
                           d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)),
@@ -273,7 +296,24 @@ class HotPath:
                                                    T["n_lab"], T["batch"], int(self.gcn_number), int(self.gcn_top), 1 if kc else 0, 0, T["cap_rows"], T["cap_nmax"], T["cap_sq"],
                                                    T["cap_unl"], T["picks"], T["d_result"].ptr, st))
             self._pending = ("device", None)
+            self.rule_path = "device"
             return
+        if (self.global_order is not None and not kc and self.global_order["dev"]["picks"] > 0 and not os.environ.get("SSDR_SELECT_HOST_RULE")):
+            # the sharded run, still without a host decision: the rule over the global ranking + this rank's graph, the all-gather of the candidates'
+            # propagated features (exchange 3), the replicated global FPS — three enqueues, nothing read back here
+            D = self.global_order; V = D["dev"]
+            _lib.check(L.ssdr_gcn_fps_sharded_local_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
+                                                        T["d_lab_off"].ptr, T["d_lab_sp"].ptr, T["n_lab"], self.B, D["d_ord"].ptr, comm.world * D["Smax"],
+                                                        V["d_glab"].ptr, V["d_gbase"].ptr, comm.rank, comm.world, D["Smax"], D["Bmax"], D["batch"],
+                                                        int(self.gcn_number), int(self.gcn_top), V["cap_rows"], V["cap_nmax"], V["cap_sq"], V["nu_max"],
+                                                        V["d_send"].ptr, V["d_plan"].ptr, st))
+            comm.allgather_(V["d_send"], V["d_gath"], st)
+            _lib.check(L.ssdr_fps_gathered_dev(V["d_gath"].ptr, V["d_plan"].ptr, comm.world, V["nu_max"], V["cap_fps"], V["rep"], 0, V["rep"] * V["picks"],
+                                               V["d_glob"].ptr, V["d_out"].ptr, st))
+            self._pending = ("sharded", comm)
+            self.rule_path = "sharded-device"
+            return
+        self.rule_path = "host"
         if self.global_order is None:          # (the D2H below runs on the selection stream, which already waits for the scoring stream's work)
             cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(st), ~self.labeled_mask, self.sp_cloud_h, self.select_per_tile * self.B)
             unl_c, unl_s = np.asarray(ccloud, np.int64), np.asarray(cand, np.int64)
@@ -383,7 +423,24 @@ class HotPath:
         """wait for the FPS chain of _select_issue and read the selection back"""
         d_out, unl = self._pending
         self._pending = None
-        if isinstance(d_out, str):                           # the device-side rule: counts, picks and the candidate list in one read-back
+        if isinstance(d_out, str) and d_out == "sharded":     # the sharded device-side rule: the plan (counts, global candidate list) and the picks
+            comm = unl
+            D = self.global_order; V = D["dev"]; W = comm.world
+            plan = V["d_plan"].to_host(self.sel_stream)          # waits for the selection stream alone
+            sel = V["d_out"].to_host(self.sel_stream)
+            _lib.check(_lib.lib().ssdr_select_status(self.sel_stream, None))
+            if plan[5] or plan[9]:
+                raise RuntimeError("gcn_fps_sharded: the candidate rule produced more rows than the capacities allow (status %d, %d)" % (int(plan[5]), int(plan[9])))
+            n_g = int(plan[8])
+            gcand = plan[16 + W + W * V["nu_max"]: 16 + W + W * V["nu_max"] + n_g].astype(np.int64)
+            mine = gcand // D["Smax"] == comm.rank
+            loc = gcand[mine] - comm.rank * D["Smax"]
+            unl = list(zip(self.sp_cloud_h[loc].tolist(), loc.tolist()))
+            self.unl_cloud_ids, self.unl_sp = D["room"][gcand], D["spin"][gcand]
+            self._comb_dev, self._comb_n = V["d_glob"], n_g
+            if V["rep"] > 1:
+                self._emu_mod = n_g
+        elif isinstance(d_out, str):                          # the device-side rule: counts, picks and the candidate list in one read-back
             T = self._sel_static
             res = T["d_result"].to_host(self.sel_stream)     # waits for the selection stream alone
             if res[5]:

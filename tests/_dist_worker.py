@@ -29,6 +29,12 @@ def main():
     hp = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine)
     comm = Comm(dist, "cpu")
     sel, unl = hp.step(comm)
+    path = hp.rule_path
+    os.environ["SSDR_SELECT_HOST_RULE"] = "1"      # the round-2 formulation (ranking read back, rule in NumPy): must pick the same regions
+    hsel, _ = hp.step(comm)
+    host_path, host_selected = hp.rule_path, hp.selected
+    del os.environ["SSDR_SELECT_HOST_RULE"]
+    sel, unl = hp.step(comm)
     # the same batches kept in flight on separate streams, exchanges included (what bench.py runs for N > 1)
     pipe = pipeline.Pipelined(lambda: pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms([all_rooms[i] for i in mine], mine), 2)
     psel, _ = pipe.run(2, comm)
@@ -36,7 +42,7 @@ def main():
     hk = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2, selector="kcenter").load_rooms([all_rooms[i] for i in mine], mine)
     hk.step(comm)
     kc_sharded = hk.selected
-    res = {"kcenter": kc_sharded, "pipelined_equal": bool(np.array_equal(psel, sel)), "pipelined_selected": pipe.hp[1].selected,"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
+    res = {"rule_path": [path, host_path], "host_rule_equal": bool(np.array_equal(hsel, sel) and host_selected == hp.selected), "kcenter": kc_sharded, "pipelined_equal": bool(np.array_equal(psel, sel)), "pipelined_selected": pipe.hp[1].selected,"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
            "expect": [int(x) for x in S.farthest_features_sample(hp.comb_all, len(sel), 0)]}
     if rank == 0:      # the same job in ONE process over the union of the rooms
         one = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms(all_rooms, list(range(per * world)))

@@ -22,6 +22,8 @@ def test_two_rank_sharded_selection_equals_single_process(tmp_path, emu_lib):
     assert len(r[0]["selected"]) == 20 and len(set(map(tuple, r[0]["selected"]))) == 20
     assert {c for c, _ in r[0]["selected"]} <= {0, 1, 2, 3}
     assert r[0]["selected"] == r[0]["single"]          # sharded == single process, index for index
+    # the sharded FPS selection took the device-side rule (no ranking read-back, no NumPy between the exchanges), and the host rule agrees with it
+    assert all(x["rule_path"] == ["sharded-device", "host"] and x["host_rule_equal"] for x in r)
     assert r[0]["kcenter"] == r[1]["kcenter"] == r[0]["single_kcenter"] and len(r[0]["kcenter"]) == 20      # global k-center (configuration 4)
     assert all(x["pipelined_equal"] and x["pipelined_selected"] == x["selected"] for x in r)    # batches in flight: same result
 
