@@ -247,8 +247,14 @@ __device__ __forceinline__ void grid_finish(const GridSearchArgs& a, const GridJ
 // tracked as well (interp_idx of a pyramid = nearest of the prefix, tf_map's sub-sampling).
 // Returns 0: rs holds the final K + 1 best; 1: fewer than K + 1 candidates inside the radius (a larger block is needed);
 // 2: the masks cannot hold this block (a row of more than 64 candidates) or the radius is not positive (query outside the support box).
-template <int K, int R>
-__device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __restrict__ cell, const float4* __restrict__ S, float qx, float qy, float qz,
+// where the records of the cell-sorted array come from: global memory, or the workgroup's LDS copy of the rows of cells its queries touch
+struct SrcGlobal { const float4* S; __device__ __forceinline__ float4 operator()(int, int, int i) const { return S[i]; } };
+struct SrcLds {
+    const float4* S; const float4* lds; const int* delta; int z0, y0, nys; bool staged;
+    __device__ __forceinline__ float4 operator()(int z, int y, int i) const { return staged ? lds[i + delta[(z - z0) * nys + (y - y0)]] : S[i]; }
+};
+template <int K, int R, class Src>
+__device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __restrict__ cell, const Src S, float qx, float qy, float qz,
                                                 RegSet<K + 1>& rs, int n1, float& b0, float& b1, int& i0, float& tau) {
     constexpr int W = 2 * R + 1;
     const int cx = cell_of(qx, d.lo[0], d.inv_c, d.nx), cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
@@ -278,7 +284,7 @@ __device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __
         for (int i = s; i < e; i += 4) {
             float4 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = S[min(i + u, e - 1)];
+            for (int u = 0; u < 4; ++u) p[u] = S(z, y, min(i + u, e - 1));
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
@@ -296,7 +302,7 @@ __device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __
                 while (mm) {
                     const int bpos = __ffsll((unsigned long long)mm) - 1;
                     mm &= mm - 1ull;
-                    const float4 p = S[rs0[r] + bpos];
+                    const float4 p = S(cz + r / W - R, cy + r % W - R, rs0[r] + bpos);
                     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
                     float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
                     if (__float_as_int(p.w) < n1 && dist < b1) { if (dist < b0) { b1 = b0; b0 = dist; i0 = __float_as_int(p.w); } else b1 = dist; }
@@ -312,7 +318,7 @@ __device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __
         while (mm) {
             const int bpos = __ffsll((unsigned long long)mm) - 1;
             mm &= mm - 1ull;
-            const float4 p = S[rs0[r] + bpos];
+            const float4 p = S(cz + r / W - R, cy + r % W - R, rs0[r] + bpos);
             const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
             float dist = dx * dx; dist = dist + dy * dy; dist = dist + dz * dz;
             const int id = __float_as_int(p.w);
@@ -326,25 +332,13 @@ __device__ __forceinline__ int grid_mark_select(const GridDesc& d, const int* __
 // first pass: grid.y = job (one support set x one query set x one output block), grid.x = blocks of 256 queries; the 3^3 block.
 // job.job1 >= 0 (pyramid): the K = 1 job over the first n1 support points is answered in the same scan when its nearest prefix point
 // lies inside the guaranteed radius and clear of the runner-up; otherwise that job's own (coarser) grid answers the row in its retry pass.
-template <int K, typename OutT>
-__global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(5) void grid_search_kernel(GridSearchArgs a) {      // 94 registers instead of 106: five waves per SIMD, no spills (six spill: slower)
-    int bx, by; xcd_tile_map(bx, by);          // a job's support set (one tile's records and cell table) into one XCD's L2
-    const int jid = a.job0 + by;
-    const GridJob job = a.jobs[jid];
-    const int qi = bx * 256 + (int)threadIdx.x;
-    if (qi >= job.nq) return;
-    const GridDesc d = a.desc[job.sup];
-    int q = qi; float qx, qy, qz;
-    if (job.ord >= 0) {       // the queries are the points of set `ord`: take them in its cell order (lanes of a wave scan the same cells)
-        const float4 r = a.sorted[a.desc[job.ord].pt_off + qi];
-        q = __float_as_int(r.w); qx = r.x; qy = r.y; qz = r.z;
-    } else {
-        qx = job.qpts[3 * (size_t)q]; qy = job.qpts[3 * (size_t)q + 1]; qz = job.qpts[3 * (size_t)q + 2];
-    }
+// what a query does in the first pass once it knows its coordinates (shared by the two forms of the kernel)
+template <int K, typename OutT, class Src>
+__device__ __forceinline__ void grid_search_query(const GridSearchArgs& a, const GridJob& job, int jid, const GridDesc& d, const Src src, int q, float qx, float qy, float qz) {
     RegSet<K + 1> rs;
     float b0 = FLT_MAX, b1 = FLT_MAX, tau = 0.f; int i0 = 0;
     const bool fuse1 = K == 16 && job.job1 >= 0;
-    const int st = grid_mark_select<K, 1>(d, a.cell + d.cell_off, a.sorted + d.pt_off, qx, qy, qz, rs, fuse1 ? job.n1 : 0, b0, b1, i0, tau);
+    const int st = grid_mark_select<K, 1>(d, a.cell + d.cell_off, src, qx, qy, qz, rs, fuse1 ? job.n1 : 0, b0, b1, i0, tau);
     if (fuse1) {
         // final iff the masks held the block, the nearest prefix point lies inside the guaranteed radius and the runner-up (seen, or anything beyond the
         // radius) is clear of it by more than the near-tie margin
@@ -363,6 +357,74 @@ __global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(5) void grid_search_kernel(G
         return;
     }
     grid_finish<K, OutT>(a, job, jid, q, true, rs);
+}
+
+template <int K, typename OutT>
+__global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(5) void grid_search_kernel(GridSearchArgs a) {      // 94 registers instead of 106: five waves per SIMD, no spills (six spill: slower)
+    int bx, by; xcd_tile_map(bx, by);          // a job's support set (one tile's records and cell table) into one XCD's L2
+    const int jid = a.job0 + by;
+    const GridJob job = a.jobs[jid];
+    const int qi = bx * 256 + (int)threadIdx.x;
+    if (qi >= job.nq) return;
+    const GridDesc d = a.desc[job.sup];
+    int q = qi; float qx, qy, qz;
+    if (job.ord >= 0) {       // the queries are the points of set `ord`: take them in its cell order (lanes of a wave scan the same cells)
+        const float4 r = a.sorted[a.desc[job.ord].pt_off + qi];
+        q = __float_as_int(r.w); qx = r.x; qy = r.y; qz = r.z;
+    } else {
+        qx = job.qpts[3 * (size_t)q]; qy = job.qpts[3 * (size_t)q + 1]; qz = job.qpts[3 * (size_t)q + 2];
+    }
+    grid_search_query<K, OutT>(a, job, jid, d, SrcGlobal{a.sorted + d.pt_off}, q, qx, qy, qz);
+}
+
+// The north_star's form of the first pass, built to be measured beside the one above: the workgroup's 256 cell-sorted queries touch a few rows of
+// cells (x is the fastest cell dimension: ~7 rows at ~0.8 points per cell), so the rows z-1..z+1 x y-1..y+1 around them — whole rows, ~30 records each —
+// are copied into LDS once (a wave per row) and every lane's scan of its 3 x 3 rows reads the records from there instead of through the vector-memory
+// path (16 bytes per candidate per lane).  A workgroup whose queries straddle the end of a z slab (its rows span the whole y range) or whose rows hold
+// more than the buffer keeps the global reads.  Same arithmetic, same results.
+constexpr int GL_CAP = 2048, GL_ROWS = 96;
+template <int K, typename OutT>
+__global__ __launch_bounds__(256) void grid_search_lds_kernel(GridSearchArgs a) {
+    __shared__ float4 s_rec[GL_CAP];
+    __shared__ int s_delta[GL_ROWS], s_start[GL_ROWS], s_len[GL_ROWS], s_mm[4], s_tot;
+    int bx, by; xcd_tile_map(bx, by);
+    const int jid = a.job0 + by;
+    const GridJob job = a.jobs[jid];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int qi = bx * 256 + tid;
+    const bool live = qi < job.nq;
+    const GridDesc d = a.desc[job.sup];
+    int q = qi; float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) {
+        if (job.ord >= 0) { const float4 r = a.sorted[a.desc[job.ord].pt_off + qi]; q = __float_as_int(r.w); qx = r.x; qy = r.y; qz = r.z; }
+        else { qx = job.qpts[3 * (size_t)q]; qy = job.qpts[3 * (size_t)q + 1]; qz = job.qpts[3 * (size_t)q + 2]; }
+    }
+    if (tid == 0) { s_mm[0] = 0x7fffffff; s_mm[1] = -1; s_mm[2] = 0x7fffffff; s_mm[3] = -1; }
+    __syncthreads();
+    if (live) {
+        const int cy = cell_of(qy, d.lo[1], d.inv_c, d.ny), cz = cell_of(qz, d.lo[2], d.inv_c, d.nz);
+        atomicMin(&s_mm[0], cz); atomicMax(&s_mm[1], cz); atomicMin(&s_mm[2], cy); atomicMax(&s_mm[3], cy);
+    }
+    __syncthreads();
+    if (s_mm[1] < 0) return;                          // a workgroup past the end of this job's queries (the grid is sized by the largest job)
+    const int z0 = max(s_mm[0] - 1, 0), z1 = min(s_mm[1] + 1, d.nz - 1), y0 = max(s_mm[2] - 1, 0), y1 = min(s_mm[3] + 1, d.ny - 1);
+    const int nys = y1 - y0 + 1, nrows = (z1 - z0 + 1) * nys;
+    const int* cell = a.cell + d.cell_off;
+    const float4* S = a.sorted + d.pt_off;
+    bool staged = nrows > 0 && nrows <= GL_ROWS;
+    if (staged) {
+        if (tid < nrows) { const int row = ((z0 + tid / nys) * d.ny + (y0 + tid % nys)) * d.nx; const int gs = cell[row]; s_start[tid] = gs; s_len[tid] = cell[row + d.nx] - gs; }
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int r = 0; r < nrows; ++r) { s_delta[r] = run - s_start[r]; run += s_len[r]; } s_tot = run; }
+        __syncthreads();
+        staged = s_tot <= GL_CAP;
+        if (staged)
+            for (int r = wid; r < nrows; r += 4)              // a wave per row of cells
+                for (int i = lane; i < s_len[r]; i += 64) s_rec[s_delta[r] + s_start[r] + i] = S[s_start[r] + i];
+        __syncthreads();
+    }
+    if (!live) return;
+    grid_search_query<K, OutT>(a, job, jid, d, SrcLds{S, s_rec, s_delta, z0, y0, nys, staged}, q, qx, qy, qz);
 }
 
 // second pass over the rows the first one left (compacted: a lane that needs a larger block no longer holds its wave): 3^3
@@ -530,8 +592,9 @@ int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, boo
     const dim3 rgrid((unsigned)std::max(1, std::min(g.work_cap / 64 + 1, ctx().num_cu * 16)));
     const bool first = max_nq > 0;      // max_nq == 0: the jobs were answered inside another scan, only their left-over rows remain
     if (K == 16) {
-        if (out_i64) { if (first) hipLaunchKernelGGL((grid_search_kernel<16, int64_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<16, int64_t>), rgrid, dim3(64), 0, s, a); }
-        else { if (first) hipLaunchKernelGGL((grid_search_kernel<16, int32_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<16, int32_t>), rgrid, dim3(64), 0, s, a); }
+        static const bool lds_form = [] { const char* e = getenv("SSDR_KNN_LDS"); return e && e[0] == '1'; }();      // the LDS-staged first pass (measured beside the default, profiles/)
+        if (out_i64) { if (first) { if (lds_form) hipLaunchKernelGGL((grid_search_lds_kernel<16, int64_t>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((grid_search_kernel<16, int64_t>), grid, dim3(256), 0, s, a); } hipLaunchKernelGGL((grid_retry_kernel<16, int64_t>), rgrid, dim3(64), 0, s, a); }
+        else { if (first) { if (lds_form) hipLaunchKernelGGL((grid_search_lds_kernel<16, int32_t>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((grid_search_kernel<16, int32_t>), grid, dim3(256), 0, s, a); } hipLaunchKernelGGL((grid_retry_kernel<16, int32_t>), rgrid, dim3(64), 0, s, a); }
     } else {
         if (out_i64) { if (first) hipLaunchKernelGGL((grid_search_kernel<1, int64_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<1, int64_t>), rgrid, dim3(64), 0, s, a); }
         else { if (first) hipLaunchKernelGGL((grid_search_kernel<1, int32_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<1, int32_t>), rgrid, dim3(64), 0, s, a); }
