@@ -335,6 +335,9 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
 // gather, no G launch), and the same registers go through a wave-private LDS image [32 rows][H] from which the weighted sum reads them back in
 // the accumulator layout (channel on the lane, neighbour in the register).  Per pair of points: 1 + 6 + H / 2 dwords per lane instead of
 // 23 + 24 (H / 16).
+// (Chaining the per-point convs behind the pool into this kernel — att_pooling's mlp, then lrelu(mlp2 + shortcut), on the workgroup's 32 or 64 pooled rows out
+// of LDS — was built and measured at d = 64: the three dense launches it removes cost 87 us, the epilogues 60-110 us: a workgroup re-reads the layers' weights
+// for 32-64 rows where the tiled dense kernel reads them for 128.  Not kept.)
 template <int D> struct Lfa32ResCfg {
     static constexpr int H = D / 2, RS = 2 * H + 16;
     static constexpr int NW = 4;                                       // waves per workgroup (they share the staged weights)
