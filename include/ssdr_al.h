@@ -142,7 +142,7 @@ int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features
 /* Which implementation ssdr_grid_subsample_batch_dev uses (process-wide).
  *   SSDR_SUBSAMPLE_AUTO (default)  rows of at most 7 words (3 + fdim + ldim <= 7): one partition pass into spatial buckets of 8 x 8 x 8 (or
  *                                  16 x 8 x 8) voxels and one workgroup per bucket that orders and reduces its voxels in LDS; clouds whose grid
- *                                  needs more than 16384 such buckets, or that hold a voxel of more than 1536 points, are reported by
+ *                                  needs more than 16384 such buckets, or that hold a voxel of more than 1024 points, are reported by
  *                                  ssdr_grid_subsample_status (bits 2 / 4) and must be repeated with SSDR_SUBSAMPLE_SORT.  Other rows: the sort.
  *   SSDR_SUBSAMPLE_SORT            segmented radix sort of (voxel key, index) words: any grid, any voxel population.
  * Both give the reference's rows bit for bit (grid_subsampling.cpp:5-106), by ascending voxel key. */

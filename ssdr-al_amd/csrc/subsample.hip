@@ -17,6 +17,7 @@
 //   order    SSDR_ORDER_KEY: rows by ascending key.  SSDR_ORDER_REFERENCE: rows permuted into the
 //            iteration order of the reference's unordered_map<size_t,...> (subsample_order.hip).
 #include "ssdr_internal.hpp"
+#include <atomic>
 #include "block_prims.hpp"
 #include "voxel_label.hpp"
 #include "subsample_types.hpp"
@@ -606,7 +607,8 @@ int grid_subsample_batch_device(const float* d_p, const float* d_f, size_t fdim,
 
 using namespace ssdr;
 
-static int g_batch_method = [] { const char* e = getenv("SSDR_SUBSAMPLE_METHOD"); return e && !strcmp(e, "sort") ? SSDR_SUBSAMPLE_SORT : SSDR_SUBSAMPLE_AUTO; }();
+// process-wide (not per stream, not per thread): read once per ssdr_grid_subsample_batch_dev call, set by ssdr_grid_subsample_set_method
+static std::atomic<int> g_batch_method{[] { const char* e = getenv("SSDR_SUBSAMPLE_METHOD"); return e && !strcmp(e, "sort") ? SSDR_SUBSAMPLE_SORT : SSDR_SUBSAMPLE_AUTO; }()};
 
 extern "C" {
 
@@ -632,7 +634,7 @@ int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features
     if (d_classes && (!ldim || !d_out_classes)) { set_error("grid_subsample_batch: classes given without ldim / output"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     return grid_subsample_batch_device(d_points, d_features, d_features ? fdim : 0, d_classes, d_classes ? ldim : 0, cloud_offsets, num_clouds, sampleDl,
-                                       d_out_points, d_out_features, d_out_classes, d_out_m, pick_stream(stream), g_batch_method);
+                                       d_out_points, d_out_features, d_out_classes, d_out_m, pick_stream(stream), g_batch_method.load());
 }
 
 /* which implementation ssdr_grid_subsample_batch_dev uses: SSDR_SUBSAMPLE_AUTO (default: the bucket partition of frontend.hip for rows of at most 7 words,
@@ -640,7 +642,7 @@ int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features
  * reported by ssdr_grid_subsample_status (bits 2, 4); the caller then repeats the call with SSDR_SUBSAMPLE_SORT. */
 int ssdr_grid_subsample_set_method(int method) {
     if (method != SSDR_SUBSAMPLE_AUTO && method != SSDR_SUBSAMPLE_SORT) { set_error("grid_subsample_set_method: unknown method %d", method); return SSDR_ERR_INVALID; }
-    g_batch_method = method;
+    g_batch_method.store(method);
     return SSDR_OK;
 }
 
@@ -710,7 +712,7 @@ int ssdr_grid_subsample_status(void* stream, int32_t* out_status) {
     if (out_status) *out_status = st;
     if (st) { set_error("grid_subsample: device status 0x%x (1 = a voxel holds more than %d distinct labels in one column; 2 = a cloud's grid is too large for "
                         "the batch flavour (partition path: more than 16384 buckets of 1024 voxels, or coordinates outside the grid; sort path: no room for the index in "
-                        "the sort words); 4 = a voxel of more than 1536 points in the partition path: repeat with ssdr_grid_subsample_set_method(SSDR_SUBSAMPLE_SORT), or "
+                        "the sort words); 4 = a voxel of more than 1024 points in the partition path: repeat with ssdr_grid_subsample_set_method(SSDR_SUBSAMPLE_SORT), or "
                         "use ssdr_grid_subsample_dev)", st, LAB_CAP); return SSDR_ERR_UNSUPPORTED; }
     return SSDR_OK;
 }

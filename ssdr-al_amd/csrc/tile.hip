@@ -94,7 +94,9 @@ constexpr int TS_BITS = 14, TS_BINS = 1 << TS_BITS, TS_SHIFT = 31 - TS_BITS;    
 
 __device__ __forceinline__ float tile_dist(const float* __restrict__ pts, int i, float cx, float cy, float cz) {
     const float dx = pts[3 * (size_t)i] - cx, dy = pts[3 * (size_t)i + 1] - cy, dz = pts[3 * (size_t)i + 2] - cz;
-    return (dx * dx + dy * dy) + dz * dz;
+    // the sign bit cleared: a sum of squares has none, but a NaN coordinate can carry one, and the bins below are indexed by the bit pattern
+    // (0xFFC00000 >> 17 lies past the histogram; a positive NaN lands in the last bins like any far point)
+    return __uint_as_float(__float_as_uint((dx * dx + dy * dy) + dz * dz) & 0x7fffffffu);
 }
 __global__ __launch_bounds__(256) void tile_hist_b(TileTab t, const float* __restrict__ pts, const long long* __restrict__ d_m, unsigned* hist, int* d_count) {
     __shared__ unsigned s_h[TS_BINS];

@@ -81,7 +81,7 @@ class HotPath:
         self.unc = DevArray((B * N,), np.float32); self.cls = DevArray((B * N,), np.int32)
         # superpoints of the (fixed) tiles: computed once from a dry run of the geometric front end.  The dry run also settles which
         # implementation of the batched grid subsample these rooms get: the bucket partition reports a cloud it cannot take (a grid of
-        # more than 16384 buckets, a voxel of more than 1536 points) through its status, and the rooms then go through the sort
+        # more than 16384 buckets, a voxel of more than 1024 points) through its status, and the rooms then go through the sort
         self.subsample_method = 1 if os.environ.get("SSDR_SUBSAMPLE_METHOD") == "sort" else 0          # (development: A/B of the two implementations)
         self._front_end()
         _lib.sync()

@@ -194,8 +194,8 @@ def test_subsample_batch_partition_paths(backend, orc):
 
 
 def test_subsample_batch_partition_reports_what_it_cannot_take(backend, orc):
-    """A grid of more than 16384 buckets, and a voxel of more than 1536 points: reported by ssdr_grid_subsample_status; the sort-based
-    implementation of the same entry point then gives the reference's rows."""
+    """A grid of more than 16384 buckets, and a voxel of more than 1024 points (FE_CAP: ~1100 and 2500 are both tried): reported by
+    ssdr_grid_subsample_status; the sort-based implementation of the same entry point then gives the reference's rows."""
     rng = np.random.default_rng(78)
     wide = [_cloud(rng, 4000, (60.0, 40.0, 3.0)), _cloud(rng, 500, (1.0, 1.0, 1.0))]
     rc, st, _ = _batch(wide, 0.04)
@@ -206,7 +206,10 @@ def test_subsample_batch_partition_reports_what_it_cannot_take(backend, orc):
     exp0 = orc.grid_subsampling(*dense[0], 0.04, order="key")          # the other cloud of the call is not affected
     for x, y in zip(got[0], exp0):
         assert_bits_equal(x, y)
-    for clouds in (wide, dense):
+    just_over = [_cloud(rng, 1100, (0.01, 0.01, 0.01), shift=0.5), _cloud(rng, 500, (1.0, 1.0, 1.0))]      # a voxel of ~1100 points: past the 1024 the reduction holds
+    rc, st, _ = _batch(just_over, 0.04)
+    assert rc != 0 and st & 4
+    for clouds in (wide, dense, just_over):
         rc, st, got = _batch(clouds, 0.04, method=1)
         assert rc == 0 and st == 0
         for r, (p, f, l) in enumerate(clouds):

@@ -10,9 +10,9 @@ D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p
 def family(name):
     n = re.sub(r"^void ", "", name).replace("ssdr::", "").replace("(anonymous namespace)::", "")
     n = n.split("(")[0]
-    for fam in ("lfa_att_kernel", "lfa_bf16_kernel", "dense_rows_kernel", "dense_small_kernel", "dense_bf16_kernel", "dense_kernel", "kd_split_kernel", "fps_block_reg", "tail_kernel"):
+    for fam in ("lfa_att_kernel", "lfa_bf16_kernel", "lfa32_", "dense_rows_kernel", "dense_small_kernel", "dense_bf16_kernel", "dense_kernel", "kd_split_kernel", "fps_block_reg", "tail_kernel"):
         if n.startswith(fam):      # bench.py's ProfScope names
-            return "dense_kernel" if fam.startswith("dense_") else ("lfa_att_kernel" if fam.startswith("lfa_") else fam)
+            return "dense_kernel" if fam.startswith("dense_") else ("lfa_att_kernel" if fam.startswith("lfa") else fam)
     m = re.match(r"grid_(search|retry)_kernel<(\d+)", n)
     if m:
         return "knn_grid_search<%s>" % m.group(2)
