@@ -30,7 +30,7 @@ METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_ROUND = "r03"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
+PROFILE_ROUND = "r04"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
 DTYPE = {"f32": "f32 (exact f32-input MFMA)",
          "bf16x3": "bf16x3: split-bf16 MFMA operands (hi*hi + lo*hi + hi*lo), fp32 accumulate, fp32 activations and non-matrix arithmetic",
          "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 activations and non-matrix arithmetic"}
