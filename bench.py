@@ -326,7 +326,7 @@ def main():
                                       "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, %s)" % (tiles_per_gpu, args.precision, "FPS start fixed to candidate 0" if args.selector == "fps" else "global k-center over candidates + labelled regions"),
                           "tiles_per_gpu": tiles_per_gpu, "tile_points": Cfg.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
                           "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * tiles_per_gpu * world), "sharding": "tiles",
-                          "selection_rule": getattr(hp, "rule_path", None) or (getattr(pipe.hp[0], "rule_path", None) if pipe is not None else None),
+                          "selection_rule": (getattr(pipe.hp[0], "rule_path", None) if pipe is not None else None) or getattr(hp, "rule_path", None),
                           **({"emulated_world": int(os.environ["SSDR_EMULATE_WORLD"])} if os.environ.get("SSDR_EMULATE_WORLD") else {}),
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,
                           "timed_region": "GPU idle at both ends (every stream drained): K launch sequences of every stage and K completed selections, fill and "
