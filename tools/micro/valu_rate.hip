@@ -4,12 +4,15 @@
 #include <cstdio>
 #include <vector>
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
 template <int OP> __global__ void k(float* out, int iters, long long* cyc) {
     extern __shared__ float pad_lds[];      // 100 KB of dynamic LDS: at most one workgroup per CU
     if (iters < 0) pad_lds[threadIdx.x] = 0.f;
     float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
     const float c = 1.0001f, d = 0.5f;
+    double q0 = a0, q1 = a1, q2 = a2, q3 = a3; const double qc = 1.0001, qd = 0.5;
+    d4 m0 = {q0, q1, q2, q3}, m1 = m0, m2 = m0, m3 = m0;
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
         if (OP == 0) { // v_fma_f32 x8 independent
@@ -36,10 +39,32 @@ template <int OP> __global__ void k(float* out, int iters, long long* cyc) {
         } else if (OP == 6) { // v_pk_add_f32 x4
             asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(f2{c, c}));
+        } else if (OP == 7) { // v_fma_f64 x4
+            asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qc), "v"(qd));
+        } else if (OP == 8) { // v_add_f64 x4
+            asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qc));
+        } else if (OP == 9) { // v_mul_f64 x4
+            asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qc));
+        } else if (OP == 10) { // v_min_f64 x4
+            asm volatile("v_min_f64 %0, %0, %4\n v_min_f64 %1, %1, %4\n v_min_f64 %2, %2, %4\n v_min_f64 %3, %3, %4\n"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qc));
+        } else if (OP == 11) { // v_mfma_f64_16x16x4_f64 x4 independent accumulators
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, qc, m0, 0, 0, 0); m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, qc, m1, 0, 0, 0);
+            m2 = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, qc, m2, 0, 0, 0); m3 = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, qc, m3, 0, 0, 0);
+        } else if (OP == 12) { // one MFMA f64 + 16 v_min_f64 on other registers (do they overlap inside one wave?)
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, qc, m0, 0, 0, 0);
+            asm volatile("v_min_f64 %0, %0, %4\n v_min_f64 %1, %1, %4\n v_min_f64 %2, %2, %4\n v_min_f64 %3, %3, %4\n"
+                         "v_min_f64 %0, %0, %4\n v_min_f64 %1, %1, %4\n v_min_f64 %2, %2, %4\n v_min_f64 %3, %3, %4\n"
+                         "v_min_f64 %0, %0, %4\n v_min_f64 %1, %1, %4\n v_min_f64 %2, %2, %4\n v_min_f64 %3, %3, %4\n"
+                         "v_min_f64 %0, %0, %4\n v_min_f64 %1, %1, %4\n v_min_f64 %2, %2, %4\n v_min_f64 %3, %3, %4\n"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qc));
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(q0 + q1 + q2 + q3) + (float)(m0[0] + m1[1] + m2[2] + m3[3]);
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
 template <int OP> void run(const char* name, int per_iter) {
@@ -63,5 +88,6 @@ template <int OP> void run(const char* name, int per_iter) {
 }
 int main() {
     run<0>("v_fma_f32", 8); run<1>("v_exp_f32", 8); run<2>("v_pk_fma_f32", 4); run<3>("v_cvt_pk_bf16_f32", 8); run<4>("v_pk_mul_f32", 4); run<5>("v_max3_f32", 8); run<6>("v_pk_add_f32", 4);
+    run<7>("v_fma_f64", 4); run<8>("v_add_f64", 4); run<9>("v_mul_f64", 4); run<10>("v_min_f64", 4); run<11>("v_mfma_f64_16x16x4", 4); run<12>("mfma_f64 + 16 min_f64", 17);
     return 0;
 }
