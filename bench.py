@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=(0, 2, 3, 4, 5),
                     help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 4 with the exchanges of N > 1")
     ap.add_argument("--select-lag", type=int, default=1, help="selections in flight behind the newest one the host waits for (pipeline.Pipelined sel_lag; 1 = the previous batch's)")
+    ap.add_argument("--spare-set", action="store_true", help="one more buffer set than batches in flight: no stage is deferred behind the wait for the previous selection (A/B timing)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
     ap.add_argument("--precision", default="bf16x3", choices=("f32", "bf16x3", "bf16"),
                     help="arithmetic of the network's matrix products (activations / accumulation are fp32 in every mode); bf16x3 = split bf16, "
@@ -142,7 +143,7 @@ def main():
     # ordered on the same streams, in the same order on every rank.
     pipe = None
     if not args.no_pipeline:
-        pipe = pipeline.Pipelined(mk, args.pipeline_depth, sel_lag=args.select_lag)
+        pipe = pipeline.Pipelined(mk, args.pipeline_depth, sel_lag=args.select_lag, spare_set=args.spare_set)
 
     def barrier():
         # EVERYTHING issued so far has finished on this rank (all stage and selection streams, not only the library stream), then all ranks meet

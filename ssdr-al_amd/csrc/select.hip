@@ -718,37 +718,40 @@ __device__ __forceinline__ bool better(double v, int i, double bv, int bi) { ret
 // Wavefront arg-max of (value, index) pairs, result in every lane.  The picks of FPS / k-center form a serial chain of
 // ~600 such reductions: inside a row of 16 lanes the partners come through DPP (quad permutes, half-row and row mirrors),
 // across rows through gfx950's v_permlane16_swap / v_permlane32_swap — no LDS crossbar round trips (ds_bpermute) at all.
+// Two passes (round 4): the maximum of the VALUES alone (two moves and one v_max_f64 per step), then the smallest index among the lanes
+// that hold it (one v_min_i32 per step) — 30 dependent instructions instead of 65 for the (value, index) pairs compared step by step,
+// on a chain where a float64 instruction of a lone wave takes 12 cycles (tools/micro/valu_rate.hip).  Values are never NaN here.
+#ifndef HIPEMU
+__device__ __forceinline__ double max_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_max_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = dpp_u32<CTRL>((unsigned)b), hi = dpp_u32<CTRL>((unsigned)(b >> 32));
+    return max_f64(v, __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_min_i32(int t) { return min(t, (int)dpp_u32<CTRL>((unsigned)t)); }
+// ... inside every row of 16 lanes (0xB1 quad_perm [1,0,3,2], 0x4E quad_perm [2,3,0,1], 0x141 row_half_mirror, 0x140 row_mirror)
+__device__ __forceinline__ double row_max_f64(double v) { v = dpp_max_f64<0xB1>(v); v = dpp_max_f64<0x4E>(v); v = dpp_max_f64<0x141>(v); return dpp_max_f64<0x140>(v); }
+__device__ __forceinline__ int row_min_i32(int t) { t = dpp_min_i32<0xB1>(t); t = dpp_min_i32<0x4E>(t); t = dpp_min_i32<0x141>(t); return dpp_min_i32<0x140>(t); }
+#endif
 __device__ __forceinline__ void wave_argmax(double& v, int& i) {
 #ifndef HIPEMU
-    auto step = [&](auto partner) {
-        const long long b = __double_as_longlong(v);
-        const unsigned lo = partner((unsigned)b), hi = partner((unsigned)(b >> 32));
-        const int oi = (int)partner((unsigned)i);
-        const double ov = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-        if (better(ov, oi, v, i)) { v = ov; i = oi; }
-    };
-    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, true); });     // quad_perm [1,0,3,2]
-    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, true); });     // quad_perm [2,3,0,1]
-    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, true); });    // row_half_mirror
-    step([](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, true); });    // row_mirror
-    // rows 0<->1, 2<->3: after swap(a, a) the two results hold the even / odd row of each pair; every lane already equals its
-    // row's best, so "the other row's value" is whichever of the two differs from mine (or both are equal)
-    auto swap_step = [&](bool thirty_two) {
-        const long long b = __double_as_longlong(v);
-        unsigned r0[3], r1[3];
-        const unsigned w[3] = {(unsigned)b, (unsigned)(b >> 32), (unsigned)i};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (thirty_two) { auto r = __builtin_amdgcn_permlane32_swap(w[k], w[k], false, false); r0[k] = r[0]; r1[k] = r[1]; }
-            else { auto r = __builtin_amdgcn_permlane16_swap(w[k], w[k], false, false); r0[k] = r[0]; r1[k] = r[1]; }
-        }
-        const double v0 = __longlong_as_double((long long)(((unsigned long long)r0[1] << 32) | r0[0]));
-        const double v1 = __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r1[0]));
-        const int i0 = (int)r0[2], i1 = (int)r1[2];
-        if (better(v1, i1, v0, i0)) { v = v1; i = i1; } else { v = v0; i = i0; }
-    };
-    swap_step(false);
-    swap_step(true);
+    double m = row_max_f64(v);
+    // rows 0<->1, 2<->3, then the halves: after swap(a, a) the two results hold the even / odd row (half) of each pair
+    {
+        const long long b = __double_as_longlong(m);
+        auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false), hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        m = max_f64(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])), __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+    }
+    {
+        const long long b = __double_as_longlong(m);
+        auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false), hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        m = max_f64(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])), __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+    }
+    int t = row_min_i32(v == m ? i : 0x7fffffff);
+    { auto r = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false); t = min((int)r[0], (int)r[1]); }
+    { auto r = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false); t = min((int)r[0], (int)r[1]); }
+    v = m; i = t;
 #else
     for (int o = 32; o > 0; o >>= 1) {
         const long long b = __double_as_longlong(v);
@@ -757,6 +760,22 @@ __device__ __forceinline__ void wave_argmax(double& v, int& i) {
         const int oi = __shfl_xor(i, o);
         if (better(ov, oi, v, i)) { v = ov; i = oi; }
     }
+#endif
+}
+// the index of the best of NW <= 16 (value, index) pairs in LDS, in every lane of the calling wave: lanes 0..NW-1 take one pair each and reduce
+// inside their row of 16 (the other rows reduce padding)
+template <int NW> __device__ __forceinline__ int pairs_argmax_index(const double* sv, const int* si, int lane) {
+    static_assert(NW <= 16, "one row of lanes");
+#ifndef HIPEMU
+    const double v = lane < NW ? sv[lane] : -2.0;
+    const int i = lane < NW ? si[lane] : 0x7fffffff;
+    const double m = row_max_f64(v);
+    return __builtin_amdgcn_readfirstlane(row_min_i32(v == m ? i : 0x7fffffff));
+#else
+    (void)lane;
+    double bv = sv[0]; int bi = si[0];
+    for (int w = 1; w < NW; ++w) if (better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    return bi;
 #endif
 }
 
@@ -877,38 +896,36 @@ __global__ __launch_bounds__(1024) void fps_block(const double* __restrict__ f, 
 // Register-resident variant for small candidate sets (n <= 512 * PPT): every thread owns PPT points whose features
 // and running min-distance never leave its registers; the current centre's features are published through LDS by
 // the owning thread, so the loop touches global memory only to store the selected index.
-template <int DF, int PPT>
-__global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ f, int n, int from_partials, int start, int use_sqrt,
-                                                     const Part* __restrict__ pin, int npart, const double* __restrict__ mind, int count, int* out,
-                                                     const int* __restrict__ dn = nullptr) {
+template <int DF, int PPT, int NT>
+__global__ __launch_bounds__(NT) void fps_block_reg(const double* __restrict__ f, int n, int from_partials, int start, int use_sqrt,
+                                                    const Part* __restrict__ pin, int npart, const double* __restrict__ mind, int count, int* out,
+                                                    const int* __restrict__ dn = nullptr) {
     if (dn) n = min(n, *dn);
-    __shared__ double s_v[2][8];
-    __shared__ int s_i[2][8];
+    constexpr int NW = NT / 64;
+    __shared__ double s_v[2][NW];
+    __shared__ int s_i[2][NW];
     __shared__ double s_fc[2][DF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double reg[PPT][DF], rmin[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        const int i = tid + q * 512;
+        const int i = tid + q * NT;
         rmin[q] = i < n ? mind[i] : -1.0;
 #pragma unroll
         for (int k = 0; k < DF; ++k) reg[q][k] = i < n ? f[(size_t)i * DF + k] : 0.0;
     }
-    // publishes this thread's best into s_v/s_i[par]; after the barrier every thread reduces the 8 wave results itself
+    // publishes this wave's best into s_v/s_i[par]; after the barrier every wave reduces the NW wave results itself
     auto block_argmax = [&](double v, int i, int par) -> int {
         wave_argmax(v, i);
         if (lane == 0) { s_v[par][wid] = v; s_i[par][wid] = i; }
         __syncthreads();
-        double bv = s_v[par][0]; int bi = s_i[par][0];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) if (better(s_v[par][w], s_i[par][w], bv, bi)) { bv = s_v[par][w]; bi = s_i[par][w]; }
-        return bi;
+        return pairs_argmax_index<NW>(s_v[par], s_i[par], lane);
     };
     int c;
     if (!from_partials) c = start;
     else {
         double v = -1.0; int i = 0x7fffffff;
-        for (int k = tid; k < npart; k += 512) if (better(pin[k].v, pin[k].i, v, i)) { v = pin[k].v; i = pin[k].i; }
+        for (int k = tid; k < npart; k += NT) if (better(pin[k].v, pin[k].i, v, i)) { v = pin[k].v; i = pin[k].i; }
         c = block_argmax(v, i, 1);
     }
     for (int it = 0; it < count; ++it) {
@@ -916,7 +933,7 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
         if (tid == 0) out[it] = c;
         if (it + 1 == count) break;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) if (c == tid + q * 512) {
+        for (int q = 0; q < PPT; ++q) if (c == tid + q * NT) {
 #pragma unroll
             for (int k = 0; k < DF; ++k) s_fc[par][k] = reg[q][k];
         }
@@ -924,7 +941,7 @@ __global__ __launch_bounds__(512) void fps_block_reg(const double* __restrict__ 
         double bv = -1.0; int bi = 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const int i = tid + q * 512;
+            const int i = tid + q * NT;
             if (i < n) {
                 double dist = np_pairwise_fixed<DF>([&](int k) { const double d = reg[q][k] - s_fc[par][k]; return d * d; });
                 if (use_sqrt) dist = sqrt(dist);
@@ -1757,9 +1774,11 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     const bool seeded = d_already && na;
     if (D == 32 && n <= 1536) {   // register-resident single workgroup
         const int fp = seeded ? 1 : 0;
-        if (n <= 512) hipLaunchKernelGGL((fps_block_reg<32, 1>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
-        else if (n <= 1024) hipLaunchKernelGGL((fps_block_reg<32, 2>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
-        else hipLaunchKernelGGL((fps_block_reg<32, 3>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
+        // (1024 threads — four waves per SIMD issue a float64 instruction every 5.5 cycles, the two of this form every 6.5, tools/micro/valu_rate.hip — with row tid in
+        // registers and rows 1024.. in LDS was built and measured: 2.42 against 2.39 ms for the selection stage; the barrier over sixteen waves takes the gain back)
+        if (n <= 512) hipLaunchKernelGGL((fps_block_reg<32, 1, 512>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
+        else if (n <= 1024) hipLaunchKernelGGL((fps_block_reg<32, 2, 512>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
+        else hipLaunchKernelGGL((fps_block_reg<32, 3, 512>), dim3(1), dim3(512), 0, s, d_feat, (int)n, fp, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, d_n);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;
     }

@@ -508,7 +508,7 @@ class Pipelined:
     STAGES = ("front", "knn", "infer", "score")
     GROUPS = {2: (0, 0, 0, 0), 3: (0, 1, 1, 1), 4: (0, 0, 1, 2), 5: (0, 1, 2, 3)}     # stage -> stream group
 
-    def __init__(self, make_hot_path, depth=5, groups=None, overlap_select=True, sel_lag=1):
+    def __init__(self, make_hot_path, depth=5, groups=None, overlap_select=True, sel_lag=1, spare_set=False):
         """groups: optional stage -> stream-group tuple for (front, knn, infer, score), non-decreasing from 0; depth = last group + 2"""
         if groups is not None:
             depth = groups[-1] + 2
@@ -542,7 +542,7 @@ class Pipelined:
         self.lead = {n: depth - 1 - g for n, g in self.group.items()}      # batches ahead of the selection
         # one buffer set per batch in flight (a spare set, so that no stage has to wait for the previous selection's buffers, was
         # measured slower: 127 vs 137 Mpoints/s — a sixth working set in the caches costs more than the deferred front end)
-        self.slots = depth + self.sel_lag - 1
+        self.slots = depth + self.sel_lag - 1 + (1 if spare_set else 0)      # spare_set: nothing is deferred behind the wait for the previous selection
         self.hp = [make_hot_path() for _ in range(self.slots)]
         for h in self.hp:
             h.pipelined = True
@@ -599,7 +599,7 @@ class Pipelined:
                     break
                 for name in self.STAGES:
                     if b == k + lead[name]:
-                        if self.overlap_select and b - k == self.slots - self.sel_lag:
+                        if self.overlap_select and b - k == self.slots - self.sel_lag:      # (never with a spare set: b - k < depth)
                             deferred.append((name, b))       # writes the buffer set of batch k - sel_lag, whose selection may still run
                         else:
                             self._stage(name, b)             # the buffer set of batch b was last read by select(b - depth), done
