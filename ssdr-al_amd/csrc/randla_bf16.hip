@@ -567,6 +567,10 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     // (a split-K form for these layers — every wave a quarter of the k steps, both operands straight from global memory in the MFMA layout, no LDS or
     // barrier in the K loop, partial tiles summed in LDS — was built and measured: 32 us per launch against 18.7: a 32-row tile re-reads its whole
     // 64-column weight panel and the CU takes ~30 bytes per clock from L2, which is what the 15 launches of this size are bound by, not the K chain)
+    // (round 4: TM x 128 tiles on the 32 x 32 x 16 instruction — half the LDS operand bytes per FLOP, half the activation re-reads — were built for the 19
+    // launches with N a multiple of 128 and measured: 534 us against 461 for those launches.  64 x 128 tiles leave the small-M layers 160-320 workgroups whose
+    // K loop waits a global-load latency per 32-k chunk with nothing else resident to cover it; 128 x 128 tiles at M = 41-164 k ran level with the kernel below,
+    // which is bound by what a CU fetches from L2 per clock, not by the matrix or LDS pipes)
     if (small) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
     return launch_dense_bf16_t<128, 32>(a, prec, vec, s);
 }
