@@ -164,6 +164,20 @@ def test_fps_mid_sizes_against_the_oracle(backend, n, count):
     assert np.array_equal(sampler.farthest_features_sample(f, count, 7), O.farthest_features_sample(f, count, 7))
 
 
+@pytest.mark.parametrize("n,count", [(300, 120), (700, 200), (1184, 400), (2368, 300)])
+def test_fps_ties_take_the_first_index(backend, n, count):
+    """Every row twice, at shuffled positions: at every pick the farthest candidate has a twin at the same distance, in the same wave or in another
+    one (or another workgroup of the cooperative kernel), and np.argmax takes the lower index (fps_gcn_cpu.py:141).  The wave arg-max finds the maximum
+    value first and then the smallest index among its holders: this is the case that tells the two apart."""
+    from ssdr_al import sampler
+    if backend == "emu":
+        count = min(count, 40)
+    rng = np.random.default_rng(n)
+    half = rng.normal(size=(n // 2, 32))
+    f = np.concatenate([half, half])[rng.permutation(n)]
+    assert np.array_equal(sampler.farthest_features_sample(f, count, 3), O.farthest_features_sample(f, count, 3))
+
+
 def test_compute_features_mean_golden(backend, golden):
     """np.mean(last_second_features[dominant_point_ids], axis=0) (sampler2.py:333, :339) with the reference's own _dominant_2 ids."""
     from ssdr_al import sampler
