@@ -1043,12 +1043,14 @@ __global__ __launch_bounds__(FC_NT) void fps_coop(FpsCoopArgs a) {
 }
 #endif
 
-// The same chain for 32-d features with every workgroup's rows IN REGISTERS (two rows per thread, 512 per workgroup) and partials that carry the candidate's
+// The same chain for 32-d features with every workgroup's rows IN REGISTERS (512 per workgroup: one row per thread on eight waves since round 4 — two waves
+// per SIMD issue a float64 instruction every 6.5 cycles, the lone wave of the 256-thread form with two rows per thread every 12: 3.21 / 3.64 / 4.51 -> 2.84 / 3.17 /
+// 3.46 us per pick at 2368 / 4736 / 9472 rows on an idle GPU; 1024 rows per workgroup on 512 threads: 3.54 / 3.65 / 3.91) and partials that carry the candidate's
 // features: a pick costs one publish (the owner's row through LDS, one 272-byte write-through store by 34 lanes, drained, counter) and ONE round of loads
 // (every workgroup reads all G partials, features included, into LDS and finds the winner there) instead of three dependent rounds (partials, the winner's
 // row from the feature table, every row's features from L2).  This is the replicated global FPS of the sharded run (2 / 4 / 8 ranks: 2368 / 4736 / 9472 rows).
 #ifndef HIPEMU
-constexpr int FR_NT = 256, FR_RPT = 2, FR_ROWS = FR_NT * FR_RPT, FR_REC = 34;        // record: v, (i, pad), f[32] as 34 doubles
+constexpr int FR_NT = 512, FR_RPT = 1, FR_ROWS = FR_NT * FR_RPT, FR_REC = 34;        // record: v, (i, pad), f[32] as 34 doubles
 __global__ __launch_bounds__(FR_NT) void fps_coop_reg(FpsCoopArgs a) {
     if (a.dn) a.n = min(a.n, *a.dn);
     extern __shared__ double s_all[];                      // [G][FR_REC]: the partials of a pick, as read
@@ -1105,7 +1107,7 @@ __global__ __launch_bounds__(FR_NT) void fps_coop_reg(FpsCoopArgs a) {
         if (wi == bi && bi != 0x7fffffff) {
             s_pub[0] = wv; s_pub[1] = __longlong_as_double((long long)(unsigned)wi);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) s_pub[2 + k] = bq == 0 ? reg[0][k] : reg[1][k];
+            for (int k = 0; k < 32; ++k) s_pub[2 + k] = bq == 0 ? reg[0][k] : reg[FR_RPT - 1][k];
         } else if (wi == 0x7fffffff && tid == 0) { s_pub[0] = -1.0; s_pub[1] = __longlong_as_double(0x7fffffffll); }      // a workgroup of padding rows only
         __syncthreads();
         const int par = it & 1;
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(FR_NT) void fps_coop_tag(FpsCoopArgs a) {
             double* pub = reinterpret_cast<double*>(s_pub);
             pub[0] = wv; pub[1] = __longlong_as_double((long long)(unsigned)wi);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) pub[2 + k] = bq == 0 ? reg[0][k] : reg[1][k];
+            for (int k = 0; k < 32; ++k) pub[2 + k] = bq == 0 ? reg[0][k] : reg[FR_RPT - 1][k];
         } else if (wi == 0x7fffffff && tid == 0) { double* pub = reinterpret_cast<double*>(s_pub); pub[0] = -1.0; pub[1] = __longlong_as_double(0x7fffffffll); }      // padding rows only
         __syncthreads();                                   // (2)
         // ... and 68 lanes write it through, one self-validating granule each
