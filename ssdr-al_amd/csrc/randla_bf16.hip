@@ -169,6 +169,176 @@ __global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(TM == 128 ? 4 : 5) void dens
 }
 
 
+// ---- att_pooling's mlp chained into lrelu(mlp2 + shortcut) (RandLANet.py:583-585, :510-512) at the wide-row levels (d <= 64) ------------------
+// y1 = lrelu(x1 Wa + ba) (d -> d), y = lrelu([y1 | x2] Wb + bb) (d + k2 -> 2 d) for a 128-row tile per workgroup: both layers stream their rows from HBM
+// (655 k / 164 k rows at levels 0 / 1: 42 MB in and out for the first, 63 in and 84 out for the second), and the d-channel intermediate between them
+// now stays in LDS (58 -> 33 us at level 0, 65.6 -> 48.6 at level 1): the A image [x1 | x2 | 0] (bf16 pieces, rows of K2P + 8) is staged ONCE, the first product overwrites its x1 columns with y1 (a wave
+// reads and writes its own 32 rows only), and the second runs over the whole K of that image, one 64-column block of Wb at a time.  One launch and
+// 84 MB of traffic less per level.
+struct ChainArgs {
+    const float* x1; const float* x2; int k2;
+    const uint16_t* wa_hi; const uint16_t* wa_lo; int kpa; const float* ba;
+    const uint16_t* wb_hi; const uint16_t* wb_lo; int kpb; const float* bb;
+    float* y; int M;
+};
+template <int D, int K2P, int TM, int TERMS>
+__global__ __launch_bounds__(256) void dense_chain_kernel(ChainArgs a) {
+    constexpr int KS = K2P + 8;                        // LDS row stride in bf16 elements
+    constexpr int TPR = K2P <= 32 ? 4 : 16;            // threads per staged row (8 k each), a power of two
+    constexpr int RPP = 256 / TPR;                     // rows per staging pass
+    // TM = 128: wave w owns rows [32 w, 32 w + 32) and every column; TM = 64 (more, smaller workgroups: 53 KB of LDS instead of 79 at d = 64): waves 2 x 2,
+    // wave (wr, wc) owns rows [32 wr, +32) and half of the column tiles
+    constexpr int WC = TM == 128 ? 1 : 2;              // waves across the columns
+    constexpr int CT1 = (D / 16 + WC - 1) / WC;        // 16-column tiles per wave of the first product
+    constexpr int CT2 = 4 / WC;                        // ... of a 64-column block of the second
+    static_assert(D % 16 == 0 && D <= 64 && K2P % 32 == 0 && TPR * 8 >= K2P && (TM == 128 || TM == 64) && TM % RPP == 0, "shapes");
+    __shared__ __attribute__((aligned(16))) uint16_t As[TERMS][TM * KS];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[TERMS][64 * KS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = TM == 128 ? w : (w >> 1), wc = TM == 128 ? 0 : (w & 1);
+    const int row0 = (int)blockIdx.x * TM;
+    const int sr = tid / TPR, sk = (tid % TPR) * 8;
+    const int K = D + a.k2;
+    // ---- A image: [x1 | x2 | 0], split into bf16 pieces
+    if (sk < K2P) {
+        float4 va[TM / RPP][2];          // every load of the tile in flight before the first conversion
+#pragma unroll
+        for (int h = 0; h < TM / RPP; ++h) {
+            const int grow = row0 + sr + RPP * h;
+            va[h][0] = make_float4(0.f, 0.f, 0.f, 0.f); va[h][1] = va[h][0];
+            if (grow < a.M) {
+                const float* src = sk < D ? a.x1 + (size_t)grow * D + sk : (sk < K ? a.x2 + (size_t)grow * a.k2 + (sk - D) : nullptr);
+                if (src) { va[h][0] = *reinterpret_cast<const float4*>(src); va[h][1] = *reinterpret_cast<const float4*>(src + 4); }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < TM / RPP; ++h) {
+            const int r = sr + RPP * h;
+            const float4 v0 = va[h][0], v1 = va[h][1];
+            u32x4 hi, lo; unsigned hq, lq;
+            split_bf16(v0.x, v0.y, hq, lq); hi[0] = hq; lo[0] = lq;
+            split_bf16(v0.z, v0.w, hq, lq); hi[1] = hq; lo[1] = lq;
+            split_bf16(v1.x, v1.y, hq, lq); hi[2] = hq; lo[2] = lq;
+            split_bf16(v1.z, v1.w, hq, lq); hi[3] = hq; lo[3] = lq;
+            st128(&As[0][r * KS + sk], hi);
+            if (TERMS == 2) st128(&As[TERMS - 1][r * KS + sk], lo);
+        }
+    }
+    // a 64-row block of transposed weights (rows = output columns), zero beyond the layer's columns and its K
+    u32x4 wreg[64 / RPP][TERMS];          // the next weight block travels in registers while the current one is multiplied
+    auto load_w = [&](const uint16_t* whi, const uint16_t* wlo, int kp, int col0, int ncols, int kvalid) {
+#pragma unroll
+        for (int h = 0; h < 64 / RPP; ++h) {
+            const int r = sr + RPP * h;
+#pragma unroll
+            for (int t = 0; t < TERMS; ++t) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (sk < K2P && col0 + r < ncols && sk < kvalid) v = ld128((t ? wlo : whi) + (size_t)(col0 + r) * kp + sk);
+                wreg[h][t] = v;
+            }
+        }
+    };
+    auto store_w = [&]() {
+        if (sk < K2P) {
+#pragma unroll
+            for (int h = 0; h < 64 / RPP; ++h)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) st128(&Bs[t][(sr + RPP * h) * KS + sk], wreg[h][t]);
+        }
+    };
+    load_w(a.wa_hi, a.wa_lo, a.kpa, 0, D, D);
+    store_w();
+    __syncthreads();
+    load_w(a.wb_hi, a.wb_lo, a.kpb, 0, 2 * D, K);          // in flight across the first product
+    const int fr = lane & 15, fk = 8 * (lane >> 4), rbase = wr * 32;
+    // ---- y1 = lrelu(x1 Wa + ba) over the wave's 32 rows (its column tiles), written over the x1 columns of the image
+    {
+        f32x4 acc[2][CT1];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CT1; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool has1 = wc * CT1 * 16 < D;          // (d = 16 on 2 x 2 waves: the second column of waves has no tile of the first product)
+        if (has1) {
+#pragma unroll
+            for (int ks = 0; ks < (D + 31) / 32; ++ks) {
+                u32x4 af[2][2], bf[CT1][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < TERMS; ++t) af[r][t] = ld128(&As[t][(rbase + r * 16 + fr) * KS + ks * 32 + fk]);
+#pragma unroll
+                for (int c = 0; c < CT1; ++c)
+#pragma unroll
+                    for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128(&Bs[t][((wc * CT1 + c) * 16 + fr) * KS + ks * 32 + fk]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT1; ++c) acc[r][c] = mma_split<TERMS>(af[r], bf[c], acc[r][c]);
+            }
+        }
+        if (WC > 1) __syncthreads();          // the other wave of these rows has read x1 before y1 goes over it (one wave per row block otherwise: its own accesses are in order)
+        if (has1) {
+#pragma unroll
+            for (int c = 0; c < CT1; ++c) {
+                const int col = (wc * CT1 + c) * 16 + (lane & 15);
+                const float bias = a.ba ? a.ba[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = rbase + r * 16 + (lane >> 4) * 4 + q;
+                        const float v = lrelu(acc[r][c][q] + bias);
+                        unsigned hq, lq; split_bf16(v, 0.f, hq, lq);
+                        As[0][row * KS + col] = (uint16_t)(hq & 0xffffu);
+                        if (TERMS == 2) As[TERMS - 1][row * KS + col] = (uint16_t)(lq & 0xffffu);
+                    }
+            }
+        }
+    }
+    // ---- y = lrelu([y1 | x2] Wb + bb), 64 columns at a time
+    for (int ct = 0; ct < (2 * D + 63) / 64; ++ct) {
+        __syncthreads();             // every wave is done with the weight block in Bs (and, the first time, has written its y1 tiles)
+        store_w();
+        __syncthreads();
+        if (ct + 1 < (2 * D + 63) / 64) load_w(a.wb_hi, a.wb_lo, a.kpb, (ct + 1) * 64, 2 * D, K);
+        f32x4 acc[2][CT2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < K2P / 32; ++ks) {
+            u32x4 af[2][2], bf[CT2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) af[r][t] = ld128(&As[t][(rbase + r * 16 + fr) * KS + ks * 32 + fk]);
+#pragma unroll
+            for (int c = 0; c < CT2; ++c)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) bf[c][t] = ld128(&Bs[t][((wc * CT2 + c) * 16 + fr) * KS + ks * 32 + fk]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) acc[r][c] = mma_split<TERMS>(af[r], bf[c], acc[r][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            const int col = ct * 64 + (wc * CT2 + c) * 16 + (lane & 15);
+            if (col >= 2 * D) continue;
+            const float bias = a.bb ? a.bb[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = row0 + rbase + r * 16 + (lane >> 4) * 4 + q;
+                    if (row < a.M) a.y[(size_t)row * (2 * D) + col] = lrelu(acc[r][c][q] + bias);
+                }
+        }
+    }
+}
+
 // ---- fused local-feature-aggregation attention half, d >= 64 -------------------------------------------------------------
 // Work split: NW waves = NCG column groups x NPG point groups.  A wave owns NCH column tiles of the neighbour-feature half and
 // the NCH matching tiles of the position half, for PW of the workgroup's PTS points.
@@ -573,6 +743,29 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     // which is bound by what a CU fetches from L2 per clock, not by the matrix or LDS pipes)
     if (small) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
     return launch_dense_bf16_t<128, 32>(a, prec, vec, s);
+}
+
+// att_pooling's mlp + lrelu(mlp2 + shortcut) in one launch; SSDR_ERR_UNSUPPORTED (no error text) for shapes without an instantiation
+int launch_dense_chain(const DenseArgs& l1, const DenseArgs& l2, int prec, hipStream_t s) {
+    const int d = l1.k1;
+    const bool shapes = l1.k2 == 0 && l1.N == d && l1.act && l2.act && l2.k1 == d && l2.N == 2 * d && l2.x1 == l1.y && l2.M == l1.M && !l2.idx2 && !l1.ldy && !l2.ldy && !l1.xyz && !l2.xyz &&
+                        l2.k2 % 8 == 0 && l2.k2 > 0 && l1.wt_hi && l2.wt_hi && (prec != PREC_BF16X3 || (l1.wt_lo && l2.wt_lo)) &&
+                        (((uintptr_t)l1.x1 | (uintptr_t)l2.x2) & 15) == 0 && l1.kp % 8 == 0 && l2.kp % 8 == 0;
+    if (!shapes || l1.M <= 0) return SSDR_ERR_UNSUPPORTED;
+    int k2p = 0;
+    if (d == 16 && d + l2.k2 <= 32) k2p = 32; else if (d == 64 && d + l2.k2 <= 96) k2p = 96; else return SSDR_ERR_UNSUPPORTED;
+    ChainArgs a{l1.x1, l2.x2, l2.k2, l1.wt_hi, l1.wt_lo, l1.kp, l1.b, l2.wt_hi, l2.wt_lo, l2.kp, l2.b, l2.y, l1.M};
+    const double np = prec == PREC_BF16X3 ? 3.0 : 1.0, m128 = std::ceil(l1.M / 128.0) * 128.0;
+    ProfScope prof("dense_kernel", s, 2.0 * (double)l1.M * ((double)d * d + (double)(d + l2.k2) * 2.0 * d),
+                   2.0 * m128 * ((d == 16 ? 32.0 * 16 : 64.0 * 64) + (double)k2p * (d == 16 ? 64.0 : 128.0)) * np);
+    const bool t64 = d == 64;          // measured: d = 64 48.6 us on 64-row tiles (three workgroups per CU) against 60.1 on 128-row tiles; d = 16 35.7 against 33.0
+    const dim3 grid((unsigned)((l1.M + (t64 ? 63 : 127)) / (t64 ? 64 : 128)));
+#define SSDR_CHAIN(D_, K_, TM_) do { if (prec == PREC_BF16X3) hipLaunchKernelGGL((dense_chain_kernel<D_, K_, TM_, 2>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((dense_chain_kernel<D_, K_, TM_, 1>), grid, dim3(256), 0, s, a); } while (0)
+    if (d == 16) { if (t64) SSDR_CHAIN(16, 32, 64); else SSDR_CHAIN(16, 32, 128); }
+    else { if (t64) SSDR_CHAIN(64, 96, 64); else SSDR_CHAIN(64, 96, 128); }
+#undef SSDR_CHAIN
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
 }
 
 int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s) {

@@ -343,10 +343,13 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
             SSDR_TRY(run_dense(*m, ga, s));
         }
         SSDR_TRY(run_lfa(true, tab0 ? tab0 : aggm, m->layers[base + 5]));                                                  // LocSE2 + att pool 2
-        SSDR_TRY(run_dense(*m, dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1), s));                   // att2 mlp d->d
+        DenseArgs a6 = dense(agg, d, m->layers[base + 6], aggm, (int)rows, 1);                               // att2 mlp d->d
         DenseArgs r = dense(aggm, d, m->layers[base + 7], out, (int)rows, 1);                               // lrelu(mlp2 + shortcut)
         r.x2 = f; r.k2 = d_in;
-        SSDR_TRY(run_dense(*m, r, s));
+        // the two in one launch where the rows are many and narrow (d <= 64: the intermediate stays in LDS)
+        int chained = m->prec != PREC_F32 ? launch_dense_chain(a6, r, m->prec, s) : SSDR_ERR_UNSUPPORTED;
+        if (chained == SSDR_ERR_UNSUPPORTED) { SSDR_TRY(run_dense(*m, a6, s)); SSDR_TRY(run_dense(*m, r, s)); }
+        else SSDR_TRY(chained);
         SSDR_TRY(launch_gather_max(out, d_neigh_idx[i], n, N[i + 1], n, 2 * d, samp, Bi, s));               // random_sample
         if (i == 0) { enc.push_back(out); enc_ch.push_back(2 * d); enc_n.push_back(n); }
         enc.push_back(samp); enc_ch.push_back(2 * d); enc_n.push_back(N[i + 1]);
