@@ -89,6 +89,33 @@ __device__ __forceinline__ T np_pairwise_w8(Get get, int n, int lane) {
     return r;
 }
 
+// The whole recursion with every block of at most 128 terms summed by np_pairwise_w8 (uniform n over the wave; result on lane 0): the call tree
+// sum(a[:n2]) + sum(a[n2:]) is walked by all lanes alike, only its leaves use the eight lanes.  A superpoint of 185 points is two such blocks of ~12 dependent
+// additions per lane instead of 185 on one lane.
+template <class T, class Get>
+__device__ T np_pairwise_wave(Get get, int n, int lane) {
+    struct Fr { int lo, n; int state; T left; };
+    Fr st[24]; int sp = 0; T ret = T(0);
+    st[0] = Fr{0, n, 0, T(0)};
+    while (sp >= 0) {
+        Fr& f = st[sp];
+        if (f.n <= 128) {
+            T res = T(0);
+            const int lo = f.lo;
+            if (f.n < 8) { if (lane == 0) for (int i = 0; i < f.n; ++i) res += get(lo + i); }
+            else res = np_pairwise_w8<T>([&](int i) { return get(lo + i); }, f.n, lane);
+            ret = res; --sp;
+        } else if (f.state == 0) {
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            f.state = 1; st[sp + 1] = Fr{f.lo, n2, 0, T(0)}; ++sp;
+        } else if (f.state == 1) {
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            f.left = ret; f.state = 2; st[sp + 1] = Fr{f.lo + n2, f.n - n2, 0, T(0)}; ++sp;
+        } else { ret = f.left + ret; --sp; }
+    }
+    return ret;
+}
+
 // ---- U1: compute_point_uncertainty (sampler2.py:28-47) + argmax class (:602) ------------------------------
 __global__ __launch_bounds__(256) void sel_point_unc(const float* __restrict__ prob, int n, int C, int mode, float* unc, int* cls) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -170,22 +197,22 @@ __global__ __launch_bounds__(256) void sel_region_stats_w(const float* __restric
         if (lane == 0) { dom[s] = d; dom_cnt[s] = h[d]; }
         auto U = [&](int j) { return staged ? s_u[w][j] : unc[sp_pts[lo + j]]; };
         auto K = [&](int j) { return staged ? s_c[w][j] : cls[sp_pts[lo + j]]; };
-        const bool w8 = staged && n >= 8 && n <= 128;                 // one block of NumPy's pairwise sum: its eight accumulators on eight lanes
+        const bool w8 = staged && n >= 8;                             // the blocks of NumPy's pairwise sum with their eight accumulators on eight lanes
         double r = 0.0;
         if (mode == 0) {
             float sum = 0.f;
-            if (w8) sum = np_pairwise_w8<float>([&](int j) { return U(j); }, n, lane);
+            if (w8) sum = np_pairwise_wave<float>([&](int j) { return U(j); }, n, lane);
             else if (lane == 0) sum = np_pairwise<float>([&](int j) { return U(j); }, n);
             r = (double)(float)((double)sum / (double)n);
         } else if (mode == 1) {                                      // weights_percentage (:92-100) * uncertainty
             auto term = [&](int j) { return ((double)h[K(j)] / (double)n) * (double)U(j); };
-            if (w8) r = np_pairwise_w8<double>(term, n, lane);
+            if (w8) r = np_pairwise_wave<double>(term, n, lane);
             else if (lane == 0) r = np_pairwise<double>(term, n);
         } else {                                                     // WetSU (:19-26)
             auto ta = [&](int j) { return (double)U(j) * (K(j) == d ? 1.0 : 0.0); };
             auto tb = [&](int j) { return (double)U(j) * (1.0 - (K(j) == d ? 1.0 : 0.0)); };
             double a = 0.0, b = 0.0;
-            if (w8) { a = np_pairwise_w8<double>(ta, n, lane); b = np_pairwise_w8<double>(tb, n, lane); }
+            if (w8) { a = np_pairwise_wave<double>(ta, n, lane); b = np_pairwise_wave<double>(tb, n, lane); }
             else if (lane == 0) { a = np_pairwise<double>(ta, n); b = np_pairwise<double>(tb, n); }
             r = a - b;
         }

@@ -219,10 +219,10 @@ def test_edcd_farthest_superpoint_sample_golden(backend, golden):
 def test_selection_fresh_inputs_against_oracle(backend):
     from ssdr_al import sampler
     rng = np.random.default_rng(21)
-    n, C = (4000, 13) if backend == "emu" else (200000, 13)
+    n, C = (8000, 13) if backend == "emu" else (200000, 13)
     prob = rng.dirichlet(np.ones(C) * 0.5, n).astype(np.float32)
     feat = rng.normal(0, 1, (n, 32)).astype(np.float32)
-    sizes = []
+    sizes = [1300, 1025, 1024, 700, 129, 128]               # above / at the wave routine's staging capacity, several blocks of the pairwise sum, one block
     while sum(sizes) < n:
         sizes.append(int(rng.integers(5, 400)))
     sizes[-1] -= sum(sizes) - n
@@ -233,6 +233,8 @@ def test_selection_fresh_inputs_against_oracle(backend):
     ru, dom, cnt = sampler.compute_region_stats(u, cls, off, pts, C, ["WetSU"])
     eru, edom, ecnt = O.region_stats(u, cls, off, pts, C, "WetSU")
     assert np.array_equal(ru, eru) and np.array_equal(dom, edom) and np.array_equal(cnt, ecnt)
+    for mode in ("mean", "sum_weight"):                     # NumPy's pairwise order in every mode, for every size class
+        assert np.array_equal(sampler.compute_region_stats(u, cls, off, pts, C, [mode])[0], O.region_stats(u, cls, off, pts, C, mode)[0]), mode
     sel = O.rank_regions(ru)[:40].astype(np.int32)
     mf = sampler.segment_mean_features(feat, cls, dom, off, pts, sel)
     sub_off = np.concatenate([[0], np.cumsum(off[sel + 1] - off[sel])]).astype(np.int32)
