@@ -67,6 +67,7 @@ struct TailArgs {         // fc1 + fc2 + fc + softmax on the bf16 cores
 int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s);      // SSDR_ERR_UNSUPPORTED (no error text) when it has no instantiation
 // randla_bf16.hip: the same two operations on the bf16 matrix cores (prec = PREC_BF16X3 / PREC_BF16)
 int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s);
+int launch_dense_rows2(const DenseArgs& a, const DenseArgs& b, hipStream_t s);      // two thin layers (6 -> 8 -> 8) in one pass over the rows; SSDR_ERR_UNSUPPORTED (no error text) otherwise
 int launch_dense_chain(const DenseArgs& l1, const DenseArgs& l2, int prec, hipStream_t s);      // y = l2([l1(x1) | x2]) in one launch; SSDR_ERR_UNSUPPORTED (no error text) for other shapes
 int launch_lfa_bf16(int D, const LfaArgs& a, bool second, int B, int prec, hipStream_t s);
 int launch_lfa32(int D, const Lfa32Args& a, bool second, int B, int prec, hipStream_t s);        // SSDR_ERR_UNSUPPORTED (no error text) for a D it has no instantiation for

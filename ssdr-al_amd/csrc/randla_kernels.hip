@@ -585,6 +585,63 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(DenseArgs a) {
     }
 }
 
+// Two thin layers in one pass over the rows (fc0 -> level 0's mlp1, RandLANet.py:139-141 / :506): h = act(x W1 + b1) is written (the residual
+// shortcut reads it later) AND fed to y = act(h W2 + b2) from registers — the same fused multiply-adds in the same order as two launches of
+// dense_rows_kernel, one read of h less.
+template <int K1, int N1, int N2>
+__global__ __launch_bounds__(256) void dense_rows2_kernel(DenseArgs a, DenseArgs b) {
+    __shared__ float W1s[K1 * N1 + N1], W2s[N1 * N2 + N2];
+    for (int i = threadIdx.x; i < K1 * N1; i += 256) W1s[i] = a.W[i];
+    for (int i = threadIdx.x; i < N1; i += 256) W1s[K1 * N1 + i] = a.b ? a.b[i] : 0.f;
+    for (int i = threadIdx.x; i < N1 * N2; i += 256) W2s[i] = b.W[i];
+    for (int i = threadIdx.x; i < N2; i += 256) W2s[N1 * N2 + i] = b.b ? b.b[i] : 0.f;
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;          // one row per thread (see dense_rows_kernel)
+    if (row < a.M) {
+        float x[K1];
+        const float* r1 = a.x1 + (size_t)row * K1;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) x[k] = r1[k];
+        float h[N1];
+#pragma unroll
+        for (int n = 0; n < N1; ++n) h[n] = W1s[K1 * N1 + n];
+#pragma unroll
+        for (int k = 0; k < K1; ++k) {
+#pragma unroll
+            for (int n = 0; n < N1; ++n) h[n] = fmaf(x[k], W1s[k * N1 + n], h[n]);
+            SSDR_SCHED_FENCE();
+        }
+        if (a.act) {
+#pragma unroll
+            for (int n = 0; n < N1; ++n) h[n] = lrelu(h[n]);
+        }
+        float4* ho = reinterpret_cast<float4*>(a.y + (size_t)row * N1);
+#pragma unroll
+        for (int q = 0; q < N1 / 4; ++q) ho[q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+        float acc[N2];
+#pragma unroll
+        for (int n = 0; n < N2; ++n) acc[n] = W2s[N1 * N2 + n];
+#pragma unroll
+        for (int k = 0; k < N1; ++k) {
+#pragma unroll
+            for (int n = 0; n < N2; ++n) acc[n] = fmaf(h[k], W2s[k * N2 + n], acc[n]);
+            SSDR_SCHED_FENCE();
+        }
+        float4* yo = reinterpret_cast<float4*>(b.y + (size_t)row * (b.ldy ? b.ldy : N2));
+        if (b.xyz) {      // the row's coordinates in front of its features: one 64-byte row of the level-0 gather table
+            const int be = row / b.xyz_rows_per_batch, i = row - be * b.xyz_rows_per_batch;
+            const float* c = b.xyz + (size_t)be * b.xyz_batch_stride + 3 * (size_t)i;
+            yo[-1] = make_float4(c[0], c[1], c[2], 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < N2 / 4; ++q) {
+            float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            if (b.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+            yo[q] = v;
+        }
+    }
+}
+
 // fc1 (32 -> 64) + fc2 (64 -> 32 = last_second_features) + fc (32 -> C) + softmax (:174-178, :84) in one pass over the
 // points: 128 bytes in, 128 + 4C bytes out per point instead of three round trips through HBM.
 template <int C>
@@ -678,6 +735,18 @@ int launch_dense(const DenseArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(dense_small_kernel, gs, dim3(256), 0, s, a);
     } else if (vec) hipLaunchKernelGGL((dense_kernel<true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((dense_kernel<false>), grid, dim3(256), 0, s, a);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+// fc0 and level 0's mlp1 (6 -> 8 -> 8) in one launch; SSDR_ERR_UNSUPPORTED (no error text) for any other pair
+int launch_dense_rows2(const DenseArgs& a, const DenseArgs& b, hipStream_t s) {
+    const bool ok = a.k1 == 6 && a.k2 == 0 && a.N == 8 && b.k1 == 8 && b.k2 == 0 && b.N == 8 && b.x1 == a.y && a.M == b.M && a.M >= 1024 && !a.ldy && !a.xyz && !a.idx2 && !b.idx2 &&
+                    (((uintptr_t)a.y | (uintptr_t)b.y) & 15) == 0 && (!b.ldy || b.ldy % 4 == 0);
+    if (!ok) return SSDR_ERR_UNSUPPORTED;
+    const double fl = 2.0 * (double)a.M * (6.0 * 8 + 8.0 * 8);
+    ProfScope prof("dense_kernel", s, fl, fl);
+    hipLaunchKernelGGL((dense_rows2_kernel<6, 8, 8>), dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a, b);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

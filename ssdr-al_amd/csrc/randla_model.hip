@@ -283,7 +283,9 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
 
     // fc0
     float* f0 = buf(6 * L + 0, B * N[0] * 8); if (!f0) return SSDR_ERR_HIP;
-    SSDR_TRY(run_dense(*m, dense(d_features, m->in_dim, m->layers[0], f0, Bi * N[0], 1), s));
+    const DenseArgs a_fc0 = dense(d_features, m->in_dim, m->layers[0], f0, Bi * N[0], 1);
+    // (launched with level 0's mlp1: the thin 6 -> 8 -> 8 pair is one pass over the rows)
+    if (L < 1) { set_error("randla_infer: no encoder level"); return SSDR_ERR_INVALID; }
     const float* f = f0; int d_in = 8;
     std::vector<const float*> enc; std::vector<int> enc_ch, enc_n;
     for (int i = 0; i < L; ++i) {
@@ -300,7 +302,11 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
         {
             DenseArgs a1 = dense(f, d_in, m->layers[base + 0], tab0 ? tab0 + 4 : f_pc, (int)rows, 1);
             if (tab0) { a1.ldy = 16; a1.xyz = d_xyz; a1.xyz_batch_stride = n0 * 3; a1.xyz_rows_per_batch = n; }
-            SSDR_TRY(run_dense(*m, a1, s));                                                                  // mlp1
+            if (i == 0) {
+                const int fused = launch_dense_rows2(a_fc0, a1, s);
+                if (fused == SSDR_ERR_UNSUPPORTED) { SSDR_TRY(run_dense(*m, a_fc0, s)); SSDR_TRY(run_dense(*m, a1, s)); }
+                else SSDR_TRY(fused);
+            } else SSDR_TRY(run_dense(*m, a1, s));                                                           // mlp1
         }
         LfaArgs la{}; la.xyz = d_xyz; la.xyz_batch_stride = n0 * 3; la.neigh = d_neigh_idx[i]; la.n = n;
         la.w_l1 = m->layers[base + 1].W.as<float>(); la.b_l1 = m->layers[base + 1].b.as<float>();
