@@ -640,31 +640,54 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float
     int tpb = 0, nbe = 0;
     if (PRE && pre.m_per_batch % 16 == 0 && M % pre.m_per_batch == 0 && (gridDim.x & 7) == 0) { tpb = pre.m_per_batch / 16; nbe = M / pre.m_per_batch; if (nbe & 7) tpb = 0; }
     const int lw = ((int)blockIdx.x >> 3) * 4 + ((int)threadIdx.x >> 6), lnw = nwaves >> 3, lnt = tpb ? (nbe >> 3) * tpb : 0;
-    for (int it = tpb ? lw : wave; it < (tpb ? lnt : ntiles); it += tpb ? lnw : nwaves) {
-        const int tile = tpb ? (((int)blockIdx.x & 7) + 8 * (it / tpb)) * tpb + it % tpb : it;
+    // The rows of the NEXT tile (and the gather index of the one after it) travel while the current tile is multiplied: a wave's tiles form a chain of
+    // ~60 matrix instructions behind two dependent global loads (index, then the gathered row), and at two waves per SIMD nothing else covers them
+    // (round 4: 112 -> see DESIGN section 5).
+    const int it_first = tpb ? lw : wave, it_end = tpb ? lnt : ntiles, it_step = tpb ? lnw : nwaves;
+    auto tile_of = [&](int it) { return tpb ? (((int)blockIdx.x & 7) + 8 * (it / tpb)) * tpb + it % tpb : it; };
+    auto row_of = [&](int it) { const int r = tile_of(it) * 16 + lc; return (it < it_end && r < M) ? r : -1; };
+    auto load8r = [&](const float* p, int ok, float4 (&v)[2]) {
+        v[0] = make_float4(0.f, 0.f, 0.f, 0.f); v[1] = v[0];
+        if (ok) { v[0] = *reinterpret_cast<const float4*>(p + 8 * lg); v[1] = *reinterpret_cast<const float4*>(p + 8 * lg + 4); }
+    };
+    auto unpack8 = [](const float4 (&a)[2], float (&v)[8]) { v[0] = a[0].x; v[1] = a[0].y; v[2] = a[0].z; v[3] = a[0].w; v[4] = a[1].x; v[5] = a[1].y; v[6] = a[1].z; v[7] = a[1].w; };
+    float4 n_sk[2], n_up[2];                 // rows of the next tile (PRE: skip and gathered; otherwise n_sk holds x)
+    int idx_next = 0;                        // PRE: gather index of the tile after the next one's rows are requested with
+    auto issue_rows = [&](int it, int idx) {
+        const int r = row_of(it);
+        if (PRE) {
+            const int rw = r < 0 ? 0 : r;
+            load8r(pre.skip + (size_t)rw * 32, r >= 0, n_sk);
+            load8r(pre.up + ((size_t)(rw / pre.m_per_batch) * pre.up_rows_per_batch + (size_t)idx) * 32, r >= 0, n_up);
+        } else load8r(x + (size_t)(r < 0 ? 0 : r) * 32, r >= 0, n_sk);
+    };
+    auto load_idx = [&](int it) { const int r = row_of(it); return (PRE && r >= 0) ? pre.idx[r] : 0; };
+    {
+        const int i0 = load_idx(it_first);
+        idx_next = load_idx(it_first + it_step);
+        issue_rows(it_first, i0);
+    }
+    for (int it = it_first; it < it_end; it += it_step) {
+        const int tile = tile_of(it);
         const int row = tile * 16 + lc;
-        auto load8 = [&](const float* p, float (&v)[8]) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-            if (row < M) { a0 = *reinterpret_cast<const float4*>(p + 8 * lg); a1 = *reinterpret_cast<const float4*>(p + 8 * lg + 4); }
-            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-        };
+        float c_sk[8], c_up[8];
+        unpack8(n_sk, c_sk);
+        if (PRE) unpack8(n_up, c_up);
+        {
+            const int idx2 = load_idx(it + 2 * it_step);
+            issue_rows(it + it_step, idx_next);
+            idx_next = idx2;
+        }
+        SSDR_SCHED_FENCE();                  // the requests above stay above the products below
         u32x4 xf[2];
         if (PRE) {
-            float sk[8], up[8];
-            const int rw = row < M ? row : 0;
-            load8(pre.skip + (size_t)rw * 32, sk);
-            load8(pre.up + ((size_t)(rw / pre.m_per_batch) * pre.up_rows_per_batch + (size_t)pre.idx[rw]) * 32, up);
-            u32x4 sf[2], uf[2]; frag(sk, sf); frag(up, uf);
+            u32x4 sf[2], uf[2]; frag(c_sk, sf); frag(c_up, uf);
             f32x4 d0 = f32x4{BD[0].x, BD[0].y, BD[0].z, BD[0].w}, d1 = f32x4{BD[1].x, BD[1].y, BD[1].z, BD[1].w};
             d0 = mma_split<TERMS>(WD[0][0], sf, d0); d0 = mma_split<TERMS>(WD[PRE ? 1 : 0][0], uf, d0);
             d1 = mma_split<TERMS>(WD[0][1], sf, d1); d1 = mma_split<TERMS>(WD[PRE ? 1 : 0][1], uf, d1);
             const float v[8] = {lrelu(d0[0]), lrelu(d0[1]), lrelu(d0[2]), lrelu(d0[3]), lrelu(d1[0]), lrelu(d1[1]), lrelu(d1[2]), lrelu(d1[3])};
             frag(v, xf);
-        } else {
-            float xin[8];
-            load8(x + (size_t)(row < M ? row : 0) * 32, xin);
-            frag(xin, xf);
-        }
+        } else frag(c_sk, xf);
         // fc1, transposed: lane (point lc, g) gets channels 16 ct + 4 g + reg
         float h1[4][4];
 #pragma unroll
@@ -773,7 +796,9 @@ int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s) {
     if ((t.C != 13 && t.C != 8) || (!t.skip && ((uintptr_t)t.x & 15)) || (t.skip && (((uintptr_t)t.skip | (uintptr_t)t.up) & 15)) || !t.w1h || !t.w2h || !t.w3h || (prec == PREC_BF16X3 && (!t.w1l || !t.w2l || !t.w3l))) return SSDR_ERR_UNSUPPORTED;
     const double m16 = std::ceil(t.M / 16.0) * 16.0;
     ProfScope prof("tail_kernel", s, (double)t.M * 4.0 * (32 + 32 + t.C), 2.0 * m16 * ((t.skip ? 64.0 * 32 : 0.0) + 32.0 * 64 + 2.0 * 64 * 32 + 32.0 * 16) * (prec == PREC_BF16X3 ? 3.0 : 1.0));
-    const dim3 g((unsigned)std::max(1, std::min((t.M + 63) / 64, ctx().num_cu * 8)));
+    // two workgroups per CU = what its ~220 registers per lane keep resident: every wave then loads its 26 weight fragments once for ~20 tiles
+    // (eight per CU, waves of 5 tiles: 117 us; four: 99; two: 90)
+    const dim3 g((unsigned)std::max(1, std::min((t.M + 63) / 64, ctx().num_cu * 2)));
     TailPre pre{t.skip, t.up, t.idx, t.m_per_batch, t.up_rows_per_batch, t.wdh, t.wdl, t.kpd, t.bd};
 #define SSDR_TAIL(TERMS_, C_) do { if (t.skip) hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_, true>), g, dim3(256), 0, s, pre, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs); \
                                else hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_, false>), g, dim3(256), 0, s, pre, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs); } while (0)
