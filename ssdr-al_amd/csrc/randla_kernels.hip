@@ -507,6 +507,30 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict
     }
 }
 
+// four channels per thread: the sixteen indices arrive as four 16-byte loads, every gather is one 16-byte load per lane and the offsets are 32-bit (the
+// one-channel form above spends 60 % of its time on address arithmetic for loads the texture path prices per dword anyway)
+__global__ __launch_bounds__(256) void gather_max4_kernel(const float* __restrict__ f, const int* __restrict__ idx, int n_in, int n_out,
+                                                          int idx_rows, int C, float* __restrict__ out) {
+    int bx, b; xcd_tile_map(bx, b);
+    const float* fb = f + (size_t)b * n_in * C;
+    const int* ib = idx + (size_t)b * idx_rows * 16;
+    float* ob = out + (size_t)b * n_out * C;
+    const unsigned C4 = (unsigned)C / 4u, total = (unsigned)n_out * C4;
+    for (unsigned e = (unsigned)bx * 256u + threadIdx.x; e < total; e += (unsigned)gridDim.x * 256u) {
+        const unsigned m = e / C4, c4 = e - m * C4;
+        const int4* ip = reinterpret_cast<const int4*>(ib + (size_t)m * 16);
+        const int4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];
+        const int id[16] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w, i3.x, i3.y, i3.z, i3.w};
+        float4 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = *reinterpret_cast<const float4*>(fb + ((unsigned)id[k] * (unsigned)C + 4u * c4));
+        float4 v = x[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { v.x = fmaxf(v.x, x[k].x); v.y = fmaxf(v.y, x[k].y); v.z = fmaxf(v.z, x[k].z); v.w = fmaxf(v.w, x[k].w); }
+        *reinterpret_cast<float4*>(ob + (size_t)e * 4) = v;
+    }
+}
+
 // ---- fc (32 -> C) + softmax (:176, :84) ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                                    int M, int C, float* __restrict__ probs) {
@@ -786,6 +810,12 @@ int launch_lfa(int D, const LfaArgs& a, bool second, int B, hipStream_t s) {
 int launch_gather_max(const float* f, const int* idx, int n_in, int n_out, int idx_rows, int C, float* out, int B, hipStream_t s) {
     if (n_out <= 0 || B <= 0) return SSDR_OK;
     const size_t total = (size_t)n_out * C;
+    if (C % 4 == 0 && (size_t)n_in * C < (1ull << 30) && total / 4 < (1ull << 31) && (((uintptr_t)f | (uintptr_t)out | (uintptr_t)idx) & 15) == 0) {
+        dim3 grid4((unsigned)std::max<size_t>(1, std::min<size_t>((total / 4 + 255) / 256, 4096)), (unsigned)B);
+        hipLaunchKernelGGL(gather_max4_kernel, grid4, dim3(256), 0, s, f, idx, n_in, n_out, idx_rows, C, out);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 4096)), (unsigned)B);
     hipLaunchKernelGGL(gather_max_kernel, grid, dim3(256), 0, s, f, idx, n_in, n_out, idx_rows, C, out);
     SSDR_HIP(hipGetLastError());
