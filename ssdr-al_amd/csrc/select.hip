@@ -117,9 +117,22 @@ __device__ T np_pairwise_wave(Get get, int n, int lane) {
 }
 
 // ---- U1: compute_point_uncertainty (sampler2.py:28-47) + argmax class (:602) ------------------------------
+// (round 4: a workgroup's 256 rows of C <= 32 probabilities are one contiguous run: loaded coalesced into LDS, read back one row per lane — a lane reading its
+// own 52-byte row straight from memory made every load instruction touch 64 lines)
 __global__ __launch_bounds__(256) void sel_point_unc(const float* __restrict__ prob, int n, int C, int mode, float* unc, int* cls) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float* p = prob + (size_t)i * C;
+    __shared__ float s_p[256 * 32];
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {          // uniform over the workgroup
+        const int rows = min(256, n - i0);
+        const bool staged = C <= 32;
+        if (staged) {
+            __syncthreads();
+            const float* src = prob + (size_t)i0 * C;
+            for (int e = threadIdx.x; e < rows * C; e += 256) s_p[e] = src[e];
+            __syncthreads();
+        }
+        const int i = i0 + (int)threadIdx.x;
+        if (i >= n) continue;
+        const float* p = staged ? s_p + (size_t)threadIdx.x * C : prob + (size_t)i * C;
         float best = p[0], second = -1.f; int bi = 0;
         for (int c = 1; c < C; ++c) {
             const float v = p[c];
