@@ -55,6 +55,8 @@ template <int D> struct Lfa32Cfg {
     static constexpr int RS = 2 * H + 16;                              // bytes per staged row: 16-byte slots rotate through the banks
     // waves per workgroup: each owns one pair of points and shares the staged chunk; 8 (two per SIMD) where the registers allow two waves per SIMD anyway
     static constexpr int nw(bool second) { return D >= 256 && !second ? 8 : 4; }
+    static constexpr int tpw(bool second) { return D == 128 && second ? 4 : 1; }      // pairs of points a wave takes one after the other (d = 128, second half: the staged weights stay;
+                                                                                      // the first half loses a wave per SIMD to the loop's registers: 68.5 -> 72.6 us, the second gains: 103.8 -> 93.7; two pairs 94.6, eight 106.7)
     static constexpr int SPR = RS / 16;                                // 16-byte slots per staged row (the last one is padding)
     static constexpr size_t buf_bytes(int terms) { return ((size_t)terms * CCF * RS + 4095) / 4096 * 4096; }      // whole 1 KB DMA blocks, the same number for each of the 4 waves
 };
@@ -131,6 +133,10 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
     constexpr int NW = C::nw(SECOND), NT = NW * 64;
     constexpr int H = C::H, KS = C::KS, HT = C::HT, CT = C::CT, CCF = C::CCF, CC2 = C::CC2, NF = C::NF, N2 = SECOND ? C::N2 : 0, RS = C::RS;
     constexpr int NCH = N2 + NF;
+    // d = 128: at most two chunks, i.e. every weight stays in the two buffers once staged: a wave takes TPW pairs of points one after the other and only the
+    // first passes the barriers (5120 workgroups of four pairs each re-staged 32-48 KB for 8 points)
+    constexpr int TPW = C::tpw(SECOND);
+    static_assert(TPW == 1 || NCH <= 2, "several pairs per wave only where the staged weights stay");
     constexpr size_t BUFB = C::buf_bytes(TERMS);
     constexpr bool OFFREG = H <= 64;            // both gather offset tables in registers
     constexpr bool W1REG = H <= 64;             // LocSE weight fragments in registers
@@ -139,8 +145,7 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     int bx, b; xcd_tile_map(bx, b);
-    const int n = a.n, rt = bx * NW + w;
-    const bool active = 2 * rt < n;             // wave-uniform: a wave past the end still stages weights and meets the barriers
+    const int n = a.n;
     const float* xyz = a.xyz + (size_t)b * a.xyz_batch_stride;
     const int* neigh = a.neigh + (size_t)b * n * 16;
 
@@ -170,6 +175,26 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
         }
     };
     stage_load(0);
+    // LocSE weights (per wave, once)
+    u32x4 w1r[W1REG ? HT : 1][TERMS];
+    auto w1_frag = [&](int t, int term) { return ld128g(a.w1p + ((size_t)(32 * t + lr) * 2 + term) * 16 + 8 * lh); };
+    if constexpr (W1REG) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int term = 0; term < TERMS; ++term) w1r[t][term] = w1_frag(t, term);
+    }
+    auto w1_get = [&](int t, u32x4 (&f)[TERMS]) {
+#pragma unroll
+        for (int term = 0; term < TERMS; ++term) { if constexpr (W1REG) f[term] = w1r[t][term]; else f[term] = w1_frag(t, term); }
+    };
+    const rsrc32_t rG = make_rsrc32(a.g + (size_t)b * n * D, (unsigned)n * D * 4u);
+    const rsrc32_t rF = make_rsrc32(a.fin + (size_t)b * n * H, (unsigned)n * H * 4u);
+
+    for (int it = 0; it < TPW; ++it) {
+    const int rt = (bx * NW + w) * TPW + it;
+    const bool active = 2 * rt < n;             // wave-uniform: a wave past the end still stages weights and meets the barriers (first pass)
+    if (it > 0 && !active) break;
 
     // ---- this lane's row of the position encoding, and its point's neighbour table -----------------------------------------------
     u32x4 relf = {0u, 0u, 0u, 0u};
@@ -191,23 +216,7 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
             }
         }
     }
-    const rsrc32_t rG = make_rsrc32(a.g + (size_t)b * n * D, (unsigned)n * D * 4u);
-    const rsrc32_t rF = make_rsrc32(a.fin + (size_t)b * n * H, (unsigned)n * H * 4u);
     auto f_off = [&](int q) -> unsigned { if constexpr (OFFREG) return foff[q]; else return (goff[q] + (unsigned)lr * 4u) >> 1; };
-
-    // LocSE weights
-    u32x4 w1r[W1REG ? HT : 1][TERMS];
-    auto w1_frag = [&](int t, int term) { return ld128g(a.w1p + ((size_t)(32 * t + lr) * 2 + term) * 16 + 8 * lh); };
-    if constexpr (W1REG) {
-#pragma unroll
-        for (int t = 0; t < HT; ++t)
-#pragma unroll
-            for (int term = 0; term < TERMS; ++term) w1r[t][term] = w1_frag(t, term);
-    }
-    auto w1_get = [&](int t, u32x4 (&f)[TERMS]) {
-#pragma unroll
-        for (int term = 0; term < TERMS; ++term) { if constexpr (W1REG) f[term] = w1r[t][term]; else f[term] = w1_frag(t, term); }
-    };
 
     // ---- T1 = lrelu(W1^T rel^T + b1): channels in the registers, neighbour rows on the lanes (LFAmlp1, :518) ----------------------------
     u32x4 Tf[KS][TERMS];
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
         for (int q = 0; q < 16; ++q) x[q] = lrelu(acc[q]);
     };
 
-    stage_store(0, ldsA);
+    if (it == 0) stage_store(0, ldsA);
     float x2[SECOND ? HT : 1][16];
     u32x4 T2f[SECOND ? KS : 1][TERMS];
     auto score_frag = [&](int s) -> const u32x4 (&)[TERMS] { if constexpr (SECOND) return T2f[s]; else return Tf[s]; };
@@ -248,8 +257,10 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         char* buf = (i & 1) ? ldsB : ldsA;
-        __syncthreads();                                       // chunk i is in place; everybody is done with the other buffer
-        if (i + 1 < NCH) stage_load(i + 1);
+        if (it == 0) {
+            __syncthreads();                                   // chunk i is in place; everybody is done with the other buffer
+            if (i + 1 < NCH) stage_load(i + 1);
+        }
         if (SECOND && i < N2) {
             // ---- f_xyz <- lrelu(f_xyz W2 + b2) (LFAmlp2, :523) in both orientations from the same staged fragments ---------------------
             if (active) {
@@ -323,8 +334,9 @@ __global__ __launch_bounds__(Lfa32Cfg<D>::nw(SECOND) * 64) SSDR_WAVES_PER_EU((D 
                 }
             }
         }
-        if (i + 1 < NCH) stage_store(i + 1, (i & 1) ? ldsA : ldsB);
+        if (it == 0 && i + 1 < NCH) stage_store(i + 1, (i & 1) ? ldsA : ldsB);
     }
+    }      // pairs of this wave
 }
 
 // ---- levels whose weights fit in LDS whole (d = 64, 128): no G table ----------------------------------------------------------------------------
@@ -620,7 +632,7 @@ static int launch_lfa32_l0(const Lfa32Args& a, bool second, int B, int prec, hip
 template <int D> static int launch_lfa32_d(const Lfa32Args& a, bool second, int B, int prec, hipStream_t s) {
     using C = Lfa32Cfg<D>;
     const int nw = C::nw(second);
-    dim3 grid((unsigned)((a.n + 2 * nw - 1) / (2 * nw)), (unsigned)B);
+    dim3 grid((unsigned)((a.n + 2 * nw * C::tpw(second) - 1) / (2 * nw * C::tpw(second))), (unsigned)B);
     const int terms = prec == PREC_BF16X3 ? 2 : 1;
     const double rows = (double)B * (double)a.n * 16.0;       // algorithmic FLOPs of the reference's formulation (as lfa_att_kernel)
     // executed on the matrix cores: LocSE with K padded to 16 in both orientations (two instructions carry the four products),
