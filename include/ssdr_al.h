@@ -304,8 +304,8 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
  * candidates' propagated features.  Global region id = rank * Smax + local id (padding counts as labelled), global cloud = rank * Bmax + local cloud.
  * ssdr_gcn_fps_sharded_local_dev: the candidate rule over the global ranking d_gorder [Sg = world * Smax] (ssdr_rank_regions_dev over the all-gathered masked
  * uncertainties) for the clouds of ALL ranks — d_gbase [world * Bmax + 1]: global cloud c spans d_gbase[c] .. d_gbase[c+1]-1 — then this rank's share of
- * GCN_FPS_sampling for its own clouds.  d_comb_out [nu_max, 32] float64: its candidates' propagated features in candidate order (what the all-gather
- * sends; nu_max >= the candidates of any rank).  d_plan (int32, 16 + world + 2 * world * nu_max words): [0..7] as d_result above for this rank, [4] the picks
+ * GCN_FPS_sampling for its own clouds.  d_comb_out [nu_max (+ nl_max), 32] float64: its candidates' propagated features in candidate order (what the all-gather
+ * sends; nu_max >= the candidates of any rank; nl_max = 0 for the FPS selector).  d_plan (int32, 16 + world + 2 * world * nu_max words): [0..7] as d_result above for this rank, [4] the picks
  * of all ranks, [8] the candidates of all ranks, [9] != 0: a rank offers more than nu_max; [16 .. 16 + world) candidates per rank; then the rows of the gathered
  * array in global candidate order; then the global candidate list (global region ids, rank by rank, cloud by cloud, descending uncertainty inside a cloud).
  * ssdr_fps_gathered_dev: d_gathered [world, nu_max, 32] -> the candidates' rows in order (d_glob [cap_rows, 32], cap_rows >= repeat x the candidates of all
@@ -314,10 +314,18 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
 int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
                                    const int32_t* d_sp_pts, const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t num_clouds,
                                    const int32_t* d_gorder, size_t Sg, const uint8_t* d_glabelled, const int32_t* d_gbase, int rank, int world, size_t Smax, size_t Bmax,
-                                   size_t batch_size, int gcn_number, int gcn_top, size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t nu_max,
+                                   size_t batch_size, int gcn_number, int gcn_top, size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t nu_max, size_t nl_max,
                                    double* d_comb_out, int32_t* d_plan, void* stream);
 int ssdr_fps_gathered_dev(const double* d_gathered, const int32_t* d_plan, int world, size_t nu_max, size_t cap_rows, int repeat, int start, size_t max_select, double* d_glob,
                           int32_t* d_out, void* stream);
+/* The k-center selector of the sharded run (BASELINE configuration 4: "a single all-gather of per-superpoint features before the global k-center step"; sampler2.py's
+ * "kcenter" branch, kcenterGreedy.py:84-128): ssdr_gcn_fps_sharded_local_dev with nl_max > 0 (>= the labelled regions of any rank) also writes this rank's labelled
+ * regions' propagated rows behind its candidates (d_comb_out [nu_max + nl_max, 32]); after the all-gather of those rows, ssdr_kcenter_gathered_dev builds
+ * [every rank's candidates | every rank's labelled regions] in d_glob [cap_rows, 32] (cap_rows > n_lab_total + the candidates of all ranks), marks the labelled rows as
+ * already selected (d_already [n_lab_total], scratch) and runs kCenterGreedy for max_select picks (indices into the global candidate list) — nothing is read back.
+ * d_nlab_off [world + 1]: prefix of the ranks' labelled counts (static). */
+int ssdr_kcenter_gathered_dev(const double* d_gathered, const int32_t* d_plan, int world, size_t nu_max, size_t nl_max, const int32_t* d_nlab_off, size_t n_lab_total,
+                              size_t cap_rows, size_t max_select, double* d_glob, int32_t* d_already, int32_t* d_out, void* stream);
 /* What the enqueue-only selection calls issued on `stream` found and could not return (bit 0: a cooperative multi-workgroup FPS / k-center
  * launch — ssdr_fps_dev / ssdr_kcenter_dev above 1536 / 4096 rows — was not co-resident: a workgroup waited for one that never arrived, the chain
  * stopped and its remaining picks read -1).  Waits for the stream; SSDR_ERR_INTERNAL when a bit is set; clears the word. */

@@ -1574,6 +1574,29 @@ __global__ __launch_bounds__(256) void copy_rows_dn(const double* __restrict__ s
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) dst[e] = src[e];
 }
 
+// rows [*off, *off + n) of src -> rows [0, n) of dst (the labelled regions' propagated rows sit behind the candidates, whose count is the device's)
+__global__ __launch_bounds__(256) void copy_rows_from(const double* __restrict__ src, double* __restrict__ dst, int row_len, int n, const int* __restrict__ off) {
+    const long total = (long)n * row_len, o = (long)*off * row_len;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) dst[e] = src[o + e];
+}
+// The global array of the sharded k-center: [every rank's candidates, in candidate order | every rank's labelled regions, rank by rank] out of the all-gather
+// of `per` = nu_max + nl_max rows per rank (candidates padded to nu_max, then the labelled ones); already[] = the labelled rows, *nrows = rows in all
+__global__ __launch_bounds__(256) void sel_gather_kc(const uint32_t* __restrict__ in, const int* __restrict__ plan, int W, int nu_max, int per, const int* __restrict__ nlab_off,
+                                                     int cap, int row_words, uint32_t* __restrict__ out, int* __restrict__ already, int* nrows) {
+    const int n_unl = plan[9] ? 0 : plan[8], n_lab = nlab_off[W], tot = min(cap, n_unl + n_lab);
+    const int* idx = plan + 16 + W;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nrows = tot;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_lab; j += gridDim.x * 256) already[j] = n_unl + j;
+    const long total = (long)tot * row_words;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int r = (int)(e / row_words), c = (int)(e % row_words);
+        int srow;
+        if (r < n_unl) { const int g = idx[r]; srow = (g / nu_max) * per + g % nu_max; }
+        else { const int j = r - n_unl; int q = 0; while (q + 1 < W && nlab_off[q + 1] <= j) ++q; srow = q * per + nu_max + (j - nlab_off[q]); }
+        out[e] = in[(size_t)srow * row_words + c];
+    }
+}
+
 struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f, status; bool status_init = false; };
 
 // scratch of the chamfer packer for nrows superpoints in nclouds clouds
@@ -2005,12 +2028,12 @@ int ssdr_select_status(void* stream, int32_t* out_status) {
 int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
                                    const int32_t* d_sp_pts, const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t num_clouds,
                                    const int32_t* d_gorder, size_t Sg, const uint8_t* d_glabelled, const int32_t* d_gbase, int rank, int world, size_t Smax, size_t Bmax,
-                                   size_t batch_size, int gcn_number, int gcn_top, size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t nu_max,
+                                   size_t batch_size, int gcn_number, int gcn_top, size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t nu_max, size_t nl_max,
                                    double* d_comb_out, int32_t* d_plan, void* stream) {
     if (!d_feat || !d_cls || !d_dom || !d_xyz || !d_sp_off || !d_sp_pts || !d_lab_off || !d_gorder || !d_glabelled || !d_gbase || !d_comb_out || !d_plan || feat_dim != 32 ||
         world < 1 || world > 64 || rank < 0 || rank >= world || num_clouds == 0 || num_clouds > Bmax || Bmax * (size_t)world > 65535 || Sg != Smax * (size_t)world || Sg > 0x7ffffff0 ||
-        cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || nu_max == 0 || gcn_number < 0 || (n_lab && !d_lab_sp)) {
-        set_error("gcn_fps_sharded_local: bad arguments (feat_dim == 32, world <= 64, Sg == world * Smax)"); return SSDR_ERR_INVALID;
+        cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || nu_max == 0 || gcn_number < 0 || (n_lab && !d_lab_sp) || (nl_max && n_lab > nl_max)) {
+        set_error("gcn_fps_sharded_local: bad arguments (feat_dim == 32, world <= 64, Sg == world * Smax, n_lab <= nl_max)"); return SSDR_ERR_INVALID;
     }
     SSDR_TRY(ensure_init());
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
@@ -2052,8 +2075,28 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     }
     // the candidates' rows (the first n_unl of comb) are what the exchange sends
     hipLaunchKernelGGL(copy_rows_dn, dim3(grid_for((long)nu_max * D)), dim3(256), 0, s, comb, d_comb_out, D, (int)nu_max, plan);
+    // ... and, for the global k-center (nl_max > 0), this rank's labelled regions' rows behind them
+    if (nl_max && n_lab) hipLaunchKernelGGL(copy_rows_from, dim3(grid_for((long)n_lab * D)), dim3(256), 0, s, comb, d_comb_out + nu_max * (size_t)D, D, (int)n_lab, plan);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
+}
+
+/* The replicated global k-center of the sharded run (BASELINE configuration 4; kcenterGreedy.py:84-128 over [candidates | labelled regions of ALL ranks], the labelled
+ * ones already selected): d_gathered = the all-gather of every rank's nu_max + nl_max rows (ssdr_gcn_fps_sharded_local_dev with nl_max > 0), d_nlab_off[world + 1] =
+ * prefix of the ranks' labelled counts (static: the host knows it), d_glob [cap_rows][32] and d_already [n_lab_total] scratch.  Nothing is read back. */
+int ssdr_kcenter_gathered_dev(const double* d_gathered, const int32_t* d_plan, int world, size_t nu_max, size_t nl_max, const int32_t* d_nlab_off, size_t n_lab_total,
+                              size_t cap_rows, size_t max_select, double* d_glob, int32_t* d_already, int32_t* d_out, void* stream) {
+    if (!d_gathered || !d_plan || !d_glob || !d_out || !d_already || !d_nlab_off || world < 1 || world > 64 || nu_max == 0 || nl_max == 0 || n_lab_total == 0 || cap_rows <= n_lab_total ||
+        n_lab_total > (size_t)world * nl_max) { set_error("kcenter_gathered: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    if (max_select == 0) return SSDR_OK;
+    hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    SSDR_TRY(Q.hist.reserve(64));
+    int* nrows = Q.hist.as<int>();
+    hipLaunchKernelGGL(sel_gather_kc, dim3(grid_for((long)cap_rows * 64)), dim3(256), 0, s, (const uint32_t*)d_gathered, d_plan, world, (int)nu_max, (int)(nu_max + nl_max), d_nlab_off,
+                       (int)cap_rows, 64, (uint32_t*)d_glob, d_already, nrows);
+    SSDR_HIP(hipGetLastError());
+    return fps_like(d_glob, cap_rows, 32, d_already, n_lab_total, 0, max_select, 1, d_out, s, nrows);
 }
 
 int ssdr_fps_gathered_dev(const double* d_gathered, const int32_t* d_plan, int world, size_t nu_max, size_t cap_rows, int repeat, int start, size_t max_select, double* d_glob,

@@ -214,13 +214,21 @@ class HotPath:
         nu_dev = max(int(np.minimum(2 * picks, nvalid_all).max()), 1)
         rep = max(int(os.environ.get("SSDR_EMULATE_WORLD", "1")), 1)       # development: the FPS load of `rep` x the ranks (tools/gpu_emulate_world.sh)
         cap_fps = max(rep * int(min(2 * picks, nvalid_all.sum())), 1)
+        nlab = comm.allgather_host(np.array([int(self.labeled_mask.sum())], np.int64)).reshape(-1)
+        # the k-center selector also sends every rank's labelled regions' rows (behind its candidates, padded to nl_max) and seeds the global chain with them
+        kc = self.selector == "kcenter"
+        nl_max = int(nlab.max()) if kc else 0
+        n_lab_all = int(nlab.sum()) if kc else 0
+        per = nu_dev + nl_max
         dev = dict(picks=picks, cap_rows=max(cap_unl + int(nlab_c.sum()), 1), cap_nmax=max(int((share + nlab_c).max()), 1), cap_sq=max(int(sq), 1), nu_max=nu_dev,
                    cap_fps=cap_fps, rep=rep, d_glab=DevArray.from_host((lab != 0).astype(np.uint8)), d_gbase=DevArray.from_host(gbase),
-                   d_send=DevArray((nu_dev, 32), np.float64), d_gath=DevArray((W, nu_dev, 32), np.float64), d_glob=DevArray((cap_fps, 32), np.float64),
+                   nl_max=nl_max, n_lab_all=n_lab_all, per=per,
+                   d_send=DevArray((per, 32), np.float64), d_gath=DevArray((W, per, 32), np.float64), d_glob=DevArray((cap_fps + n_lab_all + 1, 32), np.float64),
+                   d_nlab_off=DevArray.from_host(np.concatenate([[0], np.cumsum(nlab)]).astype(np.int32)), d_already=DevArray((max(n_lab_all, 1),), np.int32),
                    d_plan=DevArray((16 + W + 2 * W * nu_dev,), np.int32), d_out=DevArray((max(rep * picks, 1),), np.int32))
         self._dist = dict(dev=dev, comm=comm, Smax=Smax, Bmax=Bmax, valid=lab == 0, gcloud=gcloud, room=room, spin=spin, batch=batch,
                           S_total=int(S_all[:, 0].sum()), nu_max=int(min(2 * batch, Smax)),
-                          nlab=comm.allgather_host(np.array([int(self.labeled_mask.sum())], np.int64)).reshape(-1),
+                          nlab=nlab,
                           d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)),
                           d_masked=DevArray((Smax,), np.float64), d_all=DevArray((W * Smax,), np.float64), d_ord=DevArray((W * Smax,), np.int32))
         return self._dist
@@ -298,18 +306,23 @@ class HotPath:
             self._pending = ("device", None)
             self.rule_path = "device"
             return
-        if (self.global_order is not None and not kc and self.global_order["dev"]["picks"] > 0 and not os.environ.get("SSDR_SELECT_HOST_RULE")):
+        if (self.global_order is not None and self.global_order["dev"]["picks"] > 0 and (not kc or self.global_order["dev"]["n_lab_all"] > 0)
+                and not os.environ.get("SSDR_SELECT_HOST_RULE")):
             # the sharded run, still without a host decision: the rule over the global ranking + this rank's graph, the all-gather of the candidates'
             # propagated features (exchange 3), the replicated global FPS — three enqueues, nothing read back here
             D = self.global_order; V = D["dev"]
             _lib.check(L.ssdr_gcn_fps_sharded_local_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
                                                         T["d_lab_off"].ptr, T["d_lab_sp"].ptr, T["n_lab"], self.B, D["d_ord"].ptr, comm.world * D["Smax"],
                                                         V["d_glab"].ptr, V["d_gbase"].ptr, comm.rank, comm.world, D["Smax"], D["Bmax"], D["batch"],
-                                                        int(self.gcn_number), int(self.gcn_top), V["cap_rows"], V["cap_nmax"], V["cap_sq"], V["nu_max"],
+                                                        int(self.gcn_number), int(self.gcn_top), V["cap_rows"], V["cap_nmax"], V["cap_sq"], V["nu_max"], V["nl_max"],
                                                         V["d_send"].ptr, V["d_plan"].ptr, st))
             comm.allgather_(V["d_send"], V["d_gath"], st)
-            _lib.check(L.ssdr_fps_gathered_dev(V["d_gath"].ptr, V["d_plan"].ptr, comm.world, V["nu_max"], V["cap_fps"], V["rep"], 0, V["rep"] * V["picks"],
-                                               V["d_glob"].ptr, V["d_out"].ptr, st))
+            if kc:       # BASELINE configuration 4: [candidates | labelled regions] of all ranks, the labelled ones already selected
+                _lib.check(L.ssdr_kcenter_gathered_dev(V["d_gath"].ptr, V["d_plan"].ptr, comm.world, V["nu_max"], V["nl_max"], V["d_nlab_off"].ptr, V["n_lab_all"],
+                                                       V["cap_fps"] + V["n_lab_all"] + 1, V["picks"], V["d_glob"].ptr, V["d_already"].ptr, V["d_out"].ptr, st))
+            else:
+                _lib.check(L.ssdr_fps_gathered_dev(V["d_gath"].ptr, V["d_plan"].ptr, comm.world, V["nu_max"], V["cap_fps"], V["rep"], 0, V["rep"] * V["picks"],
+                                                   V["d_glob"].ptr, V["d_out"].ptr, st))
             self._pending = ("sharded", comm)
             self.rule_path = "sharded-device"
             return
@@ -437,7 +450,7 @@ class HotPath:
             loc = gcand[mine] - comm.rank * D["Smax"]
             unl = list(zip(self.sp_cloud_h[loc].tolist(), loc.tolist()))
             self.unl_cloud_ids, self.unl_sp = D["room"][gcand], D["spin"][gcand]
-            self._comb_dev, self._comb_n = V["d_glob"], n_g
+            self._comb_dev, self._comb_n = V["d_glob"], n_g + (V["n_lab_all"] if self.selector == "kcenter" else 0)
             if V["rep"] > 1:
                 self._emu_mod = n_g
         elif isinstance(d_out, str):                          # the device-side rule: counts, picks and the candidate list in one read-back

@@ -32,8 +32,13 @@ def main():
     sel1, _ = hp.step(comm)
     pipe = pipeline.Pipelined(mk, 4)
     sel2, _ = pipe.run(3, comm)
+    # the k-center selector (BASELINE configuration 4): labelled regions' rows in the all-gather, the global chain seeded with them, the rule on the device
+    mkk = lambda: pipeline.HotPath(W, Cfg, select_per_tile=9, labeled_per_tile=4, precision="bf16x3", selector="kcenter").load_rooms(rooms)
+    plain_k = mkk(); plain_k.step()
+    hk = mkk(); hk.step(comm)
     res = {"plain": [int(x) for x in sel0], "dist": [int(x) for x in sel1], "dist_pipelined": [int(x) for x in sel2],
-           "selected_plain": plain.selected, "selected_dist": hp.selected, "lib": _lib.lib_path()}
+           "selected_plain": plain.selected, "selected_dist": hp.selected, "lib": _lib.lib_path(),
+           "kcenter_plain": plain_k.selected, "kcenter_dist": hk.selected, "kcenter_rule_path": hk.rule_path, "rule_path": hp.rule_path}
     with open(os.environ["SSDR_TEST_OUT"], "w") as f:
         json.dump(res, f)
     dist.destroy_process_group()

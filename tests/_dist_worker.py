@@ -41,8 +41,12 @@ def main():
     # BASELINE configuration 4: all-gather of the candidates' AND the labelled regions' features, then the global k-center (replicated)
     hk = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2, selector="kcenter").load_rooms([all_rooms[i] for i in mine], mine)
     hk.step(comm)
-    kc_sharded = hk.selected
-    res = {"rule_path": [path, host_path], "host_rule_equal": bool(np.array_equal(hsel, sel) and host_selected == hp.selected), "kcenter": kc_sharded, "pipelined_equal": bool(np.array_equal(psel, sel)), "pipelined_selected": pipe.hp[1].selected,"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
+    kc_sharded, kc_path = hk.selected, hk.rule_path
+    os.environ["SSDR_SELECT_HOST_RULE"] = "1"      # ... and the k-center selector through the host-side rule: the same regions
+    hk.step(comm)
+    kc_host, kc_host_path = hk.selected, hk.rule_path
+    del os.environ["SSDR_SELECT_HOST_RULE"]
+    res = {"rule_path": [path, host_path], "kcenter_rule_path": [kc_path, kc_host_path], "kcenter_host_equal": kc_host == kc_sharded, "host_rule_equal": bool(np.array_equal(hsel, sel) and host_selected == hp.selected), "kcenter": kc_sharded, "pipelined_equal": bool(np.array_equal(psel, sel)), "pipelined_selected": pipe.hp[1].selected,"rank": rank, "sel": [int(x) for x in sel], "selected": hp.selected, "n_all": int(len(hp.comb_all)),
            "expect": [int(x) for x in S.farthest_features_sample(hp.comb_all, len(sel), 0)]}
     if rank == 0:      # the same job in ONE process over the union of the rooms
         one = pipeline.HotPath(W, Cfg, select_per_tile=5, labeled_per_tile=2).load_rooms(all_rooms, list(range(per * world)))

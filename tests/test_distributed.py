@@ -25,6 +25,8 @@ def test_two_rank_sharded_selection_equals_single_process(tmp_path, emu_lib):
     # the sharded FPS selection took the device-side rule (no ranking read-back, no NumPy between the exchanges), and the host rule agrees with it
     assert all(x["rule_path"] == ["sharded-device", "host"] and x["host_rule_equal"] for x in r)
     assert r[0]["kcenter"] == r[1]["kcenter"] == r[0]["single_kcenter"] and len(r[0]["kcenter"]) == 20      # global k-center (configuration 4)
+    # ... through the device-side rule as well (no read-back, no NumPy between the exchanges), and the host-side rule picks the same regions
+    assert all(x["kcenter_rule_path"] == ["sharded-device", "host"] and x["kcenter_host_equal"] for x in r)
     assert all(x["pipelined_equal"] and x["pipelined_selected"] == x["selected"] for x in r)    # batches in flight: same result
 
 
@@ -40,4 +42,6 @@ def test_rccl_exchange_path_on_one_gpu_equals_plain_path(tmp_path):
     r = json.load(open(out))
     assert len(r["plain"]) == 36 and r["plain"] == r["dist"] == r["dist_pipelined"]
     assert r["selected_plain"] == r["selected_dist"]
+    assert r["rule_path"] == "sharded-device" and r["kcenter_rule_path"] == "sharded-device"
+    assert len(r["kcenter_plain"]) == 36 and r["kcenter_plain"] == r["kcenter_dist"]      # the k-center selector through the exchange path
     assert r["lib"].endswith("libssdr_al.so")
