@@ -763,7 +763,8 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     // (round 4: TM x 128 tiles on the 32 x 32 x 16 instruction — half the LDS operand bytes per FLOP, half the activation re-reads — were built for the 19
     // launches with N a multiple of 128 and measured: 534 us against 461 for those launches.  64 x 128 tiles leave the small-M layers 160-320 workgroups whose
     // K loop waits a global-load latency per 32-k chunk with nothing else resident to cover it; 128 x 128 tiles at M = 41-164 k ran level with the kernel below,
-    // which is bound by what a CU fetches from L2 per clock, not by the matrix or LDS pipes)
+    // which is bound by what a CU fetches from L2 per clock, not by the matrix or LDS pipes.  Two more forms of THIS kernel for the small-M layers, same conclusion: 64-row
+    // tiles (waves 2 x 2, half the weight re-reads) for K x N >= 512 x 512: 37.1 -> 35.0 and 37.5 -> 36.6 us; two K chunks in flight in registers: 470 -> 486 us over the 25 launches)
     if (small) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
     return launch_dense_bf16_t<128, 32>(a, prec, vec, s);
 }
