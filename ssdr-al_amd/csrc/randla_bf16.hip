@@ -596,28 +596,39 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float
         const u32x2 a = *reinterpret_cast<const u32x2*>(p0), b = *reinterpret_cast<const u32x2*>(p1);
         return u32x4{a[0], a[1], b[0], b[1]};
     };
-    // weight fragments (both pieces), kept in registers for every tile of this wave
-    u32x4 W1[4][2], W2[2][2][2], W3[2], WD[PRE ? 2 : 1][2][2];
+    // weight fragments (both pieces) in the operand layout, ONE copy per workgroup in LDS (round 4: 104 registers per lane held them for every tile of the
+    // wave — two waves per SIMD; fetched per use from LDS the waves are three or four): slot = fragment * 2 + piece, 64 lanes x 16 bytes each
+    constexpr int F_WD = 0, F_W1 = 4, F_W2 = 8, F_W3 = 12, NFRAG = 13;
+    __shared__ u32x4 s_w[NFRAG * 2][64];
     float4 BD[2];
+    {
+        const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t < TERMS; ++t) {
-        const uint16_t* p1 = t ? w1l : w1h; const uint16_t* p2 = t ? w2l : w2h; const uint16_t* p3 = t ? w3l : w3h;
-        if (PRE) {
-            const uint16_t* pd = t ? pre.wl : pre.wh;
+        for (int t = 0; t < TERMS; ++t) {
+            const uint16_t* p1 = t ? w1l : w1h; const uint16_t* p2 = t ? w2l : w2h; const uint16_t* p3 = t ? w3l : w3h;
+            if (PRE && wv == 0) {
+                const uint16_t* pd = t ? pre.wl : pre.wh;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) WD[PRE ? kb : 0][ct][t] = ld128(pd + (size_t)(16 * ct + lc) * pre.kp + 32 * kb + 8 * lg);      // k block 0: skip channels, 1: gathered channels
+                    for (int ct = 0; ct < 2; ++ct) s_w[(F_WD + 2 * kb + ct) * 2 + t][lane] = ld128(pd + (size_t)(16 * ct + lc) * pre.kp + 32 * kb + 8 * lg);      // k block 0: skip channels, 1: gathered channels
+            }
+            if (wv == 1) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)      // fc1: k = input channel; natural order when the input comes from memory, the transposed numbering behind the decoder layer
+                    s_w[(F_W1 + ct) * 2 + t][lane] = PRE ? ld64x2(p1 + (size_t)(16 * ct + lc) * kp1 + 4 * lg, p1 + (size_t)(16 * ct + lc) * kp1 + 16 + 4 * lg) : ld128(p1 + (size_t)(16 * ct + lc) * kp1 + 8 * lg);
+            }
+            if (wv == 2) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) s_w[(F_W2 + 2 * kb + ct) * 2 + t][lane] = ld64x2(p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 4 * lg, p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 16 + 4 * lg);
+            }
+            if (wv == 3) s_w[F_W3 * 2 + t][lane] = lc < C ? ld64x2(p3 + (size_t)lc * kp3 + 4 * lg, p3 + (size_t)lc * kp3 + 16 + 4 * lg) : u32x4{0u, 0u, 0u, 0u};
         }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)      // fc1: k = input channel; natural order when the input comes from memory, the transposed numbering behind the decoder layer
-            W1[ct][t] = PRE ? ld64x2(p1 + (size_t)(16 * ct + lc) * kp1 + 4 * lg, p1 + (size_t)(16 * ct + lc) * kp1 + 16 + 4 * lg) : ld128(p1 + (size_t)(16 * ct + lc) * kp1 + 8 * lg);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) W2[kb][ct][t] = ld64x2(p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 4 * lg, p2 + (size_t)(16 * ct + lc) * kp2 + 32 * kb + 16 + 4 * lg);
-        W3[t] = lc < C ? ld64x2(p3 + (size_t)lc * kp3 + 4 * lg, p3 + (size_t)lc * kp3 + 16 + 4 * lg) : u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
     }
+    auto wfr = [&](int f, u32x4 (&w)[2]) { w[0] = s_w[f * 2][lane]; w[1] = s_w[f * 2 + (TERMS - 1)][lane]; };
     if (PRE) { BD[0] = *reinterpret_cast<const float4*>(pre.b + 4 * lg); BD[1] = *reinterpret_cast<const float4*>(pre.b + 16 + 4 * lg); }
     float4 B1[4], B2t[2], B3; float B2c[2];
 #pragma unroll
@@ -683,8 +694,8 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float
         if (PRE) {
             u32x4 sf[2], uf[2]; frag(c_sk, sf); frag(c_up, uf);
             f32x4 d0 = f32x4{BD[0].x, BD[0].y, BD[0].z, BD[0].w}, d1 = f32x4{BD[1].x, BD[1].y, BD[1].z, BD[1].w};
-            d0 = mma_split<TERMS>(WD[0][0], sf, d0); d0 = mma_split<TERMS>(WD[PRE ? 1 : 0][0], uf, d0);
-            d1 = mma_split<TERMS>(WD[0][1], sf, d1); d1 = mma_split<TERMS>(WD[PRE ? 1 : 0][1], uf, d1);
+            { u32x4 w[2]; wfr(F_WD + 0, w); d0 = mma_split<TERMS>(w, sf, d0); wfr(F_WD + 2, w); d0 = mma_split<TERMS>(w, uf, d0);
+              wfr(F_WD + 1, w); d1 = mma_split<TERMS>(w, sf, d1); wfr(F_WD + 3, w); d1 = mma_split<TERMS>(w, uf, d1); }
             const float v[8] = {lrelu(d0[0]), lrelu(d0[1]), lrelu(d0[2]), lrelu(d0[3]), lrelu(d1[0]), lrelu(d1[1]), lrelu(d1[2]), lrelu(d1[3])};
             frag(v, xf);
         } else frag(c_sk, xf);
@@ -693,7 +704,7 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             f32x4 acc = f32x4{B1[ct].x, B1[ct].y, B1[ct].z, B1[ct].w};
-            acc = mma_split<TERMS>(W1[ct], xf, acc);
+            { u32x4 w[2]; wfr(F_W1 + ct, w); acc = mma_split<TERMS>(w, xf, acc); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[ct][r] = lrelu(acc[r]);
         }
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float
             const float v[8] = {h1[2 * kb][0], h1[2 * kb][1], h1[2 * kb][2], h1[2 * kb][3], h1[2 * kb + 1][0], h1[2 * kb + 1][1], h1[2 * kb + 1][2], h1[2 * kb + 1][3]};
             u32x4 hf[2]; frag(v, hf);
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) { at[ct] = mma_split<TERMS>(W2[kb][ct], hf, at[ct]); ac[ct] = mma_split<TERMS>(hf, W2[kb][ct], ac[ct]); }
+            for (int ct = 0; ct < 2; ++ct) { u32x4 w[2]; wfr(F_W2 + 2 * kb + ct, w); at[ct] = mma_split<TERMS>(w, hf, at[ct]); ac[ct] = mma_split<TERMS>(hf, w, ac[ct]); }
         }
         // last_second_features: accumulator layout (point 4 lg + reg, channel 16 ct + lc): 64 contiguous bytes per 16 lanes
 #pragma unroll
@@ -716,7 +727,7 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(TailPre pre, const float
         const float v2[8] = {lrelu(at[0][0]), lrelu(at[0][1]), lrelu(at[0][2]), lrelu(at[0][3]), lrelu(at[1][0]), lrelu(at[1][1]), lrelu(at[1][2]), lrelu(at[1][3])};
         u32x4 ff[2]; frag(v2, ff);
         f32x4 lg3 = f32x4{B3.x, B3.y, B3.z, B3.w};
-        lg3 = mma_split<TERMS>(W3, ff, lg3);
+        { u32x4 w[2]; wfr(F_W3, w); lg3 = mma_split<TERMS>(w, ff, lg3); }
         float z[4], m = -3.402823466e+38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { z[r] = 4 * lg + r < C ? lg3[r] : -3.402823466e+38f; m = fmaxf(m, z[r]); }
@@ -797,9 +808,9 @@ int launch_tail_bf16(const TailArgs& t, int prec, hipStream_t s) {
     if ((t.C != 13 && t.C != 8) || (!t.skip && ((uintptr_t)t.x & 15)) || (t.skip && (((uintptr_t)t.skip | (uintptr_t)t.up) & 15)) || !t.w1h || !t.w2h || !t.w3h || (prec == PREC_BF16X3 && (!t.w1l || !t.w2l || !t.w3l))) return SSDR_ERR_UNSUPPORTED;
     const double m16 = std::ceil(t.M / 16.0) * 16.0;
     ProfScope prof("tail_kernel", s, (double)t.M * 4.0 * (32 + 32 + t.C), 2.0 * m16 * ((t.skip ? 64.0 * 32 : 0.0) + 32.0 * 64 + 2.0 * 64 * 32 + 32.0 * 16) * (prec == PREC_BF16X3 ? 3.0 : 1.0));
-    // two workgroups per CU = what its ~220 registers per lane keep resident: every wave then loads its 26 weight fragments once for ~20 tiles
-    // (eight per CU, waves of 5 tiles: 117 us; four: 99; two: 90)
-    const dim3 g((unsigned)std::max(1, std::min((t.M + 63) / 64, ctx().num_cu * 2)));
+    // four workgroups per CU = what its registers keep resident since the weight fragments moved to LDS (one copy per workgroup; eight per CU with the fragments in
+    // registers, waves of 5 tiles: 117 us; two: 90; fragments in LDS, 124 registers: two 85, three 80, four 77, six 78)
+    const dim3 g((unsigned)std::max(1, std::min((t.M + 63) / 64, ctx().num_cu * 4)));
     TailPre pre{t.skip, t.up, t.idx, t.m_per_batch, t.up_rows_per_batch, t.wdh, t.wdl, t.kpd, t.bd};
 #define SSDR_TAIL(TERMS_, C_) do { if (t.skip) hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_, true>), g, dim3(256), 0, s, pre, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs); \
                                else hipLaunchKernelGGL((tail_bf16_kernel<TERMS_, C_, false>), g, dim3(256), 0, s, pre, t.x, t.w1h, t.w1l, t.kp1, t.b1, t.w2h, t.w2l, t.kp2, t.b2, t.w3h, t.w3l, t.kp3, t.b3, t.M, t.feat32, t.probs); } while (0)
