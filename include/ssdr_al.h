@@ -163,10 +163,12 @@ int ssdr_tile_select_dev(const float* d_points, const float* d_colors, int color
                          float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream);
 
 /* Batch form: cloud r = rows [cloud_offsets[r], cloud_offsets[r+1]) with live count d_m[r]; centers host [num_clouds,3];
- * d_perm / d_dup_u [num_clouds, num_points]; outputs [num_clouds, num_points, ...]. */
+ * d_perm / d_dup_u [num_clouds, num_points]; outputs [num_clouds, num_points, ...].  d_out_idx = source row inside its cloud.
+ * d_labels (int32, one per row, may be NULL) -> d_out_labels [num_clouds, num_points] = queried_pc_label (s3dis_dataset.py:141). */
 int ssdr_tile_select_batch_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, const int64_t* cloud_offsets,
                                size_t num_clouds, const float* centers, size_t num_points, const int32_t* d_perm, const float* d_dup_u,
-                               float color_scale, float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream);
+                               float color_scale, float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, const int32_t* d_labels,
+                               int32_t* d_out_labels, void* stream);
 /* Test-time variant (S3/s3dis_dataset_test.py:105-143): the same tile, plus the possibility-map update
  * possibility[idx] += (1 - dists/max(dists))^2 over the tile's (un-padded) points (float64 map, float32 dists) and,
  * optionally, min / argmin of the updated map (the next pick: :106-108). */
@@ -235,12 +237,14 @@ int ssdr_region_stats_dev(const float* d_unc, const int32_t* d_cls, const int32_
 /* ssdr_max_dominant: per-superpoint dominant ground-truth label + purity (sampler2.py:102-106, :127-144) */
 int ssdr_dominant_label_dev(const int32_t* d_labels, const int32_t* d_sp_off, const int32_t* d_sp_pts, size_t S, int num_labels,
                             int32_t* d_label, double* d_purity, void* stream);
-/* add_clsbal (sampler2.py:262-266), in place on d_region_unc */
-int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected,
+/* add_clsbal (sampler2.py:262-266), in place on d_region_unc; n_selected == 0 is add_classbal (:256-260).  d_skip [S] (may be NULL) != 0: the
+ * region is not part of the population — prediction() collects region_class over the UNLABELLED regions of at least min_size points only
+ * (sampler2.py:612-627), so labelled / too small regions enter neither the histogram nor its length (their own values are scaled and never used) */
+int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const uint8_t* d_skip, const int32_t* d_selected_class_list, size_t n_selected,
                     double* d_region_unc, void* stream);
 /* the same in two steps for sharded runs: local class histogram (int32[64]), then — after the caller has summed the
  * histograms of all ranks — the scaling with the global histogram / global count */
-int ssdr_class_hist_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected,
+int ssdr_class_hist_dev(const int32_t* d_region_class, size_t S, const uint8_t* d_skip, const int32_t* d_selected_class_list, size_t n_selected,
                         int32_t* d_hist64, void* stream);
 int ssdr_clsbal_hist_dev(const int32_t* d_region_class, size_t S, const int32_t* d_hist64, size_t total, double* d_region_unc, void* stream);
 /* sorted_inds = argsort(-u) (sampler2.py:640); equal values keep ascending index */
@@ -295,9 +299,12 @@ int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_ce
  * cap_unl >= candidates (cap_rows <= 16384), max_select = min(batch_size, unlabelled regions) = the number of picks.
  * d_result (int32): [0..7] n_unl, n_lab, rows, largest block, picks, status (bit 0: rows > cap_rows, bit 1: blocks > cap_sq: nothing was selected),
  * block elements (int64 in two words); [8 .. 8+max_select) the picks (indices into the candidate list); then [cap_rows] the candidate list
- * (superpoint ids, cloud by cloud, descending uncertainty inside a cloud) followed by the labelled regions.  feat_dim = 32. */
-int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
-                              const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
+ * (superpoint ids, cloud by cloud, descending uncertainty inside a cloud) followed by the labelled regions.  feat_dim = 32.
+ * d_cls / d_dom: predicted class per point / dominant predicted class per region — the candidates' dominant_point_ids (sampler2.py:625-626);
+ * d_lab_cls / d_lab_dom (both or neither; NULL = the predicted pair): GROUND-TRUTH class per point / dominant ground-truth class per region
+ * (ssdr_dominant_label_dev) — the labelled regions' dominant_point_ids (get_labeled_selection_cloudname_spidx_pointidx, sampler2.py:288-291). */
+int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const int32_t* d_lab_cls, const int32_t* d_lab_dom,
+                              const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
                               const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t batch_size, int gcn_number, int gcn_top, int selector, int start,
                               size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream);
 /* The same for the SHARDED run (one process per GPU), again without a host decision: two enqueue-only calls around the all-gather of the
@@ -311,8 +318,8 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
  * ssdr_fps_gathered_dev: d_gathered [world, nu_max, 32] -> the candidates' rows in order (d_glob [cap_rows, 32], cap_rows >= repeat x the candidates of all
  * ranks, which never exceed 2 x the picks) -> farthest_features_sample from candidate `start` (the replicated global FPS, fps_gcn_cpu.py:169-170); max_select
  * picks (indices into the global candidate list).  repeat > 1 (measurement only): the rows are taken `repeat` times — the chain's load at `repeat` x the ranks. */
-int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
-                                   const int32_t* d_sp_pts, const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t num_clouds,
+int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const int32_t* d_lab_cls, const int32_t* d_lab_dom,
+                                   const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t num_clouds,
                                    const int32_t* d_gorder, size_t Sg, const uint8_t* d_glabelled, const int32_t* d_gbase, int rank, int world, size_t Smax, size_t Bmax,
                                    size_t batch_size, int gcn_number, int gcn_top, size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t nu_max, size_t nl_max,
                                    double* d_comb_out, int32_t* d_plan, void* stream);

@@ -332,6 +332,9 @@ int ssdr_randla_infer_dev(void* handle, size_t B, size_t n0, const float* d_feat
                 l32.fin = fin; l32.fc_hi = fc.Ph.as<uint16_t>(); l32.fc_lo = fc.Pl.as<uint16_t>();
                 const int rc = launch_lfa32(d, l32, second, Bi, m->prec, s);
                 if (rc != SSDR_ERR_UNSUPPORTED) return rc;
+                // the buffers above were laid out for the 32 x 32 kernels (level 0: the features live in tab0 only; d <= 64: no G table): the
+                // 16 x 16 kernels cannot run on them
+                if (tab0 || !gbuf) { set_error("randla: the 32 x 32-tile attention kernel refused d = %d and the level's buffers were laid out for it", d); return SSDR_ERR_INTERNAL; }
             }
             return lfa16 ? launch_lfa_bf16(d, la, second, Bi, m->prec, s) : launch_lfa(d, la, second, Bi, s);
         };

@@ -249,11 +249,14 @@ __global__ __launch_bounds__(256) void sel_dominant_label(const int* __restrict_
 }
 
 // ---- clsbal (sampler2.py:262-266): u *= exp(-freq(dominant class among candidates + already selected)) -------
-__global__ __launch_bounds__(256) void sel_class_hist(const int* __restrict__ region_class, int S, const int* __restrict__ extra, int n_extra, int* hist) {
+// `skip` != 0: the region is not in the population (labelled, or below min_size): prediction() appends only unlabelled regions to region_class
+// (sampler2.py:612-627), so only those enter list_class
+__global__ __launch_bounds__(256) void sel_class_hist(const int* __restrict__ region_class, int S, const unsigned char* __restrict__ skip, const int* __restrict__ extra, int n_extra, int* hist) {
     __shared__ int s_h[64];          // thousands of regions on a dozen classes: count in LDS, one global add per class and workgroup
     if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
     __syncthreads();
     for (int i = blockIdx.x * 256 + threadIdx.x; i < S + n_extra; i += gridDim.x * 256) {
+        if (i < S && skip && skip[i]) continue;
         const int c = i < S ? region_class[i] : extra[i - S];
         if (c >= 0 && c < 64) atomicAdd(&s_h[c], 1);
     }
@@ -261,6 +264,10 @@ __global__ __launch_bounds__(256) void sel_class_hist(const int* __restrict__ re
     if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void sel_clsbal(const int* __restrict__ region_class, int S, int total, const int* __restrict__ hist, double* region_unc) {
+    if (total < 0) {                 // len(list_class) = what the histogram counted (a population behind a mask: the count is the device's)
+        total = 0;
+        for (int c = 0; c < 64; ++c) total += hist[c];
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
         const double w = (double)hist[region_class[i]] / (double)total;
         region_unc[i] = region_unc[i] * exp(-w);
@@ -312,14 +319,19 @@ __global__ __launch_bounds__(256) void sel_rank_count(const double* __restrict__
 }
 
 // ---- U3: compute_features (sampler2.py:333,339): float32 row-sequential mean over the dominant-class members ----
-__global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict__ feat, int D, const int* __restrict__ cls, const int* __restrict__ dom,
+__global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict__ feat, int D, const int* __restrict__ cls_pred, const int* __restrict__ dom,
                                                         const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                         const int* __restrict__ sel, int nsel, float* out, const int* __restrict__ dn = nullptr,
-                                                        double* y0 = nullptr, double* y1 = nullptr) {
+                                                        double* y0 = nullptr, double* y1 = nullptr, const int* __restrict__ cls_lab = nullptr,
+                                                        const int* __restrict__ dom_lab = nullptr, const int* __restrict__ d_nfirst = nullptr) {
     if (dn) nsel = min(nsel, *dn);               // the row count is the device's (candidate rule on the device)
+    // rows >= *d_nfirst are the labelled regions: their dominant_point_ids come from the GROUND-TRUTH classes (sampler2.py:288-291), the candidates'
+    // from the predicted ones (:625-626)
+    const int nfirst = (cls_lab && d_nfirst) ? *d_nfirst : nsel;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < nsel * D; e += gridDim.x * 256) {
         const int q = e / D, c = e % D, s = sel ? sel[q] : q;
-        const int lo = sp_off[s], hi = sp_off[s + 1], d = dom[s];
+        const int* __restrict__ cls = q < nfirst ? cls_pred : cls_lab;
+        const int lo = sp_off[s], hi = sp_off[s + 1], d = (q < nfirst ? dom : dom_lab)[s];
         float sum = 0.f; int cnt = 0;
         // thirty-two members at a time: their three dependent loads (member, class, feature) are in flight together; the additions stay in
         // member order (sixteen: 40 us for the bench's 1184 regions of ~185 points — a chain of round trips, not bandwidth)
@@ -1193,8 +1205,9 @@ constexpr int FT_WORDS = 2 * FR_REC;         // 68 granules per record
 __global__ __launch_bounds__(FR_NT) void fps_coop_tag(FpsCoopArgs a) {
     if (a.dn) a.n = min(a.n, *a.dn);
     extern __shared__ unsigned s_rec[];                    // [2][G][FT_WORDS]: the records of a pick, as read (data words)
-    __shared__ double s_v[2][FR_NT / 64]; __shared__ int s_i[2][FR_NT / 64]; __shared__ unsigned s_pub[FT_WORDS]; __shared__ int s_abort; __shared__ double s_f0[32];
+    __shared__ double s_v[2][FR_NT / 64]; __shared__ int s_i[2][FR_NT / 64]; __shared__ unsigned s_pub[FT_WORDS]; __shared__ int s_abort, s_gave; __shared__ double s_f0[32];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G;
+    if (tid == 0) s_gave = 0;                              // (ordered before its first reader by the barrier behind s_f0 below)
     double reg[FR_RPT][32], rmin[FR_RPT];
 #pragma unroll
     for (int q = 0; q < FR_RPT; ++q) {
@@ -1263,10 +1276,12 @@ __global__ __launch_bounds__(FR_NT) void fps_coop_tag(FpsCoopArgs a) {
             while (((v = __hip_atomic_load(all + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) {
                 if (++spins > FPS_COOP_SPINS / 16 || (spins % 4096 == 0 && __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { gave_up = true; break; }
             }
+            if (gave_up) break;                            // (a stale granule is never stored, the remaining records are not waited for)
             mine[k] = (unsigned)v;
         }
-        if (gave_up) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); }
+        if (gave_up) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); s_gave = 1; }      // the others see sync[2] in their own polls / at their next pick
         __syncthreads();                                   // (3)
+        if (s_gave) { if (g == 0) for (int k = it + 1 + tid; k < a.count; k += FR_NT) a.out[k] = -1; return; }      // before the winner (an LDS pointer) is formed from garbage
         // the winner: every wave finds it for itself (G <= 128 records, two per lane)
         double v = -1.0; int i = 0x7fffffff;
         for (int k = lane; k < G; k += 64) {
@@ -1521,7 +1536,7 @@ __global__ __launch_bounds__(256) void cand_fill(const int* __restrict__ stage, 
 // 9 bit 0: a rank offers more than nu_max candidates; [16 .. 16 + W) candidates per rank; then [W * nu_max] the rows of the gathered array in
 // candidate order, then [W * nu_max] the global candidate list (global region ids).
 __global__ __launch_bounds__(256) void cand_global(const int* __restrict__ ncand, const int* __restrict__ ntop, int W, int Bmax, int nu_max, int* guoff, int* plan) {
-    __shared__ int s_cnt[64], s_off[65], s_top[256];
+    __shared__ int s_cnt[64], s_off[65], s_top[256], s_bad;
     const int tid = threadIdx.x, Bg = W * Bmax;
     int t = 0;
     for (int c = tid; c < Bg; c += 256) t += ntop[c];
@@ -1533,12 +1548,13 @@ __global__ __launch_bounds__(256) void cand_global(const int* __restrict__ ncand
         for (int r = 0; r < W; ++r) { s_off[r] = run; run += s_cnt[r]; bad |= s_cnt[r] > nu_max; plan[16 + r] = s_cnt[r]; }
         s_off[W] = run;
         for (int k = 0; k < 256; ++k) tot += s_top[k];
-        plan[4] = tot; plan[8] = bad ? 0 : run; plan[9] = bad;
+        plan[4] = tot; plan[8] = bad ? 0 : run; plan[9] = bad; s_bad = bad;
     }
     __syncthreads();
     // candidate offsets of the global clouds, rank-major (a rank's clouds are consecutive)
     if (tid < W) { int run = s_off[tid]; for (int b = 0; b < Bmax; ++b) { guoff[tid * Bmax + b] = run; run += ncand[tid * Bmax + b]; } }
     if (tid == 0) guoff[Bg] = s_off[W];
+    if (s_bad) return;          // a rank offers more than nu_max: the prefix sums run past the 2 * W * nu_max words behind the plan (plan[9] says so)
     int* src = plan + 16 + W;
     for (int r = 0; r < W; ++r) for (int p = tid; p < min(s_cnt[r], nu_max); p += 256) src[s_off[r] + p] = r * nu_max + p;
 }
@@ -1661,26 +1677,26 @@ int ssdr_dominant_label_dev(const int32_t* d_labels, const int32_t* d_sp_off, co
     return SSDR_OK;
 }
 
-int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected, double* d_region_unc, void* stream) {
+int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const uint8_t* d_skip, const int32_t* d_selected_class_list, size_t n_selected, double* d_region_unc, void* stream) {
     if (!d_region_class || !d_region_unc || (n_selected && !d_selected_class_list)) { set_error("clsbal: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (S == 0) return SSDR_OK;
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     SSDR_TRY(Q.hist.reserve(4 * 64)); SSDR_HIP(hipMemsetAsync(Q.hist.p, 0, 4 * 64, s));
-    hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_selected_class_list, (int)n_selected, Q.hist.as<int>());
-    hipLaunchKernelGGL(sel_clsbal, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_class, (int)S, (int)(S + n_selected), Q.hist.as<int>(), d_region_unc);
+    hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_skip, d_selected_class_list, (int)n_selected, Q.hist.as<int>());
+    hipLaunchKernelGGL(sel_clsbal, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_class, (int)S, d_skip ? -1 : (int)(S + n_selected), Q.hist.as<int>(), d_region_unc);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
 
 /* multi-GPU flavour of add_clsbal: the class histogram is supplied (all-reduced by the caller) */
-int ssdr_class_hist_dev(const int32_t* d_region_class, size_t S, const int32_t* d_selected_class_list, size_t n_selected, int32_t* d_hist64, void* stream) {
+int ssdr_class_hist_dev(const int32_t* d_region_class, size_t S, const uint8_t* d_skip, const int32_t* d_selected_class_list, size_t n_selected, int32_t* d_hist64, void* stream) {
     if (!d_region_class || !d_hist64 || (n_selected && !d_selected_class_list)) { set_error("class_hist: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     hipStream_t s = pick_stream(stream);
     SSDR_HIP(hipMemsetAsync(d_hist64, 0, 4 * 64, s));
     if (S + n_selected == 0) return SSDR_OK;
-    hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_selected_class_list, (int)n_selected, d_hist64);
+    hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_skip, d_selected_class_list, (int)n_selected, d_hist64);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
@@ -1951,11 +1967,11 @@ int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_ce
  * shape chosen by the caller's capacities.  d_result: [0..7] counts (n_unl, n_lab, ntot, nmax, sampling_batch, status, block elements as int64),
  * [8 .. 8+max_select) the selected candidates (indices into the candidate list), [8+max_select .. +cap_rows) the candidate list followed by the labelled
  * regions (superpoint ids; the first n_unl are the candidates, cloud by cloud, descending uncertainty inside a cloud). */
-int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
-                              const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
+int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const int32_t* d_lab_cls, const int32_t* d_lab_dom,
+                              const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
                               const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t batch_size, int gcn_number, int gcn_top, int selector, int start,
                               size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream) {
-    if (!d_feat || !d_cls || !d_dom || !d_xyz || !d_sp_off || !d_sp_pts || !d_order || !d_labelled || !d_sp_base || !d_lab_off || !d_result || feat_dim != 32 ||
+    if (!d_feat || !d_cls || !d_dom || (!d_lab_cls != !d_lab_dom) || !d_xyz || !d_sp_off || !d_sp_pts || !d_order || !d_labelled || !d_sp_base || !d_lab_off || !d_result || feat_dim != 32 ||
         num_clouds == 0 || num_clouds > 65535 || S == 0 || S > 0x7ffffff0 || cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || cap_unl == 0 || cap_rows > 16384 || gcn_number < 0 || start < 0 || selector < 0 || selector > 1 || (selector == 1 && n_lab == 0) || (n_lab && !d_lab_sp)) {
         set_error("gcn_fps_sampling: bad arguments (feat_dim == 32, at most 16384 candidate + labelled rows, at most 65535 clouds, k-center needs labelled regions)"); return SSDR_ERR_INVALID;
     }
@@ -1980,7 +1996,8 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     hipLaunchKernelGGL(cand_fill, dim3(B), dim3(256), 0, s, stage, d_sp_base, ncand, uoff, coff, d_lab_off, d_lab_sp, counts, sel, gsel, rows, already);
     const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
     // compute_features (sampler2.py:333,339) of the refs, widened; bbox centres of the grouped rows
-    hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, counts + 2, V, comb);
+    hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, counts + 2, V, comb,
+                       d_lab_cls, d_lab_dom, counts);
     SSDR_TRY(Q.rowsum.reserve(8 * cap_rows));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, counts + 2);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
@@ -2025,12 +2042,12 @@ int ssdr_select_status(void* stream, int32_t* out_status) {
  * chamfer graph, adjacency, propagation) for its own clouds.  d_comb_out [nu_max, 32]: its candidates' propagated features in candidate order (what the
  * all-gather sends); d_plan (int32, 16 + world + 2 * world * nu_max words): counts, candidates per rank, the rows of the gathered array in global candidate
  * order, the global candidate list.  ssdr_fps_gathered_dev: compacts the gathered array by the plan and runs the replicated global FPS from candidate `start`. */
-int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const float* d_xyz, const int32_t* d_sp_off,
-                                   const int32_t* d_sp_pts, const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t num_clouds,
+int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int32_t* d_cls, const int32_t* d_dom, const int32_t* d_lab_cls, const int32_t* d_lab_dom,
+                                   const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t num_clouds,
                                    const int32_t* d_gorder, size_t Sg, const uint8_t* d_glabelled, const int32_t* d_gbase, int rank, int world, size_t Smax, size_t Bmax,
                                    size_t batch_size, int gcn_number, int gcn_top, size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t nu_max, size_t nl_max,
                                    double* d_comb_out, int32_t* d_plan, void* stream) {
-    if (!d_feat || !d_cls || !d_dom || !d_xyz || !d_sp_off || !d_sp_pts || !d_lab_off || !d_gorder || !d_glabelled || !d_gbase || !d_comb_out || !d_plan || feat_dim != 32 ||
+    if (!d_feat || !d_cls || !d_dom || (!d_lab_cls != !d_lab_dom) || !d_xyz || !d_sp_off || !d_sp_pts || !d_lab_off || !d_gorder || !d_glabelled || !d_gbase || !d_comb_out || !d_plan || feat_dim != 32 ||
         world < 1 || world > 64 || rank < 0 || rank >= world || num_clouds == 0 || num_clouds > Bmax || Bmax * (size_t)world > 65535 || Sg != Smax * (size_t)world || Sg > 0x7ffffff0 ||
         cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || nu_max == 0 || gcn_number < 0 || (n_lab && !d_lab_sp) || (nl_max && n_lab > nl_max)) {
         set_error("gcn_fps_sharded_local: bad arguments (feat_dim == 32, world <= 64, Sg == world * Smax, n_lab <= nl_max)"); return SSDR_ERR_INVALID;
@@ -2057,7 +2074,8 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     hipLaunchKernelGGL(cand_fill_local, dim3(B), dim3(256), 0, s, stage, d_gbase + (size_t)rank * Bmax, ncand + (size_t)rank * Bmax, uoff, coff, d_lab_off, d_lab_sp, plan,
                        (int)((size_t)rank * Smax), sel, gsel, rows);
     const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
-    hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, plan + 2, V, comb);
+    hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, plan + 2, V, comb,
+                       d_lab_cls, d_lab_dom, plan);
     SSDR_TRY(Q.rowsum.reserve(8 * cap_rows));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, plan + 2);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));

@@ -34,7 +34,8 @@ __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, 
                                                    const uint32_t* __restrict__ sorted, const int* __restrict__ d_count,
                                                    const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
                                                    float cx, float cy, float cz, float color_scale,
-                                                   float* out_xyz, float* out_feat, int* out_idx, int stride = 1, int bx = -1) {
+                                                   float* out_xyz, float* out_feat, int* out_idx, int stride = 1, int bx = -1,
+                                                   const int* __restrict__ labels = nullptr, int* out_lab = nullptr) {
     const int m = *d_count;
     const int avail = min(m, num_points);
     for (int r = (bx < 0 ? (int)blockIdx.x : bx) * 256 + threadIdx.x; r < num_points; r += gridDim.x * 256) {
@@ -61,6 +62,7 @@ __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, 
             for (int c = 0; c < cdim; ++c) f[3 + c] = colors[(size_t)id * cdim + c] * color_scale;
         }
         if (out_idx) out_idx[r] = (int)id;
+        if (out_lab) out_lab[r] = labels[id];              // queried_pc_label = input_label[queried_idx] (s3dis_dataset.py:141)
     }
 }
 
@@ -77,11 +79,13 @@ __global__ __launch_bounds__(256) void tile_keys_b(TileTab t, const float* __res
 }
 __global__ __launch_bounds__(256) void tile_gather_b(TileTab t, const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted,
                                                      const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
-                                                     float color_scale, float* out_xyz, float* out_feat, int* out_idx, int stride) {
+                                                     float color_scale, float* out_xyz, float* out_feat, int* out_idx, int stride,
+                                                     const int* __restrict__ labels, int* out_lab) {
     int bx, r; xcd_tile_map(bx, r);            // the rows of a room are gathered at random: one room per XCD's L2
     const size_t o = (size_t)t.off[r], q = (size_t)r * num_points;
     tile_gather_body(pts + 3 * o, colors ? colors + o * cdim : nullptr, cdim, sorted + (size_t)t.toff[r] * stride, d_count + r, perm + q, dup_u + q, num_points, t.cx[r], t.cy[r], t.cz[r],
-                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, stride, bx);
+                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, stride, bx,
+                     labels ? labels + o : nullptr, out_lab ? out_lab + q : nullptr);
 }
 
 // ---- batch flavour: only the rows that can be among the num_points nearest are sorted ------------------------------------------
@@ -383,7 +387,8 @@ extern "C" int ssdr_tile_select_possibility_dev(const float* d_points, const flo
 
 extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_colors, int color_dim, const int64_t* d_m, const int64_t* cloud_offsets, size_t num_clouds,
                                           const float* centers, size_t num_points, const int32_t* d_perm, const float* d_dup_u, float color_scale,
-                                          float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, void* stream) {
+                                          float* d_out_xyz, float* d_out_feat, int32_t* d_out_idx, const int32_t* d_labels, int32_t* d_out_labels, void* stream) {
+    if (d_out_labels && !d_labels) { set_error("tile_select_batch: labels missing"); return SSDR_ERR_INVALID; }
     if (!d_points || !d_m || !cloud_offsets || !centers || !d_perm || !d_dup_u || !d_out_xyz || num_clouds == 0 || num_clouds > RADIX_MAX_SEG || num_points == 0) { set_error("tile_select_batch: bad arguments (1..%d clouds)", RADIX_MAX_SEG); return SSDR_ERR_INVALID; }
     if (d_out_feat && color_dim > 0 && !d_colors) { set_error("tile_select_batch: colors missing"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
@@ -415,7 +420,7 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
     hipLaunchKernelGGL(tile_binsort_b, dim3(std::min(rstride, 64), R), dim3(256), 0, s, t, T.rstart.as<unsigned>(), rstride, T.cand.as<int>(), T.keys.as<uint64_t>());
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
     hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, reinterpret_cast<const uint32_t*>(T.keys.as<uint64_t>()), T.count.as<int>(),
-                       d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2);
+                       d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2, d_labels, d_out_labels);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

@@ -80,8 +80,8 @@ def lib():
         L.ssdr_point_uncertainty_dev.argtypes = [vp, sz, i32, i32, vp, vp, vp]
         L.ssdr_region_stats_dev.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp, vp, vp]
         L.ssdr_dominant_label_dev.argtypes = [vp, vp, vp, sz, i32, vp, vp, vp]
-        L.ssdr_clsbal_dev.argtypes = [vp, sz, vp, sz, vp, vp]
-        L.ssdr_class_hist_dev.argtypes = [vp, sz, vp, sz, vp, vp]
+        L.ssdr_clsbal_dev.argtypes = [vp, sz, vp, vp, sz, vp, vp]
+        L.ssdr_class_hist_dev.argtypes = [vp, sz, vp, vp, sz, vp, vp]
         L.ssdr_clsbal_hist_dev.argtypes = [vp, sz, vp, sz, vp, vp]
         L.ssdr_rank_regions_dev.argtypes = [vp, sz, vp, vp]
         L.ssdr_segment_mean_features_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, sz, vp, vp]
@@ -95,15 +95,15 @@ def lib():
         L.ssdr_propagate_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp, i32, vp, vp, vp]
         L.ssdr_fps_dev.argtypes = [vp, sz, i32, i32, sz, vp, vp]
         L.ssdr_create_adj_dev.argtypes = [vp, sz, i32, vp, vp, vp, vp, sz, sz, vp, vp, vp, vp]
-        L.ssdr_gcn_fps_sampling_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, sz, vp, vp, sz, vp, vp, sz, sz, i32, i32, i32, i32, sz, sz, sz, sz, sz, vp, vp]
+        L.ssdr_gcn_fps_sampling_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, sz, vp, vp, sz, sz, i32, i32, i32, i32, sz, sz, sz, sz, sz, vp, vp]
         L.ssdr_fps_superpoint_dev.argtypes = [vp, vp, sz, i32, sz, vp, vp]
-        L.ssdr_gcn_fps_sharded_local_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp, sz, vp, vp, i32, i32, sz, sz, sz, i32, i32, sz, sz, sz, sz, sz, vp, vp, vp]
+        L.ssdr_gcn_fps_sharded_local_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp, sz, vp, vp, i32, i32, sz, sz, sz, i32, i32, sz, sz, sz, sz, sz, vp, vp, vp]
         L.ssdr_kcenter_gathered_dev.argtypes = [vp, vp, i32, sz, sz, vp, sz, sz, sz, vp, vp, vp, vp]
         L.ssdr_fps_gathered_dev.argtypes = [vp, vp, i32, sz, sz, i32, i32, sz, vp, vp, vp]
         L.ssdr_kcenter_dev.argtypes = [vp, sz, i32, vp, sz, sz, vp, vp]
         L.ssdr_tile_select_dev.argtypes = [vp, vp, i32, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp]
         L.ssdr_grid_subsample_batch_dev.argtypes = [vp, vp, sz, vp, sz, vp, sz, f32, vp, vp, vp, vp, vp]
-        L.ssdr_tile_select_batch_dev.argtypes = [vp, vp, i32, vp, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp]
+        L.ssdr_tile_select_batch_dev.argtypes = [vp, vp, i32, vp, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp, vp, vp]
         L.ssdr_tile_select_possibility_dev.argtypes = [vp, vp, i32, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
         L.ssdr_chamfer3d_forward_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
         L.ssdr_vote_smooth_dev.argtypes = [vp, vp, vp, sz, i32, f64, vp, vp]

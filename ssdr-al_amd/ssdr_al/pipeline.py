@@ -17,18 +17,26 @@ from .helper_tool import ConfigS3DIS
 
 class HotPath:
     def __init__(self, weights, config=ConfigS3DIS, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=1, gcn_top=0,
-                 select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32", selector="fps", tiles32=True):
+                 select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32", selector="fps", tiles32=True, min_size=1, round_num=5,
+                 label_seed=None, batch_size=None):
         self.cfg = config
-        self.net = randlanet.Network(config).load(weights).set_precision(precision).set_formulation(tiles32)
+        self.net = None if weights is None else randlanet.Network(config).load(weights).set_precision(precision).set_formulation(tiles32)
         self.sampler_args = list(sampler_args)
         self.gcn_number, self.gcn_top = gcn_number, gcn_top
         self.select_per_tile, self.labeled_per_tile = select_per_tile, labeled_per_tile
+        self.batch_size = None if batch_size is None else int(batch_size)      # sampling()'s batch_size outright (default: select_per_tile x clouds)
         self.seed = seed
+        # min_size: regions of fewer points are neither ranked nor used as labelled rows (sampler2.py:616, :628; the reference's default is 1);
+        # round_num: the class-balanced draw of the labelled rows takes (round_num - 1) * 1000 of the labelled regions (sampler2.py:297-302; SURVEY
+        # section 8d quotes the workload at round 5); label_seed seeds NumPy's legacy generator for that draw (the reference draws from np.random)
+        self.min_size, self.round_num = int(min_size), int(round_num)
+        self.label_seed = int(seed if label_seed is None else label_seed)
         # "fps": farthest_features_sample over the candidates' propagated features (the gcn_fps branch, sampler2.py:736-781);
         # "kcenter": kCenterGreedy.select_batch_ over candidates + labelled regions with the labelled ones as already selected
         # (the step the reference's gcn branch ends with, gcn.py:247, kcenterGreedy.py:60-128; BASELINE configuration 4's global k-center)
         assert selector in ("fps", "kcenter")
         self.selector = selector
+        self.fps_start = 0          # np.random.randint(0, n) in the reference (fps_gcn_cpu.py:133); fixed here
         self.stream = None          # stream of the pyramid .. scoring stages (None = the library's main stream)
         self.front_stream = None    # stream of the front end (grid-subsample + tiles)
         self.knn_stream = None      # stream of the KNN pyramid (None = self.stream)
@@ -71,6 +79,7 @@ class HotPath:
         self.perm = DevArray.from_host(np.stack(perms)); self.dup = DevArray.from_host(np.stack(dups))
         B = self.B
         self.xyz = DevArray((B, N, 3), np.float32); self.feat = DevArray((B, N, 6), np.float32)
+        self.tile_l = DevArray((B * N,), np.int32)        # queried_pc_label (s3dis_dataset.py:141): the labelled regions' ground truth
         L, K = cfg.num_layers, cfg.k_n
         self.sizes = [N]
         for ratio in cfg.sub_sampling_ratio:
@@ -100,27 +109,91 @@ class HotPath:
         for b in range(B):
             o, p = superpoints_from_tile(tiles[b])
             pts.append(p + b * N); offs.append(o[1:] + offs[-1][-1]); cloud.append(np.full(len(o) - 1, b, np.int32))
-        self.sp_off_h = np.concatenate(offs).astype(np.int32); self.sp_pts_h = np.concatenate(pts).astype(np.int32)
-        self.sp_cloud_h = np.concatenate(cloud)
+        labeled = {}
+        sp_cloud = np.concatenate(cloud)
+        for b in range(B):           # "already labelled" superpoints (stand-in for the regions total_obj["unlabeled"] no longer lists)
+            ids = np.flatnonzero(sp_cloud == b)
+            rng = np.random.default_rng([self.seed, self.room_ids[b], 1])
+            labeled[b] = set(rng.choice(ids, min(self.labeled_per_tile, len(ids)), replace=False).tolist())
+        self.n_pts = B * N
+        self._set_regions(np.concatenate(offs), np.concatenate(pts), sp_cloud, labeled,
+                          np.random.default_rng([self.seed, 999983]).integers(0, cfg.num_classes, 4000))
+        return self
+
+    @classmethod
+    def from_clouds(cls, clouds, labeled, selected_class_list, config=ConfigS3DIS, **kw):
+        """The scoring + selection half alone, over clouds given with their network outputs (no front end, no network): clouds[b] = dict(xyz [n,3],
+        gt [n], probs [n,C], feat [n,32], offsets [S_b+1], points) — what prediction() / compute_features see per cloud (sampler2.py:580-642,
+        :313-342); labeled[b] = the regions of cloud b (ids inside the cloud) that total_obj["unlabeled"] no longer lists.  Clouds may differ in
+        size: every array is the concatenation, superpoints are one CSR over it.  step_selection() runs the round."""
+        hp = cls(None, config, **kw)
+        hp.B = len(clouds); hp._dist = None; hp.room_ids = list(range(hp.B)); hp.rooms = []
+        n_of = [len(c["xyz"]) for c in clouds]
+        p0 = np.concatenate([[0], np.cumsum(n_of)]).astype(np.int64)
+        hp.n_pts = int(p0[-1])
+        hp.xyz = DevArray.from_host(np.concatenate([np.asarray(c["xyz"], np.float32) for c in clouds]))
+        hp.probs = DevArray.from_host(np.concatenate([np.asarray(c["probs"], np.float32) for c in clouds]))
+        hp.f32 = DevArray.from_host(np.concatenate([np.asarray(c["feat"], np.float32) for c in clouds]))
+        hp.tile_l = DevArray.from_host(np.concatenate([np.asarray(c["gt"]).astype(np.int32) for c in clouds]))
+        hp.unc = DevArray((hp.n_pts,), np.float32); hp.cls = DevArray((hp.n_pts,), np.int32)
+        offs, pts, cloud, lab, s0 = [np.zeros(1, np.int64)], [], [], {}, 0
+        for b, c in enumerate(clouds):
+            o = np.asarray(c["offsets"], np.int64)
+            offs.append(o[1:] + offs[-1][-1]); pts.append(np.asarray(c["points"], np.int64) + p0[b]); cloud.append(np.full(len(o) - 1, b, np.int32))
+            lab[b] = set(int(s) + s0 for s in labeled[b]); s0 += len(o) - 1
+        hp._set_regions(np.concatenate(offs), np.concatenate(pts), np.concatenate(cloud), lab, selected_class_list)
+        return hp
+
+    def step_selection(self):
+        """scoring + selection over the resident network outputs (from_clouds)"""
+        self._score_async(None)
+        return self._select(None)
+
+    def _set_regions(self, sp_off, sp_pts, sp_cloud, labeled, selected_class_list):
+        """superpoints (one CSR over the batch's points), which of them are already labelled, the already-selected class list; then everything
+        the selection derives from them once: the ranked population, the labelled rows' draw, the device rule's static tables"""
+        cfg, B = self.cfg, self.B
+        self.sp_off_h = np.asarray(sp_off).astype(np.int32); self.sp_pts_h = np.asarray(sp_pts).astype(np.int32)
+        self.sp_cloud_h = np.asarray(sp_cloud).astype(np.int32)
         self.S = len(self.sp_off_h) - 1
         self.sp_base = [int(np.flatnonzero(self.sp_cloud_h == b)[0]) for b in range(B)]
         self.sp_off = DevArray.from_host(self.sp_off_h); self.sp_pts = DevArray.from_host(self.sp_pts_h)
         self.region_unc = DevArray((self.S,), np.float64); self.dom = DevArray((self.S,), np.int32); self.dom_cnt = DevArray((self.S,), np.int32)
+        self.gt_dom = DevArray((self.S,), np.int32); self.gt_purity = DevArray((self.S,), np.float64)
         self.sorted_inds = DevArray((self.S,), np.int32)
-        # "already labelled" superpoints (stand-in for total_obj / labeled_region_reference_dict) and class list
-        self.labeled = {}
-        for b in range(B):
-            ids = np.flatnonzero(self.sp_cloud_h == b)
-            rng = np.random.default_rng([self.seed, self.room_ids[b], 1])
-            self.labeled[b] = set(rng.choice(ids, min(self.labeled_per_tile, len(ids)), replace=False).tolist())
-        self.selected_class_list = DevArray.from_host(np.random.default_rng([self.seed, 999983]).integers(0, cfg.num_classes, 4000).astype(np.int32))
+        self.selected_class_list = DevArray.from_host(np.asarray(selected_class_list).astype(np.int32).reshape(-1))
         self.hist = DevArray((64,), np.int32)
+        self.sp_size_h = np.diff(self.sp_off_h)
+        self.set_labeled(labeled)
+
+    def set_labeled(self, labeled):
+        """labeled[b] = the (global) ids of cloud b's regions that are already labelled (what total_obj["unlabeled"] no longer lists)"""
+        cfg = self.cfg
+        self.labeled = labeled
         self.labeled_mask = np.zeros(self.S, bool)
         for b in self.labeled:
             self.labeled_mask[list(self.labeled[b])] = True
-        self.sp_size_h = np.diff(self.sp_off_h)
+        # prediction()'s population (sampler2.py:612-631): unlabelled regions of at least min_size points are ranked; labelled ones of at least
+        # min_size points are the pool the labelled rows are drawn from; the rest takes no part.  skip_mask = not in the ranked population
+        big = self.sp_size_h >= self.min_size
+        self.skip_mask = self.labeled_mask | ~big
+        self.lab_pool = np.flatnonzero(self.labeled_mask & big)                 # cloud by cloud, ascending superpoint id
+        # the pool's ground-truth dominant labels from the resident labels (the reference reads them from the cloud's PLY, :283-289)
+        _lib.check(_lib.lib().ssdr_dominant_label_dev(self.tile_l.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, max(cfg.num_classes, 1), self.gt_dom.ptr,
+                                                      self.gt_purity.ptr, self.front_stream))
+        _lib.sync(self.front_stream)
+        self.lab_pool_dom = self.gt_dom.to_host()[self.lab_pool]
+        self._draw_labelled(self.lab_pool, self.lab_pool_dom, np.arange(len(self.lab_pool)))
+
+    def _draw_labelled(self, pool_sp, pool_dom_all, mine):
+        """get_labeled_selection_cloudname_spidx_pointidx's draw (sampler2.py:294-302) over the pool given by its dominant labels `pool_dom_all` (all
+        ranks' pools in cloud order for a sharded run; `mine` = this process's positions in it, pool_sp = their local superpoint ids)."""
+        from . import sampler
+        drawn = sampler.get_labeled_selection(pool_dom_all, self.cfg.num_classes, self.round_num, np.random.RandomState(self.label_seed))
+        keep = np.zeros(len(pool_dom_all), bool); keep[drawn] = True
+        rows = np.asarray(pool_sp, np.int64)[keep[np.asarray(mine, np.int64)]]
+        self.lab_rows = {b: sorted(int(x) for x in rows[self.sp_cloud_h[rows] == b]) for b in range(self.B)}      # cloud ascending, superpoint ascending
         self._select_static()
-        return self
 
     def _select_static(self):
         """Static tables and capacities of the device-side candidate rule (ssdr_gcn_fps_sampling_dev): which regions are labelled, where a
@@ -128,12 +201,12 @@ class HotPath:
         ranking's and stay on the device)."""
         B, S = self.B, self.S
         base = np.concatenate([np.asarray(self.sp_base, np.int64), [S]])
-        lab = [sorted(self.labeled.get(b, ())) for b in range(B)]
+        lab = [self.lab_rows.get(b, []) for b in range(B)]
         lab_off = np.concatenate([[0], np.cumsum([len(l) for l in lab])]).astype(np.int32)
         lab_sp = np.array([s for l in lab for s in l] + [0], np.int32)
-        nvalid = np.array([int((~self.labeled_mask[base[b]:base[b + 1]]).sum()) for b in range(B)], np.int64)
+        nvalid = np.array([int((~self.skip_mask[base[b]:base[b + 1]]).sum()) for b in range(B)], np.int64)
         nlab = np.diff(lab_off).astype(np.int64)
-        batch = self.select_per_tile * B
+        batch = self.batch_size if self.batch_size is not None else self.select_per_tile * B      # sampling()'s batch_size
         picks = int(min(batch, nvalid.sum()))
         cap_unl = int(min(2 * picks, nvalid.sum()))
         share = np.minimum(2 * picks, nvalid)                    # a cloud offers at most 2 x (its top regions) <= 2 x picks, and what it has
@@ -145,7 +218,7 @@ class HotPath:
             sq += (a + int(nlab[i])) ** 2
         self._sel_static = dict(
             lab_cloud=np.repeat(np.arange(B, dtype=np.int64), nlab), lab_sp_h=lab_sp[:-1].astype(np.int64),
-            d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)), d_base=DevArray.from_host(base.astype(np.int32)),
+            d_lab=DevArray.from_host(self.skip_mask.astype(np.uint8)), d_base=DevArray.from_host(base.astype(np.int32)),
             d_lab_off=DevArray.from_host(lab_off), d_lab_sp=DevArray.from_host(lab_sp), n_lab=int(nlab.sum()), batch=batch, picks=picks, cap_unl=max(cap_unl, 1),
             cap_rows=max(cap_rows, 1), cap_nmax=max(int((share + nlab).max()) if B else 1, 1), cap_sq=max(int(sq), 1),
             d_result=DevArray((8 + picks + max(cap_rows, 1),), np.int32))
@@ -159,7 +232,7 @@ class HotPath:
         _lib.check(L.ssdr_grid_subsample_batch_dev(self.raw_p.ptr, self.raw_c.ptr, 3, self.raw_l.ptr, 1, _lib.ptr(self.room_off), self.B, cfg.sub_grid_size,
                                                    self.sub_p.ptr, self.sub_c.ptr, self.sub_l.ptr, self.sub_m.ptr, st))
         _lib.check(L.ssdr_tile_select_batch_dev(self.sub_p.ptr, self.sub_c.ptr, 3, self.sub_m.ptr, _lib.ptr(self.room_off), self.B, _lib.ptr(self.centers),
-                                                cfg.num_points, self.perm.ptr, self.dup.ptr, 1.0 / 255.0, self.xyz.ptr, self.feat.ptr, None, st))
+                                                cfg.num_points, self.perm.ptr, self.dup.ptr, 1.0 / 255.0, self.xyz.ptr, self.feat.ptr, None, self.sub_l.ptr, self.tile_l.ptr, st))
 
     def _pyramid(self):
         cfg = self.cfg
@@ -183,11 +256,28 @@ class HotPath:
         if getattr(self, "_dist", None) is not None and self._dist["comm"] is comm:
             return self._dist
         W = comm.world
+        # the labelled rows are drawn from the pool of ALL ranks at once (sampler2.py:294-302 draws over every cloud's labelled regions): exchange the
+        # pools' ground-truth dominant labels, order them as one process over the union would meet them (room id, superpoint), draw, keep one's own
+        npool = comm.allgather_host(np.array([len(self.lab_pool)], np.int64)).reshape(-1)
+        Pmax = max(int(npool.max()), 1)
+        def padp(a):
+            out = np.full(Pmax, -1, np.int64); out[: len(a)] = a; return out
+        pc = self.sp_cloud_h[self.lab_pool]
+        g_room = comm.allgather_host(padp(np.asarray(self.room_ids, np.int64)[pc])).reshape(-1)
+        g_sp = comm.allgather_host(padp(self.lab_pool - np.asarray(self.sp_base, np.int64)[pc])).reshape(-1)
+        g_dom = comm.allgather_host(padp(self.lab_pool_dom)).reshape(-1)
+        g_rank = np.repeat(np.arange(W), Pmax); g_loc = np.tile(np.arange(Pmax), W)
+        live = np.flatnonzero(g_room >= 0)
+        live = live[np.lexsort((g_sp[live], g_room[live]))]
+        pos_of = np.full(Pmax, -1, np.int64)
+        me = g_rank[live] == comm.rank
+        pos_of[g_loc[live][me]] = np.flatnonzero(me)
+        self._draw_labelled(self.lab_pool, g_dom[live], pos_of[: len(self.lab_pool)])
         S_all = comm.allgather_host(np.array([self.S, self.B], np.int64))
         Smax = int(S_all[:, 0].max())
         def padded(a, fill):
             out = np.full(Smax, fill, np.int64); out[: self.S] = a; return out
-        lab = comm.allgather_host(padded(self.labeled_mask.astype(np.int64), 1)).reshape(-1)          # padding counts as labelled: never a candidate
+        lab = comm.allgather_host(padded(self.skip_mask.astype(np.int64), 1)).reshape(-1)          # not in the ranked population (labelled / below min_size); padding counts as such
         cloud = comm.allgather_host(padded(self.sp_cloud_h, -1))                                      # local cloud index
         room = comm.allgather_host(padded(np.asarray(self.room_ids, np.int64)[self.sp_cloud_h], -1)).reshape(-1)
         spin = comm.allgather_host(padded(np.arange(self.S) - np.asarray(self.sp_base, np.int64)[self.sp_cloud_h], -1)).reshape(-1)
@@ -200,7 +290,7 @@ class HotPath:
         base_l = np.concatenate([np.asarray(self.sp_base, np.int64), np.full(Bmax + 1 - self.B, self.S, np.int64)])      # local, padded to Bmax + 1 entries
         gbase = (comm.allgather_host(base_l[:Bmax]) + np.arange(W)[:, None] * Smax).reshape(-1)
         gbase = np.concatenate([gbase, [W * Smax]]).astype(np.int32)
-        nvalid_c = np.array([int((~self.labeled_mask[base_l[b]:base_l[b + 1]]).sum()) for b in range(self.B)], np.int64)
+        nvalid_c = np.array([int((~self.skip_mask[base_l[b]:base_l[b + 1]]).sum()) for b in range(self.B)], np.int64)
         nvalid_all = comm.allgather_host(np.array([int(nvalid_c.sum())], np.int64)).reshape(-1)
         picks = int(min(batch, nvalid_all.sum()))
         T = self._sel_static
@@ -214,7 +304,7 @@ class HotPath:
         nu_dev = max(int(np.minimum(2 * picks, nvalid_all).max()), 1)
         rep = max(int(os.environ.get("SSDR_EMULATE_WORLD", "1")), 1)       # development: the FPS load of `rep` x the ranks (tools/gpu_emulate_world.sh)
         cap_fps = max(rep * int(min(2 * picks, nvalid_all.sum())), 1)
-        nlab = comm.allgather_host(np.array([int(self.labeled_mask.sum())], np.int64)).reshape(-1)
+        nlab = comm.allgather_host(np.array([int(T["n_lab"])], np.int64)).reshape(-1)
         # the k-center selector also sends every rank's labelled regions' rows (behind its candidates, padded to nl_max) and seeds the global chain with them
         kc = self.selector == "kcenter"
         nl_max = int(nlab.max()) if kc else 0
@@ -227,9 +317,9 @@ class HotPath:
                    d_nlab_off=DevArray.from_host(np.concatenate([[0], np.cumsum(nlab)]).astype(np.int32)), d_already=DevArray((max(n_lab_all, 1),), np.int32),
                    d_plan=DevArray((16 + W + 2 * W * nu_dev,), np.int32), d_out=DevArray((max(rep * picks, 1),), np.int32))
         self._dist = dict(dev=dev, comm=comm, Smax=Smax, Bmax=Bmax, valid=lab == 0, gcloud=gcloud, room=room, spin=spin, batch=batch,
-                          S_total=int(S_all[:, 0].sum()), nu_max=int(min(2 * batch, Smax)),
+                          S_total=int(S_all[:, 0].sum()), n_pop=int(nvalid_all.sum()), nu_max=int(min(2 * batch, Smax)),
                           nlab=nlab,
-                          d_lab=DevArray.from_host(self.labeled_mask.astype(np.uint8)),
+                          d_lab=DevArray.from_host(self.skip_mask.astype(np.uint8)),
                           d_masked=DevArray((Smax,), np.float64), d_all=DevArray((W * Smax,), np.float64), d_ord=DevArray((W * Smax,), np.int32))
         return self._dist
 
@@ -237,25 +327,31 @@ class HotPath:
         """The scoring stage, enqueued, never waits.  With a communicator the two exchanges run on the same stream, on device buffers:
         all-reduce of the class histogram, all-gather of the (masked, padded) region uncertainties, then the global ranking."""
         cfg, L = self.cfg, _lib.lib()
-        n = self.B * cfg.num_points
+        n = self.n_pts
         um = {"lc": 0, "entropy": 1, "sb": 2}[[a for a in self.sampler_args if a in ("lc", "entropy", "sb")][0]]
         rm = {"mean": 0, "sum_weight": 1, "WetSU": 2}[[a for a in self.sampler_args if a in ("mean", "sum_weight", "WetSU")][0]]
         st = self.score_stream if self.score_stream is not None else self.stream
         _lib.check(L.ssdr_point_uncertainty_dev(self.probs.ptr, n, cfg.num_classes, um, self.unc.ptr, self.cls.ptr, st))
         _lib.check(L.ssdr_region_stats_dev(self.unc.ptr, self.cls.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, cfg.num_classes, rm,
                                            self.region_unc.ptr, self.dom.ptr, self.dom_cnt.ptr, st))
-        nsel = self.selected_class_list.shape[0]
+        # the labelled regions' dominant GROUND-TRUTH class (their dominant_point_ids, sampler2.py:288-291) from this batch's tile labels
+        _lib.check(L.ssdr_dominant_label_dev(self.tile_l.ptr, self.sp_off.ptr, self.sp_pts.ptr, self.S, max(cfg.num_classes, 1), self.gt_dom.ptr, self.gt_purity.ptr, st))
+        # class balance over the ranked population only (prediction() appends only unlabelled regions to region_class, :612-627): "classbal"
+        # (add_classbal, :256-260) is the same without the already-selected list and is tested first, as the reference does (:635-638)
+        bal = "classbal" in self.sampler_args or "clsbal" in self.sampler_args
+        nsel = 0 if "classbal" in self.sampler_args else self.selected_class_list.shape[0]
+        T = self._sel_static
         if comm is None:
-            if "clsbal" in self.sampler_args:
-                _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel, self.region_unc.ptr, st))
+            if bal:
+                _lib.check(L.ssdr_clsbal_dev(self.dom.ptr, self.S, T["d_lab"].ptr, self.selected_class_list.ptr, nsel, self.region_unc.ptr, st))
             _lib.check(L.ssdr_rank_regions_dev(self.region_unc.ptr, self.S, self.sorted_inds.ptr, st))
             self.global_order = None
             return
         D = self._dist_setup(comm)
-        if "clsbal" in self.sampler_args:       # exchange 1: the class histogram is global (the already-selected list is counted once, on rank 0)
-            _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, st))
+        if bal:       # exchange 1: the class histogram is global (the already-selected list is counted once, on rank 0)
+            _lib.check(L.ssdr_class_hist_dev(self.dom.ptr, self.S, D["d_lab"].ptr, self.selected_class_list.ptr, nsel if comm.rank == 0 else 0, self.hist.ptr, st))
             comm.allreduce_sum_(self.hist, st)
-            _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, D["S_total"] + nsel, self.region_unc.ptr, st))
+            _lib.check(L.ssdr_clsbal_hist_dev(self.dom.ptr, self.S, self.hist.ptr, D["n_pop"] + nsel, self.region_unc.ptr, st))
         # exchange 2: rank the regions of ALL ranks; labelled regions (and the padding) are -inf and sort last
         _lib.check(L.ssdr_mask_regions_dev(self.region_unc.ptr, D["d_lab"].ptr, self.S, D["Smax"], D["d_masked"].ptr, st))
         comm.allgather_(D["d_masked"], D["d_all"], st)
@@ -299,9 +395,9 @@ class HotPath:
         if (self.global_order is None and T["cap_rows"] <= 16384 and T["picks"] > 0 and (not kc or T["n_lab"] > 0)
                 and not os.environ.get("SSDR_SELECT_HOST_RULE")):
             # candidate rule + GCN_FPS_sampling enqueued as one chain: the host decides nothing and uploads nothing (the result is read in _select_collect)
-            _lib.check(L.ssdr_gcn_fps_sampling_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
+            _lib.check(L.ssdr_gcn_fps_sampling_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.tile_l.ptr, self.gt_dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
                                                    self.sorted_inds.ptr, self.S, T["d_lab"].ptr, T["d_base"].ptr, self.B, T["d_lab_off"].ptr, T["d_lab_sp"].ptr,
-                                                   T["n_lab"], T["batch"], int(self.gcn_number), int(self.gcn_top), 1 if kc else 0, 0, T["cap_rows"], T["cap_nmax"], T["cap_sq"],
+                                                   T["n_lab"], T["batch"], int(self.gcn_number), int(self.gcn_top), 1 if kc else 0, int(self.fps_start), T["cap_rows"], T["cap_nmax"], T["cap_sq"],
                                                    T["cap_unl"], T["picks"], T["d_result"].ptr, st))
             self._pending = ("device", None)
             self.rule_path = "device"
@@ -311,7 +407,7 @@ class HotPath:
             # the sharded run, still without a host decision: the rule over the global ranking + this rank's graph, the all-gather of the candidates'
             # propagated features (exchange 3), the replicated global FPS — three enqueues, nothing read back here
             D = self.global_order; V = D["dev"]
-            _lib.check(L.ssdr_gcn_fps_sharded_local_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
+            _lib.check(L.ssdr_gcn_fps_sharded_local_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.tile_l.ptr, self.gt_dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
                                                         T["d_lab_off"].ptr, T["d_lab_sp"].ptr, T["n_lab"], self.B, D["d_ord"].ptr, comm.world * D["Smax"],
                                                         V["d_glab"].ptr, V["d_gbase"].ptr, comm.rank, comm.world, D["Smax"], D["Bmax"], D["batch"],
                                                         int(self.gcn_number), int(self.gcn_top), V["cap_rows"], V["cap_nmax"], V["cap_sq"], V["nu_max"], V["nl_max"],
@@ -321,14 +417,14 @@ class HotPath:
                 _lib.check(L.ssdr_kcenter_gathered_dev(V["d_gath"].ptr, V["d_plan"].ptr, comm.world, V["nu_max"], V["nl_max"], V["d_nlab_off"].ptr, V["n_lab_all"],
                                                        V["cap_fps"] + V["n_lab_all"] + 1, V["picks"], V["d_glob"].ptr, V["d_already"].ptr, V["d_out"].ptr, st))
             else:
-                _lib.check(L.ssdr_fps_gathered_dev(V["d_gath"].ptr, V["d_plan"].ptr, comm.world, V["nu_max"], V["cap_fps"], V["rep"], 0, V["rep"] * V["picks"],
+                _lib.check(L.ssdr_fps_gathered_dev(V["d_gath"].ptr, V["d_plan"].ptr, comm.world, V["nu_max"], V["cap_fps"], V["rep"], int(self.fps_start), V["rep"] * V["picks"],
                                                    V["d_glob"].ptr, V["d_out"].ptr, st))
             self._pending = ("sharded", comm)
             self.rule_path = "sharded-device"
             return
         self.rule_path = "host"
         if self.global_order is None:          # (the D2H below runs on the selection stream, which already waits for the scoring stream's work)
-            cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(st), ~self.labeled_mask, self.sp_cloud_h, self.select_per_tile * self.B)
+            cand, ccloud, sampling_batch = self._candidates(self.sorted_inds.to_host(st), ~self.skip_mask, self.sp_cloud_h, self._sel_static["batch"])
             unl_c, unl_s = np.asarray(ccloud, np.int64), np.asarray(cand, np.int64)
             gl_room = np.asarray(self.room_ids, np.int64)[ccloud]; gl_sp = cand - np.asarray(self.sp_base, np.int64)[ccloud]
             counts_r = None
@@ -367,7 +463,13 @@ class HotPath:
         d_mf = DevArray((len(sel), 32), np.float32)
         d_v = DevArray((len(sel), 32), np.float64); d_comb = DevArray((rows, 32), np.float64)
         d_tmp = [DevArray(d_v.shape, np.float64), DevArray(d_v.shape, np.float64)]
-        _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel, len(sel), d_mf.ptr, st))
+        # compute_features (sampler2.py:333, :339): the candidates' members by the predicted classes, the labelled regions' by the ground truth (:288-291)
+        nu_rows = len(unl_s)
+        if nu_rows:
+            _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel, nu_rows, d_mf.ptr, st))
+        if len(sel) > nu_rows:
+            _lib.check(L.ssdr_segment_mean_features_dev(self.f32.ptr, 32, self.tile_l.ptr, self.gt_dom.ptr, self.sp_off.ptr, self.sp_pts.ptr, d_sel + 4 * nu_rows,
+                                                        len(sel) - nu_rows, d_mf.ptr + 4 * 32 * nu_rows, st))
         # float32 -> float64 as np.concatenate / np.matmul promote it (V and the running sum comb start as the same values)
         _lib.check(L.ssdr_widen_f32_f64_dev(d_mf.ptr, len(sel) * 32, d_v.ptr, d_comb.ptr, st))
         d_cen = DevArray((ntot, 3), np.float64); d_dir = DevArray((nsq,), np.float64); d_adj = DevArray((nsq,), np.float64)
@@ -421,8 +523,7 @@ class HotPath:
             d_already = DevArray.from_host((n_unl + np.arange(n_lab)).astype(np.int32), st); keep.append(d_already)
             _lib.check(L.ssdr_kcenter_dev(d_comb.ptr, n_unl + n_lab, 32, d_already.ptr, n_lab, sampling_batch, d_out.ptr, st))
         else:
-            start = 0                                        # np.random.randint(0, n) in the reference (:133); fixed here
-            _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, start, sampling_batch, d_out.ptr, st))
+            _lib.check(L.ssdr_fps_dev(d_comb.ptr, n_unl, 32, int(self.fps_start), sampling_batch, d_out.ptr, st))
         self._keep = keep
         self._pending = (d_out, unl)
 
@@ -456,6 +557,8 @@ class HotPath:
         elif isinstance(d_out, str):                          # the device-side rule: counts, picks and the candidate list in one read-back
             T = self._sel_static
             res = T["d_result"].to_host(self.sel_stream)     # waits for the selection stream alone
+            # from ~20 tiles per GPU on the chain's FPS / k-center is a cooperative launch: one that was not co-resident reports it here
+            _lib.check(_lib.lib().ssdr_select_status(self.sel_stream, None))
             if res[5]:
                 raise RuntimeError("gcn_fps_sampling: the candidate rule produced more rows than the capacities allow (status %d)" % int(res[5]))
             n_unl, picks = int(res[0]), int(res[4])
@@ -475,6 +578,8 @@ class HotPath:
         _knn.knn_status(self.knn_stream if self.knn_stream is not None else self.stream, wait=not self.pipelined)
         if not self.pipelined:                               # sequential use: the front end of this batch has finished, ask it too
             _lib.check(_lib.lib().ssdr_grid_subsample_status(self.front_stream if self.front_stream is not None else self.stream, None))
+        if len(sel) and int(np.min(sel)) < 0:                # (an aborted chain leaves -1 picks: never index the candidate list with them)
+            raise RuntimeError("selection: the FPS / k-center chain left unset picks (an aborted cooperative launch)")
         if getattr(self, "_emu_mod", 0):                    # (SSDR_EMULATE_WORLD: the picks index the repeated rows)
             sel = sel % self._emu_mod
         self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)

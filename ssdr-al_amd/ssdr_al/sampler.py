@@ -64,15 +64,45 @@ def dominant_labels(labels, offsets, points, num_labels):
     return d_lab.to_host(), d_pur.to_host()
 
 
-def add_clsbal(class_num, region_class, region_uncertainty, total_obj):
-    """sampler2.py:262-266."""
+def add_clsbal(class_num, region_class, region_uncertainty, total_obj, skip=None):
+    """sampler2.py:262-266.  The reference passes the UNLABELLED regions only (prediction(), :612-627); a caller that keeps every region in
+    one array marks the others in `skip` (non-zero: not part of the population)."""
     rc = np.ascontiguousarray(region_class, np.int32)
     sel = np.ascontiguousarray(total_obj.get("selected_class_list", []), np.int32)
     d_rc = DevArray.from_host(rc); d_sel = DevArray.from_host(sel) if len(sel) else None
+    d_skip = None if skip is None else DevArray.from_host(np.ascontiguousarray(skip).astype(np.uint8))
     d_u = DevArray.from_host(np.ascontiguousarray(region_uncertainty, np.float64))
-    _lib.check(_lib.lib().ssdr_clsbal_dev(d_rc.ptr, len(rc), d_sel.ptr if d_sel else None, len(sel), d_u.ptr, None))
+    _lib.check(_lib.lib().ssdr_clsbal_dev(d_rc.ptr, len(rc), d_skip.ptr if d_skip else None, d_sel.ptr if d_sel else None, len(sel), d_u.ptr, None))
     _lib.sync()
     return d_u.to_host()
+
+
+def add_classbal(class_num, region_class, region_uncertainty, skip=None):
+    """sampler2.py:256-260 (`--classbal 1`): add_clsbal without the already-selected list."""
+    return add_clsbal(class_num, region_class, region_uncertainty, {"selected_class_list": []}, skip)
+
+
+def labeled_class_weights(dominant_label_list, class_num):
+    """The draw probabilities of get_labeled_selection_cloudname_spidx_pointidx (sampler2.py:294-295): weights_percentage of the labelled
+    regions' ground-truth dominant labels, normalised.  Host arithmetic on a few thousand integers (it feeds np.random.choice)."""
+    lab = np.asarray(dominant_label_list, np.int64)
+    dist = np.zeros([class_num])
+    for c in lab:                                    # weights_percentage :92-100 as written (float64 counts)
+        dist[c] = dist[c] + 1
+    dist = dist / len(lab)
+    w = dist[lab]
+    return w / np.sum(w)
+
+
+def get_labeled_selection(dominant_label_list, class_num, round_num, random_state=np.random):
+    """The class-balanced draw of sampler2.py:294-302 over the labelled regions (given by their ground-truth dominant labels, in the
+    reference's order: cloud by cloud as prediction() met them, ascending superpoint id): `(round_num - 1) * 1000` of them at most,
+    without replacement, with NumPy's legacy generator exactly as the reference draws.  Returns the drawn positions in draw order."""
+    n = len(dominant_label_list)
+    batch = min((int(round_num) - 1) * 1000, n)
+    if n == 0 or batch <= 0:
+        return np.zeros(0, np.int64)
+    return np.asarray(random_state.choice(a=n, size=batch, replace=False, p=labeled_class_weights(dominant_label_list, class_num)), np.int64)
 
 
 def rank_regions(region_uncertainty):

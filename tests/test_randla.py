@@ -176,7 +176,8 @@ def test_randla_both_tile_formulations_against_fp32_oracle(backend):
 def test_randla_full_size_batch16_properties(mode):
     """BASELINE config 3 shape (B=16 x 40960) in every arithmetic of the matrix products (plain bf16 IS configuration 3): probabilities
     are a distribution, outputs finite, and the result of a tile does not depend on which batch slot it sits in (tiles are independent
-    units).  Level 0 (d = 16) runs on the exact-f32 MFMA kernel in every mode."""
+    units).  In the bf16 modes every level, level 0 (d = 16) included, runs the 32 x 32-tile bf16 kernels (lfa32_l0_kernel, round 4); the f32
+    mode keeps the exact-f32 MFMA kernel."""
     from conftest import GPU_LIB, _have_gpu
     if not _have_gpu():
         pytest.skip("no GPU")

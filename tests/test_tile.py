@@ -76,10 +76,14 @@ def test_tile_select_batch_ties_and_crowded_distance_bins(backend):
     d_perm, d_dup = DevArray.from_host(perm), DevArray.from_host(dup)
     d_xyz, d_feat, d_idx = DevArray((R, N, 3), np.float32), DevArray((R, N, 6), np.float32), DevArray((R, N), np.int32)
     cen = np.ascontiguousarray(np.stack(centers), np.float32)
+    lab = rng.integers(0, 13, len(P)).astype(np.int32)
+    d_lab, d_olab = DevArray.from_host(lab), DevArray((R, N), np.int32)
     _lib.check(_lib.lib().ssdr_tile_select_batch_dev(d_p.ptr, d_c.ptr, 3, d_m.ptr, _lib.ptr(off), R, _lib.ptr(cen), N, d_perm.ptr, d_dup.ptr, 1.0 / 255.0,
-                                                    d_xyz.ptr, d_feat.ptr, d_idx.ptr, None))
+                                                    d_xyz.ptr, d_feat.ptr, d_idx.ptr, d_lab.ptr, d_olab.ptr, None))
     _lib.sync()
     got = d_idx.to_host()
+    # queried_pc_label = input_label[queried_idx] (s3dis_dataset.py:141): the labels travel with the rows, duplicates included
+    assert np.array_equal(d_olab.to_host(), np.stack([lab[off[r]:off[r + 1]][got[r]] for r in range(R)]))
     for r in range(2):                      # full tiles: index for index
         pts = clouds[r]; dd = pts - cen[r][None]
         dist = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
