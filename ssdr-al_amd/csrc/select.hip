@@ -382,7 +382,7 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 #endif
 }
 
-constexpr int CH_TILE = 768;    // target points staged per step (18 KiB of float64 coordinates)
+constexpr int CH_TILE = 640;    // target points staged per step (20 KiB: float64 coordinates + squared norm); at most 1024 (the screening key carries a 10-bit index)
 constexpr int PACK_MAX = 4096;  // superpoints of one cloud the packer lays out (two int tables in LDS)
 constexpr int ITEM = 256;       // source points one wave takes against a target
 constexpr int NV = ITEM / 64;   // ... per lane
@@ -468,33 +468,47 @@ __device__ void chamfer_fill_body(const float* __restrict__ xyz, const int* __re
 __device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&out)[NV], const double* tb, int nj, bool staged,
                                             const float* __restrict__ xyz, const int* __restrict__ sp_pts, int loj, double cjx, double cjy, double cjz) {
     if (staged) {
+        // Screening on |b|^2 - 2 a.b (= |a - b|^2 - |a|^2: the same order over b), three fused multiply-adds per pair instead of three differences,
+        // a product and two fused multiply-adds; the target's index rides in the key's ten lowest mantissa bits (one 32-bit and-or), so the running
+        // minimum names its target and the distance itself is then evaluated ONCE per source point in the difference form, as before — the
+        // value is the exact one whenever the target it names is the nearest.  A wrong name needs two targets whose keys agree to 2^-42 of |key|
+        // (<= ~1e-13 m^2 at room scale; the fused chain's own rounding is 1e-16): the value returned is then that target's exact distance, above the
+        // minimum by at most that band.  5 instructions per pair instead of 7 on the float64 pipe that bounds this kernel.
         double m[NV][2];      // independent chains: min is order-free
+        double ax2[NV], ay2[NV], az2[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) m[v][0] = m[v][1] = 1.0e300;
+        for (int v = 0; v < NV; ++v) { m[v][0] = m[v][1] = 1.0e300; ax2[v] = -2.0 * ax[v]; ay2[v] = -2.0 * ay[v]; az2[v] = -2.0 * az[v]; }
+        auto key = [](double t, int idx) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+            const unsigned lo = ((unsigned)bits & ~1023u) | (unsigned)idx;
+            return __longlong_as_double((long long)((bits & 0xffffffff00000000ull) | lo));
+        };
         int b = 0;
         for (; b + 4 <= nj; b += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const double tx = tb[3 * (b + u)], ty = tb[3 * (b + u) + 1], tz = tb[3 * (b + u) + 2];
+                const double tx = tb[4 * (b + u)], ty = tb[4 * (b + u) + 1], tz = tb[4 * (b + u) + 2], tn = tb[4 * (b + u) + 3];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    const double dx = ax[v] - tx, dy = ay[v] - ty, dz = az[v] - tz;
-                    const double d = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
-                    m[v][u & 1] = min_f64(d, m[v][u & 1]);
+                    const double t = fma(az2[v], tz, fma(ay2[v], ty, fma(ax2[v], tx, tn)));
+                    m[v][u & 1] = min_f64(key(t, b + u), m[v][u & 1]);
                 }
             }
         }
         for (; b < nj; ++b) {
-            const double tx = tb[3 * b], ty = tb[3 * b + 1], tz = tb[3 * b + 2];
+            const double tx = tb[4 * b], ty = tb[4 * b + 1], tz = tb[4 * b + 2], tn = tb[4 * b + 3];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const double dx = ax[v] - tx, dy = ay[v] - ty, dz = az[v] - tz;
-                double d = dx * dx; d = d + dy * dy; d = d + dz * dz;
-                m[v][0] = min_f64(d, m[v][0]);
+                const double t = fma(az2[v], tz, fma(ay2[v], ty, fma(ax2[v], tx, tn)));
+                m[v][0] = min_f64(key(t, b), m[v][0]);
             }
         }
 #pragma unroll
-        for (int v = 0; v < NV; ++v) out[v] = fmin(m[v][0], m[v][1]);
+        for (int v = 0; v < NV; ++v) {
+            const int idx = (int)((unsigned)__double_as_longlong(fmin(m[v][0], m[v][1])) & 1023u);
+            const double dx = ax[v] - tb[4 * idx], dy = ay[v] - tb[4 * idx + 1], dz = az[v] - tb[4 * idx + 2];
+            out[v] = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
+        }
         return;
     }
     double m[NV];                        // very large target: stream it from global memory
@@ -550,11 +564,15 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
             __syncthreads();
             const int st = P.start[j];
             if (st >= 0) {
-                for (int b = threadIdx.x; b < nj; b += 256) { tb[3 * b] = P.x[st + b]; tb[3 * b + 1] = P.y[st + b]; tb[3 * b + 2] = P.z[st + b]; }
+                for (int b = threadIdx.x; b < nj; b += 256) {
+                    const double x = P.x[st + b], y = P.y[st + b], z = P.z[st + b];
+                    tb[4 * b] = x; tb[4 * b + 1] = y; tb[4 * b + 2] = z; tb[4 * b + 3] = fma(z, z, fma(y, y, x * x));
+                }
             } else {
                 for (int b = threadIdx.x; b < nj; b += 256) {
                     const size_t q = sp_pts[loj + b];
-                    tb[3 * b] = (double)xyz[3 * q] - cjx; tb[3 * b + 1] = (double)xyz[3 * q + 1] - cjy; tb[3 * b + 2] = (double)xyz[3 * q + 2] - cjz;
+                    const double x = (double)xyz[3 * q] - cjx, y = (double)xyz[3 * q + 1] - cjy, z = (double)xyz[3 * q + 2] - cjz;
+                    tb[4 * b] = x; tb[4 * b + 1] = y; tb[4 * b + 2] = z; tb[4 * b + 3] = fma(z, z, fma(y, y, x * x));
                 }
             }
             __syncthreads();
@@ -629,7 +647,7 @@ __global__ __launch_bounds__(256) void sel_chamfer_fill(const float* __restrict_
 
 __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                        const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P) {
-    __shared__ double tb[CH_TILE * 3];
+    __shared__ double tb[CH_TILE * 4];
     __shared__ double s_val[4][ITEM];
     chamfer_dir_body(xyz, sp_off, sp_pts, sel, nsel, centres, dir, P, P.counts, tb, s_val);
 }
@@ -638,7 +656,7 @@ __global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__
 __global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(5) void sel_chamfer_dir_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                              const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
                                                              const double* __restrict__ centres, double* dir, ChamferPack P) {
-    __shared__ double tb[CH_TILE * 3];
+    __shared__ double tb[CH_TILE * 4];
     __shared__ double s_val[4][ITEM];
     const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
     chamfer_dir_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, s_val);
