@@ -29,8 +29,9 @@ for p in (ROOT, os.path.join(ROOT, "ssdr-al_amd")):
 METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+PEAK_F64_VECTOR_TFLOPS = 78.6     # AMD's public MI355X figure for vector float64 (the guide lists none; measured issue rate: one v_fma_f64 per 5.4 cycles and SIMD = 58 TF)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_ROUND = "r04"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
+PROFILE_ROUND = "r05"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
 DTYPE = {"f32": "f32 (exact f32-input MFMA)",
          "bf16x3": "bf16x3: split-bf16 MFMA operands (hi*hi + lo*hi + hi*lo), fp32 accumulate, fp32 activations and non-matrix arithmetic",
          "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 activations and non-matrix arithmetic"}
@@ -213,7 +214,22 @@ def main():
         # behind / shares the CUs with the other streams' kernels; (a) is reported beside it as "as_timed".
         hp.step(None)      # untimed: this state's first step grows its scratch buffers
         rows = prof_rows(lambda: [hp.step(None) for _ in range(NPROF)])
-        name, calls, ms, work, work2 = rows[0]
+        # algorithmic work the library cannot know at enqueue time (counts that live on the device): the front end's one write of its rows
+        # (28 B per voxel), the chamfer's point pairs (8 FLOP per pair and direction) from the last step's result
+        sub_rows = int(hp.sub_m.to_host()[: hp.B].sum())
+        T = hp._sel_static
+        res = T["d_result"].to_host()
+        n_unl = int(res[0])
+        ref_sp = np.concatenate([res[8 + T["picks"]: 8 + T["picks"] + n_unl], np.array([s_ for b_ in range(hp.B) for s_ in hp.lab_rows.get(b_, [])], np.int64)]).astype(np.int64)
+        sz = hp.sp_size_h[ref_sp].astype(np.float64); cl = hp.sp_cloud_h[ref_sp]
+        pairs = float(sum(sz[cl == b_].sum() ** 2 - (sz[cl == b_] ** 2).sum() for b_ in range(hp.B)))      # ordered (source, target) pairs of points, i != j
+        extra_work = {"fe_reduce": 28.0 * sub_rows * NPROF, "sel_chamfer": 8.0 * pairs * NPROF}
+        rows = [(r[0], r[1], r[2], r[3] + extra_work.get(r[0], 0.0), r[4]) for r in rows]
+        # one-workgroup dependent chains occupy one CU of 256 and cost the pipelined step nothing (profiles/rNN_marginal.txt): they are listed with the
+        # others, the roofline line is the longest CHIP-WIDE kernel
+        one_cu = ("fps_chain",)
+        f64_kernels = ("sel_chamfer",)
+        name, calls, ms, work, work2 = [r for r in rows if r[0] not in one_cu][0]
         mfma = name in mfma_kernels
         unit_div = 1e12 if mfma else 1e9
         achieved = work / (ms * 1e-3) / unit_div
@@ -243,11 +259,19 @@ def main():
                                                "note": "FLOPs the MFMA instructions execute: tile padding, both orientations of the position-encoding products, "
                                                        "three bf16 products per split product; the neighbour half of the attention product runs once per point in "
                                                        "dense_kernel (G rows) and is gathered, so it is not in this kernel"}})
-        roofline["others"] = {r[0]: {"ms_per_step": round(r[2] / NPROF, 3), "launches_per_step": r[1] // NPROF,
-                                     **({"algorithmic_TFLOPs": round(r[3] / (r[2] * 1e-3) / 1e12, 2), "executed_mfma_TFLOPs": round(r[4] / (r[2] * 1e-3) / 1e12, 2),
-                                         "frac_of_mfma_peak": round(r[3] / (r[2] * 1e-3) / 1e12 / mfma_peak, 4)} if r[0] in mfma_kernels else
-                                        ({"algorithmic_GBs": round(r[3] / (r[2] * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(r[3] / (r[2] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} if r[3] > 0 else {}))}
-                              for r in rows}
+        def family(r):
+            d = {"ms_per_step": round(r[2] / NPROF, 3), "launches_per_step": r[1] // NPROF}
+            rate = r[3] / (r[2] * 1e-3) if r[2] > 0 else 0.0
+            if r[0] in mfma_kernels:
+                d.update({"algorithmic_TFLOPs": round(rate / 1e12, 2), "executed_mfma_TFLOPs": round(r[4] / (r[2] * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(rate / 1e12 / mfma_peak, 4)})
+            elif r[0] in f64_kernels:
+                d.update({"algorithmic_f64_TFLOPs": round(rate / 1e12, 2), "frac_of_f64_vector_peak": round(rate / 1e12 / PEAK_F64_VECTOR_TFLOPS, 4)})
+            elif r[3] > 0:
+                d.update({"algorithmic_GBs": round(rate / 1e9, 1), "frac_of_hbm_peak": round(rate / 1e9 / PEAK_HBM_GBS, 4)})
+            if r[0] in one_cu:
+                d["one_workgroup_chain"] = True
+            return d
+        roofline["others"] = {r[0]: family(r) for r in rows}
         for r in timed_rows:
             if r[0] == name and pipe is not None:
                 roofline["as_timed"] = {"conditions": "%d batches in flight on %d streams" % (args.pipeline_depth, args.pipeline_depth),

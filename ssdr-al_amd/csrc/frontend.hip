@@ -681,21 +681,33 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
         S.rcp_ready = true;
     }
     FeGeom* geom = S.geom.as<FeGeom>(); int* counters = S.counters.as<int>(); FeItem* items = S.items.as<FeItem>();
+    // profiler sites (ssdr_prof_enable; bench.py's roofline leg): `work` = the algorithmic bytes a site is charged with — the one read of the inputs
+    // (28 B per point) goes to the scatter, the one write of the rows (28 B per voxel: the count is the device's, bench.py adds it) to the reduction
+    {
+    ProfScope prof("fe_bbox_count_scan", s, 0.0);
     hipLaunchKernelGGL(fe_minmax_partial, dim3(PB, R), dim3(BS), 0, s, t, d_p, S.partial.as<float>());
     hipLaunchKernelGGL(fe_params, dim3(R), dim3(BS), 0, s, t, S.partial.as<float>(), dl, prm, geom, counters);
     hipLaunchKernelGGL(fe_count, dim3(t.chunks_max, R), dim3(FE_NT), 0, s, t, d_p, geom, prm, S.cntm.as<unsigned>());
     hipLaunchKernelGGL(fe_colscan, dim3(FE_NBMAX / BS, R), dim3(BS), 0, s, t, geom, S.cntm.as<unsigned>(), S.tot.as<unsigned>());
     hipLaunchKernelGGL(fe_bscan, dim3(R), dim3(FE_NT), 0, s, t, geom, S.tot.as<unsigned>(), S.boff.as<unsigned>(), items, counters);
+    }
+    {
+    ProfScope prof("fe_scatter", s, (double)(12 + 4 * (fdim + ldim)) * (double)t.n_total);
     if (fdim == 3 && ldim == 1)
         hipLaunchKernelGGL((fe_scatter<3, 1>), dim3(t.chunks_max, R), dim3(FE_SNT), 0, s, t, d_p, d_f, (int)fdim, (const int*)d_c, (int)ldim, geom, S.cntm.as<unsigned>(), S.boff.as<unsigned>(),
                            S.rec.as<uint4>());
     else
         hipLaunchKernelGGL((fe_scatter<-1, -1>), dim3(t.chunks_max, R), dim3(FE_SNT), 0, s, t, d_p, d_f, (int)fdim, (const int*)d_c, (int)ldim, geom, S.cntm.as<unsigned>(), S.boff.as<unsigned>(),
                            S.rec.as<uint4>());
+    }
     FeRedArgs ra; ra.t = t; ra.items = items; ra.prm = prm; ra.counters = counters; ra.rcp = S.rcp.as<float>(); ra.rec = S.rec.as<uint4>();
     ra.nocc = S.nocc.as<unsigned>(); ra.trow = S.trow.as<unsigned>(); ra.lrc = S.lrc.as<unsigned char>(); ra.fdim = (int)fdim; ra.ldim = (int)ldim;
+    {
+    ProfScope prof("fe_reduce", s, 0.0);
     if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1>), dim3(ctx().num_cu * 3), dim3(FE_RNT), 0, s, ra);        // the hot path's rows
     else hipLaunchKernelGGL((fe_reduce<-1, -1>), dim3(ctx().num_cu * 3), dim3(FE_RNT), 0, s, ra);
+    }
+    ProfScope prof_move("fe_rows_move", s, 0.0);
     hipLaunchKernelGGL(fe_rowpre, dim3(256, R), dim3(BS), 0, s, geom, S.boff.as<unsigned>(), S.lrc.as<unsigned char>(), S.pre.as<unsigned short>(), S.rowcnt.as<unsigned>());
     hipLaunchKernelGGL(fe_rowscan, dim3(R), dim3(FE_NT), 0, s, geom, S.rowcnt.as<unsigned>(), prm, (long long*)d_om);
     FeMoveArgs ma; ma.t = t; ma.geom = geom; ma.items = items; ma.counters = counters; ma.rec = S.rec.as<uint4>(); ma.nocc = S.nocc.as<unsigned>();

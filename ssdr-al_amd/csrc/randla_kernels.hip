@@ -810,6 +810,8 @@ int launch_lfa(int D, const LfaArgs& a, bool second, int B, hipStream_t s) {
 int launch_gather_max(const float* f, const int* idx, int n_in, int n_out, int idx_rows, int C, float* out, int B, hipStream_t s) {
     if (n_out <= 0 || B <= 0) return SSDR_OK;
     const size_t total = (size_t)n_out * C;
+    // random_sample (RandLANet.py:537-548): every input row read once, 16 indices + one output row per output point (fp32 here, SURVEY 8d counts bf16)
+    ProfScope prof("gather_max_kernel", s, (double)B * (4.0 * (double)n_in * C + (double)n_out * (64.0 + 4.0 * C)));
     if (C % 4 == 0 && (size_t)n_in * C < (1ull << 30) && total / 4 < (1ull << 31) && (((uintptr_t)f | (uintptr_t)out | (uintptr_t)idx) & 15) == 0) {
         dim3 grid4((unsigned)std::max<size_t>(1, std::min<size_t>((total / 4 + 255) / 256, 4096)), (unsigned)B);
         hipLaunchKernelGGL(gather_max4_kernel, grid4, dim3(256), 0, s, f, idx, n_in, n_out, idx_rows, C, out);

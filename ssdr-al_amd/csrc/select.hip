@@ -9,6 +9,7 @@
 //
 // Superpoints are CSR: sp_off[S+1] into sp_pts[T] (point ids), the same information as the reference's
 // pickled `components` object array (S3/partition/compute_superpoint.py:63-68).
+#include <optional>
 #include "ssdr_internal.hpp"
 #include <map>
 #include "block_prims.hpp"
@@ -1667,6 +1668,7 @@ int ssdr_point_uncertainty_dev(const float* d_probs, size_t n, int num_classes, 
     if (!d_probs || !d_unc || !d_cls || num_classes < 2 || num_classes > 128 || mode < 0 || mode > 2) { set_error("point_uncertainty: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (n == 0) return SSDR_OK;
+    ProfScope prof("sel_point_unc", pick_stream(stream), (4.0 * num_classes + 8.0) * (double)n);
     hipLaunchKernelGGL(sel_point_unc, dim3(grid_for((long)n)), dim3(256), 0, pick_stream(stream), d_probs, (int)n, num_classes, mode, d_unc, d_cls);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
@@ -1677,6 +1679,7 @@ int ssdr_region_stats_dev(const float* d_unc, const int32_t* d_cls, const int32_
     if (!d_unc || !d_cls || !d_sp_off || !d_sp_pts || !d_region_unc || !d_dom || !d_dom_cnt || num_classes > 32 || mode < 0 || mode > 2) { set_error("region_stats: bad arguments"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ensure_init());
     if (S == 0) return SSDR_OK;
+    ProfScope prof("sel_region_stats", pick_stream(stream), 0.0);
     hipLaunchKernelGGL(sel_region_stats_w, dim3((unsigned)std::min<size_t>((S + 3) / 4, (size_t)ctx().num_cu * 16)), dim3(256), 0, pick_stream(stream), d_unc, d_cls, d_sp_off, d_sp_pts,
                        (int)S, num_classes, mode, d_region_unc, d_dom, d_dom_cnt);
     SSDR_HIP(hipGetLastError());
@@ -1862,6 +1865,8 @@ int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, con
 static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_already, size_t na, int start, size_t count, int use_sqrt, int32_t* d_out, hipStream_t s,
                     const int* d_n = nullptr) {
     SelState& Q = sst(s);
+    // SURVEY 8d (F4 / F5): per pick n * D * 8 bytes of features + n * 8 of distances read and written (n = the capacity here: the count is the device's)
+    ProfScope prof("fps_chain", s, (double)count * ((double)n * D * 8.0 + 16.0 * (double)n));
     int nb = grid_for((long)n, ctx().num_cu * 2);
     // seeded single-workgroup paths: kc_init takes a wave per row and its partial maxima are read once — as many workgroups as give every
     // wave a few rows (6 workgroups for 1400 rows left the kernel latency-bound at 0.57 ms)
@@ -2007,12 +2012,14 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     double* V = Q.cand_f.as<double>(); double* comb = V + cap_rows * D; double* tmp0 = comb + cap_rows * D; double* tmp1 = tmp0 + cap_rows * D;
     double* cen = tmp1 + cap_rows * D; double* dir = cen + 3 * cap_rows; double* adj = dir + cap_sq;
     int* counts = d_result; int* out = d_result + 8; int* sel = out + max_select;
+    std::optional<ProfScope> prof; prof.emplace("sel_candidate_rule", s, 0.0);
     hipLaunchKernelGGL(cand_rank, dim3(nchunks), dim3(CR_NT), 0, s, d_order, (int)S, d_labelled, rankpos, cploc, chunk);
     hipLaunchKernelGGL(cand_chunkscan, dim3(1), dim3(256), 0, s, chunk, nchunks);
     hipLaunchKernelGGL(cand_cloud, dim3(B), dim3(256), 0, s, rankpos, cploc, chunk, d_labelled, d_sp_base, (int)S, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
     hipLaunchKernelGGL(cand_layout, dim3(1), dim3(256), 0, s, ncand, ntop, d_lab_off, B, (long long)cap_rows, (long long)cap_sq, uoff, coff, boff, counts);
     hipLaunchKernelGGL(cand_fill, dim3(B), dim3(256), 0, s, stage, d_sp_base, ncand, uoff, coff, d_lab_off, d_lab_sp, counts, sel, gsel, rows, already);
     const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
+    prof.emplace("sel_features_pack", s, 0.0);
     // compute_features (sampler2.py:333,339) of the refs, widened; bbox centres of the grouped rows
     hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, counts + 2, V, comb,
                        d_lab_cls, d_lab_dom, counts);
@@ -2020,8 +2027,10 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, counts + 2);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
+    prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
     hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
                        coff, boff, cen, dir, P);
+    prof.emplace("sel_adjacency_propagate", s, 0.0);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), coff, boff, adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(std::max(1, std::min((nm + 3) / 4, 1024)), 1, nc), dim3(256), 0, s, adj, coff, boff, gcn_top);
@@ -2032,6 +2041,7 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
         src = dst;
     }
     SSDR_HIP(hipGetLastError());
+    prof.reset();
     if (max_select == 0) return SSDR_OK;
     // selector 1: kCenterGreedy over candidates + labelled rows, seeded with the labelled ones (kcenterGreedy.py:84-128; sampler2.py's "kcenter" branch)
     if (selector == 1) return fps_like(comb, cap_rows, D, already, n_lab, 0, max_select, 1, out, s, counts + 2);
@@ -2082,6 +2092,7 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     double* V = Q.cand_f.as<double>(); double* comb = V + cap_rows * D; double* tmp0 = comb + cap_rows * D; double* tmp1 = tmp0 + cap_rows * D;
     double* cen = tmp1 + cap_rows * D; double* dir = cen + 3 * cap_rows; double* adj = dir + cap_sq;
     int* plan = d_plan;
+    std::optional<ProfScope> prof; prof.emplace("sel_candidate_rule", s, 0.0);
     hipLaunchKernelGGL(cand_rank, dim3(nchunks), dim3(CR_NT), 0, s, d_gorder, (int)Sg, d_glabelled, rankpos, cploc, chunk);
     hipLaunchKernelGGL(cand_chunkscan, dim3(1), dim3(256), 0, s, chunk, nchunks);
     hipLaunchKernelGGL(cand_cloud, dim3(Bg), dim3(256), 0, s, rankpos, cploc, chunk, d_glabelled, d_gbase, (int)Sg, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
@@ -2092,14 +2103,17 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     hipLaunchKernelGGL(cand_fill_local, dim3(B), dim3(256), 0, s, stage, d_gbase + (size_t)rank * Bmax, ncand + (size_t)rank * Bmax, uoff, coff, d_lab_off, d_lab_sp, plan,
                        (int)((size_t)rank * Smax), sel, gsel, rows);
     const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
+    prof.emplace("sel_features_pack", s, 0.0);
     hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, plan + 2, V, comb,
                        d_lab_cls, d_lab_dom, plan);
     SSDR_TRY(Q.rowsum.reserve(8 * cap_rows));
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, plan + 2);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
+    prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
     hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
                        coff, boff, cen, dir, P);
+    prof.emplace("sel_adjacency_propagate", s, 0.0);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), coff, boff, adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(std::max(1, std::min((nm + 3) / 4, 1024)), 1, nc), dim3(256), 0, s, adj, coff, boff, gcn_top);
@@ -2109,6 +2123,7 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
         hipLaunchKernelGGL(sel_propagate_batch, dim3(grid_for((long)nm * D, 256), 1, nc), dim3(256), 0, s, adj, coff, boff, rows, src, D, dst, comb);
         src = dst;
     }
+    prof.reset();
     // the candidates' rows (the first n_unl of comb) are what the exchange sends
     hipLaunchKernelGGL(copy_rows_dn, dim3(grid_for((long)nu_max * D)), dim3(256), 0, s, comb, d_comb_out, D, (int)nu_max, plan);
     // ... and, for the global k-center (nl_max > 0), this rank's labelled regions' rows behind them

@@ -410,6 +410,7 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
     if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_clear_b leaves it clear
     const unsigned R = (unsigned)num_clouds;
     const int g = std::max(1, std::min((maxn + 255) / 256, 64));
+    ProfScope prof("tile_select", s, (12.0 + 4.0 * (12 + 4 * (d_out_feat ? color_dim + 3 : 0))) * 0.0 + 40.0 * (double)num_clouds * (double)num_points);      // 40 B per tile point
     hipLaunchKernelGGL(tile_hist_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.hist.as<unsigned>(), T.count.as<int>());
     hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, t, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>(), T.rstart.as<unsigned>(), T.rcur.as<unsigned>(), rstride);
     if (rstride <= TS_RMAX)
