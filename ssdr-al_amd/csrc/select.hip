@@ -236,16 +236,35 @@ __global__ __launch_bounds__(256) void sel_region_stats_w(const float* __restric
 }
 
 // ---- D1: dominant ground-truth label + purity (sampler2.py:102-106 via oracle_labeling :127-144) ------------
+// One WAVE per superpoint (a lane per superpoint walked its ~185 members one dependent load at a time with a 64-entry private histogram: 0.18 ms
+// for the bench's 7000 regions, more than the whole scoring stage): members dealt to the lanes, histogram in LDS, first maximum like np.argmax.
 __global__ __launch_bounds__(256) void sel_dominant_label(const int* __restrict__ labels, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                           int S, int num_labels, int* out_label, double* out_purity, int* status) {
-    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) {
+    __shared__ int s_h[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nl = min(num_labels, 64);
+    for (int s = blockIdx.x * 4 + w; s < S; s += gridDim.x * 4) {
         const int lo = sp_off[s], n = sp_off[s + 1] - lo;
-        int h[64];
-        for (int c = 0; c < 64; ++c) h[c] = 0;
-        for (int j = 0; j < n; ++j) { const int c = labels[sp_pts[lo + j]]; if (c >= 0 && c < 64 && c < num_labels) h[c]++; else atomicOr(status, 1); }
-        int d = 0;
-        for (int c = 1; c < num_labels && c < 64; ++c) if (h[c] > h[d]) d = c;
-        out_label[s] = d; out_purity[s] = n > 0 ? (double)h[d] / (double)n : 0.0;
+        s_h[w][lane] = 0;
+        wave_sync();
+        bool bad = false;
+        for (int j0 = lane; j0 < n; j0 += 256) {          // four members' dependent loads (member, label) in flight per lane
+            int p[4], c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = sp_pts[lo + min(j0 + 64 * u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = labels[p[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j0 + 64 * u < n) { if (c[u] >= 0 && c[u] < nl) atomicAdd(&s_h[w][c[u]], 1); else bad = true; }
+        }
+        if (bad) atomicOr(status, 1);
+        wave_sync();
+        // (count, lowest class first) as one key: the wave's maximum is np.argmax's first maximum
+        int key = lane < nl ? (s_h[w][lane] << 6) | (63 - lane) : -1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
+        if (lane == 0) { const int d = 63 - (key & 63); out_label[s] = d; out_purity[s] = n > 0 ? (double)(key >> 6) / (double)n : 0.0; }
+        wave_sync();
     }
 }
 
@@ -479,9 +498,17 @@ __device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double
         double ax2[NV], ay2[NV], az2[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) { m[v][0] = m[v][1] = 1.0e300; ax2[v] = -2.0 * ax[v]; ay2[v] = -2.0 * ay[v]; az2[v] = -2.0 * az[v]; }
-        auto key = [](double t, int idx) {
+        // (key.lo & ~1023) | idx in ONE instruction: gfx950's three-operand encodings take no 32-bit literal and one scalar operand, so the compiler
+        // emits v_and_b32 + v_or_b32 with the literal; with the mask in a vector register v_and_or_b32 does it (idx stays scalar)
+        const unsigned keep = ~1023u;
+        auto key = [keep](double t, int idx) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
-            const unsigned lo = ((unsigned)bits & ~1023u) | (unsigned)idx;
+            unsigned lo;
+#ifndef HIPEMU
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)bits), "v"(keep), "s"(idx));
+#else
+            lo = ((unsigned)bits & keep) | (unsigned)idx;
+#endif
             return __longlong_as_double((long long)((bits & 0xffffffff00000000ull) | lo));
         };
         int b = 0;
@@ -1693,7 +1720,8 @@ int ssdr_dominant_label_dev(const int32_t* d_labels, const int32_t* d_sp_off, co
     if (S == 0) return SSDR_OK;
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     SSDR_TRY(Q.hist.reserve(4 * 64)); SSDR_HIP(hipMemsetAsync(Q.hist.p, 0, 4, s));
-    hipLaunchKernelGGL(sel_dominant_label, dim3(grid_for((long)S)), dim3(256), 0, s, d_labels, d_sp_off, d_sp_pts, (int)S, num_labels, d_label, d_purity, Q.hist.as<int>());
+    ProfScope prof("sel_dominant_label", s, 0.0);
+    hipLaunchKernelGGL(sel_dominant_label, dim3((unsigned)std::min<size_t>((S + 3) / 4, (size_t)ctx().num_cu * 16)), dim3(256), 0, s, d_labels, d_sp_off, d_sp_pts, (int)S, num_labels, d_label, d_purity, Q.hist.as<int>());
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
@@ -1704,6 +1732,7 @@ int ssdr_clsbal_dev(const int32_t* d_region_class, size_t S, const uint8_t* d_sk
     if (S == 0) return SSDR_OK;
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     SSDR_TRY(Q.hist.reserve(4 * 64)); SSDR_HIP(hipMemsetAsync(Q.hist.p, 0, 4 * 64, s));
+    ProfScope prof("sel_clsbal", s, 0.0);
     hipLaunchKernelGGL(sel_class_hist, dim3(grid_for((long)(S + n_selected))), dim3(256), 0, s, d_region_class, (int)S, d_skip, d_selected_class_list, (int)n_selected, Q.hist.as<int>());
     hipLaunchKernelGGL(sel_clsbal, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_class, (int)S, d_skip ? -1 : (int)(S + n_selected), Q.hist.as<int>(), d_region_unc);
     SSDR_HIP(hipGetLastError());
@@ -1735,6 +1764,7 @@ int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorte
     SSDR_TRY(ensure_init());
     if (S == 0) return SSDR_OK;
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
+    ProfScope prof("sel_rank", s, 0.0);
     if (S <= (size_t)RANK_SMALL) {
         hipLaunchKernelGGL(sel_rank_count, dim3((unsigned)((S + 31) / 32)), dim3(256), 0, s, d_region_unc, (int)S, d_sorted_inds);
         SSDR_HIP(hipGetLastError());
