@@ -501,7 +501,7 @@ __device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double
         // (key.lo & ~1023) | idx in ONE instruction: gfx950's three-operand encodings take no 32-bit literal and one scalar operand, so the compiler
         // emits v_and_b32 + v_or_b32 with the literal; with the mask in a vector register v_and_or_b32 does it (idx stays scalar)
         const unsigned keep = ~1023u;
-        auto key = [keep](double t, int idx) {
+        auto key = [&](double t, int idx) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
             unsigned lo;
 #ifndef HIPEMU
