@@ -151,6 +151,18 @@ int ssdr_grid_subsample_batch_dev(const float* d_points, const float* d_features
 int ssdr_grid_subsample_set_method(int method);
 int ssdr_grid_subsample_status(void* stream, int32_t* out_status);
 
+/* ---- Semantic3D sampling loader: the cut of a whole scan into network inputs ---------------------------------------
+ * split3 (SSRD_AL_semantic3d/semantic3d_dataset_sampling.py:198-236) + the merge rule of tf_map (:243-255): the cloud is halved along x and y at
+ * the middle of its bounding box (float32 comparisons against float64 mid-points, as NumPy evaluates them; the z test of :224 holds for every
+ * point and is reproduced), a part of more than max_size points is split again (the parts of THAT split against recurse_max_size: the
+ * reference's recursive call passes the literal 800000 whatever its caller's max_size was, :233), and a part of at most merge_max points joins
+ * the one before it.  d_xyz [n,3].  Outputs: d_order [n] = the points grouped by combined part (ascending index inside a leaf, leaves in the order split3
+ * appends them; the reference's order inside a part is CPython's set iteration order), part_offsets (host, max_parts + 1 entries) and
+ * *num_parts; d_part [n] (may be NULL) = the combined part of every point.  Synchronous (the recursion tree is decided on the host).
+ * SSDR_ERR_UNSUPPORTED: a part above max_size that does not split (coincident points: the reference recurses without end). */
+int ssdr_split3_dev(const float* d_xyz, size_t n, size_t max_size, size_t recurse_max_size, size_t merge_max, int32_t* d_part, int32_t* d_order, int64_t* part_offsets,
+                    size_t max_parts, size_t* num_parts, void* stream);
+
 /* ---- tile generator (spatially_regular_gen, S3/s3dis_dataset.py:115-154; data_aug, S3/helper_tool.py:185-199) --
  * From a (sub-sampled) cloud resident on the device — d_points [*,3], d_colors [*,color_dim], live row count
  * *d_m (device int64, as written by ssdr_grid_subsample_dev; n_max bounds it) — take the num_points points nearest

@@ -105,6 +105,7 @@ def lib():
         L.ssdr_grid_subsample_batch_dev.argtypes = [vp, vp, sz, vp, sz, vp, sz, f32, vp, vp, vp, vp, vp]
         L.ssdr_tile_select_batch_dev.argtypes = [vp, vp, i32, vp, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp, vp, vp]
         L.ssdr_tile_select_possibility_dev.argtypes = [vp, vp, i32, vp, sz, vp, sz, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
+        L.ssdr_split3_dev.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp, sz, C.POINTER(sz), vp]
         L.ssdr_chamfer3d_forward_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
         L.ssdr_vote_smooth_dev.argtypes = [vp, vp, vp, sz, i32, f64, vp, vp]
         L.ssdr_confusion_dev.argtypes = [vp, i32, vp, vp, sz, vp, vp, vp, vp]
