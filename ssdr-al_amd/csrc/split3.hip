@@ -18,9 +18,9 @@ namespace {
 constexpr int S3_OPEN_MAX = 64;      // open (splitting) nodes of one level
 
 __device__ __forceinline__ unsigned f2o(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }      // order-preserving
-__host__ __device__ inline float o2f(unsigned o) {
+inline float o2f(unsigned o) {          // (host: the boxes come back as ordered integers)
     const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    float f; memcpy(&f, &u, 4); return f;
+    union { unsigned u; float f; } c; c.u = u; return c.f;
 }
 
 // box[slot][0..3] = min x, max x, min y, max y of the points whose node is open (slot_of[node] >= 0), as ordered integers
