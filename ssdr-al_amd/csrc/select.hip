@@ -1891,6 +1891,45 @@ int ssdr_propagate_dev(const double* d_adj, size_t n, const int32_t* d_rows, con
     return SSDR_OK;
 }
 
+#ifndef HIPEMU
+// Co-operative chains of DIFFERENT streams share the chip: each is sized against the workgroups that can be resident together, so the sum of the
+// grids in flight must stay inside that number too (three selection streams with `--select-lag 2` each launched "half the resident grid": not
+// co-resident -> 0.3 s of polling -> abort).  Every cooperative launch leaves an event; a new one first drops the finished ones from the account
+// and, while the sum would pass the budget, makes its stream wait for the oldest (device-side: the host never blocks).
+struct CoopFlight { hipEvent_t ev; int g; };
+static std::mutex g_coop_mu;
+static std::vector<CoopFlight> g_coop_flights;
+static std::vector<hipEvent_t> g_coop_pool;
+static int coop_admit(hipStream_t s, int g, int budget) {
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    static const int env_budget = [] { const char* e = getenv("SSDR_FPS_COOP_BUDGET"); return e ? atoi(e) : 0; }();      // tests: a budget that forces the serialisation
+    if (env_budget > 0) budget = std::max(env_budget, g);
+    size_t keep = 0; int sum = 0;
+    for (size_t i = 0; i < g_coop_flights.size(); ++i) {
+        if (hipEventQuery(g_coop_flights[i].ev) == hipSuccess) { g_coop_pool.push_back(g_coop_flights[i].ev); continue; }
+        g_coop_flights[keep++] = g_coop_flights[i]; sum += g_coop_flights[i].g;
+    }
+    g_coop_flights.resize(keep);
+    (void)hipGetLastError();          // (hipErrorNotReady of the queries is not an error)
+    while (!g_coop_flights.empty() && sum + g > budget) {
+        SSDR_HIP(hipStreamWaitEvent(s, g_coop_flights.front().ev, 0));
+        sum -= g_coop_flights.front().g;
+        g_coop_pool.push_back(g_coop_flights.front().ev);      // (a recorded event may be re-recorded once nothing new waits on it: the wait above is already enqueued)
+        g_coop_flights.erase(g_coop_flights.begin());
+    }
+    return SSDR_OK;
+}
+static int coop_launched(hipStream_t s, int g) {
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    hipEvent_t ev;
+    if (!g_coop_pool.empty()) { ev = g_coop_pool.back(); g_coop_pool.pop_back(); }
+    else SSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    SSDR_HIP(hipEventRecord(ev, s));
+    g_coop_flights.push_back({ev, g});
+    return SSDR_OK;
+}
+#endif
+
 // d_n (optional): the row count on the device; n is then the bound the launch shapes are chosen by
 static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_already, size_t na, int start, size_t count, int use_sqrt, int32_t* d_out, hipStream_t s,
                     const int* d_n = nullptr) {
@@ -1919,7 +1958,7 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
 #ifndef HIPEMU
     // cooperative kernels (G workgroups that meet at a counter per pick): only above the sizes one workgroup sweeps well (the 160 x 129 / 1000 x 129
     // k-center shapes keep the 1024-thread fps_block), and only with G workgroups the occupancy query says are resident together — checked, not assumed
-    int coop_g = 0; bool coop_reg = false;
+    int coop_g = 0, coop_budget = 0; bool coop_reg = false;
     if (D == 32 && n > 1536 && n <= (size_t)FR_ROWS * (size_t)(ctx().num_cu / 2)) { coop_g = (int)((n + FR_ROWS - 1) / FR_ROWS); coop_reg = true; }
     else if (n > 4096 && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) coop_g = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
     if (coop_g) {
@@ -1933,9 +1972,11 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
             // half of what the query admits: the query is known to answer one block per CU high at some register counts (MI355X_MICROARCH.md), and
             // other chains / stage kernels share the CUs
             if (oe != hipSuccess || (long)per_cu * ctx().num_cu / 2 < coop_g) coop_g = 0;
+            coop_budget = (int)((long)per_cu * ctx().num_cu / 2);
         }
     }
     const bool coop_ok = coop_g > 0;
+    if (coop_ok) SSDR_TRY(coop_admit(s, coop_g, std::max(coop_budget, coop_g)));
     if (coop_ok && !Q.status_init) { SSDR_TRY(Q.status.reserve(64)); SSDR_HIP(hipMemsetAsync(Q.status.p, 0, 64, s)); Q.status_init = true; }
 #else
     const bool coop_ok = false;
@@ -1966,11 +2007,11 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
             std::call_once(once2, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_tag), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * FT_WORDS * 128); });
             hipLaunchKernelGGL(fps_coop_tag, dim3(G), dim3(FR_NT), 4 * 2 * (size_t)G * FT_WORDS, s, a);
             SSDR_HIP(hipGetLastError());
-            return SSDR_OK;
+            return coop_launched(s, G);
         }
         hipLaunchKernelGGL(fps_coop_reg, dim3(G), dim3(FR_NT), 8 * (size_t)G * FR_REC, s, a);
         SSDR_HIP(hipGetLastError());
-        return SSDR_OK;
+        return coop_launched(s, G);
     }
     if (coop_ok) {          // one launch: co-resident workgroups meeting at a counter per pick
         const int G = coop_g;
@@ -1980,7 +2021,7 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>(), d_n};
         hipLaunchKernelGGL(fps_coop, dim3(G), dim3(FC_NT), 0, s, a);
         SSDR_HIP(hipGetLastError());
-        return SSDR_OK;
+        return coop_launched(s, G);
     }
 #endif
     for (size_t it = 0; it < count; ++it) {

@@ -289,3 +289,23 @@ def test_cooperative_fps_reports_a_launch_that_is_not_co_resident():
     assert bad.returncode == 0, bad.stderr[-2000:]
     line = [l for l in bad.stdout.splitlines() if l.startswith("RC")][0].split()
     assert int(line[1]) != 0 and int(line[3]) & 1 and int(line[5]) > 0, bad.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget", ["", "40"])
+def test_cooperative_chains_in_flight_on_several_streams(budget):
+    """Three cooperative chains on three streams enqueued back to back (`--select-lag 2` keeps three global chains in flight): every launch is
+    sized against the co-resident workgroups, so their SUM must fit as well — the library keeps an account of the cooperative grids in
+    flight and makes a launch's stream wait for the oldest ones when it would not (select.hip: coop_admit).  With the default budget and with a
+    budget of one chain's grid (full serialisation, SSDR_FPS_COOP_BUDGET) all three give the reference's sequences and no stream reports an abort."""
+    from conftest import GPU_LIB, _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("SSDR_FPS_COOP_BUDGET", None); env.pop("SSDR_FPS_COOP_G", None)
+    if budget:
+        env["SSDR_FPS_COOP_BUDGET"] = budget
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_fps_coop_multi_worker.py")], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ALL 1" in r.stdout, r.stdout
