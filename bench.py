@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="run the batches strictly one after the other")
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=(0, 2, 3, 4, 5),
                     help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 4 with the exchanges of N > 1")
+    ap.add_argument("--global-batch", type=int, default=0, help="sampling()'s batch_size as ONE number for the job (the reference's 10 000 / 3 000 regions per round, "
+                    "ssdr_main_S3DIS2.py:134) instead of 37 regions per tile: with N ranks the replicated global chain then stays the size of one rank's")
     ap.add_argument("--select-lag", type=int, default=1, help="selections in flight behind the newest one the host waits for (pipeline.Pipelined sel_lag; 1 = the previous batch's)")
     ap.add_argument("--spare-set", action="store_true", help="one more buffer set than batches in flight: no stage is deferred behind the wait for the previous selection (A/B timing)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
@@ -124,6 +126,8 @@ def main():
             num_points = 1024
         tiles_per_gpu, density, hp_kw = 2, 80.0, dict(select_per_tile=5, labeled_per_tile=2)
         args.no_cpu_baseline = True
+    if args.global_batch > 0:
+        hp_kw = dict(hp_kw, batch_size=args.global_batch)
     _lib.check(_lib.lib().ssdr_init(0 if args.emu else local_rank))
 
     weights = synthetic.init_weights(0)         # random-init weights of the reference architecture (helper_tf_util.py:43-48 rule)
@@ -350,7 +354,7 @@ def main():
                                       "dl=0.04 -> tile -> KNN pyramid k=16 [4,4,4,4,2] -> RandLA-Net infer (random-init weights, %s matrix products) -> WetSU/sb/clsbal "
                                       "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, %s)" % (tiles_per_gpu, args.precision, "FPS start fixed to candidate 0" if args.selector == "fps" else "global k-center over candidates + labelled regions"),
                           "tiles_per_gpu": tiles_per_gpu, "tile_points": Cfg.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
-                          "superpoints_per_gpu": int(hp.S), "selected_per_step": int(hp.select_per_tile * tiles_per_gpu * world), "sharding": "tiles",
+                          "superpoints_per_gpu": int(hp.S), "selected_per_step": int(args.global_batch if args.global_batch > 0 else hp.select_per_tile * tiles_per_gpu * world), "sharding": "tiles",
                           "selection_rule": (getattr(pipe.hp[0], "rule_path", None) if pipe is not None else None) or getattr(hp, "rule_path", None),
                           **({"emulated_world": int(os.environ["SSDR_EMULATE_WORLD"])} if os.environ.get("SSDR_EMULATE_WORLD") else {}),
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,

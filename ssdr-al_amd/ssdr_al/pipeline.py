@@ -284,7 +284,9 @@ class HotPath:
         Bmax = int(S_all[:, 1].max())
         gcloud = (cloud + (np.arange(W)[:, None] * Bmax)).reshape(-1)                                 # global cloud index, rank-major
         gcloud[cloud.reshape(-1) < 0] = -1
-        batch = self.select_per_tile * int(S_all[:, 1].sum())
+        # sampling()'s batch_size is ONE number for the whole round (ssdr_main_S3DIS2.py:134: 10 000 regions whatever the number of clouds): with
+        # batch_size set it stays that, however many ranks share the clouds; the default grows it with the tiles (select_per_tile each)
+        batch = self.batch_size if self.batch_size is not None else self.select_per_tile * int(S_all[:, 1].sum())
         # the device-side rule of the sharded run (ssdr_gcn_fps_sharded_local_dev): global labelled mask (padding = labelled), where every global cloud's
         # regions start, and the capacities the static tables bound
         base_l = np.concatenate([np.asarray(self.sp_base, np.int64), np.full(Bmax + 1 - self.B, self.S, np.int64)])      # local, padded to Bmax + 1 entries
