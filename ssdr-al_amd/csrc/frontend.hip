@@ -259,10 +259,14 @@ struct FeRedArgs {
     uint4* rec; unsigned* nocc; unsigned* trow; unsigned char* lrc; int fdim, ldim;
 };
 
+// IMG: the bucket's (or slice's) records are also kept in LDS and the ordered walk reads them there — 51 KB per workgroup, three workgroups per CU.
+// !IMG: the walk reads the records where the scatter left them (the workgroup has just streamed them: L2) and the rows go to the overflow region —
+// 19 KB per workgroup, the occupancy is the registers'.
+template <bool IMG>
 struct FeRedLds {
-    uint4 rec[FE_CAP * 2];                 // the records of the bucket (or slice), in arrival order
+    uint4 rec[IMG ? FE_CAP * 2 : 1];       // IMG: the records of the bucket (or slice), in arrival order
     unsigned midx[FE_CAP];                 // per voxel segment: the members' indices, in arrival order
-    unsigned short perm[FE_CAP];           // per voxel segment: the members' positions in `rec`, by ascending index (input order)
+    unsigned short perm[FE_CAP];           // per voxel segment: the members' positions in `rec` (IMG) / among the bucket's records (!IMG), by ascending index (input order)
     unsigned cnt[FE_VMAX + 1];             // histogram, then start of every voxel's segment
     union {
         unsigned fill[FE_VMAX];            // slices: members of a voxel seen so far (while a slice's records arrive)
@@ -291,8 +295,8 @@ __device__ __attribute__((noinline)) int fe_label_exact(const uint32_t* W, const
 // reference's vote takes the first maximum in the iteration order of its unordered_map<int,int>, which for labels in [0,13) is "first
 // seen last" (voxel_label.hpp).  Labels outside [0,13) or more than 255 members: noted in L.slow, settled by a second pass.
 // s0 = start of the slice's first segment.  FD / LD >= 0: row layout known at compile time.
-template <int FD, int LD>
-__device__ __forceinline__ void fe_reduce_voxels(FeRedLds& L, const FeRedArgs& a, int* status, int o_begin, int o_end, unsigned s0, uint4* rows) {
+template <int FD, int LD, bool IMG>
+__device__ __forceinline__ void fe_reduce_voxels(FeRedLds<IMG>& L, const FeRedArgs& a, int* status, int o_begin, int o_end, unsigned s0, uint4* rows, const uint4* __restrict__ Rg) {
     const int fdim = FD >= 0 ? FD : a.fdim, ldim = LD >= 0 ? LD : a.ldim;
     const int half = (int)threadIdx.x & 1;
     for (int o = o_begin + ((int)threadIdx.x >> 1); o < o_end; o += FE_RNT / 2) {
@@ -307,7 +311,7 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds& L, const FeRedArgs& a
 #pragma unroll
             for (int h = 0; h < 4; ++h) p[h] = L.perm[min(j + h, e - 1)];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) w[h] = L.rec[2 * p[h] + half];
+            for (int h = 0; h < 4; ++h) w[h] = IMG ? L.rec[2 * p[h] + half] : Rg[2 * (size_t)p[h] + half];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 if (j + h < e) {
@@ -356,7 +360,7 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds& L, const FeRedArgs& a
     }
     __syncthreads();
     if (L.nslow) {
-        const uint32_t* W = reinterpret_cast<const uint32_t*>(L.rec);
+        const uint32_t* W = IMG ? reinterpret_cast<const uint32_t*>(L.rec) : reinterpret_cast<const uint32_t*>(Rg);
         for (int t = (int)threadIdx.x; t < L.nslow; t += FE_RNT) {
             const int o = o_begin + (L.slow[t] & 1023), hf = (L.slow[t] >> 10) & 1;
             const unsigned mask = L.slow[t] >> 11;
@@ -369,7 +373,8 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds& L, const FeRedArgs& a
 }
 
 // segment starts, the occupied voxels and their ranks from the histogram in L.cnt (V = 512 or 1024 voxels)
-__device__ __forceinline__ void fe_segments(FeRedLds& L, int V) {
+template <bool IMG>
+__device__ __forceinline__ void fe_segments(FeRedLds<IMG>& L, int V) {
     const int tid = threadIdx.x, E = V / FE_RNT;           // 2 or 4 voxels per thread
     unsigned c4[4]; unsigned tot = 0, occ = 0;
 #pragma unroll
@@ -396,9 +401,12 @@ __device__ __forceinline__ void fe_segments(FeRedLds& L, int V) {
 // One workgroup per bucket (work items dealt round robin).  A bucket of at most FE_CAP records is read once: its records go to LDS as they
 // arrive, with the voxel histogram's returning atomics handing every record its arrival slot inside its voxel.  A larger bucket is cut into
 // slices of consecutive voxels (at most FE_CAP records each) after a histogram pass, and read again once per slice.
-template <int FD, int LD>
-__global__ __launch_bounds__(FE_RNT) void fe_reduce(FeRedArgs a) {
-    __shared__ FeRedLds L;
+#ifndef FE_RED_WAVES
+#define FE_RED_WAVES 4          // waves per SIMD asked of the no-image variant (A/B builds: -DFE_RED_WAVES=5 / 6 spill 24 / 36 dwords)
+#endif
+template <int FD, int LD, bool IMG>
+__global__ __launch_bounds__(FE_RNT) SSDR_WAVES_PER_EU(IMG ? 3 : FE_RED_WAVES) void fe_reduce(FeRedArgs a) {
+    __shared__ FeRedLds<IMG> L;
     const int tid = threadIdx.x;
 #ifdef SSDR_FE_STAMPS
     long long t_last = clock64(); unsigned long long t_acc[5] = {0, 0, 0, 0, 0};
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(FE_RNT) void fe_reduce(FeRedArgs a) {
                 const int p = tid + k * FE_RNT;
                 vv[k] = fe_vid(it, __uint_as_float(r0[k].x), __uint_as_float(r0[k].y), __uint_as_float(r0[k].z));
                 ix[k] = r1[k].w;
-                if (p < n) { uu[k] = atomicAdd(&L.cnt[vv[k]], 1u); L.rec[2 * p] = r0[k]; L.rec[2 * p + 1] = r1[k]; }
+                if (p < n) { uu[k] = atomicAdd(&L.cnt[vv[k]], 1u); if (IMG) { L.rec[2 * p] = r0[k]; L.rec[2 * p + 1] = r1[k]; } }
             }
         } else {
             for (int p0 = 0; p0 < n; p0 += FE_CAP) {
@@ -458,11 +466,14 @@ __global__ __launch_bounds__(FE_RNT) void fe_reduce(FeRedArgs a) {
         }
         if (tid == 0) {
             if (fast) { L.nslice = 1; L.slice[0] = 0; L.slice[1] = (unsigned short)V; }
-            else {
-                // ... unless the bucket is cut into slices that are read again: its rows then go to the overflow region behind the records
+            if (!fast || !IMG) {
+                // ... unless the bucket is cut into slices that are read again (or the walk reads the records in place): its rows then go to the
+                // overflow region behind the records
                 const unsigned at = (unsigned)atomicAdd(&a.counters[3], nocc);
                 L.ovf = at + (unsigned)nocc <= (unsigned)a.t.ovf_cap ? at : 0xffffffffu;
                 if (L.ovf == 0xffffffffu) L.bad = 1;
+            }
+            if (!fast) {
                 int ns = 0, v = 0; L.slice[0] = 0;
                 while (v < V && ns < FE_SLICES) {
                     const unsigned s0 = L.cnt[v]; int w = v;
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(FE_RNT) void fe_reduce(FeRedArgs a) {
             }
             __syncthreads();
         }
-        if (!fast && !L.bad) rows = a.rec + 2 * ((size_t)a.t.n_total + L.ovf);
+        if ((!fast || !IMG) && !L.bad) rows = a.rec + 2 * ((size_t)a.t.n_total + L.ovf);
         const size_t tb = (size_t)r * FE_NBMAX + b;
         if (L.bad) {           // a voxel of more than FE_CAP points (or more slices / overflow rows than there is room for): not this entry point's case
             if (tid == 0) { atomicOr(&prm->status, 4); a.nocc[tb] = 0u; a.trow[tb] = 0u; }
@@ -515,8 +526,9 @@ __global__ __launch_bounds__(FE_RNT) void fe_reduce(FeRedArgs a) {
                         for (int k = 0; k < FE_RPT; ++k) {
                             const int v = fe_vid(it, __uint_as_float(q0[k].x), __uint_as_float(q0[k].y), __uint_as_float(q0[k].z));
                             if (p0 + tid + k * FE_RNT < n && v >= v0 && v < v1) {
-                                const int q = atomicAdd(&L.nq, 1);
-                                L.rec[2 * q] = q0[k]; L.rec[2 * q + 1] = q1[k];
+                                int q;
+                                if (IMG) { q = atomicAdd(&L.nq, 1); L.rec[2 * q] = q0[k]; L.rec[2 * q + 1] = q1[k]; }
+                                else q = p0 + tid + k * FE_RNT;          // the record's place among the bucket's own (<= FE_SLICES * FE_CAP < 65536)
                                 // (index, position) pairs of a voxel, in arrival order: midx holds the indices, perm the positions until the ranks are known
                                 const unsigned at = L.cnt[v] - s0 + atomicAdd(&L.fill[v], 1u);
                                 L.midx[at] = q1[k].w; L.perm[at] = (unsigned short)q;
@@ -539,11 +551,11 @@ __global__ __launch_bounds__(FE_RNT) void fe_reduce(FeRedArgs a) {
                     __syncthreads();
                 }
                 FE_STAMP(2);
-                if (ns > 0) fe_reduce_voxels<FD, LD>(L, a, &prm->status, L.orank[v0], L.orank[v1], s0, rows);
+                if (ns > 0) fe_reduce_voxels<FD, LD, IMG>(L, a, &prm->status, L.orank[v0], L.orank[v1], s0, rows, R);
                 FE_STAMP(3);
             }
             // what the move needs: number of rows, where they are, occupied voxels per local row (y, z)
-            if (tid == 0) { a.nocc[tb] = (unsigned)nocc; a.trow[tb] = fast ? it.base : 0x80000000u | L.ovf; }
+            if (tid == 0) { a.nocc[tb] = (unsigned)nocc; a.trow[tb] = (fast && IMG) ? it.base : 0x80000000u | L.ovf; }
             for (int l = tid; l < FE_LR; l += FE_RNT) a.lrc[tb * FE_LR + l] = (unsigned char)(L.orank[(l + 1) << it.sx] - L.orank[l << it.sx]);
         }
         __syncthreads();
@@ -667,7 +679,13 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     t.off[nr] = (int)room_off[nr];
     t.n_total = (int)room_off[nr];
     t.chunks_max = (maxn + FE_CH - 1) / FE_CH;
-    t.ovf_cap = std::max(65536, t.n_total / 8);
+    // The reduction reads a bucket's records in place (no LDS image: 19 KB instead of 51 KB per workgroup, four workgroups per CU by registers) and every
+    // bucket's rows go to the overflow region, which then holds up to one row per point.  Measured on one box (tools/gpu_fe_ab.sh, round 5): fe_reduce 0.51-0.56
+    // -> 0.45-0.46 ms, front end 1.23-1.26 -> 1.16-1.18 ms, headline 178.2-178.7 -> 180.9-181.8 Mpoints/s; 5 / 6 waves per SIMD (spilling 24 / 36 dwords)
+    // 0.45-0.51 ms.  SSDR_FE_IMAGE=1 keeps the LDS-image kernel (A/B runs).
+    static const bool fe_image = [] { const char* e = getenv("SSDR_FE_IMAGE"); return e && e[0] == '1'; }();
+    static const int fe_wgs = [] { const char* e = getenv("SSDR_FE_WGS"); return e ? atoi(e) : 0; }();
+    t.ovf_cap = fe_image ? std::max(65536, t.n_total / 8) : t.n_total;
     const unsigned R = (unsigned)nr;
     SSDR_TRY(S.partial.reserve(24 * (size_t)PB * nr)); SSDR_TRY(S.geom.reserve(sizeof(FeGeom) * nr)); SSDR_TRY(S.counters.reserve(256));
     SSDR_TRY(S.cntm.reserve(4 * (size_t)FE_NBMAX * t.chunks_max * nr)); SSDR_TRY(S.tot.reserve(4 * (size_t)FE_NBMAX * nr)); SSDR_TRY(S.boff.reserve(4 * (size_t)(FE_NBMAX + 1) * nr));
@@ -704,8 +722,12 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     ra.nocc = S.nocc.as<unsigned>(); ra.trow = S.trow.as<unsigned>(); ra.lrc = S.lrc.as<unsigned char>(); ra.fdim = (int)fdim; ra.ldim = (int)ldim;
     {
     ProfScope prof("fe_reduce", s, 0.0);
-    if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1>), dim3(ctx().num_cu * 3), dim3(FE_RNT), 0, s, ra);        // the hot path's rows
-    else hipLaunchKernelGGL((fe_reduce<-1, -1>), dim3(ctx().num_cu * 3), dim3(FE_RNT), 0, s, ra);
+    if (!fe_image) {
+        const int g = ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 2 * FE_RED_WAVES);          // (twice the resident workgroups: the items are dealt round robin and differ in size)
+        if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, false>), dim3(g), dim3(FE_RNT), 0, s, ra);
+        else hipLaunchKernelGGL((fe_reduce<-1, -1, false>), dim3(g), dim3(FE_RNT), 0, s, ra);
+    } else if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, true>), dim3(ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 3)), dim3(FE_RNT), 0, s, ra);        // the hot path's rows
+    else hipLaunchKernelGGL((fe_reduce<-1, -1, true>), dim3(ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 3)), dim3(FE_RNT), 0, s, ra);
     }
     ProfScope prof_move("fe_rows_move", s, 0.0);
     hipLaunchKernelGGL(fe_rowpre, dim3(256, R), dim3(BS), 0, s, geom, S.boff.as<unsigned>(), S.lrc.as<unsigned char>(), S.pre.as<unsigned short>(), S.rowcnt.as<unsigned>());
