@@ -41,7 +41,11 @@ constexpr int FE_PPT = 12, FE_SNT = 1024;      // points per thread and step of 
                                               // 512 threads x 24 the same, x 32 = the whole chunk in one step spills: 0.37)
 constexpr int FE_LR = 64;            // local rows (y, z) of a bucket: 8 x 8
 constexpr int FE_VMAX = 1024;        // voxels per bucket (sx <= 4)
-constexpr int FE_RNT = 256;          // workgroup size of the reduction
+#ifndef FE_RNT_OPT
+#define FE_RNT_OPT 128
+#endif
+constexpr int FE_RNT = FE_RNT_OPT;   // workgroup size of the reduction: 128 threads with eight records each (two waves per barrier; 256 threads: front end 1.154-1.161 against
+                                     // 1.106-1.110 ms on one box, tools/gpu_fe_ab2.sh; 512 threads were 13 % slower in round 4; 64 threads leave two waves per SIMD by LDS)
 constexpr int FE_CAP = 1024;         // records of a bucket (or of a slice of it) the reduction holds in LDS
 constexpr int FE_RPT = FE_CAP / FE_RNT;
 constexpr int FE_SLICES = 62;        // slices of a bucket with more than FE_CAP records
@@ -375,15 +379,16 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds<IMG>& L, const FeRedAr
 // segment starts, the occupied voxels and their ranks from the histogram in L.cnt (V = 512 or 1024 voxels)
 template <bool IMG>
 __device__ __forceinline__ void fe_segments(FeRedLds<IMG>& L, int V) {
-    const int tid = threadIdx.x, E = V / FE_RNT;           // 2 or 4 voxels per thread
-    unsigned c4[4]; unsigned tot = 0, occ = 0;
+    constexpr int EM = FE_VMAX / FE_RNT;
+    const int tid = threadIdx.x, E = V / FE_RNT;           // 2 or 4 voxels per thread (256 threads)
+    unsigned c4[EM]; unsigned tot = 0, occ = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { c4[k] = k < E ? L.cnt[tid * E + k] : 0u; tot += c4[k]; occ += c4[k] ? 1u : 0u; if (c4[k] > (unsigned)FE_CAP) L.bad = 1; }
+    for (int k = 0; k < EM; ++k) { c4[k] = k < E ? L.cnt[tid * E + k] : 0u; tot += c4[k]; occ += c4[k] ? 1u : 0u; if (c4[k] > (unsigned)FE_CAP) L.bad = 1; }
     unsigned long long total;
     const unsigned long long ex = fe_block_scan(((unsigned long long)tot << 20) | occ, L.sw, FE_RNT, total);
     unsigned st = (unsigned)(ex >> 20), orr = (unsigned)(ex & 0xfffffull);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k < E) {
+    for (int k = 0; k < EM; ++k) if (k < E) {
         const int v = tid * E + k;
         L.cnt[v] = st; L.orank[v] = (unsigned short)orr;
         if (c4[k]) { L.ovid[orr] = (unsigned short)v; ++orr; }
@@ -723,7 +728,7 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     {
     ProfScope prof("fe_reduce", s, 0.0);
     if (!fe_image) {
-        const int g = ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 2 * FE_RED_WAVES);          // (twice the resident workgroups: the items are dealt round robin and differ in size)
+        const int g = ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 2 * FE_RED_WAVES * (256 / FE_RNT));          // (twice the resident workgroups: the items are dealt round robin and differ in size)
         if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, false>), dim3(g), dim3(FE_RNT), 0, s, ra);
         else hipLaunchKernelGGL((fe_reduce<-1, -1, false>), dim3(g), dim3(FE_RNT), 0, s, ra);
     } else if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, true>), dim3(ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 3)), dim3(FE_RNT), 0, s, ra);        // the hot path's rows
