@@ -410,7 +410,7 @@ __device__ __forceinline__ void fe_segments(FeRedLds<IMG>& L, int V) {
 #define FE_RED_WAVES 4          // waves per SIMD asked of the no-image variant (A/B builds: -DFE_RED_WAVES=5 / 6 spill 24 / 36 dwords)
 #endif
 template <int FD, int LD, bool IMG>
-__global__ __launch_bounds__(FE_RNT) SSDR_WAVES_PER_EU(IMG ? 3 : FE_RED_WAVES) void fe_reduce(FeRedArgs a) {
+__global__ __launch_bounds__(FE_RNT) SSDR_WAVES_PER_EU(IMG ? 2 : FE_RED_WAVES) void fe_reduce(FeRedArgs a) {
     __shared__ FeRedLds<IMG> L;
     const int tid = threadIdx.x;
 #ifdef SSDR_FE_STAMPS
