@@ -39,6 +39,9 @@ constexpr int FE_NT = 1024;          // their workgroup size
 constexpr int FE_PPT = 12, FE_SNT = 1024;      // points per thread and step of the scatter, its workgroup size: 12288 points per step leave ~12 records = three
                                               // whole lines in a bucket at a time, and one workgroup per CU halves the lines the L2 has open (PPT 4: 0.51 ms, 8: 0.44, 12: 0.36;
                                               // 512 threads x 24 the same, x 32 = the whole chunk in one step spills: 0.37)
+#ifndef FE_PAIR_STORES
+#define FE_PAIR_STORES 1
+#endif
 constexpr int FE_LR = 64;            // local rows (y, z) of a bucket: 8 x 8
 constexpr int FE_VMAX = 1024;        // voxels per bucket (sx <= 4)
 #ifndef FE_RNT_OPT
@@ -247,12 +250,26 @@ __global__ __launch_bounds__(FE_SNT) void fe_scatter(FeTab t, const float* __res
         for (int k = 0; k < FE_PPT; ++k) {
             const int i = i0 + k * FE_SNT + tid;
             int ix, iy, iz;
-            if (i < hi && fe_voxel(g, cur[k].x, cur[k].y, cur[k].z, ix, iy, iz)) {
-                const unsigned slot = atomicAdd(&s_cur[fe_bucket(g, ix, iy, iz)], 1u);
-                // (non-temporal stores here: 2.6x slower — the L2 merges the two halves of a record, and little else: a chunk adds ~4 records to a bucket)
+            unsigned slot = 0xffffffffu;
+            if (i < hi && fe_voxel(g, cur[k].x, cur[k].y, cur[k].z, ix, iy, iz)) slot = atomicAdd(&s_cur[fe_bucket(g, ix, iy, iz)], 1u);
+            // (non-temporal stores here: 2.6x slower — the L2 merges the two halves of a record, and little else: a chunk adds ~4 records to a bucket)
+#if FE_PAIR_STORES
+            // the two 16-byte halves of a record leave from ADJACENT lanes, so a store instruction carries 32 runs of 32 bytes instead of 64 of 16: lanes
+            // 2j and 2j + 1 swap a half each (the even lane hands over its second half and takes the odd lane's first)
+            const bool odd = tid & 1;
+            const uint32_t a0 = __float_as_uint(cur[k].x), a1 = __float_as_uint(cur[k].y), a2 = __float_as_uint(cur[k].z), a3 = cur[k].w[0];
+            const uint32_t b0 = cur[k].w[1], b1 = cur[k].w[2], b2 = cur[k].w[3], b3 = (uint32_t)i;
+            const uint32_t g0 = __shfl_xor(odd ? a0 : b0, 1), g1 = __shfl_xor(odd ? a1 : b1, 1), g2 = __shfl_xor(odd ? a2 : b2, 1), g3 = __shfl_xor(odd ? a3 : b3, 1);
+            const unsigned pslot = __shfl_xor(slot, 1);
+            const unsigned se = odd ? pslot : slot, so = odd ? slot : pslot;          // the even lane's record, the odd lane's record
+            if (se != 0xffffffffu) R[2 * (size_t)se + (odd ? 1 : 0)] = odd ? make_uint4(g0, g1, g2, g3) : make_uint4(a0, a1, a2, a3);
+            if (so != 0xffffffffu) R[2 * (size_t)so + (odd ? 1 : 0)] = odd ? make_uint4(b0, b1, b2, b3) : make_uint4(g0, g1, g2, g3);
+#else
+            if (slot != 0xffffffffu) {
                 R[2 * (size_t)slot] = make_uint4(__float_as_uint(cur[k].x), __float_as_uint(cur[k].y), __float_as_uint(cur[k].z), cur[k].w[0]);
                 R[2 * (size_t)slot + 1] = make_uint4(cur[k].w[1], cur[k].w[2], cur[k].w[3], (uint32_t)i);
             }
+#endif
         }
     }
 }

@@ -10,9 +10,17 @@ D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p
 def family(name):
     n = re.sub(r"^void ", "", name).replace("ssdr::", "").replace("(anonymous namespace)::", "")
     n = n.split("(")[0]
-    for fam in ("lfa_att_kernel", "lfa_bf16_kernel", "lfa32_", "dense_rows_kernel", "dense_small_kernel", "dense_bf16_kernel", "dense_kernel", "kd_split_kernel", "fps_block_reg", "tail_kernel"):
+    for fam in ("lfa_att_kernel", "lfa_bf16_kernel", "lfa32_", "dense_rows", "dense_small_kernel", "dense_bf16_kernel", "dense_chain_kernel", "dense_kernel", "tail_bf16_kernel", "tail_kernel"):
         if n.startswith(fam):      # bench.py's ProfScope names
-            return "dense_kernel" if fam.startswith("dense_") else ("lfa_att_kernel" if fam.startswith("lfa") else fam)
+            return "dense_kernel" if fam.startswith("dense_") else ("lfa_att_kernel" if fam.startswith("lfa") else ("tail_kernel" if fam.startswith("tail") else fam))
+    # the profiler sites of round 5 (bench.py's roofline.others): one family per site
+    for pre, fam in (("fe_scatter", "fe_scatter"), ("fe_reduce", "fe_reduce"), ("fe_row", "fe_rows_move"), ("fe_move", "fe_rows_move"), ("fe_", "fe_bbox_count_scan"),
+                     ("tile_", "tile_select"), ("sel_chamfer_dir", "sel_chamfer"), ("fps_", "fps_chain"), ("kc_init", "fps_chain"), ("fill_double", "fps_chain"),
+                     ("gather_max", "gather_max_kernel"), ("sel_region_stats", "sel_region_stats"), ("sel_rank", "sel_rank"), ("sel_class_hist", "sel_clsbal"), ("sel_clsbal", "sel_clsbal"),
+                     ("cand_", "sel_candidate_rule"), ("sel_segment_mean", "sel_features_pack"), ("sel_centres", "sel_features_pack"), ("sel_chamfer_", "sel_features_pack"),
+                     ("sel_adj", "sel_adjacency_propagate"), ("sel_propagate", "sel_adjacency_propagate"), ("kd_", "knn_tree_handover")):
+        if n.startswith(pre):
+            return fam
     m = re.match(r"grid_(search|retry)_kernel<(\d+)", n)
     if m:
         return "knn_grid_search<%s>" % m.group(2)
@@ -59,7 +67,9 @@ for k in sorted(set(f) | set(w), key=lambda k: -(2 * f[k][1] + w[k][1])):
             out["kernels"][k]["grbm_gui_active"] = int(MFMA[k][2])
             out["kernels"][k]["mfma_utilisation"] = round(MFMA[k][0] / (1024.0 * MFMA[k][2] / 8.0), 4)
 # HBM bytes of ONE step: every kernel family's bytes per launch x its launches per step (a step = one selection: the FPS kernel runs once)
-steps = max([v[0] for k, v in f.items() if k.startswith("fps_block") or k.startswith("fps_coop") or k.startswith("fps_step")] + [1])
+# steps in the pass = launches of the FPS kernel proper (one per selection), counted on the kernel's own name
+steps = max(1, sum(1 for r in csv.DictReader(open(os.path.join(D, "%s_pmc_fetch_size.csv" % R)))
+                   if re.sub(r"^void ", "", r["Kernel_Name"]).replace("ssdr::", "").replace("(anonymous namespace)::", "").startswith(("fps_block", "fps_coop", "fps_step"))))
 out["steps_in_pass"] = steps
 out["step_hbm_bytes"] = int(sum(out["kernels"][k]["hbm_bytes_per_launch"] * max(1, round(out["kernels"][k]["launches"] / steps)) for k in out["kernels"]
                                 if not k.startswith("__amd_rocclr")))
