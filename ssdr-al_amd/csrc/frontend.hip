@@ -212,6 +212,14 @@ __global__ __launch_bounds__(FE_NT) void fe_bscan(FeTab t, const FeGeom* __restr
 // together).  The kernel runs at the rate the memory system takes scattered 32-byte writes: what helps is more records per bucket and step (lines
 // complete before the L2 drops them); issuing a step's loads ahead of the previous step's stores changed nothing.  FD / LD >= 0: row layout known at compile time (straight-line loads).
 struct FePoint { float x, y, z; uint32_t w[4]; };
+// the value of lane ^ 1: a DPP move (quad_perm [1,0,3,2]) instead of a trip through the LDS crossbar, which the cursors' atomics already use
+__device__ __forceinline__ uint32_t fe_swap1(uint32_t v) {
+#ifndef HIPEMU
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+#else
+    return (uint32_t)__shfl_xor((int)v, 1);
+#endif
+}
 template <int FD, int LD>
 __device__ __forceinline__ FePoint fe_load_point(const float* __restrict__ Pr, const float* __restrict__ Fr, const int* __restrict__ Cr, int fdim, int ldim, int i) {
     FePoint pt;
@@ -259,8 +267,8 @@ __global__ __launch_bounds__(FE_SNT) void fe_scatter(FeTab t, const float* __res
             const bool odd = tid & 1;
             const uint32_t a0 = __float_as_uint(cur[k].x), a1 = __float_as_uint(cur[k].y), a2 = __float_as_uint(cur[k].z), a3 = cur[k].w[0];
             const uint32_t b0 = cur[k].w[1], b1 = cur[k].w[2], b2 = cur[k].w[3], b3 = (uint32_t)i;
-            const uint32_t g0 = __shfl_xor(odd ? a0 : b0, 1), g1 = __shfl_xor(odd ? a1 : b1, 1), g2 = __shfl_xor(odd ? a2 : b2, 1), g3 = __shfl_xor(odd ? a3 : b3, 1);
-            const unsigned pslot = __shfl_xor(slot, 1);
+            const uint32_t g0 = fe_swap1(odd ? a0 : b0), g1 = fe_swap1(odd ? a1 : b1), g2 = fe_swap1(odd ? a2 : b2), g3 = fe_swap1(odd ? a3 : b3);
+            const unsigned pslot = fe_swap1(slot);
             const unsigned se = odd ? pslot : slot, so = odd ? slot : pslot;          // the even lane's record, the odd lane's record
             if (se != 0xffffffffu) R[2 * (size_t)se + (odd ? 1 : 0)] = odd ? make_uint4(g0, g1, g2, g3) : make_uint4(a0, a1, a2, a3);
             if (so != 0xffffffffu) R[2 * (size_t)so + (odd ? 1 : 0)] = odd ? make_uint4(b0, b1, b2, b3) : make_uint4(g0, g1, g2, g3);
