@@ -14,7 +14,7 @@
 //                     [chunk][bucket] table
 //   colscan / bscan   column prefix over the chunks and prefix over the buckets -> where each chunk's points of each bucket go; one
 //                     work item per non-empty bucket
-//   scatter           second read of the points: 32-byte records (xyz, features, label, index in the cloud) written behind LDS cursors,
+//   scatter           second read of the points: 32-byte records (xyz, index in the cloud | features, labels) written behind LDS cursors,
 //                     a bucket's records contiguous (order inside a bucket is whatever the LDS atomics give: the index travels)
 //   reduce            one workgroup per bucket: records -> LDS, LDS histogram over the bucket's <= 1024 voxels, every voxel's members
 //                     ranked by their index (input order), sequential sums, label vote; the bucket's rows (32 bytes: row + voxel id) go
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(FE_SNT) void fe_scatter(FeTab t, const float* __res
             // the two 16-byte halves of a record leave from ADJACENT lanes, so a store instruction carries 32 runs of 32 bytes instead of 64 of 16: lanes
             // 2j and 2j + 1 swap a half each (the even lane hands over its second half and takes the odd lane's first)
             const bool odd = tid & 1;
-            const uint32_t a0 = __float_as_uint(cur[k].x), a1 = __float_as_uint(cur[k].y), a2 = __float_as_uint(cur[k].z), a3 = cur[k].w[0];
-            const uint32_t b0 = cur[k].w[1], b1 = cur[k].w[2], b2 = cur[k].w[3], b3 = (uint32_t)i;
+            const uint32_t a0 = __float_as_uint(cur[k].x), a1 = __float_as_uint(cur[k].y), a2 = __float_as_uint(cur[k].z), a3 = (uint32_t)i;
+            const uint32_t b0 = cur[k].w[0], b1 = cur[k].w[1], b2 = cur[k].w[2], b3 = cur[k].w[3];
             const uint32_t g0 = fe_swap1(odd ? a0 : b0), g1 = fe_swap1(odd ? a1 : b1), g2 = fe_swap1(odd ? a2 : b2), g3 = fe_swap1(odd ? a3 : b3);
             const unsigned pslot = fe_swap1(slot);
             const unsigned se = odd ? pslot : slot, so = odd ? slot : pslot;          // the even lane's record, the odd lane's record
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(FE_SNT) void fe_scatter(FeTab t, const float* __res
             if (so != 0xffffffffu) R[2 * (size_t)so + (odd ? 1 : 0)] = odd ? make_uint4(b0, b1, b2, b3) : make_uint4(g0, g1, g2, g3);
 #else
             if (slot != 0xffffffffu) {
-                R[2 * (size_t)slot] = make_uint4(__float_as_uint(cur[k].x), __float_as_uint(cur[k].y), __float_as_uint(cur[k].z), cur[k].w[0]);
-                R[2 * (size_t)slot + 1] = make_uint4(cur[k].w[1], cur[k].w[2], cur[k].w[3], (uint32_t)i);
+                R[2 * (size_t)slot] = make_uint4(__float_as_uint(cur[k].x), __float_as_uint(cur[k].y), __float_as_uint(cur[k].z), (uint32_t)i);
+                R[2 * (size_t)slot + 1] = make_uint4(cur[k].w[0], cur[k].w[1], cur[k].w[2], cur[k].w[3]);
             }
 #endif
         }
@@ -318,7 +318,7 @@ __device__ __attribute__((noinline)) int fe_label_exact(const uint32_t* W, const
 }
 
 // Rows o_begin .. o_end - 1 of the bucket.  TWO lanes per occupied voxel walk its members in input order (L.perm), 16 bytes per member and
-// lane: the even lane owns words 0..3 of the row (x, y, z, w0), the odd lane words 4..6 (w1, w2, w3) and the voxel id.  Sums are taken
+// lane: the even lane owns words 0..3 of the row (x, y, z and the voxel id in place of the record's index), the odd lane words 4..7 (features, labels).  Sums are taken
 // sequentially in that order (what makes them the reference's, grid_subsampling.cpp:59-70); a label word is voted on with packed byte
 // counters (labels 0..15; pk0: 0..7, pk1: 8..15) and the step at which a label is first seen kept the same way (fp0 / fp1): the
 // reference's vote takes the first maximum in the iteration order of its unordered_map<int,int>, which for labels in [0,13) is "first
@@ -347,10 +347,9 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds<IMG>& L, const FeRedAr
                     const uint32_t ww[4] = {w[h].x, w[h].y, w[h].z, w[h].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        // row word half * 4 + q: words 0..2 positions, 3..3+fdim-1 features, then ldim labels; word 7 is the index (no sum)
-                        const int word = half * 4 + q;
-                        const bool is_sum = word < 3 + fdim, is_lab = !is_sum && word < 3 + fdim + ldim;
-                        if (FD >= 0 ? ((q < 3 && half == 0) || is_sum) : is_sum) f[q] += __uint_as_float(ww[q]);
+                        // record word half * 4 + q: words 0..2 positions, word 3 the index (no sum); words 4.. the fdim features, then the ldim labels
+                        const bool is_sum = half == 0 ? q < 3 : q < fdim, is_lab = half == 1 && q >= fdim && q < fdim + ldim;
+                        if (is_sum) f[q] += __uint_as_float(ww[q]);
                         else if (is_lab) {
                             const unsigned Lb = ww[q], sh = (Lb & 7u) * 8u;
                             big |= Lb >= 13u;
@@ -369,10 +368,9 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds<IMG>& L, const FeRedAr
         unsigned slow = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int word = half * 4 + q;
-            if (word < 3) out[q] = __float_as_uint(f[q] * rc);
-            else if (word < 3 + fdim) out[q] = __float_as_uint(f[q] / (float)count);          // :90-94
-            else if (word < 3 + fdim + ldim) {
+            if (half == 0) out[q] = q < 3 ? __float_as_uint(f[q] * rc) : (uint32_t)v;          // the row: (x, y, z, voxel id | features, labels)
+            else if (q < fdim) out[q] = __float_as_uint(f[q] / (float)count);          // :90-94
+            else if (q < fdim + ldim) {
                 int best = 0, bestc = -1, bestf = -1;          // largest count; among equals the label first seen last
 #pragma unroll
                 for (int l = 0; l < 13; ++l) {
@@ -382,7 +380,7 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds<IMG>& L, const FeRedAr
                 }
                 if (big || count > 255) slow |= 1u << q;          // labels outside [0,13) or byte counters too small: the exact routines
                 out[q] = (uint32_t)best;
-            } else if (word == 7) out[q] = (uint32_t)v;
+            }
         }
         if (slow) L.slow[atomicAdd(&L.nslow, 1)] = (unsigned short)((o - o_begin) | (half << 10) | (slow << 11));
         rows[2 * (size_t)o + half] = make_uint4(out[0], out[1], out[2], out[3]);
@@ -458,15 +456,16 @@ __global__ __launch_bounds__(FE_RNT) SSDR_WAVES_PER_EU(IMG ? 2 : FE_RED_WAVES) v
 #pragma unroll
         for (int k = 0; k < FE_RPT; ++k) { vv[k] = 0; uu[k] = 0u; ix[k] = 0u; }
         if (fast) {
-            uint4 r0[FE_RPT], r1[FE_RPT];
+            // (x, y, z, index) is the FIRST half of a record: without the LDS image this pass reads 16 of its 32 bytes
+            uint4 r0[FE_RPT], r1[IMG ? FE_RPT : 1];
 #pragma unroll
-            for (int k = 0; k < FE_RPT; ++k) { const size_t p = (size_t)min(tid + k * FE_RNT, n - 1); r0[k] = R[2 * p]; r1[k] = R[2 * p + 1]; }
+            for (int k = 0; k < FE_RPT; ++k) { const size_t p = (size_t)min(tid + k * FE_RNT, n - 1); r0[k] = R[2 * p]; if (IMG) r1[k] = R[2 * p + 1]; }
 #pragma unroll
             for (int k = 0; k < FE_RPT; ++k) {
                 const int p = tid + k * FE_RNT;
                 vv[k] = fe_vid(it, __uint_as_float(r0[k].x), __uint_as_float(r0[k].y), __uint_as_float(r0[k].z));
-                ix[k] = r1[k].w;
-                if (p < n) { uu[k] = atomicAdd(&L.cnt[vv[k]], 1u); if (IMG) { L.rec[2 * p] = r0[k]; L.rec[2 * p + 1] = r1[k]; } }
+                ix[k] = r0[k].w;
+                if (p < n) { uu[k] = atomicAdd(&L.cnt[vv[k]], 1u); if (IMG) { L.rec[2 * p] = r0[k]; L.rec[2 * p + 1] = r1[IMG ? k : 0]; } }
             }
         } else {
             for (int p0 = 0; p0 < n; p0 += FE_CAP) {
@@ -549,19 +548,19 @@ __global__ __launch_bounds__(FE_RNT) SSDR_WAVES_PER_EU(IMG ? 2 : FE_RED_WAVES) v
                     for (int v = v0 + tid; v < v1; v += FE_RNT) L.fill[v] = 0u;
                     __syncthreads();
                     for (int p0 = 0; p0 < n; p0 += FE_CAP) {
-                        uint4 q0[FE_RPT], q1[FE_RPT];
+                        uint4 q0[FE_RPT], q1[IMG ? FE_RPT : 1];
 #pragma unroll
-                        for (int k = 0; k < FE_RPT; ++k) { const size_t p = (size_t)min(p0 + tid + k * FE_RNT, n - 1); q0[k] = R[2 * p]; q1[k] = R[2 * p + 1]; }
+                        for (int k = 0; k < FE_RPT; ++k) { const size_t p = (size_t)min(p0 + tid + k * FE_RNT, n - 1); q0[k] = R[2 * p]; if (IMG) q1[k] = R[2 * p + 1]; }
 #pragma unroll
                         for (int k = 0; k < FE_RPT; ++k) {
                             const int v = fe_vid(it, __uint_as_float(q0[k].x), __uint_as_float(q0[k].y), __uint_as_float(q0[k].z));
                             if (p0 + tid + k * FE_RNT < n && v >= v0 && v < v1) {
                                 int q;
-                                if (IMG) { q = atomicAdd(&L.nq, 1); L.rec[2 * q] = q0[k]; L.rec[2 * q + 1] = q1[k]; }
+                                if (IMG) { q = atomicAdd(&L.nq, 1); L.rec[2 * q] = q0[k]; L.rec[2 * q + 1] = q1[IMG ? k : 0]; }
                                 else q = p0 + tid + k * FE_RNT;          // the record's place among the bucket's own (<= FE_SLICES * FE_CAP < 65536)
                                 // (index, position) pairs of a voxel, in arrival order: midx holds the indices, perm the positions until the ranks are known
                                 const unsigned at = L.cnt[v] - s0 + atomicAdd(&L.fill[v], 1u);
-                                L.midx[at] = q1[k].w; L.perm[at] = (unsigned short)q;
+                                L.midx[at] = q0[k].w; L.perm[at] = (unsigned short)q;
                             }
                         }
                     }
@@ -672,13 +671,13 @@ __global__ __launch_bounds__(BS) void fe_move(FeMoveArgs a) {
             const bool on = j < nocc;
             uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
             if (on) { r0 = rows[2 * (size_t)j]; r1 = rows[2 * (size_t)j + 1]; }
-            const int l = on ? (int)(r1.w >> g.sx) : 0;
+            const int l = on ? (int)(r0.w >> g.sx) : 0;
             const unsigned lp = __shfl(lpre, l);
             if (on) {
                 const int iy = by * 8 + (l & 7), iz = bz * 8 + (l >> 3);
                 const size_t fin = o + rb[iy + g.nby * 8 * iz] + pre[l] + ((unsigned)j - lp);
                 a.out_p[3 * fin] = __uint_as_float(r0.x); a.out_p[3 * fin + 1] = __uint_as_float(r0.y); a.out_p[3 * fin + 2] = __uint_as_float(r0.z);
-                const uint32_t w[4] = {r0.w, r1.x, r1.y, r1.z};
+                const uint32_t w[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k < a.fdim) a.out_f[fin * a.fdim + k] = __uint_as_float(w[k]);
@@ -715,6 +714,7 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     // 0.45-0.51 ms.  SSDR_FE_IMAGE=1 keeps the LDS-image kernel (A/B runs).
     static const bool fe_image = [] { const char* e = getenv("SSDR_FE_IMAGE"); return e && e[0] == '1'; }();
     static const int fe_wgs = [] { const char* e = getenv("SSDR_FE_WGS"); return e ? atoi(e) : 0; }();
+    static const int fe_pad = [] { const char* e = getenv("SSDR_FE_PADLDS"); return e ? atoi(e) : 0; }();      // (development: unused dynamic LDS caps the workgroups per CU)
     t.ovf_cap = fe_image ? std::max(65536, t.n_total / 8) : t.n_total;
     const unsigned R = (unsigned)nr;
     SSDR_TRY(S.partial.reserve(24 * (size_t)PB * nr)); SSDR_TRY(S.geom.reserve(sizeof(FeGeom) * nr)); SSDR_TRY(S.counters.reserve(256));
@@ -754,8 +754,8 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     ProfScope prof("fe_reduce", s, 0.0);
     if (!fe_image) {
         const int g = ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 2 * FE_RED_WAVES * (256 / FE_RNT));          // (twice the resident workgroups: the items are dealt round robin and differ in size)
-        if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, false>), dim3(g), dim3(FE_RNT), 0, s, ra);
-        else hipLaunchKernelGGL((fe_reduce<-1, -1, false>), dim3(g), dim3(FE_RNT), 0, s, ra);
+        if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, false>), dim3(g), dim3(FE_RNT), (size_t)fe_pad, s, ra);
+        else hipLaunchKernelGGL((fe_reduce<-1, -1, false>), dim3(g), dim3(FE_RNT), (size_t)fe_pad, s, ra);
     } else if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, true>), dim3(ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 3)), dim3(FE_RNT), 0, s, ra);        // the hot path's rows
     else hipLaunchKernelGGL((fe_reduce<-1, -1, true>), dim3(ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 3)), dim3(FE_RNT), 0, s, ra);
     }
