@@ -64,7 +64,7 @@ def labelled_selection(clouds, labelled, class_num, round_num, random_state):
 
 
 def selection_round(clouds, labelled, selected_class_list, class_num, sampler_args, min_size, round_num, batch_size, gcn_number, gcn_top,
-                    start, random_state, selector="fps"):
+                    start, random_state, selector="fps", max_size=None):
     """TSampler.sampling, gcn_fps branch (sampler2.py:736-781), over in-memory clouds instead of files.  clouds[b] = dict(xyz [n,3] f32,
     gt [n] int, probs [n,C] f32, feat [n,32] f32, offsets [S+1], points [T]); labelled[b] = ids of the regions NOT in total_obj["unlabeled"].
 
@@ -86,7 +86,7 @@ def selection_round(clouds, labelled, selected_class_list, class_num, sampler_ar
         off, pts = cl["offsets"], cl["points"]
         for s in range(len(off) - 1):
             ids = pts[off[s]:off[s + 1]]
-            if len(ids) < min_size:
+            if len(ids) < min_size or (max_size is not None and len(ids) > max_size):      # (the Semantic3D flavour: len <= 1000, S3D/sampler2.py:644, :655)
                 continue
             if s in labelled[b]:
                 lab_ge[b].append(s)
@@ -176,7 +176,7 @@ def run(hp, rooms, weights, threads=1, net_outputs=None, stop_after=None):
         clouds.append(dict(xyz=xyz0[b], gt=labels[b], probs=probs[b * N:(b + 1) * N], feat=f32[b * N:(b + 1) * N], offsets=off, points=pts))
         labelled.append(set(int(s) - lo for s in hp.labeled.get(b, ())))
     r = selection_round(clouds, labelled, hp.selected_class_list.to_host(), cfg.num_classes, hp.sampler_args, hp.min_size, hp.round_num,
-                        hp._sel_static["batch"], hp.gcn_number, hp.gcn_top, 0, np.random.RandomState(hp.label_seed), getattr(hp, "selector", "fps"))
+                        hp._sel_static["batch"], hp.gcn_number, hp.gcn_top, 0, np.random.RandomState(hp.label_seed), getattr(hp, "selector", "fps"), getattr(hp, "max_size", None))
     t += [r["t_rank"], time.perf_counter()]
     um = [a for a in hp.sampler_args if a in ("lc", "entropy", "sb")][0]
     out.update(unc=S.point_uncertainty(probs, um), cls=np.argmax(probs, -1).astype(np.int32))

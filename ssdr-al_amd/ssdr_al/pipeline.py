@@ -18,7 +18,7 @@ from .helper_tool import ConfigS3DIS
 class HotPath:
     def __init__(self, weights, config=ConfigS3DIS, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=1, gcn_top=0,
                  select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32", selector="fps", tiles32=True, min_size=1, round_num=5,
-                 label_seed=None, batch_size=None):
+                 label_seed=None, batch_size=None, max_size=None):
         self.cfg = config
         self.net = None if weights is None else randlanet.Network(config).load(weights).set_precision(precision).set_formulation(tiles32)
         self.sampler_args = list(sampler_args)
@@ -29,6 +29,8 @@ class HotPath:
         # min_size: regions of fewer points are neither ranked nor used as labelled rows (sampler2.py:616, :628; the reference's default is 1);
         # round_num: the class-balanced draw of the labelled rows takes (round_num - 1) * 1000 of the labelled regions (sampler2.py:297-302; SURVEY
         # section 8d quotes the workload at round 5); label_seed seeds NumPy's legacy generator for that draw (the reference draws from np.random)
+        # max_size: the Semantic3D flavour also drops regions of more than 1000 points from both populations (SSRD_AL_semantic3d/sampler2.py:644, :655)
+        self.max_size = None if max_size is None else int(max_size)
         self.min_size, self.round_num = int(min_size), int(round_num)
         self.label_seed = int(seed if label_seed is None else label_seed)
         # "fps": farthest_features_sample over the candidates' propagated features (the gcn_fps branch, sampler2.py:736-781);
@@ -176,6 +178,8 @@ class HotPath:
         # prediction()'s population (sampler2.py:612-631): unlabelled regions of at least min_size points are ranked; labelled ones of at least
         # min_size points are the pool the labelled rows are drawn from; the rest takes no part.  skip_mask = not in the ranked population
         big = self.sp_size_h >= self.min_size
+        if self.max_size is not None:
+            big &= self.sp_size_h <= self.max_size
         self.skip_mask = self.labeled_mask | ~big
         self.lab_pool = np.flatnonzero(self.labeled_mask & big)                 # cloud by cloud, ascending superpoint id
         # the pool's ground-truth dominant labels from the resident labels (the reference reads them from the cloud's PLY, :283-289)

@@ -157,3 +157,26 @@ def test_product_labelled_features_use_ground_truth_members(golden, backend):
         _, pdom, _ = sampler.compute_region_stats(np.zeros(len(cls), np.float32), cls, off, pts, 13, ["WetSU"])
         differs += int((sampler.segment_mean_features(g["a/%d/feat" % b], cls, pdom, off, pts, sel) != exp).any())
     assert differs == 3          # the round-4 composition (predicted members for labelled rows) is a different answer on every cloud
+
+
+def test_semantic3d_population_filter(golden, backend):
+    """the Semantic3D sampler ranks (and draws labelled rows from) regions of at most 1000 points only (SSRD_AL_semantic3d/sampler2.py:644, :655): product ==
+    oracle with a size cap on the clouds of the composition case (the cap itself is not pinned by a reference run: the S3D loader feeds parts)"""
+    from oracle import pipeline_np as P
+    from ssdr_al import pipeline
+    from ssdr_al.helper_tool import ConfigS3DIS
+    g = golden("composition_golden.npz")
+    clouds, labelled, p = _case_a(g)
+    cap = 25
+    r = P.selection_round(clouds, labelled, g["a/selected_class_list"], p["C"], ["sb", "WetSU", "clsbal", "gcn_fps"], p["min_size"], p["round_num"],
+                          p["batch_size"], p["gcn_number"], p["gcn_top"], 0, np.random.RandomState(7), max_size=cap)
+
+    class Cfg(ConfigS3DIS):
+        num_classes = p["C"]
+    hp = pipeline.HotPath.from_clouds(clouds, labelled, g["a/selected_class_list"], Cfg, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=p["gcn_number"],
+                                      gcn_top=p["gcn_top"], min_size=p["min_size"], round_num=p["round_num"], label_seed=7, batch_size=p["batch_size"], max_size=cap)
+    sel, unl = hp.step_selection()
+    base = np.asarray(hp.sp_base)
+    assert 0 < len(r["region"]) < len(g["a/region_sp"])          # the cap removed regions
+    assert [(b, s - int(base[b])) for b, s in unl] == r["unl"]
+    assert np.array_equal(sel, r["seq"])
