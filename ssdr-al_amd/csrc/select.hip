@@ -1692,6 +1692,12 @@ int chamfer_pack_launch(const ChamferPack& P, const float* d_xyz, const int* d_s
     hipLaunchKernelGGL(sel_chamfer_fill, dim3(std::max(1, std::min((n_max + 3) / 4, 1024)), nclouds), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, nsingle, d_centres, P);
     return SSDR_OK;
 }
+// slices of the source items per target (blockIdx.y): a workgroup stages its target once and its four waves take items slice * 4 + wave, + 4 * slices, ...
+// (measured, tools/gpu_chamfer_slices.sh, the bench's ~35 items per cloud: 16 slices 0.491-0.495 ms, 8: 0.481-0.484, 4: 0.53, 2: 0.62, 1: 0.83)
+inline int chamfer_slices(int nm) {
+    static const int env = [] { const char* e = getenv("SSDR_CHAMFER_SLICES"); return e ? atoi(e) : 0; }();
+    return std::max(1, std::min((nm + 3) / 4, env > 0 ? env : 8));
+}
 // one scratch set per stream: calls on different streams may run concurrently (include/ssdr_al.h)
 SelState& sst(hipStream_t st = nullptr) { return per_stream<SelState>(st); }
 
@@ -1875,7 +1881,7 @@ int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, cons
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, nt, d_centres);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, n_total, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, 0, n_total, nm, nc, d_centres, s));
-    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel,
+    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), chamfer_slices(nm), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel,
                        d_coff, (const long long*)d_boff, d_centres, d_cd_dir, P);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, d_centres, d_cd_dir, d_coff, (const long long*)d_boff, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), d_coff, (const long long*)d_boff, d_adj);
@@ -2112,7 +2118,7 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
     prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
-    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
+    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), chamfer_slices(nm), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
                        coff, boff, cen, dir, P);
     prof.emplace("sel_adjacency_propagate", s, 0.0);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
@@ -2195,7 +2201,7 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
     prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
-    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), std::max(1, std::min((nm + 3) / 4, 16)), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
+    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), chamfer_slices(nm), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
                        coff, boff, cen, dir, P);
     prof.emplace("sel_adjacency_propagate", s, 0.0);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
