@@ -30,18 +30,17 @@ def compute_graph_nn(xyz, k_nn):
 def compute_graph_nn_2(xyz, k_nn1, k_nn2, voronoi=0.0):
     """graphs.py:23-70: (graph of the k_nn1 neighbours, flat targets of the k_nn2 neighbours)"""
     graph, target2 = _knn_graph(xyz, k_nn1, k_nn2)
-    if voronoi > 0:             # graphs.py:38-62, statement for statement (`tri.vertices` is `tri.simplices` since SciPy 1.11)
+    if voronoi > 0:
+        # graphs.py:38-62.  The six edges of every Delaunay tetrahedron (edge-major, as the reference stacks them: its `distances` keep that order),
+        # those shorter than sqrt(voronoi) joined with the k_nn1 edges, one copy of every (source, target) pair in order of source + n * target
         from scipy.spatial import Delaunay
-        n_ver = xyz.shape[0]
-        v = Delaunay(xyz).simplices
-        src = np.hstack((v[:, 0], v[:, 0], v[:, 0], v[:, 1], v[:, 1], v[:, 2])).astype("uint64")
-        tgt = np.hstack((v[:, 1], v[:, 2], v[:, 3], v[:, 2], v[:, 3], v[:, 3])).astype("uint64")
-        dist = ((xyz[src, :] - xyz[tgt, :]) ** 2).sum(1)
-        keep_edges = dist < voronoi
-        src, tgt = src[keep_edges], tgt[keep_edges]
-        src = np.hstack((src, graph["source"]))                # the k_nn1 edges: repmat(range(n), k_nn1).flatten('F') / neighbours[:, :k_nn1]
-        tgt = np.hstack((tgt, graph["target"]))
-        _, unique_edges = np.unique(src + n_ver * tgt, return_index=True)
-        graph["source"], graph["target"] = src[unique_edges], tgt[unique_edges]
-        graph["distances"] = dist[keep_edges]                   # :60 — the Delaunay edges' squared lengths only, as the reference leaves it
+        tets = Delaunay(xyz).simplices.astype(np.uint64)          # (`tri.vertices` until SciPy 1.11)
+        ends = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])
+        a, b = tets[:, ends[:, 0]].T.ravel(), tets[:, ends[:, 1]].T.ravel()
+        d2 = np.square(xyz[a] - xyz[b]).sum(axis=1)
+        short = d2 < voronoi
+        src = np.concatenate([a[short], graph["source"]])
+        tgt = np.concatenate([b[short], graph["target"]])
+        first = np.unique(src + np.uint64(xyz.shape[0]) * tgt, return_index=True)[1]
+        graph.update(source=src[first], target=tgt[first], distances=d2[short])      # (:60 leaves the Delaunay edges' squared lengths only)
     return graph, target2
