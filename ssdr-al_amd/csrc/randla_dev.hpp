@@ -71,6 +71,10 @@ __device__ __forceinline__ float rows_sum(float v) {
     return combine_xor32(combine_xor16(v, ad), ad);
 }
 
+// (fmaxf() on a value the compiler cannot prove canonical — every MFMA result — costs a second `v_max_f32 x, x, x` in front of it in IEEE mode; the attention
+// kernels' translation unit is therefore compiled with -fno-honor-nans, csrc/Makefile.  Inline `v_max_f32` / `v_max3_f32` were tried first: identical tiles then
+// gave different results in different batch slots — the hazard recogniser does not place the wait states a read of an MFMA result needs in front of inline
+// assembly; `__builtin_amdgcn_fmed3f(a, b, inf)` is folded back into the canonicalising form.)
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.2f); }     // = v > 0 ? v : 0.2 v, one instruction less
 
 // x0, x1 -> packed hi pair and packed lo pair (lo = bf16_rn(x - hi))
