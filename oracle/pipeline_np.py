@@ -123,7 +123,8 @@ def selection_round(clouds, labelled, selected_class_list, class_num, sampler_ar
     for b, s in lab:
         lf.append(np.mean(np.asarray(clouds[b]["feat"])[gt_ids[(b, s)]], axis=0))
     refs = unl + lab
-    V = np.concatenate([np.asarray(uf, np.float32).reshape(len(unl), -1), np.asarray(lf, np.float32).reshape(len(lab), -1)]).astype(np.float64)
+    nf = np.asarray(clouds[0]["feat"]).shape[1]
+    V = np.concatenate([np.asarray(uf, np.float32).reshape(len(unl), nf), np.asarray(lf, np.float32).reshape(len(lab), nf)]).astype(np.float64)
     blocks, rows_l = [], []
     for b in sorted(set(c for c, _ in refs)):
         rows = np.array([i for i, (c, _) in enumerate(refs) if c == b])

@@ -180,3 +180,25 @@ def test_semantic3d_population_filter(golden, backend):
     assert 0 < len(r["region"]) < len(g["a/region_sp"])          # the cap removed regions
     assert [(b, s - int(base[b])) for b, s in unl] == r["unl"]
     assert np.array_equal(sel, r["seq"])
+
+
+def test_round_without_labelled_regions(golden, backend):
+    """round 1 of the loop's shape: nothing labelled yet in the clouds at hand (no labelled rows, no draw): product == oracle, FPS and k-center refused
+    (kCenterGreedy needs its seeds: the reference's gcn branch is not run before labelled regions exist)"""
+    from oracle import pipeline_np as P
+    from ssdr_al import pipeline
+    from ssdr_al.helper_tool import ConfigS3DIS
+    g = golden("composition_golden.npz")
+    clouds, labelled, p = _case_a(g)
+    none = [set() for _ in clouds]
+    r = P.selection_round(clouds, none, g["a/selected_class_list"], p["C"], ["sb", "WetSU", "clsbal", "gcn_fps"], 1, p["round_num"], 30, 1, 0, 0, np.random.RandomState(1))
+
+    class Cfg(ConfigS3DIS):
+        num_classes = p["C"]
+    hp = pipeline.HotPath.from_clouds(clouds, none, g["a/selected_class_list"], Cfg, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=1, gcn_top=0,
+                                      min_size=1, round_num=p["round_num"], label_seed=1, batch_size=30)
+    sel, unl = hp.step_selection()
+    base = np.asarray(hp.sp_base)
+    assert hp._sel_static["n_lab"] == 0 and len(r["lab"]) == 0
+    assert [(b, s - int(base[b])) for b, s in unl] == r["unl"]
+    assert np.array_equal(sel, r["seq"])

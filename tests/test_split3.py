@@ -72,3 +72,19 @@ def test_split3_refuses_coincident_points(backend):
     xyz = np.zeros((5000, 3), np.float32)
     with pytest.raises(_lib.SsdrError):
         S3.split3_parts(xyz, max_size=1000)
+
+
+def test_split3_tiny_and_degenerate_clouds(backend):
+    """a handful of points (every part at most merge_max: one combined part), points on a line (empty quadrants), one point"""
+    from oracle import split3_np
+    from ssdr_al import semantic3d_sampling as S3
+    rng = np.random.default_rng(8)
+    for xyz in (rng.random((5, 3)).astype(np.float32),
+                np.stack([np.linspace(0, 1, 50), np.zeros(50), np.zeros(50)], 1).astype(np.float32),
+                np.zeros((1, 3), np.float32),
+                np.concatenate([rng.random((3000, 3)), rng.random((40, 3)) + 5.0]).astype(np.float32)):
+        got = S3.split3_parts(xyz)
+        exp = split3_np.parts(xyz)
+        assert len(got) == len(exp)
+        for a, b in zip(got, exp):
+            assert np.array_equal(np.sort(a), np.sort(b))
