@@ -645,7 +645,11 @@ struct FeMoveArgs {
     FeTab t; const FeGeom* geom; const FeItem* items; const int* counters; const uint4* rec; const unsigned* nocc; const unsigned* trow;
     const unsigned char* lrc; const unsigned short* pre; const unsigned* rowbase; int fdim, ldim; float* out_p; float* out_f; int* out_c;
 };
+// FD / LD >= 0: row layout known at compile time (the hot path's 3 features + 1 label: one 12-byte store each for the position and the features instead of
+// seven guarded 4-byte stores)
+template <int FD, int LD>
 __global__ __launch_bounds__(BS) void fe_move(FeMoveArgs a) {
+    const int fdim = FD >= 0 ? FD : a.fdim, ldim = LD >= 0 ? LD : a.ldim;
     const int lane = threadIdx.x & 63;
     const int nw = a.counters[0], nwaves = (int)gridDim.x * (BS / 64);
     for (int tk = (int)blockIdx.x * (BS / 64) + (int)(threadIdx.x >> 6); tk < nw; tk += nwaves) {
@@ -666,22 +670,32 @@ __global__ __launch_bounds__(BS) void fe_move(FeMoveArgs a) {
         const unsigned short* pre = a.pre + tb * FE_LR;
         const unsigned* rb = a.rowbase + (size_t)r * FE_ROWCAP;
         const size_t o = (size_t)a.t.off[r];
+        // a lane PAIR takes a row: the even lane its first half (x, y, z, voxel) and the position, the odd lane the second (features, labels) — a load
+        // instruction then reads 32 whole rows as one contiguous kilobyte instead of 64 half rows at a stride of 32 bytes
+        const int half = lane & 1, pl = lane >> 1;
         for (int j0 = 0; j0 < nocc; j0 += 64) {
-            const int j = j0 + lane;
-            const bool on = j < nocc;
-            uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
-            if (on) { r0 = rows[2 * (size_t)j]; r1 = rows[2 * (size_t)j + 1]; }
-            const int l = on ? (int)(r0.w >> g.sx) : 0;
-            const unsigned lp = __shfl(lpre, l);
-            if (on) {
-                const int iy = by * 8 + (l & 7), iz = bz * 8 + (l >> 3);
-                const size_t fin = o + rb[iy + g.nby * 8 * iz] + pre[l] + ((unsigned)j - lp);
-                a.out_p[3 * fin] = __uint_as_float(r0.x); a.out_p[3 * fin + 1] = __uint_as_float(r0.y); a.out_p[3 * fin + 2] = __uint_as_float(r0.z);
-                const uint32_t w[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k < a.fdim) a.out_f[fin * a.fdim + k] = __uint_as_float(w[k]);
-                    else if (k - a.fdim < a.ldim) a.out_c[fin * a.ldim + (k - a.fdim)] = (int)w[k];
+            for (int h = 0; h < 2; ++h) {
+                const int j = j0 + 32 * h + pl;
+                const bool on = j < nocc;
+                uint4 rr = make_uint4(0, 0, 0, 0);
+                if (on) rr = rows[2 * (size_t)j + half];
+                const unsigned other = fe_swap1(rr.w);                      // (unconditional: a DPP move reads its partner lane only while that lane is active)
+                const unsigned vw = half ? other : rr.w;                    // the voxel word lives in the first half
+                const int l = on ? (int)(vw >> g.sx) : 0;
+                const unsigned lp = __shfl(lpre, l);
+                if (on) {
+                    const int iy = by * 8 + (l & 7), iz = bz * 8 + (l >> 3);
+                    const size_t fin = o + rb[iy + g.nby * 8 * iz] + pre[l] + ((unsigned)j - lp);
+                    if (!half) { a.out_p[3 * fin] = __uint_as_float(rr.x); a.out_p[3 * fin + 1] = __uint_as_float(rr.y); a.out_p[3 * fin + 2] = __uint_as_float(rr.z); }
+                    else {
+                        const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (k < fdim) a.out_f[fin * fdim + k] = __uint_as_float(w[k]);
+                            else if (k - fdim < ldim) a.out_c[fin * ldim + (k - fdim)] = (int)w[k];
+                        }
+                    }
                 }
             }
         }
@@ -765,7 +779,8 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     FeMoveArgs ma; ma.t = t; ma.geom = geom; ma.items = items; ma.counters = counters; ma.rec = S.rec.as<uint4>(); ma.nocc = S.nocc.as<unsigned>();
     ma.trow = S.trow.as<unsigned>(); ma.lrc = S.lrc.as<unsigned char>(); ma.pre = S.pre.as<unsigned short>(); ma.rowbase = S.rowcnt.as<unsigned>(); ma.fdim = (int)fdim; ma.ldim = (int)ldim;
     ma.out_p = d_op; ma.out_f = d_of; ma.out_c = d_oc;
-    hipLaunchKernelGGL(fe_move, dim3(ctx().num_cu * 8), dim3(BS), 0, s, ma);
+    if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_move<3, 1>), dim3(ctx().num_cu * 8), dim3(BS), 0, s, ma);
+    else hipLaunchKernelGGL((fe_move<-1, -1>), dim3(ctx().num_cu * 8), dim3(BS), 0, s, ma);
     SSDR_HIP(hipGetLastError());
 #ifdef SSDR_FE_STAMPS
     {
