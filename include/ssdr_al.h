@@ -63,7 +63,8 @@ float ssdr_last_gpu_ms(void);
 /* ---- KNN (replaces S3/utils/nearest_neighbors: knn_.h:4-26, knn_.cxx:22-135, knn.pyx:33-109) --
  * Exact K nearest neighbours of every query among `npts` support points, ascending squared
  * distance, with nanoflann v1.2.3's tie order (kd-tree traversal order, leaf size 10), i.e. the
- * int64 indices equal the reference's cpp_knn* output bit for bit.  dim must be 3.
+ * int64 indices equal the reference's cpp_knn* output bit for bit.  dim must be 3; the host entry points also take dim 1 and 2 (answered exactly as the
+ * 3-D problem with the missing coordinates at zero); dim > 3: SSDR_ERR_UNSUPPORTED.
  * If K > npts the slots >= npts hold 0 (what the reference's zero-initialised buffers leave there).
  * ssdr_knn           <-> cpp_knn / cpp_knn_omp              (knn_.cxx:22-69)
  * ssdr_knn_batch     <-> cpp_knn_batch / cpp_knn_batch_omp  (knn_.cxx:72-135)

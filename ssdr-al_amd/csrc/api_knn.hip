@@ -90,7 +90,7 @@ int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<G
 }
 
 int check_knn_args(const void* p, size_t npts, size_t dim, const void* q, size_t nq, size_t K, const void* out) {
-    if (dim != 3) { set_error("dim=%zu: only dim == 3 is implemented", dim); return SSDR_ERR_UNSUPPORTED; }
+    if (dim != 3) { set_error("dim=%zu: only dim <= 3 is implemented (1 and 2 through the host entry points)", dim); return SSDR_ERR_UNSUPPORTED; }
     if ((!p && npts) || (!q && nq) || (!out && nq && K)) { set_error("NULL pointer argument"); return SSDR_ERR_INVALID; }
     if (npts > 0x3fffffff || nq > 0x3fffffff) { set_error("too many points"); return SSDR_ERR_INVALID; }
     return SSDR_OK;
@@ -119,6 +119,15 @@ int knn_batch_device(const float* d_pts, size_t B, size_t npts, const float* d_q
 
 int knn_batch_host(const float* pts, size_t B, size_t npts, size_t dim, const float* q, size_t nq, size_t K,
                    void* out, bool i64) {
+    if ((dim == 1 || dim == 2) && pts && q) {
+        // knn_.cxx is dim-generic.  One and two dimensions are the 3-D problem with the missing coordinates at zero, EXACTLY: a zero-span dimension is never
+        // the cut dimension (nanoflann.hpp:898-937: its span does not exceed (1 - 1e-5) x the largest, and with every span zero the cut stays on dimension 0 as it
+        // does in the dim-generic code), the metric adds (0 - 0)^2 = +0 behind the other terms, the boxes and the far-branch bounds never see it.  dim > 3 is refused.
+        std::vector<float> p3(B * npts * 3, 0.f), q3(B * nq * 3, 0.f);
+        for (size_t i = 0; i < B * npts; ++i) for (size_t d = 0; d < dim; ++d) p3[3 * i + d] = pts[dim * i + d];
+        for (size_t i = 0; i < B * nq; ++i) for (size_t d = 0; d < dim; ++d) q3[3 * i + d] = q[dim * i + d];
+        return knn_batch_host(p3.data(), B, npts, 3, (pts == q && npts == nq) ? p3.data() : q3.data(), nq, K, out, i64);
+    }
     SSDR_TRY(check_knn_args(pts, npts, dim, q, nq, K, out));
     SSDR_TRY(ensure_init());
     if (B == 0 || nq == 0 || K == 0) return SSDR_OK;

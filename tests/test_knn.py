@@ -124,6 +124,24 @@ def test_knn_rejects_unsupported_dim(backend):
     assert e.value.status == 5
 
 
+@pytest.mark.parametrize("dim", [1, 2])
+def test_knn_one_and_two_dimensions(backend, dim):
+    """knn_.cxx:22-135 is dim-generic; dim 1 and 2 are answered as the 3-D problem with zero coordinates, bit for bit the REAL reference's answer
+    (the compiled reference in the build container, the dim-generic C oracle elsewhere): lattices and duplicates for the tie order."""
+    import oracle
+    from ssdr_al import knn
+    rng = np.random.default_rng(31 + dim)
+    n = 1500 if backend == "emu" else 20000
+    pts = rng.random((n, dim)).astype(np.float32)
+    pts[: n // 4] = np.round(pts[: n // 4] * 20) / 20            # a lattice: equal distances
+    pts[-50:] = pts[:50]                                         # duplicates
+    q = np.concatenate([pts[:200], rng.random((100, dim)).astype(np.float32)])
+    r = oracle.ref()
+    exp = r.knn(pts, q, 16, omp=False) if r is not None else oracle.c().knn(pts, q, 16)
+    assert_bits_equal(knn.knn(pts, q, 16), exp, "dim %d" % dim)
+    assert_bits_equal(knn.knn_batch(pts[None], pts[None], 1)[0], (r.knn(pts, pts, 1) if r is not None else oracle.c().knn(pts, pts, 1)), "dim %d, K = 1" % dim)
+
+
 def test_knn_fresh_inputs_against_oracle(backend, orc):
     from ssdr_al import knn
     rng = np.random.default_rng(11)
