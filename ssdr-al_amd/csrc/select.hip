@@ -13,6 +13,7 @@
 #include "ssdr_internal.hpp"
 #include <map>
 #include "block_prims.hpp"
+#include "select_chamfer.hpp"
 
 namespace ssdr {
 namespace {
@@ -392,40 +393,6 @@ __global__ __launch_bounds__(256) void sel_centres(const float* __restrict__ xyz
     }
 }
 
-// min of two non-NaN doubles in ONE instruction (`a < b ? a : b` compiles to a compare and two 32-bit selects, fmin() to a
-// canonicalising v_max in front of the v_min: 3 of the 10 vector instructions of one point pair)
-__device__ __forceinline__ double min_f64(double a, double b) {
-#ifndef HIPEMU
-    double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
-#else
-    return a < b ? a : b;
-#endif
-}
-
-constexpr int CH_TILE = 640;    // target points staged per step (20 KiB: float64 coordinates + squared norm); at most 1024 (the screening key carries a 10-bit index)
-constexpr int PACK_MAX = 4096;  // superpoints of one cloud the packer lays out (two int tables in LDS)
-constexpr int ITEM = 256;       // source points one wave takes against a target
-constexpr int NV = ITEM / 64;   // ... per lane
-constexpr int SEQ_MAX = 16;     // superpoints up to this size are summed by one lane each, larger ones by the whole wave
-
-// The staged target is the same for every lane, and a wave-wide LDS read of 24 bytes per lane costs the LDS pipe 12 cycles whether
-// or not the addresses agree: with one source point per lane the kernel waited on LDS (33 % instruction issue), and a wave per
-// (source, target) pair left the lanes beyond the source's size idle.  Hence:
-//   * sel_chamfer_pack lays the centred points of the superpoints of a cloud out in 256-slot ITEMS — as many whole superpoints as
-//     fit, in order, never split — and sel_chamfer_dir takes one item per wave and target: every lane owns FOUR source points
-//     (slots l, l + 64, l + 128, l + 192), so one read of a target point serves four distance evaluations;
-//   * the roots of a superpoint's points are added up in an order that depends on its size alone (segment_sum), so the mean does
-//     not depend on what else shares the item;
-//   * superpoints above 256 points (and empty ones) are taken pair by pair in passes of 256 with the same summation rule.
-struct ChamferPack {
-    double* x; double* y; double* z;      // per slot: the centred point
-    int* seg; int* cnt;                   // per slot: local index of its superpoint (-1: padding); the superpoint's size on its first slot, else 0
-    int* item_slot;                       // per item: its first slot
-    int* big;                             // superpoints taken pair by pair
-    int* start;                           // per superpoint: first slot, -1 for the pair-by-pair ones
-    int* counts;                          // per cloud: items, pair-by-pair superpoints
-};
-
 // The lay-out of one cloud (one workgroup): slots of the cloud start at ITEM * (its first row), the per-superpoint tables at its first row.
 __device__ void chamfer_plan_body(const int* __restrict__ sp_off, const int* __restrict__ sel, int n, ChamferPack P, int* counts, int* s_n) {
     const int tid = threadIdx.x;
@@ -479,200 +446,32 @@ __device__ void chamfer_plan_body(const int* __restrict__ sp_off, const int* __r
         else if ((st & (ITEM - 1)) == 0) P.item_slot[ci++] = st;
     }
 }
-// ... and its slots: one wave per superpoint (seg / cnt of the padding slots were preset by the launcher: -1 / 0)
+// ... and its slots: one wave per superpoint (seg / cnt / r2item of the padding slots and unused items were preset by the launcher: -1 / 0 / 0).
+// r2sp / r2item: the largest |p|^2 of the superpoint / of the item's superpoints, rounded up — what bounds the float32 screening's error (select_chamfer.hip)
 __device__ void chamfer_fill_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts, const int* __restrict__ sel, int n,
                                   const double* __restrict__ centres, ChamferPack P) {
     const int lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
         const int st = P.start[i];
-        if (st < 0) continue;
         const int sp = sel[i], lo = sp_off[sp], ni = sp_off[sp + 1] - lo;
         const double cx = centres[3 * i], cy = centres[3 * i + 1], cz = centres[3 * i + 2];
+        double r2 = 0.0;
         for (int a = lane; a < ni; a += 64) {
             const size_t q = sp_pts[lo + a];
-            const int k = st + a;
-            P.x[k] = (double)xyz[3 * q] - cx; P.y[k] = (double)xyz[3 * q + 1] - cy; P.z[k] = (double)xyz[3 * q + 2] - cz;
-            P.seg[k] = i; P.cnt[k] = a == 0 ? ni : 0;
-        }
-    }
-}
-
-// squared distances from NV centred source points to the nearest point of target j: its staged points (tb), or streamed
-__device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&out)[NV], const double* tb, int nj, bool staged,
-                                            const float* __restrict__ xyz, const int* __restrict__ sp_pts, int loj, double cjx, double cjy, double cjz) {
-    if (staged) {
-        // Screening on |b|^2 - 2 a.b (= |a - b|^2 - |a|^2: the same order over b), three fused multiply-adds per pair instead of three differences,
-        // a product and two fused multiply-adds; the target's index rides in the key's ten lowest mantissa bits (one 32-bit and-or), so the running
-        // minimum names its target and the distance itself is then evaluated ONCE per source point in the difference form, as before — the
-        // value is the exact one whenever the target it names is the nearest.  A wrong name needs two targets whose keys agree to 2^-42 of |key|
-        // (<= ~1e-13 m^2 at room scale; the fused chain's own rounding is 1e-16): the value returned is then that target's exact distance, above the
-        // minimum by at most that band.  5 instructions per pair instead of 7 on the float64 pipe that bounds this kernel.
-        double m[NV][2];      // independent chains: min is order-free
-        double ax2[NV], ay2[NV], az2[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) { m[v][0] = m[v][1] = 1.0e300; ax2[v] = -2.0 * ax[v]; ay2[v] = -2.0 * ay[v]; az2[v] = -2.0 * az[v]; }
-        // (key.lo & ~1023) | idx in ONE instruction: gfx950's three-operand encodings take no 32-bit literal and one scalar operand, so the compiler
-        // emits v_and_b32 + v_or_b32 with the literal; with the mask in a vector register v_and_or_b32 does it (idx stays scalar)
-        const unsigned keep = ~1023u;
-        auto key = [&](double t, int idx) {
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
-            unsigned lo;
-#ifndef HIPEMU
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)bits), "v"(keep), "s"(idx));
-#else
-            lo = ((unsigned)bits & keep) | (unsigned)idx;
-#endif
-            return __longlong_as_double((long long)((bits & 0xffffffff00000000ull) | lo));
-        };
-        int b = 0;
-        for (; b + 4 <= nj; b += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double tx = tb[4 * (b + u)], ty = tb[4 * (b + u) + 1], tz = tb[4 * (b + u) + 2], tn = tb[4 * (b + u) + 3];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const double t = fma(az2[v], tz, fma(ay2[v], ty, fma(ax2[v], tx, tn)));
-                    m[v][u & 1] = min_f64(key(t, b + u), m[v][u & 1]);
-                }
-            }
-        }
-        for (; b < nj; ++b) {
-            const double tx = tb[4 * b], ty = tb[4 * b + 1], tz = tb[4 * b + 2], tn = tb[4 * b + 3];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const double t = fma(az2[v], tz, fma(ay2[v], ty, fma(ax2[v], tx, tn)));
-                m[v][0] = min_f64(key(t, b), m[v][0]);
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int idx = (int)((unsigned)__double_as_longlong(fmin(m[v][0], m[v][1])) & 1023u);
-            const double dx = ax[v] - tb[4 * idx], dy = ay[v] - tb[4 * idx + 1], dz = az[v] - tb[4 * idx + 2];
-            out[v] = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
-        }
-        return;
-    }
-    double m[NV];                        // very large target: stream it from global memory
-#pragma unroll
-    for (int v = 0; v < NV; ++v) m[v] = 1.0e300;
-    for (int b = 0; b < nj; ++b) {
-        const size_t q = sp_pts[loj + b];
-        const double tx = (double)xyz[3 * q] - cjx, ty = (double)xyz[3 * q + 1] - cjy, tz = (double)xyz[3 * q + 2] - cjz;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) { const double dx = ax[v] - tx, dy = ay[v] - ty, dz = az[v] - tz; double d = dx * dx; d = d + dy * dy; d = d + dz * dz; m[v] = fmin(m[v], d); }
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) out[v] = m[v];
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long b = __double_as_longlong(v);
-        const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
-        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-    }
-    return v;
-}
-
-// v[0] + ... + v[n-1], n <= SEQ_MAX, by one lane
-__device__ __forceinline__ double sum_short(const double* v, int n) {
-    double a = 0.0;
-    for (int t = 0; t < n; ++t) a += v[t];
-    return a;
-}
-// v[0] + ... + v[n-1] by the whole wave (uniform arguments): lane l adds v[l], v[l + 64], ... up, then the xor tree
-__device__ __forceinline__ double sum_wave(const double* v, int n, int lane) {
-    double a = 0.0;
-    for (int t = lane; t < n; t += 64) a += v[t];
-    return wave_sum_f64(a);
-}
-
-// dir[i*nsel + j] = mean over points a of sp_i of min over points b of sp_j of |(a-c_i) - (b-c_j)|   (float64).
-// One workgroup per target superpoint j (and slice of the sources): its centred points are staged in LDS once and re-used against
-// every source item.  The mean is (sum_short | sum_wave) / size, so it can differ from NumPy's pairwise np.mean in the last ulps
-// (sqrt is monotone: min of roots == root of min).
-__device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                 const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P, const int* counts,
-                                 double* tb, double (*s_val)[ITEM]) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nitems = counts[0], nbig = counts[1];
-    for (int j = blockIdx.x; j < nsel; j += gridDim.x) {
-        const int sj = sel[j], loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
-        const double cjx = centres[3 * j], cjy = centres[3 * j + 1], cjz = centres[3 * j + 2];
-        const bool staged = nj <= CH_TILE;
-        if (staged) {
-            __syncthreads();
-            const int st = P.start[j];
+            const double x = (double)xyz[3 * q] - cx, y = (double)xyz[3 * q + 1] - cy, z = (double)xyz[3 * q + 2] - cz;
+            r2 = fmax(r2, (x * x + y * y) + z * z);
             if (st >= 0) {
-                for (int b = threadIdx.x; b < nj; b += 256) {
-                    const double x = P.x[st + b], y = P.y[st + b], z = P.z[st + b];
-                    tb[4 * b] = x; tb[4 * b + 1] = y; tb[4 * b + 2] = z; tb[4 * b + 3] = fma(z, z, fma(y, y, x * x));
-                }
-            } else {
-                for (int b = threadIdx.x; b < nj; b += 256) {
-                    const size_t q = sp_pts[loj + b];
-                    const double x = (double)xyz[3 * q] - cjx, y = (double)xyz[3 * q + 1] - cjy, z = (double)xyz[3 * q + 2] - cjz;
-                    tb[4 * b] = x; tb[4 * b + 1] = y; tb[4 * b + 2] = z; tb[4 * b + 3] = fma(z, z, fma(y, y, x * x));
-                }
+                const int k = st + a;
+                P.x[k] = x; P.y[k] = y; P.z[k] = z;
+                P.seg[k] = i; P.cnt[k] = a == 0 ? ni : 0;
             }
-            __syncthreads();
         }
-        for (int it = blockIdx.y * 4 + wid; it < nitems; it += 4 * gridDim.y) {          // NV source points per lane, whole superpoints per wave
-            const int k = P.item_slot[it] + lane;
-            double ax[NV], ay[NV], az[NV], m[NV];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) { ax[v] = P.x[k + 64 * v]; ay[v] = P.y[k + 64 * v]; az[v] = P.z[k + 64 * v]; }
-            chamfer_min(ax, ay, az, m, tb, nj, staged, xyz, sp_pts, loj, cjx, cjy, cjz);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
-            (void)__ballot(1);                               // the wave's LDS writes are visible to its lanes
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int cnt = P.cnt[k + 64 * v], seg = P.seg[k + 64 * v];
-                if (cnt > 0 && cnt <= SEQ_MAX) dir[(size_t)seg * nsel + j] = seg == j ? 0.0 : sum_short(&s_val[wid][lane + 64 * v], cnt) / (double)cnt;
-                unsigned long long todo = __ballot(cnt > SEQ_MAX);          // the larger ones, one after the other, all lanes on each
-                while (todo) {
-                    const int src = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    const int c = __shfl(cnt, src), sg = __shfl(seg, src);
-                    const double sum = sum_wave(&s_val[wid][src + 64 * v], c, lane);
-                    if (lane == 0) dir[(size_t)sg * nsel + j] = sg == j ? 0.0 : sum / (double)c;
-                }
-            }
-            (void)__ballot(1);
-        }
-        for (int bi = blockIdx.y * 4 + wid; bi < nbig; bi += 4 * gridDim.y) {            // pair by pair: more than ITEM points (or none)
-            const int i = P.big[bi];
-            if (i == j) { if (lane == 0) dir[(size_t)i * nsel + j] = 0.0; continue; }
-            const int si = sel[i], loi = sp_off[si], ni = sp_off[si + 1] - loi;
-            const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
-            double acc = 0.0;
-            for (int a0 = 0; a0 < ni; a0 += ITEM) {
-                double ax[NV], ay[NV], az[NV], m[NV];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const int a = min(a0 + lane + 64 * v, ni - 1);          // beyond the end: the last point again, not summed
-                    const size_t p = sp_pts[loi + a];
-                    ax[v] = (double)xyz[3 * p] - cix; ay[v] = (double)xyz[3 * p + 1] - ciy; az[v] = (double)xyz[3 * p + 2] - ciz;
-                }
-                chamfer_min(ax, ay, az, m, tb, nj, staged, xyz, sp_pts, loj, cjx, cjy, cjz);
-#pragma unroll
-                for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
-                (void)__ballot(1);
-                if (ni <= SEQ_MAX) { if (lane == 0) acc = sum_short(&s_val[wid][0], ni); }      // same rule as inside an item
-                else acc += sum_wave(&s_val[wid][0], min(ITEM, ni - a0), lane);
-                (void)__ballot(1);
-            }
-            if (lane == 0) dir[(size_t)i * nsel + j] = ni > 0 ? acc / (double)ni : 0.0;
+        const float r = wave_max((float)(r2 * 1.000001));
+        if (lane == 0) {
+            P.r2sp[i] = r;
+            if (st >= 0) atomicMax((unsigned*)&P.r2item[st / ITEM], __float_as_uint(r));      // non-negative floats order like their bit patterns
         }
     }
-}
-
-__device__ __forceinline__ ChamferPack pack_at(ChamferPack P, int row0) {
-    const size_t s0 = (size_t)ITEM * (size_t)row0;
-    P.x += s0; P.y += s0; P.z += s0; P.seg += s0; P.cnt += s0; P.item_slot += row0; P.big += row0; P.start += row0;
-    return P;
 }
 
 __global__ __launch_bounds__(256) void sel_chamfer_plan(const int* __restrict__ sp_off, const int* __restrict__ sel, const int* __restrict__ coff, int nsingle, ChamferPack P) {
@@ -684,23 +483,6 @@ __global__ __launch_bounds__(256) void sel_chamfer_fill(const float* __restrict_
                                                         const int* __restrict__ sel, const int* __restrict__ coff, int nsingle, const double* __restrict__ centres, ChamferPack P) {
     const int c = blockIdx.y, lo = coff ? coff[c] : 0, n = coff ? coff[c + 1] - lo : nsingle;
     chamfer_fill_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, pack_at(P, lo));
-}
-
-__global__ __launch_bounds__(256) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P) {
-    __shared__ double tb[CH_TILE * 4];
-    __shared__ double s_val[4][ITEM];
-    chamfer_dir_body(xyz, sp_off, sp_pts, sel, nsel, centres, dir, P, P.counts, tb, s_val);
-}
-// all clouds of a batch in one launch: blockIdx.z = cloud, coff[c] = first row of cloud c in sel / centres, boff[c] = first
-// element of its n_c x n_c blocks in dir / adj
-__global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(5) void sel_chamfer_dir_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                             const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
-                                                             const double* __restrict__ centres, double* dir, ChamferPack P) {
-    __shared__ double tb[CH_TILE * 4];
-    __shared__ double s_val[4][ITEM];
-    const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
-    chamfer_dir_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, s_val);
 }
 
 // adj = exp(-(ED + CD)) - I (fps_gcn_cpu.py:102-104); rowsum (:106)
@@ -1677,9 +1459,10 @@ struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum
 // scratch of the chamfer packer for nrows superpoints in nclouds clouds
 int chamfer_pack_buffers(SelState& Q, size_t nrows, size_t nclouds, ChamferPack& P) {
     const size_t slots = (size_t)ITEM * nrows;
-    SSDR_TRY(Q.pack_xyz.reserve(3 * 8 * slots + 64)); SSDR_TRY(Q.pack_int.reserve(4 * (2 * slots + 3 * nrows + 2 * nclouds) + 64));
+    SSDR_TRY(Q.pack_xyz.reserve(3 * 8 * slots + 64)); SSDR_TRY(Q.pack_int.reserve(4 * (2 * slots + 5 * nrows + 2 * nclouds) + 64));
     P.x = Q.pack_xyz.as<double>(); P.y = P.x + slots; P.z = P.y + slots;
-    P.seg = Q.pack_int.as<int>(); P.cnt = P.seg + slots; P.item_slot = P.cnt + slots; P.big = P.item_slot + nrows; P.start = P.big + nrows; P.counts = P.start + nrows;
+    P.seg = Q.pack_int.as<int>(); P.cnt = P.seg + slots; P.r2item = (float*)(P.cnt + slots); P.r2sp = P.r2item + nrows;
+    P.item_slot = (int*)(P.r2sp + nrows); P.big = P.item_slot + nrows; P.start = P.big + nrows; P.counts = P.start + nrows;
     return SSDR_OK;
 }
 // plan + fill of the packer for nclouds clouds (coff == nullptr: one cloud of nsingle superpoints)
@@ -1687,16 +1470,10 @@ int chamfer_pack_launch(const ChamferPack& P, const float* d_xyz, const int* d_s
                         size_t nrows, int n_max, unsigned nclouds, const double* d_centres, hipStream_t s) {
     const size_t slots = (size_t)ITEM * nrows;
     SSDR_HIP(hipMemsetAsync(P.seg, 0xff, 4 * slots, s));          // padding slots: no superpoint ...
-    SSDR_HIP(hipMemsetAsync(P.cnt, 0, 4 * slots, s));             // ... and nothing to sum
+    SSDR_HIP(hipMemsetAsync(P.cnt, 0, 4 * (slots + nrows), s));   // ... and nothing to sum; r2item (behind cnt) = 0
     hipLaunchKernelGGL(sel_chamfer_plan, dim3(nclouds), dim3(256), 0, s, d_sp_off, d_sel, d_coff, nsingle, P);
     hipLaunchKernelGGL(sel_chamfer_fill, dim3(std::max(1, std::min((n_max + 3) / 4, 1024)), nclouds), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, nsingle, d_centres, P);
     return SSDR_OK;
-}
-// slices of the source items per target (blockIdx.y): a workgroup stages its target once and its four waves take items slice * 4 + wave, + 4 * slices, ...
-// (measured, tools/gpu_chamfer_slices.sh, the bench's ~35 items per cloud: 16 slices 0.491-0.495 ms, 8: 0.481-0.484, 4: 0.53, 2: 0.62, 1: 0.83)
-inline int chamfer_slices(int nm) {
-    static const int env = [] { const char* e = getenv("SSDR_CHAMFER_SLICES"); return e ? atoi(e) : 0; }();
-    return std::max(1, std::min((nm + 3) / 4, env > 0 ? env : 8));
 }
 // one scratch set per stream: calls on different streams may run concurrently (include/ssdr_al.h)
 SelState& sst(hipStream_t st = nullptr) { return per_stream<SelState>(st); }
@@ -1861,7 +1638,7 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, nsel, 1, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, d_sel, nullptr, n, nsel, n, 1, d_centres, s));
-    hipLaunchKernelGGL(sel_chamfer_dir, dim3(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir, P);
+    SSDR_TRY(chamfer_dir_launch(d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir, P, s));
     hipLaunchKernelGGL(sel_adj_build, dim3(std::min(n, 2048)), dim3(256), 0, s, d_centres, d_cd_dir, n, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm, dim3(grid_for((long)n * n)), dim3(256), 0, s, Q.rowsum.as<double>(), n, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_adj, n, gcn_top);
@@ -1881,8 +1658,7 @@ int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, cons
     hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, nt, d_centres);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, n_total, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, 0, n_total, nm, nc, d_centres, s));
-    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), chamfer_slices(nm), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel,
-                       d_coff, (const long long*)d_boff, d_centres, d_cd_dir, P);
+    SSDR_TRY(chamfer_dir_batch_launch(d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, (const long long*)d_boff, nm, nc, d_centres, d_cd_dir, P, s));
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, d_centres, d_cd_dir, d_coff, (const long long*)d_boff, d_adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), d_coff, (const long long*)d_boff, d_adj);
     if (gcn_top > 0) hipLaunchKernelGGL(sel_adj_topk_batch, dim3(std::max(1, std::min((nm + 3) / 4, 1024)), 1, nc), dim3(256), 0, s, d_adj, d_coff, (const long long*)d_boff, gcn_top);
@@ -2118,8 +1894,7 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
     prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
-    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), chamfer_slices(nm), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
-                       coff, boff, cen, dir, P);
+    SSDR_TRY(chamfer_dir_batch_launch(d_xyz, d_sp_off, d_sp_pts, gsel, coff, boff, nm, nc, cen, dir, P, s));
     prof.emplace("sel_adjacency_propagate", s, 0.0);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), coff, boff, adj);
@@ -2201,8 +1976,7 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
     prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
-    hipLaunchKernelGGL(sel_chamfer_dir_batch, dim3(std::min(nm, 1024), chamfer_slices(nm), nc), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel,
-                       coff, boff, cen, dir, P);
+    SSDR_TRY(chamfer_dir_batch_launch(d_xyz, d_sp_off, d_sp_pts, gsel, coff, boff, nm, nc, cen, dir, P, s));
     prof.emplace("sel_adjacency_propagate", s, 0.0);
     hipLaunchKernelGGL(sel_adj_build_batch, dim3(std::min(nm, 1024), 1, nc), dim3(256), 0, s, cen, dir, coff, boff, adj, Q.rowsum.as<double>());
     hipLaunchKernelGGL(sel_adj_norm_batch, dim3(grid_for((long)nm * nm, 256), 1, nc), dim3(256), 0, s, Q.rowsum.as<double>(), coff, boff, adj);

@@ -1,0 +1,427 @@
+// Directed chamfer means between the candidate superpoints of a cloud (F1: fps_gcn_cpu.py:12-38 `chamfer_distance`, called pair by pair from
+// :84-100) for gfx950:  dir[i*n + j] = mean over the points a of superpoint i of  min over the points b of superpoint j of |(a - c_i) - (b - c_j)|,
+// float64, every superpoint centred on its own bounding box (:33).
+//
+// Where the time goes is the minimum over b for every a: 2.2 G point pairs per bench step.  Rounds 2-5 evaluated every pair on the float64 vector
+// pipe (7, then 5 instructions per pair: 0.70, then 0.50 ms).  This file SCREENS the pairs on the matrix cores and evaluates in float64 only what
+// the screening cannot decide:
+//
+//   * key(a, b) = |b|^2 - 2 a.b  (= |a - b|^2 - |a|^2: the same order over b).  Every coordinate is scaled by 128 and cut into two half-precision
+//     pieces (hi + lo = 22 bits), |b|^2 likewise; the products hi*hi + lo*hi + hi*lo of the three dimensions and the two pieces of |b|^2 are 11 of
+//     the 16 k-slots of ONE `v_mfma_f32_32x32x16_f16` — 32 target points x 32 source points per instruction, a lane holding 16 targets (four
+//     runs of four consecutive ones) of one source, float32 accumulation.  The half-precision matrix instruction runs beside the vector pipe;
+//     the float32-input one (first version of this file, 2 x `v_mfma_f32_32x32x2_f32` per tile) turned out to SHARE it, like the float64 one
+//     (tools/micro/valu_rate.hip: one of them + 16 v_max3_f32 take 64 + 75 cycles, the half-precision one + the same 16: 82) — measured 0.50 ms, no gain.
+//   * per run of four the vector pipe takes the minimum (v_min3 + v_min), and per source keeps the smallest run minimum m1, the run it came from
+//     and the second smallest run minimum m2 (v_med3, compare, select, v_min): 6 instructions per 4 x 64 pairs where the float64 form needed 20.
+//   * the screened key is off the true one by at most eps (bound below); m2 - m1 > 2 eps proves that the nearest target lies in the winning run:
+//     its four points are then evaluated in float64 in the difference form exactly as before and their minimum IS the minimum over the whole
+//     target.  Otherwise (near-ties between runs, duplicated points: ~3 per thousand sources) the source is swept over the whole target in
+//     float64 by the wave, one target point per lane.
+//
+// eps, in the scaled units (A = 128 a, B = 128 b, key' = 2^14 key; Ra', Rb' the largest |A|, |B|): pieces: x = hi + lo + d, |d| <= 1.25 * 2^-22 |x|
+// (float64 -> float32 -> two roundings to half precision) + 2^-25 where a piece is subnormal; dropped lo*lo <= 2^-22 |A||B|; so the eleven products
+// miss 2 A.B - |B|^2 by <= 2^-20.1 (Ra'^2 + Rb'^2) + 2^-22 (Ra' + Rb') + 2^-13; the matrix instruction's float32 accumulation of eleven non-zero
+// terms, in whatever order, each addition off by at most 2^-23 of a partial sum <= sum |terms| <= 1.01 (Ra'^2 + 2 Rb'^2): <= 2^-18.4 (Ra'^2 + Rb'^2).
+// Together < 2^-17.9 (Ra'^2 + Rb'^2) + ...; the kernel uses eps = 2^-17 (Ra'^2 + Rb'^2) + 2^-22 (Ra' + Rb') + 2^-12.  Superpoints beyond 31 m
+// from their box centre (half precision's range after the scaling) take the float64 path.
+//
+// So the value written is the float64 difference-form distance to the nearest target point in every case.  The float64 kernel (kept:
+// SSDR_CHAMFER_F64=1, and for targets too large to stage) writes that distance for the target its float64 key names: the same bits wherever the
+// nearest target is unique, and within the last ulp where two targets are equally near (a lattice); `tests/test_select.py` compares the two on
+// random, duplicated and lattice clouds.
+#include "select_chamfer.hpp"
+#include "block_prims.hpp"
+#include <cfloat>
+#include <cstdlib>
+
+namespace ssdr {
+namespace {
+
+#ifndef HIPEMU
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float f16_val(unsigned b) { return (float)__builtin_bit_cast(_Float16, (unsigned short)b); }
+// what lanes l and l ^ 32 hold, as (lower half's, upper half's) in both of them: one v_permlane32_swap
+__device__ __forceinline__ void halves(unsigned v, int, unsigned& lo, unsigned& hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); lo = r[0]; hi = r[1];
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return wave_reduce_u32(v, [](unsigned a, unsigned b) { return a < b ? a : b; }); }
+#else
+typedef hipemu_u32x4 u32x4;
+typedef hipemu_f32x16 f32x16;
+static inline f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) { return hipemu_mfma_f32_32x32x16_f16(a, b, c); }
+static inline float med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+static inline unsigned f16_bits(float x) { return hipemu_f32_to_f16(x); }
+static inline float f16_val(unsigned b) { return hipemu_f16_to_f32((unsigned short)b); }
+static inline void halves(unsigned v, int h, unsigned& lo, unsigned& hi) { const unsigned o = __shfl_xor(v, 32); lo = h ? o : v; hi = h ? v : o; }
+static inline unsigned wave_min_u32(unsigned v) { for (int o = 32; o > 0; o >>= 1) { const unsigned w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
+#endif
+__device__ __forceinline__ void halves_f32(float v, int h, float& lo, float& hi) { unsigned a, b; halves(__float_as_uint(v), h, a, b); lo = __uint_as_float(a); hi = __uint_as_float(b); }
+// x = hi + lo (+ 2^-22 |x|): two half-precision pieces, as bit patterns
+__device__ __forceinline__ void split16(float x, unsigned& hi, unsigned& lo) { hi = f16_bits(x); lo = f16_bits(x - f16_val(hi)); }
+
+// min of two non-NaN doubles in ONE instruction (`a < b ? a : b` compiles to a compare and two 32-bit selects)
+__device__ __forceinline__ double min_f64(double a, double b) {
+#ifndef HIPEMU
+    double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return a < b ? a : b;
+#endif
+}
+__device__ __forceinline__ double xor_f64(double v, int o) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += xor_f64(v, o);
+    return v;
+}
+// minimum of non-negative doubles over the wave (they order like their bit patterns): two 32-bit reductions on the vector pipe
+__device__ __forceinline__ double wave_min_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned hi = wave_min_u32((unsigned)(b >> 32));
+    const unsigned lo = wave_min_u32((unsigned)(b >> 32) == hi ? (unsigned)b : 0xffffffffu);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+constexpr float MF_SCALE = 128.0f;          // coordinates are screened as 128 x: pieces of centimetre-scale coordinates stay normal half-precision numbers
+constexpr float MF_R2_MAX = 1000.0f;        // |p|^2 (m^2) up to which a superpoint is screened: 256 |p| and 4 |p|^2 fit half precision, padding keys stay above every real one
+constexpr int TS_F64 = 4, TS_MF = 3;      // doubles per staged target point: x, y, z (+ |b|^2 for the float64 screening)
+
+// ---- float64 screening (rounds 2-5; now for SSDR_CHAMFER_F64=1 and for targets beyond CH_TILE points) -----------------------------------------------
+// squared distances from NV centred source points to the nearest point of target j: its staged points (tb), or streamed
+__device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&out)[NV], const double* tb, int nj, bool staged,
+                                            const float* __restrict__ xyz, const int* __restrict__ sp_pts, int loj, double cjx, double cjy, double cjz) {
+    if (staged) {
+        // Screening on |b|^2 - 2 a.b, three fused multiply-adds per pair instead of three differences, a product and two fused multiply-adds; the
+        // target's index rides in the key's ten lowest mantissa bits (one 32-bit and-or), so the running minimum names its target and the distance
+        // itself is then evaluated ONCE per source point in the difference form — the value is the exact one whenever the target it names is the
+        // nearest.  A wrong name needs two targets whose keys agree to 2^-42 of |key| (<= ~1e-13 m^2 at room scale): the value returned is then
+        // that target's exact distance, above the minimum by at most that band.  5 instructions per pair on the float64 pipe.
+        double m[NV][2];      // independent chains: min is order-free
+        double ax2[NV], ay2[NV], az2[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { m[v][0] = m[v][1] = 1.0e300; ax2[v] = -2.0 * ax[v]; ay2[v] = -2.0 * ay[v]; az2[v] = -2.0 * az[v]; }
+        // (key.lo & ~1023) | idx in ONE instruction: gfx950's three-operand encodings take no 32-bit literal and one scalar operand, so the compiler
+        // emits v_and_b32 + v_or_b32 with the literal; with the mask in a vector register v_and_or_b32 does it (idx stays scalar)
+        const unsigned keep = ~1023u;
+        auto key = [&](double t, int idx) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+            unsigned lo;
+#ifndef HIPEMU
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)bits), "v"(keep), "s"(idx));
+#else
+            lo = ((unsigned)bits & keep) | (unsigned)idx;
+#endif
+            return __longlong_as_double((long long)((bits & 0xffffffff00000000ull) | lo));
+        };
+        int b = 0;
+        for (; b + 4 <= nj; b += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double tx = tb[TS_F64 * (b + u)], ty = tb[TS_F64 * (b + u) + 1], tz = tb[TS_F64 * (b + u) + 2], tn = tb[TS_F64 * (b + u) + 3];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const double t = fma(az2[v], tz, fma(ay2[v], ty, fma(ax2[v], tx, tn)));
+                    m[v][u & 1] = min_f64(key(t, b + u), m[v][u & 1]);
+                }
+            }
+        }
+        for (; b < nj; ++b) {
+            const double tx = tb[TS_F64 * b], ty = tb[TS_F64 * b + 1], tz = tb[TS_F64 * b + 2], tn = tb[TS_F64 * b + 3];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double t = fma(az2[v], tz, fma(ay2[v], ty, fma(ax2[v], tx, tn)));
+                m[v][0] = min_f64(key(t, b), m[v][0]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = (int)((unsigned)__double_as_longlong(min_f64(m[v][0], m[v][1])) & 1023u);
+            const double dx = ax[v] - tb[TS_F64 * idx], dy = ay[v] - tb[TS_F64 * idx + 1], dz = az[v] - tb[TS_F64 * idx + 2];
+            out[v] = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
+        }
+        return;
+    }
+    double m[NV];                        // very large target: stream it from global memory
+#pragma unroll
+    for (int v = 0; v < NV; ++v) m[v] = 1.0e300;
+    for (int b = 0; b < nj; ++b) {
+        const size_t q = sp_pts[loj + b];
+        const double tx = (double)xyz[3 * q] - cjx, ty = (double)xyz[3 * q + 1] - cjy, tz = (double)xyz[3 * q + 2] - cjz;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { const double dx = ax[v] - tx, dy = ay[v] - ty, dz = az[v] - tz; double d = dx * dx; d = d + dy * dy; d = d + dz * dz; m[v] = min_f64(m[v], d); }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = m[v];
+}
+
+// ---- screening on the matrix cores -------------------------------------------------------------------------------------------------------------------
+// The wave's 256 source slots against the staged target: sv[slot] = the distance (root taken) from slot's point to its nearest target point.
+//   comp(slot, d): coordinate d of the slot's centred point (float64); live(slot): the slot holds a point whose distance is used;
+//   ta0 / ta1: the target as MFMA operand tiles (stage_target below), padded to whole tiles of 32 with keys above every real one;
+//   tb: its float64 points, TS_MF doubles each;  thr = 2 eps of (this item, this target) in the scaled units.
+// Lane (c = lane & 31, h = lane >> 5), source tile t: slot 32 t + c.  k-slots of the instruction (lane half h holds k = 8 h .. 8 h + 7):
+//     k      0        1        2        3        4        5        6       7       8        9        10      11..15
+//   source  Xh       Xl       Xh       Yh       Yl       Yh       2^12    2^12    Zh       Zl       Zh       0          (X = -256 ax, ...)
+//   target  Xh       Xh       Xl       Yh       Yh       Yl       Wh      Wl      Zh       Zh       Zl       0          (X = 128 bx, ..., W = 4 |b|^2)
+// The lane's sixteen results are rows (reg & 3) + 8 (reg >> 2) + 4 h of column c: run q = reg >> 2 holds targets 32 T + 8 q + 4 h .. + 3.
+struct TargetTiles { const u32x4* t0; const unsigned long long* t1; };      // [tile][32] operands of the lower / the upper lane half
+__device__ __forceinline__ u32x4 source_operand(double u, double v, int h) {   // h = 0: (ax, ay), h = 1: (az, -)
+    unsigned uh, ul, vh, vl;
+    split16((float)(u * (double)(-2.0f * MF_SCALE)), uh, ul); split16((float)(v * (double)(-2.0f * MF_SCALE)), vh, vl);
+    const unsigned one = 0x6c00u;                                               // 4096.0
+    u32x4 r;
+    r[0] = uh | (ul << 16); r[1] = h ? uh : (uh | (vh << 16)); r[2] = h ? 0u : (vl | (vh << 16)); r[3] = h ? 0u : (one | (one << 16));
+    return r;
+}
+template <class Comp, class Live>
+__device__ __forceinline__ void chamfer_min_mf(Comp comp, Live live, TargetTiles ta, const double* __restrict__ tb, int nj, float thr, double* sv, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    u32x4 B[8]; float m1[8], m2[8]; int id[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        B[t] = source_operand(comp(32 * t + c, h ? 2 : 0), comp(32 * t + c, 1), h);
+        m1[t] = m2[t] = FLT_MAX; id[t] = 0;
+    }
+    const int ntiles = (nj + 31) >> 5;
+    for (int T = 0; T < ntiles; ++T) {
+        u32x4 A = {0u, 0u, 0u, 0u};
+        if (h) { const unsigned long long v = ta.t1[T * 32 + c]; A[0] = (unsigned)v; A[1] = (unsigned)(v >> 32); }
+        else A = ta.t0[T * 32 + c];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x16 acc = {};
+            acc = mfma_f16(A, B[t], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float cq = fminf(fminf(fminf(acc[4 * q], acc[4 * q + 1]), acc[4 * q + 2]), acc[4 * q + 3]);
+                m2[t] = med3(cq, m1[t], m2[t]);                 // m1 <= m2 before and after
+                id[t] = cq < m1[t] ? 4 * T + q : id[t];
+                m1[t] = fminf(m1[t], cq);
+            }
+        }
+    }
+    // The two halves of the wave saw different runs of the same source: merge (both lanes of a source get the same answer) ...
+    int first[8]; unsigned unsure = 0;          // bit t: source (t, c) is not decided by the screening
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        float lo1, hi1, lo2, hi2; unsigned lid, hid;
+        halves_f32(m1[t], h, lo1, hi1); halves_f32(m2[t], h, lo2, hi2); halves((unsigned)id[t], h, lid, hid);
+        const bool up = hi1 < lo1;
+        first[t] = 8 * (int)(up ? hid : lid) + (up ? 4 : 0);
+        const float n1 = fminf(lo1, hi1), n2 = fminf(fmaxf(lo1, hi1), fminf(lo2, hi2));
+        unsure |= (n2 - n1 > thr) ? 0u : 1u << t;
+    }
+    // ... then the lower half evaluates the winning runs of tiles 0-3, the upper half those of tiles 4-7: four float64 distances per source
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int slot = 32 * (4 * h + u) + c, f = h ? first[4 + u] : first[u];
+        const double ax = comp(slot, 0), ay = comp(slot, 1), az = comp(slot, 2);
+        double best = 1.0e300;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = min(f + e, nj - 1);                   // (a run that reaches into the padding: the last point again)
+            const double dx = ax - tb[TS_MF * b], dy = ay - tb[TS_MF * b + 1], dz = az - tb[TS_MF * b + 2];
+            best = min_f64(best, fma(dz, dz, fma(dy, dy, dx * dx)));
+        }
+        sv[slot] = sqrt(best);
+    }
+    // the undecided ones: the whole target in float64, a target point per lane
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        unsigned long long todo = __ballot(((unsure >> t) & 1u) && !h && live(32 * t + c));
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int s = 32 * t + l;
+            const double sx = comp(s, 0), sy = comp(s, 1), sz = comp(s, 2);
+            double bm = 1.0e300;
+            for (int b = lane; b < nj; b += 64) {
+                const double dx = sx - tb[TS_MF * b], dy = sy - tb[TS_MF * b + 1], dz = sz - tb[TS_MF * b + 2];
+                bm = min_f64(bm, fma(dz, dz, fma(dy, dy, dx * dx)));
+            }
+            bm = wave_min_f64(bm);
+            if (lane == 0) sv[s] = sqrt(bm);
+        }
+    }
+}
+
+// v[0] + ... + v[n-1], n <= SEQ_MAX, by one lane
+__device__ __forceinline__ double sum_short(const double* v, int n) {
+    double a = 0.0;
+    for (int t = 0; t < n; ++t) a += v[t];
+    return a;
+}
+// v[0] + ... + v[n-1] by the whole wave (uniform arguments): lane l adds v[l], v[l + 64], ... up, then the xor tree
+__device__ __forceinline__ double sum_wave(const double* v, int n, int lane) {
+    double a = 0.0;
+    for (int t = lane; t < n; t += 64) a += v[t];
+    return wave_sum_f64(a);
+}
+
+// One workgroup per target superpoint j (and slice of the sources): its centred points are staged in LDS once and re-used against
+// every source item.  The mean is (sum_short | sum_wave) / size, so it can differ from NumPy's pairwise np.mean in the last ulps
+// (sqrt is monotone: min of roots == root of min).
+template <bool MF>
+__device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                 const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P, const int* counts,
+                                 double* tb, u32x4* ta0, unsigned long long* ta1, double (*s_val)[ITEM]) {
+    constexpr int TS = MF ? TS_MF : TS_F64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nitems = counts[0], nbig = counts[1];
+    for (int j = blockIdx.x; j < nsel; j += gridDim.x) {
+        const int sj = sel[j], loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
+        const double cjx = centres[3 * j], cjy = centres[3 * j + 1], cjz = centres[3 * j + 2];
+        const float r2j = MF ? P.r2sp[j] : 0.0f;
+        const bool staged = nj <= CH_TILE && (!MF || r2j <= MF_R2_MAX);
+        if (staged) {
+            __syncthreads();
+            const int st = P.start[j];
+            const int padded = MF ? ((nj + 31) & ~31) : nj;
+            for (int b = threadIdx.x; b < padded; b += 256) {
+                double x = 0.0, y = 0.0, z = 0.0;
+                if (b < nj) {
+                    if (st >= 0) { x = P.x[st + b]; y = P.y[st + b]; z = P.z[st + b]; }
+                    else { const size_t q = sp_pts[loj + b]; x = (double)xyz[3 * q] - cjx; y = (double)xyz[3 * q + 1] - cjy; z = (double)xyz[3 * q + 2] - cjz; }
+                    const double w = fma(z, z, fma(y, y, x * x));
+                    tb[TS * b] = x; tb[TS * b + 1] = y; tb[TS * b + 2] = z;
+                    if constexpr (!MF) tb[TS * b + 3] = w;
+                    if constexpr (MF) {             // the operand images of chamfer_min_mf's k-slot table
+                        unsigned xh, xl, yh, yl, zh, zl, wh, wl;
+                        split16((float)(x * (double)MF_SCALE), xh, xl); split16((float)(y * (double)MF_SCALE), yh, yl); split16((float)(z * (double)MF_SCALE), zh, zl);
+                        split16((float)(w * 4.0), wh, wl);
+                        u32x4 o; o[0] = xh | (xh << 16); o[1] = xl | (yh << 16); o[2] = yh | (yl << 16); o[3] = wh | (wl << 16);
+                        ta0[b] = o; ta1[b] = (unsigned long long)(zh | (zh << 16)) | ((unsigned long long)zl << 32);
+                    }
+                } else if constexpr (MF) { u32x4 o = {0u, 0u, 0u, 0x7800u}; ta0[b] = o; ta1[b] = 0ull; }      // W = 32768: a key of 2^27, above every real one (<= 3 * 2^14 * 1000)
+            }
+            __syncthreads();
+        }
+        const TargetTiles ta{ta0, ta1};
+        // 2 eps in the scaled units (file header), from the largest |a|^2 of the item and |b|^2 of the target
+        auto thr_of = [&](float r2a) { return 2.0f * (0x1p-17f * (MF_SCALE * MF_SCALE) * (r2a + r2j) + 0x1p-22f * MF_SCALE * (sqrtf(r2a) + sqrtf(r2j)) + 0x1p-12f); };
+        for (int it = blockIdx.y * 4 + wid; it < nitems; it += 4 * gridDim.y) {          // whole superpoints per wave
+            const int k0 = P.item_slot[it], k = k0 + lane;
+            const float r2i = MF ? P.r2item[k0 / ITEM] : 0.0f;
+            if (MF && staged && r2i <= MF_R2_MAX) {
+                const float thr = thr_of(r2i);
+                chamfer_min_mf([&](int slot, int d) { return (d == 0 ? P.x : d == 1 ? P.y : P.z)[k0 + slot]; }, [&](int slot) { return P.seg[k0 + slot] >= 0; },
+                               ta, tb, nj, thr, s_val[wid], lane);
+            } else {
+                double ax[NV], ay[NV], az[NV], m[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { ax[v] = P.x[k + 64 * v]; ay[v] = P.y[k + 64 * v]; az[v] = P.z[k + 64 * v]; }
+                chamfer_min(ax, ay, az, m, tb, nj, staged && !MF, xyz, sp_pts, loj, cjx, cjy, cjz);      // (with MF: out of the screening's range)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+            }
+            (void)__ballot(1);                               // the wave's LDS writes are visible to its lanes
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cnt = P.cnt[k + 64 * v], seg = P.seg[k + 64 * v];
+                if (cnt > 0 && cnt <= SEQ_MAX) dir[(size_t)seg * nsel + j] = seg == j ? 0.0 : sum_short(&s_val[wid][lane + 64 * v], cnt) / (double)cnt;
+                unsigned long long todo = __ballot(cnt > SEQ_MAX);          // the larger ones, one after the other, all lanes on each
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int c = __shfl(cnt, src), sg = __shfl(seg, src);
+                    const double sum = sum_wave(&s_val[wid][src + 64 * v], c, lane);
+                    if (lane == 0) dir[(size_t)sg * nsel + j] = sg == j ? 0.0 : sum / (double)c;
+                }
+            }
+            (void)__ballot(1);
+        }
+        for (int bi = blockIdx.y * 4 + wid; bi < nbig; bi += 4 * gridDim.y) {            // pair by pair: more than ITEM points (or none)
+            const int i = P.big[bi];
+            if (i == j) { if (lane == 0) dir[(size_t)i * nsel + j] = 0.0; continue; }
+            const int si = sel[i], loi = sp_off[si], ni = sp_off[si + 1] - loi;
+            const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
+            const float r2i = MF ? P.r2sp[i] : 0.0f, thr = MF ? thr_of(r2i) : 0.0f;
+            double acc = 0.0;
+            for (int a0 = 0; a0 < ni; a0 += ITEM) {
+                if (MF && staged && r2i <= MF_R2_MAX) {
+                    chamfer_min_mf([&](int slot, int d) {           // beyond the end: the last point again, not summed
+                                       const size_t p = sp_pts[loi + min(a0 + slot, ni - 1)];
+                                       return (double)xyz[3 * p + d] - (d == 0 ? cix : d == 1 ? ciy : ciz); },
+                                   [&](int slot) { return a0 + slot < ni; }, ta, tb, nj, thr, s_val[wid], lane);
+                } else {
+                    double ax[NV], ay[NV], az[NV], m[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const int a = min(a0 + lane + 64 * v, ni - 1);          // beyond the end: the last point again, not summed
+                        const size_t p = sp_pts[loi + a];
+                        ax[v] = (double)xyz[3 * p] - cix; ay[v] = (double)xyz[3 * p + 1] - ciy; az[v] = (double)xyz[3 * p + 2] - ciz;
+                    }
+                    chamfer_min(ax, ay, az, m, tb, nj, staged && !MF, xyz, sp_pts, loj, cjx, cjy, cjz);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+                }
+                (void)__ballot(1);
+                if (ni <= SEQ_MAX) { if (lane == 0) acc = sum_short(&s_val[wid][0], ni); }      // same rule as inside an item
+                else acc += sum_wave(&s_val[wid][0], min(ITEM, ni - a0), lane);
+                (void)__ballot(1);
+            }
+            if (lane == 0) dir[(size_t)i * nsel + j] = ni > 0 ? acc / (double)ni : 0.0;
+        }
+    }
+}
+
+template <bool MF>
+__global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(MF ? 4 : 5) void sel_chamfer_dir(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P) {
+    __shared__ double tb[CH_TILE * (MF ? TS_MF : TS_F64)];
+    __shared__ u32x4 ta0[MF ? CH_TILE : 1];
+    __shared__ unsigned long long ta1[MF ? CH_TILE : 1];
+    __shared__ double s_val[4][ITEM];
+    chamfer_dir_body<MF>(xyz, sp_off, sp_pts, sel, nsel, centres, dir, P, P.counts, tb, ta0, ta1, s_val);
+}
+// all clouds of a batch in one launch: blockIdx.z = cloud
+template <bool MF>
+__global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(MF ? 4 : 5) void sel_chamfer_dir_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                             const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
+                                                             const double* __restrict__ centres, double* dir, ChamferPack P) {
+    __shared__ double tb[CH_TILE * (MF ? TS_MF : TS_F64)];
+    __shared__ u32x4 ta0[MF ? CH_TILE : 1];
+    __shared__ unsigned long long ta1[MF ? CH_TILE : 1];
+    __shared__ double s_val[4][ITEM];
+    const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
+    chamfer_dir_body<MF>(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, ta0, ta1, s_val);
+}
+
+bool chamfer_f64() { const char* e = getenv("SSDR_CHAMFER_F64"); return e && atoi(e) != 0; }      // read per launch: the tests run both forms in one process
+// slices of the source items per target (blockIdx.y): a workgroup stages its target once and its four waves take items slice * 4 + wave, + 4 * slices, ...
+// (measured for the float64 kernel, tools/gpu_chamfer_slices.sh, the bench's ~35 items per cloud: 16 slices 0.491-0.495 ms, 8: 0.481-0.484, 4: 0.53, 2: 0.62, 1: 0.83)
+int chamfer_slices(int nm) {
+    static const int env = [] { const char* e = getenv("SSDR_CHAMFER_SLICES"); return e ? atoi(e) : 0; }();
+    return std::max(1, std::min((nm + 3) / 4, env > 0 ? env : 8));
+}
+
+}  // namespace
+
+int chamfer_dir_launch(const float* d_xyz, const int* d_sp_off, const int* d_sp_pts, const int* d_sel, int n, const double* d_centres, double* d_dir,
+                       const ChamferPack& P, hipStream_t s) {
+    const dim3 grid(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16)));
+    if (chamfer_f64()) hipLaunchKernelGGL(sel_chamfer_dir<false>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir, P);
+    else hipLaunchKernelGGL(sel_chamfer_dir<true>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir, P);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+int chamfer_dir_batch_launch(const float* d_xyz, const int* d_sp_off, const int* d_sp_pts, const int* d_sel, const int* d_coff, const long long* d_boff,
+                             int n_max, unsigned nclouds, const double* d_centres, double* d_dir, const ChamferPack& P, hipStream_t s) {
+    const dim3 grid(std::min(n_max, 1024), chamfer_slices(n_max), nclouds);
+    if (chamfer_f64()) hipLaunchKernelGGL(sel_chamfer_dir_batch<false>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, d_boff, d_centres, d_dir, P);
+    else hipLaunchKernelGGL(sel_chamfer_dir_batch<true>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, d_boff, d_centres, d_dir, P);
+    SSDR_HIP(hipGetLastError());
+    return SSDR_OK;
+}
+
+}  // namespace ssdr

@@ -116,6 +116,37 @@ def test_chamfer_mixed_superpoint_sizes(backend):
     assert np.allclose(got, want[np.ix_(sel, sel)], rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("kind", ["blobs", "duplicates", "lattice"])
+def test_chamfer_matrix_screening_equals_float64(backend, kind, monkeypatch):
+    """The float32 screening on the matrix cores (select_chamfer.hip) against the float64 kernel it replaced (SSDR_CHAMFER_F64=1), the same call twice:
+    the same bits where the nearest target point is unique (random blobs; duplicated points tie at EQUAL coordinates, so the distance is the same
+    whichever copy is named), within the last ulps on a lattice (equally near targets at different offsets).  Sizes on both sides of every path:
+    items shared by several superpoints, passes of 256 over larger ones, targets of one to twenty tiles of 32 and one beyond the staging limit."""
+    from ssdr_al import sampler
+    rng = np.random.default_rng({"blobs": 51, "duplicates": 52, "lattice": 53}[kind])
+    sizes = [1, 2, 5, 31, 32, 33, 64, 90, 100, 127, 128, 160, 200, 255, 256, 257, 300, 420, 511, 640, 641, 700, 9, 17, 40, 75]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(off[-1])
+    xyz = np.empty((n, 3), np.float32)
+    for a, b in zip(off[:-1], off[1:]):
+        seat = rng.random(3) * np.array([6, 5, 2.5]) + 20.0
+        if kind == "lattice": blob = seat.round(1) + rng.integers(-4, 5, (b - a, 3)) * 0.25          # many exactly equal distances
+        else: blob = seat + rng.normal(0, 0.12, (b - a, 3)) * np.array([1.5, 1.0, 0.4])
+        if kind == "duplicates" and b - a > 4: blob[(b - a) // 2:] = blob[: (b - a) - (b - a) // 2]   # every point twice: the runs tie exactly
+        xyz[a:b] = blob.astype(np.float32)
+    pts = rng.permutation(n).astype(np.int32)
+    xyz = xyz[np.argsort(pts)]
+    sel = np.arange(len(sizes))
+    got = sampler.create_cd(xyz, off, pts, sel)
+    monkeypatch.setenv("SSDR_CHAMFER_F64", "1")
+    ref = sampler.create_cd(xyz, off, pts, sel)
+    monkeypatch.delenv("SSDR_CHAMFER_F64")
+    if kind == "lattice": assert np.allclose(got, ref, rtol=4e-16, atol=0)
+    else: assert np.array_equal(got, ref)
+    cent = O.bbox_centres(xyz, off, pts)
+    assert np.allclose(got, O.create_cd(xyz, off, pts, cent), rtol=1e-12, atol=1e-14)
+
+
 @pytest.mark.gpu
 def test_chamfer_more_superpoints_than_the_packer_lays_out():
     """4300 superpoints in one cloud (> PACK_MAX = 4096): the packer hands every superpoint to the pair-by-pair path.  The summation
