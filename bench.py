@@ -269,7 +269,11 @@ def main():
             if r[0] in mfma_kernels:
                 d.update({"algorithmic_TFLOPs": round(rate / 1e12, 2), "executed_mfma_TFLOPs": round(r[4] / (r[2] * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(rate / 1e12 / mfma_peak, 4)})
             elif r[0] in f64_kernels:
-                d.update({"algorithmic_f64_TFLOPs": round(rate / 1e12, 2), "frac_of_f64_vector_peak": round(rate / 1e12 / PEAK_F64_VECTOR_TFLOPS, 4)})
+                d.update({"algorithmic_f64_TFLOPs": round(rate / 1e12, 2), "frac_of_f64_vector_peak": round(rate / 1e12 / PEAK_F64_VECTOR_TFLOPS, 4),
+                          "note": "8 float64 FLOP per point pair of the reference's formulation; since round 5 the pairs are screened by v_mfma_f32_32x32x16_f16 "
+                                  "(two half-precision pieces per coordinate, 11 of 16 k-slots) and only the winning run of four targets per source is evaluated "
+                                  "in float64, so the float64 vector peak no longer bounds the kernel: it runs at the float32 vector issue rate "
+                                  "(6 instructions per 4 x 64 pairs), csrc/select_chamfer.hip"})
             elif r[3] > 0:
                 d.update({"algorithmic_GBs": round(rate / 1e9, 1), "frac_of_hbm_peak": round(rate / 1e9 / PEAK_HBM_GBS, 4)})
             if r[0] in one_cu:
@@ -297,7 +301,7 @@ def main():
                 else:
                     stage_roofline[k] = {"bound": "mfma", "algorithmic_flops": int(w), "achieved_TFLOPs": round(w / t / 1e12, 2), "peak_TFLOPs": mfma_peak,
                                          "frac": round(w / t / 1e12 / mfma_peak, 4), "hbm_bytes": int(63.1e6 * B), "hbm_frac": round(63.1e6 * B / t / 1e9 / PEAK_HBM_GBS, 4)}
-            stage_roofline["select"] = {"bound": "latency", "note": "one-workgroup FPS chain (592 dependent picks) + float64 chamfer graph; overlapped with the other stages"}
+            stage_roofline["select"] = {"bound": "latency", "note": "one-workgroup FPS chain (592 dependent picks) + chamfer graph (float64 values, screened on the matrix cores); overlapped with the other stages"}
             # the whole step against both rooflines: algorithmic bytes and FLOPs of all stages over the measured time per step
             alg_bytes = sum(w for b, w in stage_work.values() if b == "hbm") + 63.1e6 * B
             alg_flops = 16.71e9 * B

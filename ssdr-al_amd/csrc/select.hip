@@ -464,6 +464,9 @@ __device__ void chamfer_fill_body(const float* __restrict__ xyz, const int* __re
                 const int k = st + a;
                 P.x[k] = x; P.y[k] = y; P.z[k] = z;
                 P.seg[k] = i; P.cnt[k] = a == 0 ? ni : 0;
+                P.src0[k] = source_operand(x, y, 0);
+                const uint4 up = source_operand(z, 0.0, 1);
+                P.src1[k] = (unsigned long long)up.x | ((unsigned long long)up.y << 32);
             }
         }
         const float r = wave_max((float)(r2 * 1.000001));
@@ -1459,8 +1462,8 @@ struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum
 // scratch of the chamfer packer for nrows superpoints in nclouds clouds
 int chamfer_pack_buffers(SelState& Q, size_t nrows, size_t nclouds, ChamferPack& P) {
     const size_t slots = (size_t)ITEM * nrows;
-    SSDR_TRY(Q.pack_xyz.reserve(3 * 8 * slots + 64)); SSDR_TRY(Q.pack_int.reserve(4 * (2 * slots + 5 * nrows + 2 * nclouds) + 64));
-    P.x = Q.pack_xyz.as<double>(); P.y = P.x + slots; P.z = P.y + slots;
+    SSDR_TRY(Q.pack_xyz.reserve((3 * 8 + 16 + 8) * slots + 64)); SSDR_TRY(Q.pack_int.reserve(4 * (2 * slots + 5 * nrows + 2 * nclouds) + 64));
+    P.x = Q.pack_xyz.as<double>(); P.y = P.x + slots; P.z = P.y + slots; P.src1 = (unsigned long long*)(P.z + slots); P.src0 = (uint4*)(P.src1 + slots);
     P.seg = Q.pack_int.as<int>(); P.cnt = P.seg + slots; P.r2item = (float*)(P.cnt + slots); P.r2sp = P.r2item + nrows;
     P.item_slot = (int*)(P.r2sp + nrows); P.big = P.item_slot + nrows; P.start = P.big + nrows; P.counts = P.start + nrows;
     return SSDR_OK;

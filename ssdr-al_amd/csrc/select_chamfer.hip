@@ -44,8 +44,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
 __device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
-__device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
-__device__ __forceinline__ float f16_val(unsigned b) { return (float)__builtin_bit_cast(_Float16, (unsigned short)b); }
 // what lanes l and l ^ 32 hold, as (lower half's, upper half's) in both of them: one v_permlane32_swap
 __device__ __forceinline__ void halves(unsigned v, int, unsigned& lo, unsigned& hi) {
     auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); lo = r[0]; hi = r[1];
@@ -56,14 +54,10 @@ typedef hipemu_u32x4 u32x4;
 typedef hipemu_f32x16 f32x16;
 static inline f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) { return hipemu_mfma_f32_32x32x16_f16(a, b, c); }
 static inline float med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
-static inline unsigned f16_bits(float x) { return hipemu_f32_to_f16(x); }
-static inline float f16_val(unsigned b) { return hipemu_f16_to_f32((unsigned short)b); }
 static inline void halves(unsigned v, int h, unsigned& lo, unsigned& hi) { const unsigned o = __shfl_xor(v, 32); lo = h ? o : v; hi = h ? v : o; }
 static inline unsigned wave_min_u32(unsigned v) { for (int o = 32; o > 0; o >>= 1) { const unsigned w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
 #endif
 __device__ __forceinline__ void halves_f32(float v, int h, float& lo, float& hi) { unsigned a, b; halves(__float_as_uint(v), h, a, b); lo = __uint_as_float(a); hi = __uint_as_float(b); }
-// x = hi + lo (+ 2^-22 |x|): two half-precision pieces, as bit patterns
-__device__ __forceinline__ void split16(float x, unsigned& hi, unsigned& lo) { hi = f16_bits(x); lo = f16_bits(x - f16_val(hi)); }
 
 // min of two non-NaN doubles in ONE instruction (`a < b ? a : b` compiles to a compare and two 32-bit selects)
 __device__ __forceinline__ double min_f64(double a, double b) {
@@ -91,8 +85,6 @@ __device__ __forceinline__ double wave_min_f64(double v) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-constexpr float MF_SCALE = 128.0f;          // coordinates are screened as 128 x: pieces of centimetre-scale coordinates stay normal half-precision numbers
-constexpr float MF_R2_MAX = 1000.0f;        // |p|^2 (m^2) up to which a superpoint is screened: 256 |p| and 4 |p|^2 fit half precision, padding keys stay above every real one
 constexpr int TS_F64 = 4, TS_MF = 3;      // doubles per staged target point: x, y, z (+ |b|^2 for the float64 screening)
 
 // ---- float64 screening (rounds 2-5; now for SSDR_CHAMFER_F64=1 and for targets beyond CH_TILE points) -----------------------------------------------
@@ -165,6 +157,7 @@ __device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double
 
 // ---- screening on the matrix cores -------------------------------------------------------------------------------------------------------------------
 // The wave's 256 source slots against the staged target: sv[slot] = the distance (root taken) from slot's point to its nearest target point.
+//   oper(slot, h): the slot's point as the source operand of lane half h (source_operand; the packer keeps it per slot);
 //   comp(slot, d): coordinate d of the slot's centred point (float64); live(slot): the slot holds a point whose distance is used;
 //   ta0 / ta1: the target as MFMA operand tiles (stage_target below), padded to whole tiles of 32 with keys above every real one;
 //   tb: its float64 points, TS_MF doubles each;  thr = 2 eps of (this item, this target) in the scaled units.
@@ -173,22 +166,18 @@ __device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double
 //   source  Xh       Xl       Xh       Yh       Yl       Yh       2^12    2^12    Zh       Zl       Zh       0          (X = -256 ax, ...)
 //   target  Xh       Xh       Xl       Yh       Yh       Yl       Wh      Wl      Zh       Zh       Zl       0          (X = 128 bx, ..., W = 4 |b|^2)
 // The lane's sixteen results are rows (reg & 3) + 8 (reg >> 2) + 4 h of column c: run q = reg >> 2 holds targets 32 T + 8 q + 4 h .. + 3.
+#ifndef MF_RUN
+#define MF_RUN 4          // targets per run: 4 (the four consecutive rows of a result register quad) or 8 (two quads, rows r .. r + 3 and r + 8 .. r + 11)
+#endif
 struct TargetTiles { const u32x4* t0; const unsigned long long* t1; };      // [tile][32] operands of the lower / the upper lane half
-__device__ __forceinline__ u32x4 source_operand(double u, double v, int h) {   // h = 0: (ax, ay), h = 1: (az, -)
-    unsigned uh, ul, vh, vl;
-    split16((float)(u * (double)(-2.0f * MF_SCALE)), uh, ul); split16((float)(v * (double)(-2.0f * MF_SCALE)), vh, vl);
-    const unsigned one = 0x6c00u;                                               // 4096.0
-    u32x4 r;
-    r[0] = uh | (ul << 16); r[1] = h ? uh : (uh | (vh << 16)); r[2] = h ? 0u : (vl | (vh << 16)); r[3] = h ? 0u : (one | (one << 16));
-    return r;
-}
-template <class Comp, class Live>
-__device__ __forceinline__ void chamfer_min_mf(Comp comp, Live live, TargetTiles ta, const double* __restrict__ tb, int nj, float thr, double* sv, int lane) {
+template <class Oper, class Comp, class Live>
+__device__ __forceinline__ void chamfer_min_mf(Oper oper, Comp comp, Live live, TargetTiles ta, const double* __restrict__ tb, int nj, float thr, double* sv, int lane) {
     const int c = lane & 31, h = lane >> 5;
     u32x4 B[8]; float m1[8], m2[8]; int id[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        B[t] = source_operand(comp(32 * t + c, h ? 2 : 0), comp(32 * t + c, 1), h);
+        const uint4 o = oper(32 * t + c, h);
+        B[t][0] = o.x; B[t][1] = o.y; B[t][2] = o.z; B[t][3] = o.w;
         m1[t] = m2[t] = FLT_MAX; id[t] = 0;
     }
     const int ntiles = (nj + 31) >> 5;
@@ -201,10 +190,12 @@ __device__ __forceinline__ void chamfer_min_mf(Comp comp, Live live, TargetTiles
             f32x16 acc = {};
             acc = mfma_f16(A, B[t], acc);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float cq = fminf(fminf(fminf(acc[4 * q], acc[4 * q + 1]), acc[4 * q + 2]), acc[4 * q + 3]);
+            for (int q = 0; q < 16 / MF_RUN; ++q) {
+                float cq = acc[MF_RUN * q];
+#pragma unroll
+                for (int e = 1; e < MF_RUN; ++e) cq = fminf(cq, acc[MF_RUN * q + e]);
                 m2[t] = med3(cq, m1[t], m2[t]);                 // m1 <= m2 before and after
-                id[t] = cq < m1[t] ? 4 * T + q : id[t];
+                id[t] = cq < m1[t] ? (16 / MF_RUN) * T + q : id[t];
                 m1[t] = fminf(m1[t], cq);
             }
         }
@@ -216,7 +207,7 @@ __device__ __forceinline__ void chamfer_min_mf(Comp comp, Live live, TargetTiles
         float lo1, hi1, lo2, hi2; unsigned lid, hid;
         halves_f32(m1[t], h, lo1, hi1); halves_f32(m2[t], h, lo2, hi2); halves((unsigned)id[t], h, lid, hid);
         const bool up = hi1 < lo1;
-        first[t] = 8 * (int)(up ? hid : lid) + (up ? 4 : 0);
+        first[t] = 2 * MF_RUN * (int)(up ? hid : lid) + (up ? 4 : 0);
         const float n1 = fminf(lo1, hi1), n2 = fminf(fmaxf(lo1, hi1), fminf(lo2, hi2));
         unsure |= (n2 - n1 > thr) ? 0u : 1u << t;
     }
@@ -227,8 +218,8 @@ __device__ __forceinline__ void chamfer_min_mf(Comp comp, Live live, TargetTiles
         const double ax = comp(slot, 0), ay = comp(slot, 1), az = comp(slot, 2);
         double best = 1.0e300;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int b = min(f + e, nj - 1);                   // (a run that reaches into the padding: the last point again)
+        for (int e = 0; e < MF_RUN; ++e) {
+            const int b = min(f + (e & 3) + 8 * (e >> 2), nj - 1);      // (a run that reaches into the padding: the last point again)
             const double dx = ax - tb[TS_MF * b], dy = ay - tb[TS_MF * b + 1], dz = az - tb[TS_MF * b + 2];
             best = min_f64(best, fma(dz, dz, fma(dy, dy, dx * dx)));
         }
@@ -313,7 +304,8 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
             const float r2i = MF ? P.r2item[k0 / ITEM] : 0.0f;
             if (MF && staged && r2i <= MF_R2_MAX) {
                 const float thr = thr_of(r2i);
-                chamfer_min_mf([&](int slot, int d) { return (d == 0 ? P.x : d == 1 ? P.y : P.z)[k0 + slot]; }, [&](int slot) { return P.seg[k0 + slot] >= 0; },
+                chamfer_min_mf([&](int slot, int h) { if (!h) return P.src0[k0 + slot]; const unsigned long long v = P.src1[k0 + slot]; return uint4{(unsigned)v, (unsigned)(v >> 32), 0u, 0u}; },
+                               [&](int slot, int d) { return (d == 0 ? P.x : d == 1 ? P.y : P.z)[k0 + slot]; }, [&](int slot) { return P.seg[k0 + slot] >= 0; },
                                ta, tb, nj, thr, s_val[wid], lane);
             } else {
                 double ax[NV], ay[NV], az[NV], m[NV];
@@ -348,9 +340,11 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
             double acc = 0.0;
             for (int a0 = 0; a0 < ni; a0 += ITEM) {
                 if (MF && staged && r2i <= MF_R2_MAX) {
-                    chamfer_min_mf([&](int slot, int d) {           // beyond the end: the last point again, not summed
-                                       const size_t p = sp_pts[loi + min(a0 + slot, ni - 1)];
-                                       return (double)xyz[3 * p + d] - (d == 0 ? cix : d == 1 ? ciy : ciz); },
+                    auto at = [&](int slot, int d) {                // beyond the end: the last point again, not summed
+                        const size_t p = sp_pts[loi + min(a0 + slot, ni - 1)];
+                        return (double)xyz[3 * p + d] - (d == 0 ? cix : d == 1 ? ciy : ciz);
+                    };
+                    chamfer_min_mf([&](int slot, int h) { return source_operand(at(slot, h ? 2 : 0), at(slot, 1), h); }, at,
                                    [&](int slot) { return a0 + slot < ni; }, ta, tb, nj, thr, s_val[wid], lane);
                 } else {
                     double ax[NV], ay[NV], az[NV], m[NV];
