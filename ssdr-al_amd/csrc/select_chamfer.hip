@@ -219,7 +219,7 @@ __device__ __forceinline__ void chamfer_min_mf(Oper oper, Comp comp, Live live, 
         double best = 1.0e300;
 #pragma unroll
         for (int e = 0; e < MF_RUN; ++e) {
-            const int b = min(f + (e & 3) + 8 * (e >> 2), nj - 1);      // (a run that reaches into the padding: the last point again)
+            const int b = max(min(f + (e & 3) + 8 * (e >> 2), nj - 1), 0);      // (a run that reaches into the padding: the last point again; an empty target: undecided, swept below)
             const double dx = ax - tb[TS_MF * b], dy = ay - tb[TS_MF * b + 1], dz = az - tb[TS_MF * b + 2];
             best = min_f64(best, fma(dz, dz, fma(dy, dy, dx * dx)));
         }

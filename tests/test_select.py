@@ -147,6 +147,30 @@ def test_chamfer_matrix_screening_equals_float64(backend, kind, monkeypatch):
     assert np.allclose(got, O.create_cd(xyz, off, pts, cent), rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 50.0, 80.0, 250.0])
+def test_chamfer_matrix_screening_at_other_scales(backend, scale, monkeypatch):
+    """The screening's error bound has absolute terms (half-precision subnormals) and a range limit (|p|^2 <= 1000 m^2 after centring): superpoints a
+    few tenths of a millimetre across are mostly left to the float64 sweep, superpoints tens of metres across take the float64 kernel's path inside
+    the screening kernel — the values must not change."""
+    from ssdr_al import sampler
+    rng = np.random.default_rng(61)
+    sizes = [5, 40, 130, 257, 300, 64, 33]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(off[-1])
+    xyz = np.empty((n, 3), np.float32)
+    for a, b in zip(off[:-1], off[1:]):
+        xyz[a:b] = ((rng.random(3) * np.array([6, 5, 2.5]) + rng.normal(0, 0.12, (b - a, 3))) * scale).astype(np.float32)
+    pts = np.arange(n, dtype=np.int32)
+    sel = np.arange(len(sizes))
+    got = sampler.create_cd(xyz, off, pts, sel)
+    monkeypatch.setenv("SSDR_CHAMFER_F64", "1")
+    ref = sampler.create_cd(xyz, off, pts, sel)
+    monkeypatch.delenv("SSDR_CHAMFER_F64")
+    assert np.array_equal(got, ref)
+    cent = O.bbox_centres(xyz, off, pts)
+    assert np.allclose(got, O.create_cd(xyz, off, pts, cent), rtol=1e-12, atol=1e-14 * scale)
+
+
 @pytest.mark.gpu
 def test_chamfer_more_superpoints_than_the_packer_lays_out():
     """4300 superpoints in one cloud (> PACK_MAX = 4096): the packer hands every superpoint to the pair-by-pair path.  The summation
