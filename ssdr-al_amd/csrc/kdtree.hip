@@ -310,6 +310,48 @@ __global__ __launch_bounds__(TREE_NT) void kd_tree_kernel(ForestPtrs f) {
     }
 }
 
+// The levels a balanced tree does not reach: ONE launch instead of one per level.  The level-wide launches below go on for BIG_LEVELS levels because a
+// degenerate cloud needs them; a cloud of n points has big nodes (above 64 points) down to level log2(n / 64) or a few more (nanoflann splits boxes in
+// the middle, not point sets).  Past that, every workgroup of this kernel takes one of the big nodes that are still open (usually none) and splits the
+// big nodes of its subtree itself, one after the other from a stack in LDS (depth first: the stack holds one node per level).  Which workgroup splits a node changes the numbering of the nodes, not the tree.
+constexpr int REST_NT = 256, REST_Q = 64;
+__global__ __launch_bounds__(REST_NT) void kd_rest_kernel(ForestPtrs f, int level0) {
+    __shared__ SplitLds<REST_NT> L;
+    __shared__ int s_q[REST_Q];              // open big nodes of the subtree, last in first out: at most one per level below the top one, plus one
+    __shared__ unsigned char s_lv[REST_Q];
+    __shared__ int s_top;
+    const int tid = threadIdx.x;
+    const int nq = min(f.ctr[CTR_QUEUE0 + level0], f.queue_cap);
+    const int nballs = f.balls.q ? *f.balls.count : 0;
+    const bool cut_to_balls = f.balls.q && nballs <= f.balls.cap;
+    const int* qin = f.queue + (level0 & 1) * f.queue_cap;
+    int maxlevel = -1;
+    for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        __syncthreads();
+        if (tid == 0) { s_q[0] = qin[qi]; s_lv[0] = (unsigned char)level0; s_top = 1; }
+        __syncthreads();
+        for (;;) {
+            const int top = s_top;
+            if (top == 0) break;
+            const int node = s_q[top - 1], level = s_lv[top - 1];
+            __syncthreads();
+            if (tid == 0) s_top = top - 1;
+            maxlevel = max(maxlevel, level);
+            kd_split_node<REST_NT>(f, L, node, level, cut_to_balls, nballs, [&](int c) {       // (its barriers order the pop above before these pushes)
+                const int q = atomicAdd(&s_top, 1);                // (both children may be pushed, by two threads)
+                if (q >= REST_Q) { atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF); return; }
+                s_q[q] = c; s_lv[q] = (unsigned char)(level + 1);  // (kd_split_node flags a big node at BIG_LEVELS - 1: levels stay below 24)
+            });
+            __syncthreads();
+            if (tid == 0 && s_top > REST_Q) s_top = REST_Q;
+        }
+    }
+    if (tid == 0 && maxlevel >= 0) {
+        atomicMax(&f.ctr[CTR_DEPTH], maxlevel + 1);
+        if (maxlevel + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
+    }
+}
+
 // Nodes of at most 64 points: ONE wavefront builds the node's whole subtree (one lane per point, the points stay in
 // registers / LDS).  min/max are wave reductions, the counts are ballots, and the two-pointer sweeps of planeSplit
 // become two LDS permutations whose destinations come from ballot prefix counts (left-side misplaced k <-> right-side
@@ -767,7 +809,13 @@ static int launch_build(const KdForest& f, const ForestPtrs& p, hipStream_t s, b
     const int grid = std::max(1, std::min(f.queue_cap, ctx().num_cu * 8));
     // nodes above 64 points: one workgroup each, level by level; deeper than BIG_LEVELS a node that large means a
     // degenerate cloud (flagged, not mis-built).  Everything at or below 64 points: one launch, one wavefront per subtree.
+    // level-wide launches down to where a balanced tree's nodes reach 64 points and REST_MARGIN levels more, then one launch for whatever is still open
+    // (SSDR_KD_REST_MARGIN: 99 = level-wide all the way, as rounds 1-4 did)
+    const char* me = getenv("SSDR_KD_REST_MARGIN");          // (read per build: the tests run several settings in one process)
+    const int margin = me ? atoi(me) : 2;
+    int balanced = 0; while ((f.max_n >> balanced) > SMALL_MAX) ++balanced;
     for (int level = 0; level < BIG_LEVELS && f.max_n > SMALL_MAX; ++level) {
+        if (level >= balanced + margin) { hipLaunchKernelGGL(kd_rest_kernel, dim3(grid), dim3(REST_NT), 0, s, p, level); break; }
         // the first levels have few, large nodes: 8 waves per node (16 would spill at the 128-VGPR cap); later 4
         if ((f.max_n >> level) > 1024) hipLaunchKernelGGL((kd_split_kernel<512>), dim3(grid), dim3(512), 0, s, p, level);
         else hipLaunchKernelGGL((kd_split_kernel<256>), dim3(grid), dim3(256), 0, s, p, level);

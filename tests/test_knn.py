@@ -181,6 +181,26 @@ def test_tree_hand_over_cut_to_balls(backend, orc, scale, monkeypatch, capfd):
     assert_bits_equal(got1, orc.knn_batch(p[:, : n // 4], p, 1, threads=4), "K=1 scale " + scale)
 
 
+@pytest.mark.parametrize("margin", ["-20", "0", "99"])
+def test_tree_lower_levels_in_one_launch(backend, orc, margin, monkeypatch):
+    """The kd forest's big nodes are split by level-wide launches down to the depth a balanced tree needs + SSDR_KD_REST_MARGIN levels, the rest by one
+    launch whose workgroups walk their subtrees depth first (kd_rest_kernel).  -20: that launch builds everything from the roots; 99: it never runs
+    (rounds 1-4).  Complete trees (ball scale 0) over clustered points with duplicates: deep, uneven trees, every tie row through the tree."""
+    from ssdr_al import knn
+    rng = np.random.default_rng(23)
+    n = 3000 if backend == "emu" else 30000
+    seats = rng.random((12, 3)) * np.array([8, 6, 3])
+    p = (seats[rng.integers(0, 12, n)] + rng.normal(0, 1, (n, 3)) * np.exp(rng.normal(-2, 0.7, (n, 1)))).astype(np.float32)
+    p[-60:] = p[:60]
+    p = p[rng.permutation(n)][None]
+    monkeypatch.setenv("SSDR_KNN_BALL_SCALE", "0")
+    monkeypatch.setenv("SSDR_KD_REST_MARGIN", margin)
+    got = knn.knn_batch(p, p, 16)
+    st = knn.knn_status()
+    assert st[0] > 0, "the case must hand rows over to the trees"
+    assert_bits_equal(got, orc.knn_batch(p, p, 16, threads=4), "margin " + margin)
+
+
 @pytest.mark.gpu
 def test_pyramid_full_size_properties():
     """BASELINE config 2 shape: B=16 tiles of 40960 points.  Size-independent properties + oracle on 2 tiles."""
