@@ -214,7 +214,7 @@ __device__ __forceinline__ void chamfer_min_mf(Oper oper, Comp comp, Live live, 
     // ... then the lower half evaluates the winning runs of tiles 0-3, the upper half those of tiles 4-7: four float64 distances per source
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int slot = 32 * (4 * h + u) + c, f = h ? first[4 + u] : first[u];
+        const int slot = 32 * (4 * h + u) + c, f = first[u] ^ ((first[u] ^ first[4 + u]) & -h);      // h ? first[4 + u] : first[u] (written as a select, the compiler indexes a copy of first[] in scratch)
         const double ax = comp(slot, 0), ay = comp(slot, 1), az = comp(slot, 2);
         double best = 1.0e300;
 #pragma unroll
