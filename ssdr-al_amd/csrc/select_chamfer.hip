@@ -44,20 +44,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
 __device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
-// what lanes l and l ^ 32 hold, as (lower half's, upper half's) in both of them: one v_permlane32_swap
-__device__ __forceinline__ void halves(unsigned v, int, unsigned& lo, unsigned& hi) {
-    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); lo = r[0]; hi = r[1];
-}
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return wave_reduce_u32(v, [](unsigned a, unsigned b) { return a < b ? a : b; }); }
 #else
 typedef hipemu_u32x4 u32x4;
 typedef hipemu_f32x16 f32x16;
 static inline f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) { return hipemu_mfma_f32_32x32x16_f16(a, b, c); }
 static inline float med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
-static inline void halves(unsigned v, int h, unsigned& lo, unsigned& hi) { const unsigned o = __shfl_xor(v, 32); lo = h ? o : v; hi = h ? v : o; }
 static inline unsigned wave_min_u32(unsigned v) { for (int o = 32; o > 0; o >>= 1) { const unsigned w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
 #endif
-__device__ __forceinline__ void halves_f32(float v, int h, float& lo, float& hi) { unsigned a, b; halves(__float_as_uint(v), h, a, b); lo = __uint_as_float(a); hi = __uint_as_float(b); }
+// a (a value of the tile the LOWER half of the wave will finish) and b (of the tile the UPPER half will finish), each held by both lanes of a source with
+// the lane half's own partial result: afterwards a = the lower half's partial result, b = the upper half's, of the tile this lane finishes — ONE
+// v_permlane32_swap (a's upper 32 lanes <-> b's lower 32 lanes), no copies
+__device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b, int h) {
+#ifndef HIPEMU
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; (void)h;
+#else
+    const unsigned ta = __shfl_xor(a, 32), tb_ = __shfl_xor(b, 32); a = h ? tb_ : a; b = h ? b : ta;
+#endif
+}
+__device__ __forceinline__ void swap_halves_f32(float& a, float& b, int h) { unsigned x = __float_as_uint(a), y = __float_as_uint(b); swap_halves(x, y, h); a = __uint_as_float(x); b = __uint_as_float(y); }
+constexpr int TS_MF_ = 3;      // doubles per staged target point of the screening kernel (TS_MF below)
+// the staged float64 point b (a 32-bit multiply is a quarter-rate instruction; byte offsets are far below 2^24)
+__device__ __forceinline__ const double* target_at(const double* tb, int b) {
+#ifndef HIPEMU
+    unsigned o;                 // (__umul24 is folded back into the 32-bit multiply)
+    asm("v_mul_u32_u24_e32 %0, 24, %1" : "=v"(o) : "v"(b));
+    static_assert(8 * TS_MF_ == 24, "byte stride of a staged target point");
+    return reinterpret_cast<const double*>(reinterpret_cast<const char*>(tb) + o);
+#else
+    return tb + TS_MF_ * b;
+#endif
+}
 
 // min of two non-NaN doubles in ONE instruction (`a < b ? a : b` compiles to a compare and two 32-bit selects)
 __device__ __forceinline__ double min_f64(double a, double b) {
@@ -200,43 +217,46 @@ __device__ __forceinline__ void chamfer_min_mf(Oper oper, Comp comp, Live live, 
             }
         }
     }
-    // The two halves of the wave saw different runs of the same source: merge (both lanes of a source get the same answer) ...
-    int first[8]; unsigned unsure = 0;          // bit t: source (t, c) is not decided by the screening
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        float lo1, hi1, lo2, hi2; unsigned lid, hid;
-        halves_f32(m1[t], h, lo1, hi1); halves_f32(m2[t], h, lo2, hi2); halves((unsigned)id[t], h, lid, hid);
-        const bool up = hi1 < lo1;
-        first[t] = 2 * MF_RUN * (int)(up ? hid : lid) + (up ? 4 : 0);
-        const float n1 = fminf(lo1, hi1), n2 = fminf(fmaxf(lo1, hi1), fminf(lo2, hi2));
-        unsure |= (n2 - n1 > thr) ? 0u : 1u << t;
-    }
-    // ... then the lower half evaluates the winning runs of tiles 0-3, the upper half those of tiles 4-7: four float64 distances per source
+    // The two halves of the wave saw different runs of the same source.  The lower half finishes source tiles 0-3, the upper half tiles 4-7: one swap per
+    // quantity and pair of tiles (u, 4 + u) hands every lane both halves' partial results of ITS tile.
+    int first[4]; unsigned unsure = 0;          // bit u: this lane's source of tile 4 h + u is not decided by the screening
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int slot = 32 * (4 * h + u) + c, f = first[u] ^ ((first[u] ^ first[4 + u]) & -h);      // h ? first[4 + u] : first[u] (written as a select, the compiler indexes a copy of first[] in scratch)
+        float lo1 = m1[u], hi1 = m1[4 + u], lo2 = m2[u], hi2 = m2[4 + u]; unsigned lid = (unsigned)id[u], hid = (unsigned)id[4 + u];
+        swap_halves_f32(lo1, hi1, h); swap_halves_f32(lo2, hi2, h); swap_halves(lid, hid, h);
+        const bool up = hi1 < lo1;
+        first[u] = 2 * MF_RUN * (int)(up ? hid : lid) + (up ? 4 : 0);
+        const float n1 = fminf(lo1, hi1), n2 = fminf(fmaxf(lo1, hi1), fminf(lo2, hi2));
+        unsure |= (n2 - n1 > thr) ? 0u : 1u << u;
+    }
+    // ... the winning run in float64: four distances per source
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int slot = 32 * (4 * h + u) + c, f = first[u];
         const double ax = comp(slot, 0), ay = comp(slot, 1), az = comp(slot, 2);
         double best = 1.0e300;
 #pragma unroll
         for (int e = 0; e < MF_RUN; ++e) {
             const int b = max(min(f + (e & 3) + 8 * (e >> 2), nj - 1), 0);      // (a run that reaches into the padding: the last point again; an empty target: undecided, swept below)
-            const double dx = ax - tb[TS_MF * b], dy = ay - tb[TS_MF * b + 1], dz = az - tb[TS_MF * b + 2];
+            const double* tp = target_at(tb, b);
+            const double dx = ax - tp[0], dy = ay - tp[1], dz = az - tp[2];
             best = min_f64(best, fma(dz, dz, fma(dy, dy, dx * dx)));
         }
         sv[slot] = sqrt(best);
     }
     // the undecided ones: the whole target in float64, a target point per lane
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        unsigned long long todo = __ballot(((unsure >> t) & 1u) && !h && live(32 * t + c));
+    for (int u = 0; u < 4; ++u) {
+        unsigned long long todo = __ballot(((unsure >> u) & 1u) && live(32 * (4 * h + u) + c));
         while (todo) {
             const int l = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const int s = 32 * t + l;
+            const int s = 32 * (4 * (l >> 5) + u) + (l & 31);
             const double sx = comp(s, 0), sy = comp(s, 1), sz = comp(s, 2);
             double bm = 1.0e300;
             for (int b = lane; b < nj; b += 64) {
-                const double dx = sx - tb[TS_MF * b], dy = sy - tb[TS_MF * b + 1], dz = sz - tb[TS_MF * b + 2];
+                const double* tp = target_at(tb, b);
+                const double dx = sx - tp[0], dy = sy - tp[1], dz = sz - tp[2];
                 bm = min_f64(bm, fma(dz, dz, fma(dy, dy, dx * dx)));
             }
             bm = wave_min_f64(bm);
