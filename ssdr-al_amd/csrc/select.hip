@@ -372,27 +372,6 @@ __global__ __launch_bounds__(256) void sel_segment_mean(const float* __restrict_
 }
 
 // ---- F1/F2: bbox centres, chamfer, adjacency, propagation for the superpoints `sel` of ONE cloud ----------------
-__global__ __launch_bounds__(256) void sel_centres(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                   const int* __restrict__ sel, int nsel, double* centres, const int* __restrict__ dn = nullptr) {
-    const int lane = threadIdx.x & 63;
-    if (dn) nsel = min(nsel, *dn);
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nsel; q += gridDim.x * 4) {      // one wave per superpoint
-        const int s = sel[q], lo = sp_off[s], hi = sp_off[s + 1];
-        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (int j = lo + lane; j < hi; j += 64) {
-            const size_t p = sp_pts[j];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { const float v = xyz[3 * p + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
-        if (lane == 0) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) centres[3 * (size_t)q + d] = (double)(mn[d] + mx[d]) / 2.0;   // float32 add, exact halving (fps_gcn_cpu.py:86-88)
-        }
-    }
-}
-
 // The lay-out of one cloud (one workgroup): slots of the cloud start at ITEM * (its first row), the per-superpoint tables at its first row.
 __device__ void chamfer_plan_body(const int* __restrict__ sp_off, const int* __restrict__ sel, int n, ChamferPack P, int* counts, int* s_n) {
     const int tid = threadIdx.x;
@@ -430,15 +409,23 @@ __device__ void chamfer_plan_body(const int* __restrict__ sp_off, const int* __r
     }
     __syncthreads();
     // ranks of the item openers and of the pair-by-pair superpoints: counted per thread over a contiguous piece, then offset by the pieces before
-    __shared__ int s_ci[257], s_cb[257];
     const int per = (n + 255) / 256, lo = min(n, tid * per), hi = min(n, lo + per);
     int ci = 0, cb = 0;
     for (int i = lo; i < hi; ++i) { const int st = s_start[i]; if (st < 0) ++cb; else if ((st & (ITEM - 1)) == 0) ++ci; }
-    s_ci[tid] = ci; s_cb[tid] = cb;
-    __syncthreads();
-    if (tid == 0) { int a = 0, b = 0; for (int t = 0; t < 256; ++t) { const int x = s_ci[t], y = s_cb[t]; s_ci[t] = a; s_cb[t] = b; a += x; b += y; } counts[0] = a; counts[1] = b; }
-    __syncthreads();
-    ci = s_ci[tid]; cb = s_cb[tid];
+    // exclusive prefix over the 256 pieces: inside a wave by shuffles, across the four waves through LDS (a serial pass by one lane took ~10 us)
+    {
+        const int lane = tid & 63, w = tid >> 6;
+        int pi = ci, pb = cb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int ui = __shfl_up(pi, o), ub = __shfl_up(pb, o); if (lane >= o) { pi += ui; pb += ub; } }
+        __shared__ int s_wi[4], s_wb[4];
+        if (lane == 63) { s_wi[w] = pi; s_wb[w] = pb; }
+        __syncthreads();
+        int oi = 0, ob = 0;
+        for (int k = 0; k < w; ++k) { oi += s_wi[k]; ob += s_wb[k]; }
+        if (tid == 255) { counts[0] = oi + pi; counts[1] = ob + pb; }
+        ci = oi + pi - ci; cb = ob + pb - cb;          // exclusive
+    }
     for (int i = lo; i < hi; ++i) {
         const int st = s_start[i];
         P.start[i] = st;
@@ -449,12 +436,23 @@ __device__ void chamfer_plan_body(const int* __restrict__ sp_off, const int* __r
 // ... and its slots: one wave per superpoint (seg / cnt / r2item of the padding slots and unused items were preset by the launcher: -1 / 0 / 0).
 // r2sp / r2item: the largest |p|^2 of the superpoint / of the item's superpoints, rounded up — what bounds the float32 screening's error (select_chamfer.hip)
 __device__ void chamfer_fill_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts, const int* __restrict__ sel, int n,
-                                  const double* __restrict__ centres, ChamferPack P) {
+                                  double* __restrict__ centres, ChamferPack P) {
     const int lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
         const int st = P.start[i];
         const int sp = sel[i], lo = sp_off[sp], ni = sp_off[sp + 1] - lo;
-        const double cx = centres[3 * i], cy = centres[3 * i + 1], cz = centres[3 * i + 2];
+        // the superpoint's bounding-box centre (sel_centres' arithmetic; its launch is saved: the wave reads the points twice, the second time from L2)
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int a = lane; a < ni; a += 64) {
+            const size_t q = sp_pts[lo + a];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { const float v = xyz[3 * q + d]; mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+        }
+        double cen[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) cen[d] = (double)(wave_min(mn[d]) + wave_max(mx[d])) / 2.0;      // float32 add, exact halving (fps_gcn_cpu.py:86-88)
+        if (lane < 3) centres[3 * (size_t)i + lane] = lane == 0 ? cen[0] : lane == 1 ? cen[1] : cen[2];
+        const double cx = cen[0], cy = cen[1], cz = cen[2];
         double r2 = 0.0;
         for (int a = lane; a < ni; a += 64) {
             const size_t q = sp_pts[lo + a];
@@ -483,7 +481,7 @@ __global__ __launch_bounds__(256) void sel_chamfer_plan(const int* __restrict__ 
     chamfer_plan_body(sp_off, sel + lo, n, pack_at(P, lo), P.counts + 2 * c, s_n);
 }
 __global__ __launch_bounds__(256) void sel_chamfer_fill(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
-                                                        const int* __restrict__ sel, const int* __restrict__ coff, int nsingle, const double* __restrict__ centres, ChamferPack P) {
+                                                        const int* __restrict__ sel, const int* __restrict__ coff, int nsingle, double* __restrict__ centres, ChamferPack P) {
     const int c = blockIdx.y, lo = coff ? coff[c] : 0, n = coff ? coff[c + 1] - lo : nsingle;
     chamfer_fill_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, pack_at(P, lo));
 }
@@ -1468,9 +1466,10 @@ int chamfer_pack_buffers(SelState& Q, size_t nrows, size_t nclouds, ChamferPack&
     P.item_slot = (int*)(P.r2sp + nrows); P.big = P.item_slot + nrows; P.start = P.big + nrows; P.counts = P.start + nrows;
     return SSDR_OK;
 }
-// plan + fill of the packer for nclouds clouds (coff == nullptr: one cloud of nsingle superpoints)
+// plan + fill of the packer for nclouds clouds (coff == nullptr: one cloud of nsingle superpoints); the fill also writes the superpoints' bounding-box
+// centres (d_centres [nrows, 3]: what the adjacency kernels read) — rows the device-side count leaves unused are not touched
 int chamfer_pack_launch(const ChamferPack& P, const float* d_xyz, const int* d_sp_off, const int* d_sp_pts, const int* d_sel, const int* d_coff, int nsingle,
-                        size_t nrows, int n_max, unsigned nclouds, const double* d_centres, hipStream_t s) {
+                        size_t nrows, int n_max, unsigned nclouds, double* d_centres, hipStream_t s) {
     const size_t slots = (size_t)ITEM * nrows;
     SSDR_HIP(hipMemsetAsync(P.seg, 0xff, 4 * slots, s));          // padding slots: no superpoint ...
     SSDR_HIP(hipMemsetAsync(P.cnt, 0, 4 * (slots + nrows), s));   // ... and nothing to sum; r2item (behind cnt) = 0
@@ -1638,7 +1637,6 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
     const int n = (int)nsel;
     SSDR_TRY(Q.rowsum.reserve(8 * nsel));
-    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((n + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, nsel, 1, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, d_sel, nullptr, n, nsel, n, 1, d_centres, s));
     SSDR_TRY(chamfer_dir_launch(d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_cd_dir, P, s));
@@ -1656,9 +1654,8 @@ int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, cons
     SSDR_TRY(ensure_init());
     if (num_clouds == 0 || n_total == 0 || n_max == 0) return SSDR_OK;
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
-    const int nt = (int)n_total, nm = (int)n_max; const unsigned nc = (unsigned)num_clouds;
+    const int nm = (int)n_max; const unsigned nc = (unsigned)num_clouds;
     SSDR_TRY(Q.rowsum.reserve(8 * n_total));
-    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, nt, d_centres);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, n_total, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, 0, n_total, nm, nc, d_centres, s));
     SSDR_TRY(chamfer_dir_batch_launch(d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, (const long long*)d_boff, nm, nc, d_centres, d_cd_dir, P, s));
@@ -1893,7 +1890,6 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, counts + 2, V, comb,
                        d_lab_cls, d_lab_dom, counts);
     SSDR_TRY(Q.rowsum.reserve(8 * cap_rows));
-    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, counts + 2);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
     prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
@@ -1975,7 +1971,6 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     hipLaunchKernelGGL(sel_segment_mean, dim3(grid_for((long)nt * D)), dim3(256), 0, s, d_feat, D, d_cls, d_dom, d_sp_off, d_sp_pts, sel, nt, (float*)nullptr, plan + 2, V, comb,
                        d_lab_cls, d_lab_dom, plan);
     SSDR_TRY(Q.rowsum.reserve(8 * cap_rows));
-    hipLaunchKernelGGL(sel_centres, dim3(std::max(1, std::min((nt + 3) / 4, 2048))), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, gsel, nt, cen, plan + 2);
     ChamferPack P; SSDR_TRY(chamfer_pack_buffers(Q, cap_rows, num_clouds, P));
     SSDR_TRY(chamfer_pack_launch(P, d_xyz, d_sp_off, d_sp_pts, gsel, coff, 0, cap_rows, nm, nc, cen, s));
     prof.emplace("sel_chamfer", s, 0.0);          // (pairs of points: the counts are the device's; bench.py derives the FLOPs from the result)
