@@ -767,7 +767,12 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     {
     ProfScope prof("fe_reduce", s, 0.0);
     if (!fe_image) {
-        const int g = ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 2 * FE_RED_WAVES * (256 / FE_RNT));          // (twice the resident workgroups: the items are dealt round robin and differ in size)
+        // The items (buckets) differ in size and are dealt to the workgroups round robin: with twice the resident workgroups (16 per CU: rounds 4-5) the
+        // kernel ended with its unluckiest workgroup; with ~ one workgroup per item the hardware's dispatcher does the balancing.  Same box, workgroups
+        // per CU (SSDR_FE_WGS): 16: 0.43 ms, 32: 0.39, 64: 0.35, **128: 0.338**, 256: 0.337, 512: 0.343, 4096: slower than 16 (front end 1.08 -> 1.00 ms,
+        // 198 -> 201 Mpoints/s).  Capped by the points (a bucket holds ~10^3 of them; workgroups beyond the item count exit at once).
+        const long cap = std::max<long>((long)ctx().num_cu * 16, (long)t.n_total / 64);
+        const int g = (int)std::min<long>((long)ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 128), fe_wgs > 0 ? (1L << 30) : cap);
         if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, false>), dim3(g), dim3(FE_RNT), (size_t)fe_pad, s, ra);
         else hipLaunchKernelGGL((fe_reduce<-1, -1, false>), dim3(g), dim3(FE_RNT), (size_t)fe_pad, s, ra);
     } else if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_reduce<3, 1, true>), dim3(ctx().num_cu * (fe_wgs > 0 ? fe_wgs : 3)), dim3(FE_RNT), 0, s, ra);        // the hot path's rows
@@ -779,8 +784,10 @@ int frontend_batch_device(const float* d_p, const float* d_f, size_t fdim, const
     FeMoveArgs ma; ma.t = t; ma.geom = geom; ma.items = items; ma.counters = counters; ma.rec = S.rec.as<uint4>(); ma.nocc = S.nocc.as<unsigned>();
     ma.trow = S.trow.as<unsigned>(); ma.lrc = S.lrc.as<unsigned char>(); ma.pre = S.pre.as<unsigned short>(); ma.rowbase = S.rowcnt.as<unsigned>(); ma.fdim = (int)fdim; ma.ldim = (int)ldim;
     ma.out_p = d_op; ma.out_f = d_of; ma.out_c = d_oc;
-    if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_move<3, 1>), dim3(ctx().num_cu * 8), dim3(BS), 0, s, ma);
-    else hipLaunchKernelGGL((fe_move<-1, -1>), dim3(ctx().num_cu * 8), dim3(BS), 0, s, ma);
+    // a wave per item, round robin: 8 workgroups per CU give every wave two items of different sizes, 32 one (0.100 -> 0.094 ms; SSDR_FE_MOVE_WGS)
+    static const int mv_wgs = [] { const char* e = getenv("SSDR_FE_MOVE_WGS"); return e ? atoi(e) : 32; }();
+    if (fdim == 3 && ldim == 1) hipLaunchKernelGGL((fe_move<3, 1>), dim3(ctx().num_cu * mv_wgs), dim3(BS), 0, s, ma);
+    else hipLaunchKernelGGL((fe_move<-1, -1>), dim3(ctx().num_cu * mv_wgs), dim3(BS), 0, s, ma);
     SSDR_HIP(hipGetLastError());
 #ifdef SSDR_FE_STAMPS
     {
