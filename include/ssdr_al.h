@@ -309,7 +309,7 @@ int ssdr_create_adj_dev(const float* d_feat, size_t N, int F, const double* d_ce
  * (ascending superpoint id), n_lab of them in all.  batch_size = sampling_batch.  selector 0: farthest_features_sample from candidate `start`
  * (fps_gcn_cpu.py:119-147); 1: kCenterGreedy over candidates + labelled rows seeded with the labelled ones (kcenterGreedy.py:84-128).  Capacities the caller sizes the run by (upper bounds, computable from the static tables):
  * cap_rows >= candidates + labelled regions, cap_nmax >= the largest cloud's share of them, cap_sq >= the sum over clouds of its share squared,
- * cap_unl >= candidates (cap_rows <= 16384), max_select = min(batch_size, unlabelled regions) = the number of picks.
+ * cap_unl >= candidates (cap_rows <= 2^22: the reference's own round, 20 000 candidates + 4 000 labelled rows of 272 clouds, is one call), max_select = min(batch_size, unlabelled regions) = the number of picks.
  * d_result (int32): [0..7] n_unl, n_lab, rows, largest block, picks, status (bit 0: rows > cap_rows, bit 1: blocks > cap_sq: nothing was selected),
  * block elements (int64 in two words); [8 .. 8+max_select) the picks (indices into the candidate list); then [cap_rows] the candidate list
  * (superpoint ids, cloud by cloud, descending uncertainty inside a cloud) followed by the labelled regions.  feat_dim = 32.
@@ -320,6 +320,10 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
                               const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_order, size_t S, const uint8_t* d_labelled, const int32_t* d_sp_base, size_t num_clouds,
                               const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t batch_size, int gcn_number, int gcn_top, int selector, int start,
                               size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream);
+/* The propagated rows of the last ssdr_gcn_fps_sampling_dev call on `stream`: device pointer to [cap_rows][32] float64, the candidates first, then the
+ * labelled regions (sum_i A^i V, fps_gcn_cpu.py:162-167 — what GCN_FPS_sampling hands to farthest_features_sample, :169-170).  Valid until the
+ * next selection call on that stream. */
+int ssdr_gcn_fps_sampling_rows(void* stream, const double** d_rows, size_t* cap_rows);
 /* The same for the SHARDED run (one process per GPU), again without a host decision: two enqueue-only calls around the all-gather of the
  * candidates' propagated features.  Global region id = rank * Smax + local id (padding counts as labelled), global cloud = rank * Bmax + local cloud.
  * ssdr_gcn_fps_sharded_local_dev: the candidate rule over the global ranking d_gorder [Sg = world * Smax] (ssdr_rank_regions_dev over the all-gathered masked

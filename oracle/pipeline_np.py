@@ -64,7 +64,7 @@ def labelled_selection(clouds, labelled, class_num, round_num, random_state):
 
 
 def selection_round(clouds, labelled, selected_class_list, class_num, sampler_args, min_size, round_num, batch_size, gcn_number, gcn_top,
-                    start, random_state, selector="fps", max_size=None):
+                    start, random_state, selector="fps", max_size=None, graph_clouds=None):
     """TSampler.sampling, gcn_fps branch (sampler2.py:736-781), over in-memory clouds instead of files.  clouds[b] = dict(xyz [n,3] f32,
     gt [n] int, probs [n,C] f32, feat [n,32] f32, offsets [S+1], points [T]); labelled[b] = ids of the regions NOT in total_obj["unlabeled"].
 
@@ -74,7 +74,10 @@ def selection_round(clouds, labelled, selected_class_list, class_num, sampler_ar
     create_file_top_and_all (:533-552) + :745-753: the first batch_size ranked regions fix selected_num per cloud, each cloud offers its first
     2 x selected_num ranked regions.  compute_features (:313-342): candidates' means over the dominant PREDICTED class members, labelled
     regions' over the dominant GROUND-TRUTH class members.  Orders the reference leaves to a shuffled DataLoader / a random draw are
-    canonical here: candidates cloud ascending, descending uncertainty inside a cloud; labelled rows cloud ascending, superpoint ascending."""
+    canonical here: candidates cloud ascending, descending uncertainty inside a cloud; labelled rows cloud ascending, superpoint ascending.
+
+    graph_clouds (checks at the reference's scale, 272 clouds: the float64 chamfer loops of every cloud take minutes here): only these clouds' graphs are
+    built; `comb` is then valid for their rows alone (`graph_rows`), no sequence is drawn (`seq` None) — the caller runs the FPS oracle over the rows it has."""
     um = [a for a in sampler_args if a in ("lc", "entropy", "sb")][0]
     rm = [a for a in sampler_args if a in ("mean", "sum_weight", "WetSU")][0]
     ref, ru, rclass, lab_ge, cls_of = [], [], [], [], []
@@ -126,8 +129,11 @@ def selection_round(clouds, labelled, selected_class_list, class_num, sampler_ar
     nf = np.asarray(clouds[0]["feat"]).shape[1]
     V = np.concatenate([np.asarray(uf, np.float32).reshape(len(unl), nf), np.asarray(lf, np.float32).reshape(len(lab), nf)]).astype(np.float64)
     blocks, rows_l = [], []
+    ref_cloud = np.array([c for c, _ in refs], np.int64)
     for b in sorted(set(c for c, _ in refs)):
-        rows = np.array([i for i, (c, _) in enumerate(refs) if c == b])
+        if graph_clouds is not None and b not in graph_clouds:
+            continue
+        rows = np.flatnonzero(ref_cloud == b)
         cl = clouds[b]
         so = np.concatenate([[0], np.cumsum([cl["offsets"][refs[i][1] + 1] - cl["offsets"][refs[i][1]] for i in rows])]).astype(np.int32)
         spts = np.concatenate([cl["points"][cl["offsets"][refs[i][1]]:cl["offsets"][refs[i][1] + 1]] for i in rows])
@@ -135,6 +141,10 @@ def selection_round(clouds, labelled, selected_class_list, class_num, sampler_ar
         cen = S.bbox_centres(xyz, so, spts)
         blocks.append(S.keep_top(S.block_adjacency(cen, S.create_cd(xyz, so, spts, cen)), gcn_top)); rows_l.append(rows)
     comb = S.propagate(blocks, rows_l, V, gcn_number)
+    if graph_clouds is not None:
+        return dict(region=ref, region_class=np.asarray(rclass, np.int32), region_unc_raw=raw, region_unc=np.asarray(ru, np.float64), sorted_inds=sorted_inds,
+                    labelled_ge_min=lab_ge, labsel=labsel, unl=unl, lab=lab, unl_feat=np.asarray(uf, np.float32), lab_feat=np.asarray(lf, np.float32),
+                    sampling_batch=sampling_batch, comb=comb, graph_rows=np.concatenate(rows_l) if rows_l else np.zeros(0, np.int64), seq=None, selected=None)
     if sampling_batch == 0:
         seq = np.zeros(0, np.int32)
     elif selector == "kcenter":      # kCenterGreedy over candidates + labelled rows, the labelled ones already selected (gcn.py:247)

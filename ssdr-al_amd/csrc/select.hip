@@ -1136,6 +1136,408 @@ __global__ __launch_bounds__(FR_NT) void fps_coop_tag(FpsCoopArgs a) {
         fc = reinterpret_cast<const double*>(mine + (size_t)(c / FR_ROWS) * FT_WORDS) + 2;      // the winner's row: the record of the workgroup that owns row c
     }
 }
+
+// Round 6: the chain at the reference's own scale (10 000 picks over 20 000 candidates, ssdr_main_S3DIS2.py:134) is all hand-off: 0.5 us of float64
+// arithmetic per pick, the rest the all-to-all of the G partials.  Two changes against fps_coop_tag:
+//  (1) the SWEEP: a record is 34 slots of 16 bytes, each slot two self-validating 8-byte granules {data, tag}; every thread issues ALL its slot loads
+//      (16-byte `sc1` loads) before it looks at a tag and re-reads only the slots that were not there yet — one memory round trip per pass instead of one
+//      per granule (the polled form walked ceil(68 G / 512) dependent round trips per pick: 6.3 us at G = 40).  The owner's features go to the record
+//      straight from a per-wave LDS image written beside the wave arg-max: two barriers per pick instead of four.
+//  (2) the TEAM (team = 1): only workgroups that find themselves on ONE XCD take part — HW_REG_XCC_ID is read, not assumed: the first workgroup to
+//      arrive names the XCD, the others of that XCD take tickets for the G row blocks, everybody else leaves at once — so that the records travel
+//      through that XCD's own L2 (plain stores keep the line there; `sc1` loads by-pass the reading CU's L1 only) instead of the fabric.  Launched with
+//      8 (G + 2) workgroups: placement is the dispatcher's (round-robin over the XCDs as observed, promised nowhere); too few workgroups on the XCD is
+//      the same bounded wait -> abort -> status as a launch that was not co-resident, never a wrong selection.
+constexpr int FS_SLOTS = FR_REC;             // 16-byte slots per record: words (v lo, v hi), (i, 0), 32 x (f lo, f hi)
+constexpr int FS_XCC_ID = ((4 - 1) << 11) | 20;      // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
+typedef unsigned fs_u4 __attribute__((ext_vector_type(4)));
+// TIMED (development, SSDR_FPS_DBG=1): wave 0 of every workgroup accumulates s_memtime between the phases of a pick into dbg[g][8]
+template <bool TIMED>
+__global__ __launch_bounds__(FR_NT, 4) void fps_coop_sweep(FpsCoopArgs a, int team, int plain_store, long long* dbg) {
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto mark = [&](int k) { if (TIMED) { const long long t = (long long)__builtin_readcyclecounter(); tacc[k] += t - tprev; tprev = t; } };
+    if (a.dn) a.n = min(a.n, *a.dn);
+    extern __shared__ __attribute__((aligned(16))) unsigned s_rec[];      // [2][G][FT_WORDS] data words of the records of a pick
+    __shared__ double s_v[2][FR_NT / 64]; __shared__ int s_i[2][FR_NT / 64]; __shared__ __attribute__((aligned(16))) unsigned s_pubw[FR_NT / 64][FT_WORDS];
+    __shared__ int s_g, s_gave; __shared__ double s_f0[32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, G = a.G;
+    if (tid == 0) {
+        s_gave = 0;
+        int g = blockIdx.x;
+        if (team) {
+            const int xcc = (int)(__builtin_amdgcn_s_getreg(FS_XCC_ID) & 0xf);
+            const int seen = atomicCAS(&a.sync[4], 0, xcc + 1);
+            g = (seen == 0 || seen == xcc + 1) ? atomicAdd(&a.sync[5], 1) : G;
+        }
+        s_g = g;
+    }
+    __syncthreads();
+    const int g = s_g;
+    if (g >= G) return;                                     // another XCD's workgroup, or a spare of the team's
+    const int row = g * FR_ROWS + tid;
+    double reg[32], rmin = row < a.n ? a.mind[row] : -1.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) reg[k] = row < a.n ? a.f[(size_t)row * 32 + k] : 0.0;
+    int c;
+    if (!a.from_partials) c = a.start;
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < a.npart; k += FR_NT) if (better(a.pin[k].v, a.pin[k].i, v, i)) { v = a.pin[k].v; i = a.pin[k].i; }
+        wave_argmax(v, i);
+        if (lane == 0) { s_v[0][wid] = v; s_i[0][wid] = i; }
+        __syncthreads();
+        v = s_v[0][0]; c = s_i[0][0];
+        for (int w = 1; w < FR_NT / 64; ++w) if (better(s_v[0][w], s_i[0][w], v, c)) { v = s_v[0][w]; c = s_i[0][w]; }
+        __syncthreads();
+    }
+    if (tid < 32) s_f0[tid] = a.f[(size_t)c * 32 + tid];    // the first centre's row comes from the table
+    __syncthreads();
+    const double* fc = s_f0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 2 * G * FS_SLOTS * 16, 0x00020000);
+    const int total = G * FS_SLOTS;
+    for (int it = 0; it < a.count; ++it) {
+        if (g == 0 && tid == 0) a.out[it] = c;
+        if (it + 1 == a.count) break;
+        const int par = it & 1;
+        if (TIMED) tprev = (long long)__builtin_readcyclecounter();
+        double wv = -1.0; int wi = 0x7fffffff;
+        if (row < a.n) {
+            double dist = np_pairwise_fixed<32>([&](int k) { const double d = reg[k] - fc[k]; return d * d; });
+            if (a.use_sqrt) dist = sqrt(dist);
+            if (dist < rmin) rmin = dist;
+            wv = rmin; wi = row;
+        }
+        mark(0);
+        wave_argmax(wv, wi);
+        mark(1);
+        // the wave's best row lays its record out (the workgroup's winner is read from the winning wave's image)
+        if (wi == row) {
+            double* pub = reinterpret_cast<double*>(s_pubw[wid]);
+            pub[0] = wv; pub[1] = __longlong_as_double((long long)(unsigned)wi);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) pub[2 + k] = reg[k];
+        }
+        if (lane == 0) { s_v[par][wid] = wv; s_i[par][wid] = wi; }
+        mark(2);
+        __syncthreads();                                   // (1)
+        mark(3);
+        const unsigned tag = (unsigned)it + 1u;
+        const unsigned base = (unsigned)(par * G) * FS_SLOTS * 16u;
+        if (tid < FS_SLOTS) {
+            double bv = s_v[par][0]; int bi = s_i[par][0], bw = 0;
+#pragma unroll
+            for (int w = 1; w < FR_NT / 64; ++w) if (better(s_v[par][w], s_i[par][w], bv, bi)) { bv = s_v[par][w]; bi = s_i[par][w]; bw = w; }
+            fs_u4 v;
+            if (bi != 0x7fffffff) { v.x = s_pubw[bw][2 * tid]; v.z = s_pubw[bw][2 * tid + 1]; }
+            else {          // padding rows only
+                const unsigned long long neg1 = (unsigned long long)__double_as_longlong(-1.0);
+                v.x = tid == 0 ? (unsigned)neg1 : tid == 1 ? 0x7fffffffu : 0u; v.z = tid == 0 ? (unsigned)(neg1 >> 32) : 0u;
+            }
+            v.y = tag; v.w = tag;
+            const unsigned off = base + (unsigned)(g * FS_SLOTS + tid) * 16u;
+            if (plain_store) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);                          // sc1: write-through
+        }
+        mark(4);
+        // every record of the pick: all of a thread's slots in flight, the missing ones again
+        unsigned* mine = s_rec + (size_t)par * G * FT_WORDS;
+        bool gave_up = false; int passes = 0;
+        for (int k0 = tid; k0 < total && !gave_up; k0 += 4 * FR_NT) {
+            unsigned pend = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k0 + j * FR_NT < total) pend |= 1u << j;
+            long spins = 0;
+            while (pend) {
+                fs_u4 v[4];
+                if (TIMED) ++passes;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if ((pend >> j) & 1u) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)(k0 + j * FR_NT) * 16u, 0, 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((pend >> j) & 1u) && v[j].y == tag && v[j].w == tag) {
+                        *reinterpret_cast<uint2*>(mine + 2 * (size_t)(k0 + j * FR_NT)) = make_uint2(v[j].x, v[j].z);
+                        pend &= ~(1u << j);
+                    }
+                if (pend && (++spins > FPS_COOP_SPINS / 16 || (spins % 1024 == 0 && __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) { gave_up = true; break; }
+            }
+        }
+        if (gave_up) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); s_gave = 1; }
+        mark(5);
+        if (TIMED) tacc[7] += passes;
+        __syncthreads();                                   // (2)
+        mark(6);
+        if (s_gave) { if (g == 0) for (int k = it + 1 + tid; k < a.count; k += FR_NT) a.out[k] = -1; return; }
+        // the winner: every wave finds it for itself (G <= 64 records, one per lane)
+        double v = -1.0; int i = 0x7fffffff;
+        if (lane < G) {
+            const double* r = reinterpret_cast<const double*>(mine + (size_t)lane * FT_WORDS);
+            v = r[0]; i = (int)(unsigned)__double_as_longlong(r[1]);
+        }
+        wave_argmax(v, i);
+        c = i;
+        fc = reinterpret_cast<const double*>(mine + (size_t)(c / FR_ROWS) * FT_WORDS) + 2;
+        if (TIMED) { const long long t = (long long)__builtin_readcyclecounter(); tacc[6] += t - tprev; tprev = t; }      // (the last arg-max joins slot 6)
+    }
+    if (TIMED && tid == 0) for (int k = 0; k < 8; ++k) dbg[(size_t)g * 8 + k] = tacc[k];
+}
+#endif
+
+#ifndef HIPEMU
+// Round 6, second form (the phase clocks of fps_coop_sweep, tools/gpu_fps6_dbg.sh: of 4.3 us per pick at 20 000 rows 2.7 are INSIDE the workgroup — 0.73 the
+// 95 dependent float64 instructions of a row's distance on a wave that issues one every ~12 cycles, 0.56 the wave arg-max and the owner's 272-byte LDS
+// image, 0.43 the skew of two waves per SIMD at the barrier, 0.48 + 0.5 the two combines — and 1.5 the sweep of 40 x 544 bytes):
+//  * a ROW IS SPLIT OVER LPR = 2 or 4 LANES: NumPy's eight pairwise accumulators are dealt to the lanes (lane q owns accumulators A q .. A q + A - 1, A = 8 / LPR,
+//    i.e. features 8 k + A q + e), each lane adds its accumulators in the reference's order and the tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) closes through one
+//    or two quad exchanges (a + b == b + a bit for bit): 29 / 50 dependent instructions instead of 95;
+//  * a RECORD IS ONE 16-BYTE SLOT: two self-validating 8-byte granules {value half, 16-bit tag | index half} — one lane publishes, ONE wave sweeps all G
+//    slots with every load in flight; the winner's ROW is then read from the feature table itself (it is immutable during the chain: plain, cacheable loads,
+//    every lane straight into its registers) instead of travelling in every record.  G = n / (512 / LPR) workgroups: 79 / 157 at 20 000 rows.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = dpp_u32<CTRL>((unsigned)b), hi = dpp_u32<CTRL>((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int FQ_NT = 512;
+template <int LPR, bool TIMED>
+__global__ __launch_bounds__(FQ_NT) void fps_coop_split(FpsCoopArgs a, int slot_shift, int stagger, long long* dbg) {
+    static_assert(LPR == 2 || LPR == 4, "lanes per row");
+    constexpr int A = 8 / LPR, F = 32 / LPR, ROWS = FQ_NT / LPR, NW = FQ_NT / 64, P = LPR == 2 ? 2 : 4;      // 64 P >= G slots per sweeping lane
+    if (a.dn) a.n = min(a.n, *a.dn);
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto mark = [&](int k) { if (TIMED) { const long long t = (long long)__builtin_readcyclecounter(); tacc[k] += t - tprev; tprev = t; } };
+    __shared__ double s_v[2][NW]; __shared__ int s_i[2][NW]; __shared__ int s_c[2], s_gave;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G, q = tid & (LPR - 1);
+    if (tid == 0) s_gave = 0;
+    const int row = g * ROWS + tid / LPR;
+    // this lane's share of its row: x[k * A + e] = f[row][8 k + A q + e]
+    double x[F], rmin = row < a.n ? a.mind[row] : -1.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < A; ++e) x[k * A + e] = row < a.n ? a.f[(size_t)row * 32 + 8 * k + A * q + e] : 0.0;
+    int c;
+    if (!a.from_partials) c = a.start;
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < a.npart; k += FQ_NT) if (better(a.pin[k].v, a.pin[k].i, v, i)) { v = a.pin[k].v; i = a.pin[k].i; }
+        wave_argmax(v, i);
+        if (lane == 0) { s_v[0][wid] = v; s_i[0][wid] = i; }
+        __syncthreads();
+        v = s_v[0][0]; c = s_i[0][0];
+        for (int w = 1; w < NW; ++w) if (better(s_v[0][w], s_i[0][w], v, c)) { v = s_v[0][w]; c = s_i[0][w]; }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, (2 * G) << slot_shift, 0x00020000);
+    for (int it = 0; it < a.count; ++it) {
+        if (g == 0 && tid == 0) a.out[it] = c;
+        if (it + 1 == a.count) break;
+        const int par = it & 1;
+        if (TIMED) tprev = (long long)__builtin_readcyclecounter();
+        // the centre's row, this lane's share of it, from the table
+        double fc[F];
+        {
+            const double* src = a.f + (size_t)c * 32 + A * q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < A; ++e) fc[k * A + e] = src[8 * k + e];
+        }
+        mark(0);
+        double wv = -1.0; int wi = 0x7fffffff;
+        {
+            double r[A];
+#pragma unroll
+            for (int e = 0; e < A; ++e) { const double d = x[e] - fc[e]; r[e] = d * d; }
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < A; ++e) { const double d = x[k * A + e] - fc[k * A + e]; r[e] += d * d; }
+            double p;
+            if (LPR == 4) { p = r[0] + r[1]; p = p + dpp_f64<0xB1>(p); p = p + dpp_f64<0x4E>(p); }
+            else { p = (r[0] + r[1]) + (r[A > 2 ? 2 : 0] + r[A > 2 ? 3 : 1]); p = p + dpp_f64<0xB1>(p); }
+            if (a.use_sqrt) p = sqrt(p);
+            if (row < a.n) { if (p < rmin) rmin = p; wv = rmin; wi = row; }
+        }
+        mark(1);
+        wave_argmax(wv, wi);
+        if (lane == 0) { s_v[par][wid] = wv; s_i[par][wid] = wi; }
+        mark(2);
+        __syncthreads();                                   // (1)
+        mark(3);
+        if (wid == 0) {
+            // the eight waves' pairs: one per lane, reduced inside the row of 16 lanes (two DPP passes instead of a chain of eight dependent compares)
+            const double pv0 = lane < NW ? s_v[par][lane] : -2.0;
+            const int pi0 = lane < NW ? s_i[par][lane] : 0x7fffffff;
+            const double bv = row_max_f64(pv0);
+            const int bi = row_min_i32(pv0 == bv ? pi0 : 0x7fffffff);
+            const unsigned tag = ((unsigned)it % 0xffffu + 1u) << 16;
+            const unsigned base = (unsigned)(par * G) << slot_shift;
+            if (lane == 0) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(bv);
+                fs_u4 v; v.x = (unsigned)b; v.y = tag | ((unsigned)bi >> 16); v.z = (unsigned)(b >> 32); v.w = tag | ((unsigned)bi & 0xffffu);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + ((unsigned)g << slot_shift), 0, 16);      // sc1: write-through
+            }
+            mark(4);
+            // every record of the pick: all of a lane's slots in flight, the missing ones again
+            double v = -1.0; int i = 0x7fffffff; bool gave_up = false; int passes = 0;
+            for (int k0 = lane; k0 < G && !gave_up; k0 += P * 64) {
+                unsigned pend = 0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) if (k0 + j * 64 < G) pend |= 1u << j;
+                long spins = 0;
+                while (pend) {
+                    // two passes in flight, the second a few hundred cycles behind the first: a record that lands just after the first pass read its slot
+                    // costs that stagger, not another round trip through the fabric (~2700 cycles; 30 % of the picks needed a second pass)
+                    fs_u4 u[P], u2[P];
+                    if (TIMED) ++passes;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) if ((pend >> j) & 1u) u[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + ((unsigned)(k0 + j * 64) << slot_shift), 0, 16);
+                    if (stagger > 0) {
+                        for (int z = 0; z < stagger; ++z) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int j = 0; j < P; ++j) if ((pend >> j) & 1u) u2[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + ((unsigned)(k0 + j * 64) << slot_shift), 0, 16);
+                    }
+                    auto take = [&](const fs_u4& w, int j) {
+                        if (((pend >> j) & 1u) && (w.y & 0xffff0000u) == tag && (w.w & 0xffff0000u) == tag) {
+                            const double pv = __longlong_as_double((long long)(((unsigned long long)w.z << 32) | w.x));
+                            const int pi = (int)(((w.y & 0xffffu) << 16) | (w.w & 0xffffu));
+                            if (better(pv, pi, v, i)) { v = pv; i = pi; }
+                            pend &= ~(1u << j);
+                        }
+                    };
+#pragma unroll
+                    for (int j = 0; j < P; ++j) take(u[j], j);
+                    if (stagger > 0 && __any(pend != 0)) {
+#pragma unroll
+                        for (int j = 0; j < P; ++j) take(u2[j], j);
+                    }
+                    if (pend && (++spins > FPS_COOP_SPINS / 16 || (spins % 1024 == 0 && __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) { gave_up = true; break; }
+                }
+            }
+            if (gave_up) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); s_gave = 1; }
+            mark(5);
+            if (TIMED) tacc[7] += passes;
+            wave_argmax(v, i);
+            if (lane == 0) s_c[par] = i;
+        }
+        __syncthreads();                                   // (2)
+        mark(6);
+        if (s_gave) { if (g == 0) for (int k = it + 1 + tid; k < a.count; k += FQ_NT) a.out[k] = -1; return; }
+        c = s_c[par];
+    }
+    if (TIMED && tid == 0) for (int k = 0; k < 8; ++k) dbg[(size_t)g * 8 + k] = tacc[k];
+}
+#endif
+
+#ifndef HIPEMU
+// Third form (round 6; the phase clocks of fps_coop_split: of 3.05 us per pick 0.27 are the barrier in front of the workgroup's combine and 0.47 the combine
+// itself — eight (value, index) pairs through LDS and a chain of dependent float64 compares by one wave): EVERY WAVE PUBLISHES ITS OWN 16-byte record, the
+// eight records of a workgroup side by side in one 128-byte line, and ONE wave per workgroup sweeps all 8 G of them with every load in flight — the
+// workgroup-level combine and its barrier are gone (a sweeper reads the same G lines as before); what is left per pick is the row fetch, 50 dependent
+// float64 instructions, one wave arg-max, the hand-off (a write-through store becoming visible + ~1.2 loads' round trip through the fabric, ~1.5 us), one
+// wave arg-max over the records and one barrier that hands the winner to the other seven waves.
+constexpr int FW_NT = 512, FW_LPR = 2, FW_ROWS = FW_NT / FW_LPR, FW_NW = FW_NT / 64, FW_MAXP = 16;      // at most 64 * 16 / 8 = 128 workgroups = 32768 rows
+template <bool TIMED>
+__global__ __launch_bounds__(FW_NT) void fps_coop_wave(FpsCoopArgs a, long long* dbg) {
+    constexpr int A = 8 / FW_LPR, F = 32 / FW_LPR;
+    if (a.dn) a.n = min(a.n, *a.dn);
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto mark = [&](int k) { if (TIMED) { const long long t = (long long)__builtin_readcyclecounter(); tacc[k] += t - tprev; tprev = t; } };
+    __shared__ double s_v[FW_NW]; __shared__ int s_i[FW_NW]; __shared__ int s_c[2], s_gave;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x, G = a.G, q = tid & (FW_LPR - 1);
+    const int row = g * FW_ROWS + tid / FW_LPR;
+    if (tid == 0) s_gave = 0;
+    double x[F], rmin = row < a.n ? a.mind[row] : -1.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < A; ++e) x[k * A + e] = row < a.n ? a.f[(size_t)row * 32 + 8 * k + A * q + e] : 0.0;
+    int c;
+    if (!a.from_partials) c = a.start;
+    else {
+        double v = -1.0; int i = 0x7fffffff;
+        for (int k = tid; k < a.npart; k += FW_NT) if (better(a.pin[k].v, a.pin[k].i, v, i)) { v = a.pin[k].v; i = a.pin[k].i; }
+        wave_argmax(v, i);
+        if (lane == 0) { s_v[wid] = v; s_i[wid] = i; }
+        __syncthreads();
+        v = s_v[0]; c = s_i[0];
+        for (int w = 1; w < FW_NW; ++w) if (better(s_v[w], s_i[w], v, c)) { v = s_v[w]; c = s_i[w]; }
+    }
+    __syncthreads();
+    const int total = G * FW_NW;                            // records of a pick: [g][wave], 16 bytes each
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 2 * total * 16, 0x00020000);
+    for (int it = 0; it < a.count; ++it) {
+        if (g == 0 && tid == 0) a.out[it] = c;
+        if (it + 1 == a.count) break;
+        const int par = it & 1;
+        if (TIMED) tprev = (long long)__builtin_readcyclecounter();
+        double fc[F];
+        {
+            const double* src = a.f + (size_t)c * 32 + A * q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < A; ++e) fc[k * A + e] = src[8 * k + e];
+        }
+        double wv = -1.0; int wi = 0x7fffffff;
+        {
+            double r[A];
+#pragma unroll
+            for (int e = 0; e < A; ++e) { const double d = x[e] - fc[e]; r[e] = d * d; }
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < A; ++e) { const double d = x[k * A + e] - fc[k * A + e]; r[e] += d * d; }
+            double p = (r[0] + r[1]) + (r[2] + r[3]);
+            p = p + dpp_f64<0xB1>(p);
+            if (a.use_sqrt) p = sqrt(p);
+            if (row < a.n) { if (p < rmin) rmin = p; wv = rmin; wi = row; }
+        }
+        wave_argmax(wv, wi);
+        const unsigned tag = ((unsigned)it % 0xffffu + 1u) << 16;
+        const unsigned base = (unsigned)(par * total) * 16u;
+        if (lane == 0) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(wv);
+            fs_u4 v; v.x = (unsigned)b; v.y = tag | ((unsigned)wi >> 16); v.z = (unsigned)(b >> 32); v.w = tag | ((unsigned)wi & 0xffffu);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (unsigned)(g * FW_NW + wid) * 16u, 0, 16);      // sc1: write-through
+        }
+        mark(0);
+        if (wid == 0) {
+            // every record of the pick: all of a lane's slots in flight, the missing ones again
+            double v = -1.0; int i = 0x7fffffff; bool gave_up = false; int passes = 0;
+            unsigned pend = 0;
+#pragma unroll
+            for (int j = 0; j < FW_MAXP; ++j) if (lane + j * 64 < total) pend |= 1u << j;
+            long spins = 0;
+            while (pend) {
+                fs_u4 u[FW_MAXP];
+                if (TIMED) ++passes;
+#pragma unroll
+                for (int j = 0; j < FW_MAXP; ++j) if ((pend >> j) & 1u) u[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)(lane + j * 64) * 16u, 0, 16);
+#pragma unroll
+                for (int j = 0; j < FW_MAXP; ++j)
+                    if (((pend >> j) & 1u) && (u[j].y & 0xffff0000u) == tag && (u[j].w & 0xffff0000u) == tag) {
+                        const double pv = __longlong_as_double((long long)(((unsigned long long)u[j].z << 32) | u[j].x));
+                        const int pi = (int)(((u[j].y & 0xffffu) << 16) | (u[j].w & 0xffffu));
+                        if (better(pv, pi, v, i)) { v = pv; i = pi; }
+                        pend &= ~(1u << j);
+                    }
+                if (pend && (++spins > FPS_COOP_SPINS / 16 || (spins % 1024 == 0 && __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) { gave_up = true; break; }
+            }
+            if (gave_up) { atomicOr(&a.sync[2], 1); atomicOr(a.status, 1); s_gave = 1; }
+            mark(1);
+            if (TIMED) tacc[7] += passes;
+            wave_argmax(v, i);
+            if (lane == 0) s_c[par] = i;
+            mark(2);
+        }
+        __syncthreads();
+        mark(3);
+        if (s_gave) { if (g == 0) for (int k = it + 1 + tid; k < a.count; k += FW_NT) a.out[k] = -1; return; }
+        c = s_c[par];
+    }
+    if (TIMED && tid == 0) for (int k = 0; k < 8; ++k) dbg[(size_t)g * 8 + k] = tacc[k];
+}
 #endif
 
 // farthest_superpoint_sample (sampler2.py:49-80, the "edcd" branch): FPS over one cloud's superpoints with the
@@ -1455,7 +1857,8 @@ __global__ __launch_bounds__(256) void sel_gather_kc(const uint32_t* __restrict_
     }
 }
 
-struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f, status; bool status_init = false; };
+struct SelState { RadixSorter sorter; DevBuf keys, vals, hist, mins, dir, rowsum, part, mind, vtmp, pack_xyz, pack_int, cand_i, cand_f, status; bool status_init = false;
+                  const double* last_comb = nullptr; size_t last_cap = 0; };
 
 // scratch of the chamfer packer for nrows superpoints in nclouds clouds
 int chamfer_pack_buffers(SelState& Q, size_t nrows, size_t nclouds, ChamferPack& P) {
@@ -1795,6 +2198,91 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         // two hand-off forms, measured (tools/gpu_fps.sh, us per pick at 2368 / 4736 / 9472 / 20000 rows): self-validating granules 3.46 / 3.92 / 4.71 / 6.30,
         // drained record + counter 3.90 / 4.14 / 4.77 / 5.74 — the granule form polls 68 words per record and loses from ~24 workgroups on
         static const int form_env = [] { const char* e = getenv("SSDR_FPS_COOP_COUNTER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        // round 6, the swept hand-off (fps_coop_sweep): SSDR_FPS_COOP_SWEEP = 1 chip-wide with write-through stores, 2 one XCD's workgroups with plain
+        // stores (records through that XCD's L2), 3 one XCD's workgroups with write-through stores (placement alone), 0 the forms of rounds 3-5
+        static const int sweep_env = [] { const char* e = getenv("SSDR_FPS_COOP_SWEEP"); return e ? atoi(e) : -1; }();
+        const int sweep = sweep_env >= 0 ? sweep_env : 0;
+        if (sweep == 6 && (n + FW_ROWS - 1) / FW_ROWS <= 64 * FW_MAXP / FW_NW) {          // a record per wave, one sweeping wave per workgroup
+            const int G2 = (int)((n + FW_ROWS - 1) / FW_ROWS);
+            const size_t recb = (size_t)2 * G2 * FW_NW * 16;
+            SSDR_TRY(Q.vtmp.reserve(recb + 64));
+            SSDR_HIP(hipMemsetAsync(Q.vtmp.p, 0, recb + 64, s));      // tags start at 0: no pick has that number; abort word
+            a.part = Q.vtmp.as<Part>(); a.sync = reinterpret_cast<int*>(Q.vtmp.as<char>() + recb); a.G = G2;
+            static const bool dbg_env = getenv("SSDR_FPS_DBG") != nullptr;
+            if (dbg_env) {
+                static DevBuf dbgbuf; SSDR_TRY(dbgbuf.reserve(8 * 8 * 512)); SSDR_HIP(hipMemsetAsync(dbgbuf.p, 0, 8 * 8 * 512, s));
+                hipLaunchKernelGGL(fps_coop_wave<true>, dim3(G2), dim3(FW_NT), 0, s, a, dbgbuf.as<long long>());
+                SSDR_HIP(hipStreamSynchronize(s));
+                std::vector<long long> h(8 * 512); SSDR_HIP(hipMemcpy(h.data(), dbgbuf.p, 8 * 8 * 512, hipMemcpyDeviceToHost));
+                const char* nm[8] = {"fetch+dist+argmax+store", "sweep", "argmax", "barrier", "-", "-", "-", "passes"};
+                for (int k = 0; k < 8; ++k) {
+                    long long mn = 1LL << 62, mx = 0, sum = 0;
+                    for (int g2 = 0; g2 < G2; ++g2) { const long long v = h[(size_t)g2 * 8 + k]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
+                    fprintf(stderr, "fps_coop_wave G=%d %-24s per pick: mean %.1f min %.1f max %.1f\n", G2, nm[k], (double)sum / G2 / count, (double)mn / count, (double)mx / count);
+                }
+                return coop_launched(s, G2);
+            }
+            hipLaunchKernelGGL(fps_coop_wave<false>, dim3(G2), dim3(FW_NT), 0, s, a, (long long*)nullptr);
+            SSDR_HIP(hipGetLastError());
+            return coop_launched(s, G2);
+        }
+        if (sweep == 4 || sweep == 5) {          // rows split over 2 / 4 lanes, 16-byte records, the winner's row from the table
+            const int lpr = sweep == 4 ? 2 : 4, rows = FQ_NT / lpr, G2 = (int)((n + rows - 1) / rows);
+            static const int shift = [] { const char* e = getenv("SSDR_FPS_SLOT_SHIFT"); return e ? atoi(e) : 6; }();      // a record's slot: 16 bytes, or a line / several of its own
+            static const int team = [] { const char* e = getenv("SSDR_FPS_STAGGER"); return e ? atoi(e) : 0; }();      // s_sleep units between the two passes in flight (0: one pass)
+            const int launch_g = G2;
+            const size_t recb = ((size_t)2 * G2) << shift;
+            SSDR_TRY(Q.vtmp.reserve(recb + 64));
+            SSDR_HIP(hipMemsetAsync(Q.vtmp.p, 0, recb + 64, s));      // tags start at 0: no pick has that number; abort word
+            a.part = Q.vtmp.as<Part>(); a.sync = reinterpret_cast<int*>(Q.vtmp.as<char>() + recb); a.G = G2;
+            static const bool dbg_env = getenv("SSDR_FPS_DBG") != nullptr;
+            if (dbg_env) {
+                static DevBuf dbgbuf; SSDR_TRY(dbgbuf.reserve(8 * 8 * 512)); SSDR_HIP(hipMemsetAsync(dbgbuf.p, 0, 8 * 8 * 512, s));
+                if (lpr == 2) hipLaunchKernelGGL((fps_coop_split<2, true>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, dbgbuf.as<long long>());
+                else hipLaunchKernelGGL((fps_coop_split<4, true>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, dbgbuf.as<long long>());
+                SSDR_HIP(hipStreamSynchronize(s));
+                std::vector<long long> h(8 * 512); SSDR_HIP(hipMemcpy(h.data(), dbgbuf.p, 8 * 8 * 512, hipMemcpyDeviceToHost));
+                const char* nm[8] = {"row fetch", "dist", "wave_argmax", "barrier1", "combine+store", "sweep", "argmax+barrier2", "passes"};
+                for (int k = 0; k < 8; ++k) {
+                    long long mn = 1LL << 62, mx = 0, sum = 0;
+                    for (int g2 = 0; g2 < G2 && g2 < 512; ++g2) { const long long v = h[(size_t)g2 * 8 + k]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
+                    fprintf(stderr, "fps_coop_split<%d> G=%d %-16s per pick: mean %.1f min %.1f max %.1f\n", lpr, G2, nm[k], (double)sum / std::min(G2, 512) / count, (double)mn / count, (double)mx / count);
+                }
+                return coop_launched(s, G2);
+            }
+            if (lpr == 2) hipLaunchKernelGGL((fps_coop_split<2, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, (long long*)nullptr);
+            else hipLaunchKernelGGL((fps_coop_split<4, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, (long long*)nullptr);
+            SSDR_HIP(hipGetLastError());
+            return coop_launched(s, G2);
+        }
+        if (sweep > 0 && G <= 64) {
+            const bool team = sweep >= 2;
+            SSDR_TRY(Q.vtmp.reserve(16 * 2 * (size_t)G * FS_SLOTS + 64));
+            int* sync2 = reinterpret_cast<int*>(Q.vtmp.as<char>() + 16 * 2 * (size_t)G * FS_SLOTS);
+            SSDR_HIP(hipMemsetAsync(Q.vtmp.p, 0, 16 * 2 * (size_t)G * FS_SLOTS + 64, s));      // tags start at 0: no pick has that number; abort word, team words
+            static std::once_flag once3;
+            std::call_once(once3, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * FT_WORDS * 64);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * FT_WORDS * 64); });
+            a.part = Q.vtmp.as<Part>(); a.sync = sync2;
+            static const bool dbg_env = getenv("SSDR_FPS_DBG") != nullptr;
+            if (dbg_env) {       // development: where a pick's time goes, per workgroup (wave 0's clock)
+                static DevBuf dbgbuf; SSDR_TRY(dbgbuf.reserve(8 * 8 * 64)); SSDR_HIP(hipMemsetAsync(dbgbuf.p, 0, 8 * 8 * 64, s));
+                hipLaunchKernelGGL(fps_coop_sweep<true>, dim3(team ? 8 * (G + 2) : G), dim3(FR_NT), 4 * 2 * (size_t)G * FT_WORDS, s, a, team ? 1 : 0, sweep == 2 ? 1 : 0, dbgbuf.as<long long>());
+                SSDR_HIP(hipStreamSynchronize(s));
+                std::vector<long long> h(8 * 64); SSDR_HIP(hipMemcpy(h.data(), dbgbuf.p, 8 * 8 * 64, hipMemcpyDeviceToHost));
+                const char* nm[8] = {"dist", "wave_argmax", "pub", "barrier1", "store", "sweep", "barrier2+argmax", "passes"};
+                for (int k = 0; k < 8; ++k) {
+                    long long mn = 1LL << 62, mx = 0, sum = 0;
+                    for (int g2 = 0; g2 < G; ++g2) { const long long v = h[(size_t)g2 * 8 + k]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
+                    fprintf(stderr, "fps_coop_sweep G=%d %-16s per pick: mean %.1f min %.1f max %.1f (%s)\n", G, nm[k], (double)sum / G / count, (double)mn / count, (double)mx / count, k == 7 ? "passes" : "s_memtime ticks");
+                }
+                return coop_launched(s, G);
+            }
+            hipLaunchKernelGGL(fps_coop_sweep<false>, dim3(team ? 8 * (G + 2) : G), dim3(FR_NT), 4 * 2 * (size_t)G * FT_WORDS, s, a, team ? 1 : 0, sweep == 2 ? 1 : 0, (long long*)nullptr);
+            SSDR_HIP(hipGetLastError());
+            return coop_launched(s, G);
+        }
         const bool counter_form = form_env >= 0 ? form_env == 1 : G > 24;
         if (!counter_form) {
             SSDR_HIP(hipMemsetAsync(part, 0, 8 * 2 * (size_t)G * FR_REC * 2, s));      // tags start at 0: no pick has that number
@@ -1861,8 +2349,8 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
                               const int32_t* d_lab_off, const int32_t* d_lab_sp, size_t n_lab, size_t batch_size, int gcn_number, int gcn_top, int selector, int start,
                               size_t cap_rows, size_t cap_nmax, size_t cap_sq, size_t cap_unl, size_t max_select, int32_t* d_result, void* stream) {
     if (!d_feat || !d_cls || !d_dom || (!d_lab_cls != !d_lab_dom) || !d_xyz || !d_sp_off || !d_sp_pts || !d_order || !d_labelled || !d_sp_base || !d_lab_off || !d_result || feat_dim != 32 ||
-        num_clouds == 0 || num_clouds > 65535 || S == 0 || S > 0x7ffffff0 || cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || cap_unl == 0 || cap_rows > 16384 || gcn_number < 0 || start < 0 || selector < 0 || selector > 1 || (selector == 1 && n_lab == 0) || (n_lab && !d_lab_sp)) {
-        set_error("gcn_fps_sampling: bad arguments (feat_dim == 32, at most 16384 candidate + labelled rows, at most 65535 clouds, k-center needs labelled regions)"); return SSDR_ERR_INVALID;
+        num_clouds == 0 || num_clouds > 65535 || S == 0 || S > 0x7ffffff0 || cap_rows == 0 || cap_nmax == 0 || cap_sq == 0 || cap_unl == 0 || cap_rows > (1u << 22) || gcn_number < 0 || start < 0 || selector < 0 || selector > 1 || (selector == 1 && n_lab == 0) || (n_lab && !d_lab_sp)) {
+        set_error("gcn_fps_sampling: bad arguments (feat_dim == 32, at most 2^22 candidate + labelled rows, at most 65535 clouds, k-center needs labelled regions)"); return SSDR_ERR_INVALID;
     }
     SSDR_TRY(ensure_init());
     hipStream_t s = pick_stream(stream); SelState& Q = sst(s);
@@ -1877,6 +2365,7 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     SSDR_TRY(Q.cand_f.reserve(8 * (4 * cap_rows * D + 3 * cap_rows + 2 * cap_sq)));
     double* V = Q.cand_f.as<double>(); double* comb = V + cap_rows * D; double* tmp0 = comb + cap_rows * D; double* tmp1 = tmp0 + cap_rows * D;
     double* cen = tmp1 + cap_rows * D; double* dir = cen + 3 * cap_rows; double* adj = dir + cap_sq;
+    Q.last_comb = comb; Q.last_cap = cap_rows;
     int* counts = d_result; int* out = d_result + 8; int* sel = out + max_select;
     std::optional<ProfScope> prof; prof.emplace("sel_candidate_rule", s, 0.0);
     hipLaunchKernelGGL(cand_rank, dim3(nchunks), dim3(CR_NT), 0, s, d_order, (int)S, d_labelled, rankpos, cploc, chunk);
@@ -1910,6 +2399,17 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     // selector 1: kCenterGreedy over candidates + labelled rows, seeded with the labelled ones (kcenterGreedy.py:84-128; sampler2.py's "kcenter" branch)
     if (selector == 1) return fps_like(comb, cap_rows, D, already, n_lab, 0, max_select, 1, out, s, counts + 2);
     return fps_like(comb, cap_unl, D, nullptr, 0, start, max_select, 0, out, s, counts);
+}
+
+/* The propagated rows of the last ssdr_gcn_fps_sampling_dev call on `stream` (device pointer, [cap_rows][32] float64: the candidates first, then the labelled
+ * regions — sum_i A^i V of fps_gcn_cpu.py:162-167, what its FPS / k-center ran over).  Valid until the next selection call on that stream. */
+int ssdr_gcn_fps_sampling_rows(void* stream, const double** d_rows, size_t* cap_rows) {
+    if (!d_rows) { set_error("gcn_fps_sampling_rows: bad arguments"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ensure_init());
+    SelState& Q = sst(pick_stream(stream));
+    if (!Q.last_comb) { set_error("gcn_fps_sampling_rows: no ssdr_gcn_fps_sampling_dev call on this stream yet"); return SSDR_ERR_INVALID; }
+    *d_rows = Q.last_comb; if (cap_rows) *cap_rows = Q.last_cap;
+    return SSDR_OK;
 }
 
 /* What the enqueue-only selection calls on `stream` found and could not return: bit 0 = a cooperative FPS / k-center launch was not co-resident (a

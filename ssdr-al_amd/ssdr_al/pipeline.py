@@ -50,6 +50,16 @@ class HotPath:
         self.timing = None
 
     # ---- setup (untimed): upload raw rooms, fix the per-room randomness, derive superpoints -------------------
+    def draw_room(self, xyz, rid):
+        """the host-drawn randomness of one tile, a function of (seed, global room id): pick point, shuffle, padding draws"""
+        cfg, N = self.cfg, self.cfg.num_points
+        self.rng = np.random.default_rng([self.seed, rid])
+        n = len(xyz)
+        pick = xyz[self.rng.integers(0, n)] + self.rng.normal(0, cfg.noise_init / 10, 3)      # s3dis_dataset.py:119-126
+        return dict(n=n, center=np.ascontiguousarray(pick, np.float32),
+                    perm=self.rng.permutation(N).astype(np.int32),                             # DP.shuffle_idx :137
+                    dup=self.rng.random(N).astype(np.float32))                                 # DP.data_aug's np.random.choice
+
     def load_rooms(self, rooms, room_ids=None):
         """room_ids: global ids of the rooms (sharded runs); all host-drawn randomness is a function of (seed, id), so a
         sharded run and a single-process run over the union see the same tiles."""
@@ -61,12 +71,7 @@ class HotPath:
         self.rooms = []
         centers, perms, dups = [], [], []
         for (xyz, rgb, lab), rid in zip(rooms, self.room_ids):
-            self.rng = np.random.default_rng([self.seed, rid])
-            n = len(xyz)
-            pick = xyz[self.rng.integers(0, n)] + self.rng.normal(0, cfg.noise_init / 10, 3)      # s3dis_dataset.py:119-126
-            r = dict(n=n, center=np.ascontiguousarray(pick, np.float32),
-                     perm=self.rng.permutation(N).astype(np.int32),                             # DP.shuffle_idx :137
-                     dup=self.rng.random(N).astype(np.float32))                                 # DP.data_aug's np.random.choice
+            r = self.draw_room(xyz, rid)
             centers.append(r["center"]); perms.append(r["perm"]); dups.append(r["dup"])
             self.rooms.append(r)
         # the rooms of the batch live concatenated in HBM: one batched call per front-end stage
@@ -128,22 +133,33 @@ class HotPath:
         gt [n], probs [n,C], feat [n,32], offsets [S_b+1], points) — what prediction() / compute_features see per cloud (sampler2.py:580-642,
         :313-342); labeled[b] = the regions of cloud b (ids inside the cloud) that total_obj["unlabeled"] no longer lists.  Clouds may differ in
         size: every array is the concatenation, superpoints are one CSR over it.  step_selection() runs the round."""
-        hp = cls(None, config, **kw)
-        hp.B = len(clouds); hp._dist = None; hp.room_ids = list(range(hp.B)); hp.rooms = []
         n_of = [len(c["xyz"]) for c in clouds]
         p0 = np.concatenate([[0], np.cumsum(n_of)]).astype(np.int64)
-        hp.n_pts = int(p0[-1])
-        hp.xyz = DevArray.from_host(np.concatenate([np.asarray(c["xyz"], np.float32) for c in clouds]))
-        hp.probs = DevArray.from_host(np.concatenate([np.asarray(c["probs"], np.float32) for c in clouds]))
-        hp.f32 = DevArray.from_host(np.concatenate([np.asarray(c["feat"], np.float32) for c in clouds]))
-        hp.tile_l = DevArray.from_host(np.concatenate([np.asarray(c["gt"]).astype(np.int32) for c in clouds]))
-        hp.unc = DevArray((hp.n_pts,), np.float32); hp.cls = DevArray((hp.n_pts,), np.int32)
         offs, pts, cloud, lab, s0 = [np.zeros(1, np.int64)], [], [], {}, 0
         for b, c in enumerate(clouds):
             o = np.asarray(c["offsets"], np.int64)
             offs.append(o[1:] + offs[-1][-1]); pts.append(np.asarray(c["points"], np.int64) + p0[b]); cloud.append(np.full(len(o) - 1, b, np.int32))
             lab[b] = set(int(s) + s0 for s in labeled[b]); s0 += len(o) - 1
-        hp._set_regions(np.concatenate(offs), np.concatenate(pts), np.concatenate(cloud), lab, selected_class_list)
+        return cls.from_device(DevArray.from_host(np.concatenate([np.asarray(c["xyz"], np.float32) for c in clouds])),
+                               DevArray.from_host(np.concatenate([np.asarray(c["probs"], np.float32) for c in clouds])),
+                               DevArray.from_host(np.concatenate([np.asarray(c["feat"], np.float32) for c in clouds])),
+                               DevArray.from_host(np.concatenate([np.asarray(c["gt"]).astype(np.int32) for c in clouds])),
+                               np.concatenate(offs), np.concatenate(pts), np.concatenate(cloud), lab, selected_class_list, config, **kw)
+
+    @classmethod
+    def from_device(cls, xyz, probs, f32, labels, sp_off, sp_pts, sp_cloud, labeled, selected_class_list, config=ConfigS3DIS, **kw):
+        """from_clouds over arrays that are already resident (xyz [n,3] f32, probs [n,C] f32, f32 [n,32] f32, labels [n] i32: DevArray or anything
+        with .ptr): the superpoints as one CSR over the n points (host arrays), sp_cloud [S] = the cloud of every superpoint (ascending),
+        labeled[b] = GLOBAL ids of cloud b's labelled regions.  This is how one AL round ends at the reference's scale (ALRound): the network
+        outputs of all clouds stay where the batches' inference left them."""
+        hp = cls(None, config, **kw)
+        sp_cloud = np.asarray(sp_cloud, np.int32)
+        hp.B = int(sp_cloud.max()) + 1 if len(sp_cloud) else 0
+        hp._dist = None; hp.room_ids = list(range(hp.B)); hp.rooms = []
+        hp.n_pts = int(xyz.shape[0])
+        hp.xyz, hp.probs, hp.f32, hp.tile_l = xyz, probs, f32, labels
+        hp.unc = DevArray((hp.n_pts,), np.float32); hp.cls = DevArray((hp.n_pts,), np.int32)
+        hp._set_regions(sp_off, sp_pts, sp_cloud, labeled, selected_class_list)
         return hp
 
     def step_selection(self):
@@ -158,7 +174,7 @@ class HotPath:
         self.sp_off_h = np.asarray(sp_off).astype(np.int32); self.sp_pts_h = np.asarray(sp_pts).astype(np.int32)
         self.sp_cloud_h = np.asarray(sp_cloud).astype(np.int32)
         self.S = len(self.sp_off_h) - 1
-        self.sp_base = [int(np.flatnonzero(self.sp_cloud_h == b)[0]) for b in range(B)]
+        self.sp_base = np.searchsorted(self.sp_cloud_h, np.arange(B)).astype(np.int64).tolist()      # (clouds are ascending: every cloud owns at least one region)
         self.sp_off = DevArray.from_host(self.sp_off_h); self.sp_pts = DevArray.from_host(self.sp_pts_h)
         self.region_unc = DevArray((self.S,), np.float64); self.dom = DevArray((self.S,), np.int32); self.dom_cnt = DevArray((self.S,), np.int32)
         self.gt_dom = DevArray((self.S,), np.int32); self.gt_purity = DevArray((self.S,), np.float64)
@@ -398,7 +414,7 @@ class HotPath:
         st = self.sel_stream          # None: the library stream; a stream of its own lets the selections of consecutive batches overlap
         T = self._sel_static
         kc = self.selector == "kcenter"
-        if (self.global_order is None and T["cap_rows"] <= 16384 and T["picks"] > 0 and (not kc or T["n_lab"] > 0)
+        if (self.global_order is None and T["picks"] > 0 and (not kc or T["n_lab"] > 0)
                 and not os.environ.get("SSDR_SELECT_HOST_RULE")):
             # candidate rule + GCN_FPS_sampling enqueued as one chain: the host decides nothing and uploads nothing (the result is read in _select_collect)
             _lib.check(L.ssdr_gcn_fps_sampling_dev(self.f32.ptr, 32, self.cls.ptr, self.dom.ptr, self.tile_l.ptr, self.gt_dom.ptr, self.xyz.ptr, self.sp_off.ptr, self.sp_pts.ptr,
@@ -605,6 +621,118 @@ class HotPath:
         out = self._select(comm); mark()
         if timed_stages:
             self.timing = dict(zip(("subsample+tile", "knn_pyramid", "randla_infer", "score", "select"), np.diff(t) * 1e3))
+        return out
+
+
+class _Rows:
+    """rows [lo, hi) of a DevArray's first axis with the surface the stages use (ptr / shape / dtype / to_host): the batches of an AL round write
+    their tiles and network outputs straight into their slice of the round's arrays"""
+    def __init__(self, arr, lo, hi):
+        rowb = arr.dtype.itemsize * int(np.prod(arr.shape[1:], dtype=np.int64))
+        self.base, self.dtype, self.shape = arr, arr.dtype, (int(hi - lo),) + tuple(arr.shape[1:])
+        self.ptr, self.nbytes = int(arr.ptr) + int(lo) * rowb, int(hi - lo) * rowb
+
+    def to_host(self, stream=None):
+        out = np.empty(self.shape, self.dtype)
+        if stream is None:
+            _lib.check(_lib.lib().ssdr_memcpy_d2h(_lib.ptr(out), self.ptr, self.nbytes))
+        else:
+            _lib.check(_lib.lib().ssdr_memcpy_d2h_on(_lib.ptr(out), self.ptr, self.nbytes, stream))
+        return out
+
+
+class ALRound:
+    """ONE active-learning round at the reference's own scale: the network runs over ALL clouds of the pool and then ONE selection picks
+    `batch_size` regions among 2 x batch_size candidates (+ the labelled rows) of all of them (ssdr_main_S3DIS2.py:134: 10 000 regions per round;
+    sampler2.py:580-642 prediction over every cloud, :736-781 one GCN_FPS_sampling).  bench.py's step selects per 16-tile batch instead, which
+    keeps the reference's picks-per-tile ratio but under-represents the quadratic term of the farthest-point chain 17-fold; this class is the
+    round as the reference runs it: `n_batches` batches of len(rooms) tiles go through front end -> KNN pyramid -> inference (three streams, three
+    buffer sets, batches overlapped), their tiles / labels / probabilities / features land in the round's arrays, then scoring over all points and
+    the one-call device chain (ssdr_gcn_fps_sampling_dev) over all clouds' regions.  Tiles of batch b are cut from the same raw rooms with the
+    randomness of room id b * len(rooms) + i (another pick point, shuffle and padding draw: another tile)."""
+    SLOTS = 3
+
+    def __init__(self, weights, rooms, n_batches, config=ConfigS3DIS, batch_size=10000, round_num=5, labeled_per_tile=15, precision="f32",
+                 selector="fps", tiles32=True, seed=0, gcn_number=1, gcn_top=0, min_size=1):
+        L = _lib.lib()
+        self.cfg, self.nb, self.B, self.rooms = config, int(n_batches), len(rooms), rooms
+        N = config.num_points
+        self.tiles = self.nb * self.B
+        self.streams = []
+        for _ in range(3):
+            st = C.c_void_p(); _lib.check(L.ssdr_stream_create(C.byref(st))); self.streams.append(st.value)
+        s_f, s_k, s_i = self.streams
+        self.work = []
+        for w in range(self.SLOTS):
+            h = HotPath(weights, config, precision=precision, tiles32=tiles32, seed=seed, select_per_tile=1, labeled_per_tile=1)
+            h.front_stream, h.knn_stream, h.stream, h.pipelined = s_f, s_k, s_i, True
+            h.load_rooms(rooms, list(range(self.B)))
+            self.work.append(h)
+        P = self.tiles * N
+        self.xyz = DevArray((P, 3), np.float32); self.tile_l = DevArray((P,), np.int32)
+        self.probs = DevArray((P, config.num_classes), np.float32); self.f32 = DevArray((P, 32), np.float32)
+        # per batch: the tiles' randomness and where its outputs go
+        self.batches = []
+        h0 = self.work[0]
+        for b in range(self.nb):
+            draws = [h0.draw_room(r[0], b * self.B + i) for i, r in enumerate(rooms)]
+            lo, hi = b * self.B * N, (b + 1) * self.B * N
+            self.batches.append(dict(centers=np.ascontiguousarray(np.stack([d["center"] for d in draws]), np.float32),
+                                     perm=DevArray.from_host(np.stack([d["perm"] for d in draws])), dup=DevArray.from_host(np.stack([d["dup"] for d in draws])),
+                                     xyz=_Rows(self.xyz, lo, hi), tile_l=_Rows(self.tile_l, lo, hi), probs=_Rows(self.probs, lo, hi), f32=_Rows(self.f32, lo, hi)))
+        # setup (untimed): every batch's tiles once, their superpoints (stand-in for the partition, as HotPath.load_rooms), the labelled stand-in
+        for b in range(self.nb):
+            self._bind(b)._front_end()
+        _lib.sync(s_f)
+        _lib.check(L.ssdr_grid_subsample_status(s_f, None))
+        from .synthetic import superpoints_from_tile
+        tiles = self.xyz.to_host().reshape(self.tiles, N, 3)
+        offs, pts, cloud, labeled = [np.zeros(1, np.int64)], [], [], {}
+        for t in range(self.tiles):
+            o, p = superpoints_from_tile(tiles[t])
+            base = int(sum(len(x) for x in cloud))
+            pts.append(p.astype(np.int64) + t * N); offs.append(o[1:].astype(np.int64) + offs[-1][-1]); cloud.append(np.full(len(o) - 1, t, np.int32))
+            rng = np.random.default_rng([seed, t, 1])
+            n_sp = len(o) - 1
+            labeled[t] = set((base + rng.choice(n_sp, min(labeled_per_tile, n_sp), replace=False)).tolist())
+        sel_list = np.random.default_rng([seed, 999983]).integers(0, config.num_classes, 4000)
+        self.sel = HotPath.from_device(self.xyz, self.probs, self.f32, self.tile_l, np.concatenate(offs), np.concatenate(pts), np.concatenate(cloud), labeled, sel_list,
+                                       config, batch_size=batch_size, round_num=round_num, selector=selector, gcn_number=gcn_number, gcn_top=gcn_top, min_size=min_size, seed=seed)
+        self.sel.stream = self.sel.score_stream = self.sel.sel_stream = s_i
+        self.sel.front_stream = s_i; self.sel.pipelined = True
+        self.tile_points = P
+
+    def _bind(self, b):
+        """worker of batch b with the batch's randomness and output slices"""
+        h, d = self.work[b % self.SLOTS], self.batches[b]
+        h.centers, h.perm, h.dup = d["centers"], d["perm"], d["dup"]
+        h.xyz, h.tile_l, h.probs, h.f32 = d["xyz"], d["tile_l"], d["probs"], d["f32"]
+        return h
+
+    def infer_all(self):
+        """front end | KNN pyramid | inference of every batch, enqueued: batch k's inference runs beside batch k + 1's front end and pyramid"""
+        L = _lib.lib()
+        s_f, s_k, s_i = self.streams
+        for k in range(self.nb + 2):
+            if 0 <= k - 2 < self.nb:
+                _lib.check(L.ssdr_stream_wait(s_i, s_k))          # (the pyramid stream holds batch k - 2's pyramid and nothing later)
+                self._bind(k - 2)._infer()
+                _lib.check(L.ssdr_stream_wait(s_f, s_i))          # the next front end reuses a buffer set whose inference must have finished
+            if 0 <= k - 1 < self.nb:
+                _lib.check(L.ssdr_stream_wait(s_k, s_f))
+                self._bind(k - 1)._pyramid()
+            if k < self.nb:
+                self._bind(k)._front_end()
+
+    def run(self):
+        """the whole round; returns (picked candidate indices, candidate list) as HotPath.step does"""
+        self.infer_all()
+        self.sel._score_async(None)
+        self.sel._select_issue(None)
+        out = self.sel._select_collect()
+        from . import knn as _knn
+        _knn.knn_status(self.streams[1])
+        _lib.check(_lib.lib().ssdr_grid_subsample_status(self.streams[0], None))
         return out
 
 
