@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--tiles16", action="store_true", help="bf16 modes: the 16 x 16-tile attention kernels of rounds 1-3 instead of the 32 x 32 formulation (A/B timing)")
     ap.add_argument("--selector", default="fps", choices=("fps", "kcenter"),
                     help="final selection over the (gathered) propagated features: FPS (the paper's gcn_fps branch) or the global k-center of BASELINE configuration 4")
+    ap.add_argument("--no-al-round", action="store_true", help="skip the untimed-by-the-headline leg that runs ONE active-learning round at the reference's scale")
+    ap.add_argument("--al-batches", type=int, default=17, help="batches of 16 tiles in that round (17 = the 272 rooms of S3DIS)")
+    ap.add_argument("--al-batch-size", type=int, default=10000, help="sampling()'s batch_size in that round (ssdr_main_S3DIS2.py:134)")
     ap.add_argument("--emu", action="store_true",
                     help="TEST ONLY (tests/test_bench_launch.py): CPU logic build of the kernels + gloo, a tiny workload; exercises the launcher and the "
                          "N > 1 control flow on a box without GPUs, measures nothing")
@@ -315,6 +318,39 @@ def main():
             if args.stages:
                 print("stages(ms, sequential):", stage_ms, file=sys.stderr)
 
+    # ---- one AL round at the reference's own scale (rank 0, N = 1; not the headline): inference over ALL rooms, then ONE selection ----
+    # The headline step selects per 16-tile batch (the reference's picks-per-tile ratio), which under-represents the quadratic term of the
+    # farthest-point chain 17-fold: the reference runs the network over all 272 rooms and then ONE GCN_FPS_sampling of batch_size = 10 000
+    # over 2 x 10 000 candidates + the labelled rows (ssdr_main_S3DIS2.py:134, sampler2.py:736-781).  pipeline.ALRound is that round.
+    al_round = None
+    if rank == 0 and world == 1 and not args.emu and not args.no_al_round:
+        ar = pipeline.ALRound(weights, rooms, args.al_batches, Cfg, batch_size=args.al_batch_size, precision=args.precision, selector=args.selector, tiles32=not args.tiles16)
+        ar.run()                                   # untimed: grows the scratch buffers
+        _lib.sync()
+        t_al = []
+        for _ in range(2):
+            ta = time.perf_counter(); ar.infer_all()
+            for st_ in ar.streams:
+                _lib.sync(st_)
+            tb = time.perf_counter(); ar.sel._score_async(None); ar.sel._select_issue(None); sel_al, unl_al = ar.sel._select_collect(); tc = time.perf_counter()
+            t_al.append((tc - ta, tb - ta, tc - tb))
+        ta = time.perf_counter(); sel_al, unl_al = ar.run(); t_run = time.perf_counter() - ta          # the round as one enqueue sequence
+        L.ssdr_prof_enable(1); ar.sel._score_async(None); ar.sel._select_issue(None); ar.sel._select_collect()
+        rep = {ln.rsplit(" ", 4)[0]: float(ln.rsplit(" ", 4)[2]) for ln in L.ssdr_prof_report().decode().strip().splitlines()}
+        L.ssdr_prof_enable(0)
+        best = min(t_al)
+        Tal = ar.sel._sel_static
+        al_round = {"rooms": ar.tiles, "tile_points": int(ar.tile_points), "regions": int(ar.sel.S), "picks": int(len(sel_al)), "candidates": int(len(unl_al)), "labelled_rows": int(Tal["n_lab"]),
+                    "ms": round(t_run * 1e3, 2), "Mpoints_per_s": round(ar.tile_points / t_run / 1e6, 2),
+                    "inference_ms": round(best[1] * 1e3, 2), "selection_ms": round(best[2] * 1e3, 2), "fps_ms": round(rep.get("fps_chain", 0.0), 2),
+                    "fps_us_per_pick": round(rep.get("fps_chain", 0.0) * 1e3 / max(len(sel_al), 1), 3), "chamfer_ms": round(rep.get("sel_chamfer", 0.0), 2),
+                    "selection_families_ms": {k_: round(v_, 3) for k_, v_ in sorted(rep.items(), key=lambda kv: -kv[1])},
+                    "selection_rule": ar.sel.rule_path,
+                    "note": "front end -> KNN pyramid -> inference of %d batches of %d tiles (three streams, batches overlapped), then scoring over all points and ONE "
+                            "ssdr_gcn_fps_sampling_dev over all clouds' regions; ms = the whole round, GPU idle at both ends; inference_ms + selection_ms = the same with a "
+                            "sync between the two halves; fps_ms = the farthest-point chain alone (hipEvent pair)" % (ar.nb, ar.B)}
+        del ar
+
     # ---- CPU baseline leg (rank 0, N = 1 only): the oracle pipeline on ONE room/tile of the same workload ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -364,7 +400,7 @@ def main():
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,
                           "timed_region": "GPU idle at both ends (every stream drained): K launch sequences of every stage and K completed selections, fill and "
                                           "drain of the %d-deep pipe included" % args.pipeline_depth if pipe is not None else "strictly sequential steps"},
-               "stage_ms": stage_ms, "stage_roofline": stage_roofline, "whole_step": whole_step, "roofline": roofline, "cpu_baseline": cpu}
+               "stage_ms": stage_ms, "stage_roofline": stage_roofline, "whole_step": whole_step, "al_round": al_round, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

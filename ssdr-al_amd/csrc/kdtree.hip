@@ -344,6 +344,7 @@ __global__ __launch_bounds__(REST_NT) void kd_rest_kernel(ForestPtrs f, int leve
             });
             __syncthreads();
             if (tid == 0 && s_top > REST_Q) s_top = REST_Q;
+            __syncthreads();          // every thread reads the clamped top: after an overflow (flagged, survivable) they must still agree on it
         }
     }
     if (tid == 0 && maxlevel >= 0) {

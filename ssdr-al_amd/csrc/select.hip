@@ -1299,9 +1299,9 @@ template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
 }
 constexpr int FQ_NT = 512;
 template <int LPR, bool TIMED>
-__global__ __launch_bounds__(FQ_NT) void fps_coop_split(FpsCoopArgs a, int slot_shift, int stagger, long long* dbg) {
+__global__ __launch_bounds__(FQ_NT) void fps_coop_split(FpsCoopArgs a, int slot_shift, int delay, long long* dbg) {
     static_assert(LPR == 2 || LPR == 4, "lanes per row");
-    constexpr int A = 8 / LPR, F = 32 / LPR, ROWS = FQ_NT / LPR, NW = FQ_NT / 64, P = LPR == 2 ? 2 : 4;      // 64 P >= G slots per sweeping lane
+    constexpr int A = 8 / LPR, F = 32 / LPR, ROWS = FQ_NT / LPR, NW = FQ_NT / 64, P = 4;      // 64 P >= G slots per sweeping lane
     if (a.dn) a.n = min(a.n, *a.dn);
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto mark = [&](int k) { if (TIMED) { const long long t = (long long)__builtin_readcyclecounter(); tacc[k] += t - tprev; tprev = t; } };
@@ -1385,32 +1385,20 @@ __global__ __launch_bounds__(FQ_NT) void fps_coop_split(FpsCoopArgs a, int slot_
 #pragma unroll
                 for (int j = 0; j < P; ++j) if (k0 + j * 64 < G) pend |= 1u << j;
                 long spins = 0;
+                for (int z = 0; z < delay; ++z) __builtin_amdgcn_s_sleep(1);      // (development: the first pass a little later, when more records have landed)
                 while (pend) {
-                    // two passes in flight, the second a few hundred cycles behind the first: a record that lands just after the first pass read its slot
-                    // costs that stagger, not another round trip through the fabric (~2700 cycles; 30 % of the picks needed a second pass)
-                    fs_u4 u[P], u2[P];
+                    fs_u4 u[P];
                     if (TIMED) ++passes;
 #pragma unroll
                     for (int j = 0; j < P; ++j) if ((pend >> j) & 1u) u[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + ((unsigned)(k0 + j * 64) << slot_shift), 0, 16);
-                    if (stagger > 0) {
-                        for (int z = 0; z < stagger; ++z) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                        for (int j = 0; j < P; ++j) if ((pend >> j) & 1u) u2[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + ((unsigned)(k0 + j * 64) << slot_shift), 0, 16);
-                    }
-                    auto take = [&](const fs_u4& w, int j) {
-                        if (((pend >> j) & 1u) && (w.y & 0xffff0000u) == tag && (w.w & 0xffff0000u) == tag) {
-                            const double pv = __longlong_as_double((long long)(((unsigned long long)w.z << 32) | w.x));
-                            const int pi = (int)(((w.y & 0xffffu) << 16) | (w.w & 0xffffu));
+                    for (int j = 0; j < P; ++j)
+                        if (((pend >> j) & 1u) && (u[j].y & 0xffff0000u) == tag && (u[j].w & 0xffff0000u) == tag) {
+                            const double pv = __longlong_as_double((long long)(((unsigned long long)u[j].z << 32) | u[j].x));
+                            const int pi = (int)(((u[j].y & 0xffffu) << 16) | (u[j].w & 0xffffu));
                             if (better(pv, pi, v, i)) { v = pv; i = pi; }
                             pend &= ~(1u << j);
                         }
-                    };
-#pragma unroll
-                    for (int j = 0; j < P; ++j) take(u[j], j);
-                    if (stagger > 0 && __any(pend != 0)) {
-#pragma unroll
-                        for (int j = 0; j < P; ++j) take(u2[j], j);
-                    }
                     if (pend && (++spins > FPS_COOP_SPINS / 16 || (spins % 1024 == 0 && __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) { gave_up = true; break; }
                 }
             }
@@ -2098,34 +2086,39 @@ struct CoopFlight { hipEvent_t ev; int g; };
 static std::mutex g_coop_mu;
 static std::vector<CoopFlight> g_coop_flights;
 static std::vector<hipEvent_t> g_coop_pool;
-static int coop_admit(hipStream_t s, int g, int budget) {
-    std::lock_guard<std::mutex> lk(g_coop_mu);
-    static const int env_budget = [] { const char* e = getenv("SSDR_FPS_COOP_BUDGET"); return e ? atoi(e) : 0; }();      // tests: a budget that forces the serialisation
-    if (env_budget > 0) budget = std::max(env_budget, g);
-    size_t keep = 0; int sum = 0;
-    for (size_t i = 0; i < g_coop_flights.size(); ++i) {
-        if (hipEventQuery(g_coop_flights[i].ev) == hipSuccess) { g_coop_pool.push_back(g_coop_flights[i].ev); continue; }
-        g_coop_flights[keep++] = g_coop_flights[i]; sum += g_coop_flights[i].g;
+// One admission: holds the account's lock from the admit to the recorded event of the launch it admitted (two threads can no longer both pass
+// on the same sum), and never takes a chain out of the account before its event reports it finished: a chain that stream A was made to wait for
+// still runs, and a stream C admitted right afterwards must see it in the sum (and waits for it as well) — the polling-abort case the account exists for.
+struct CoopGuard {
+    std::unique_lock<std::mutex> lk;
+    int admit(hipStream_t s, int g, int budget) {
+        lk = std::unique_lock<std::mutex>(g_coop_mu);
+        static const int env_budget = [] { const char* e = getenv("SSDR_FPS_COOP_BUDGET"); return e ? atoi(e) : 0; }();      // tests: a budget that forces the serialisation
+        if (env_budget > 0) budget = std::max(env_budget, g);
+        size_t keep = 0; int sum = 0;
+        for (size_t i = 0; i < g_coop_flights.size(); ++i) {
+            if (hipEventQuery(g_coop_flights[i].ev) == hipSuccess) { g_coop_pool.push_back(g_coop_flights[i].ev); continue; }      // finished: its event may be re-recorded
+            g_coop_flights[keep++] = g_coop_flights[i]; sum += g_coop_flights[i].g;
+        }
+        g_coop_flights.resize(keep);
+        (void)hipGetLastError();          // (hipErrorNotReady of the queries is not an error)
+        for (size_t k = 0; k < g_coop_flights.size() && sum + g > budget; ++k) {      // oldest first; the flights stay in the account
+            SSDR_HIP(hipStreamWaitEvent(s, g_coop_flights[k].ev, 0));
+            sum -= g_coop_flights[k].g;
+        }
+        return SSDR_OK;
     }
-    g_coop_flights.resize(keep);
-    (void)hipGetLastError();          // (hipErrorNotReady of the queries is not an error)
-    while (!g_coop_flights.empty() && sum + g > budget) {
-        SSDR_HIP(hipStreamWaitEvent(s, g_coop_flights.front().ev, 0));
-        sum -= g_coop_flights.front().g;
-        g_coop_pool.push_back(g_coop_flights.front().ev);      // (a recorded event may be re-recorded once nothing new waits on it: the wait above is already enqueued)
-        g_coop_flights.erase(g_coop_flights.begin());
+    int launched(hipStream_t s, int g) {
+        if (!lk.owns_lock()) lk = std::unique_lock<std::mutex>(g_coop_mu);
+        hipEvent_t ev;
+        if (!g_coop_pool.empty()) { ev = g_coop_pool.back(); g_coop_pool.pop_back(); }
+        else SSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        SSDR_HIP(hipEventRecord(ev, s));
+        g_coop_flights.push_back({ev, g});
+        lk.unlock();
+        return SSDR_OK;
     }
-    return SSDR_OK;
-}
-static int coop_launched(hipStream_t s, int g) {
-    std::lock_guard<std::mutex> lk(g_coop_mu);
-    hipEvent_t ev;
-    if (!g_coop_pool.empty()) { ev = g_coop_pool.back(); g_coop_pool.pop_back(); }
-    else SSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    SSDR_HIP(hipEventRecord(ev, s));
-    g_coop_flights.push_back({ev, g});
-    return SSDR_OK;
-}
+};
 #endif
 
 // d_n (optional): the row count on the device; n is then the bound the launch shapes are chosen by
@@ -2157,14 +2150,25 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     // cooperative kernels (G workgroups that meet at a counter per pick): only above the sizes one workgroup sweeps well (the 160 x 129 / 1000 x 129
     // k-center shapes keep the 1024-thread fps_block), and only with G workgroups the occupancy query says are resident together — checked, not assumed
     int coop_g = 0, coop_budget = 0; bool coop_reg = false;
+    // The form of the 32-d chain (round 6; us per pick at 2368 / 4736 / 9472 / 20000 / 24000 rows on one box, profiles/r06_fps_*.txt): rounds 3-5 (polled granules up to 24
+    // workgroups, drained record + counter above) 2.85 / 3.21 / 3.68 / 5.22 / 5.36; rows split over two lanes with 16-byte records (fps_coop_split<2>) 2.47 / 2.49 / 2.56 /
+    // 2.61 / 2.73 — the default.  SSDR_FPS_COOP_SWEEP selects the others for A/B runs: 0 rounds 3-5, 1 swept 544-byte records, 2 / 3 the same among one XCD's workgroups
+    // (plain / write-through stores), 5 rows over four lanes, 6 a record per wave.
+    static const int sweep_env = [] { const char* e = getenv("SSDR_FPS_COOP_SWEEP"); return e ? atoi(e) : -1; }();
+    const int sweep = sweep_env >= 0 ? sweep_env : 4;
+    const int split_lpr = sweep == 4 ? 2 : sweep == 5 ? 4 : 0;
     if (D == 32 && n > 1536 && n <= (size_t)FR_ROWS * (size_t)(ctx().num_cu / 2)) { coop_g = (int)((n + FR_ROWS - 1) / FR_ROWS); coop_reg = true; }
     else if (n > 4096 && n <= (size_t)FC_NT * FC_PPT * (size_t)(ctx().num_cu / 2)) coop_g = (int)std::min<size_t>((size_t)ctx().num_cu / 2, (n + 2 * FC_NT - 1) / (2 * FC_NT));
+    const bool split = coop_reg && split_lpr && (n + FQ_NT / split_lpr - 1) / (FQ_NT / split_lpr) <= 256;      // (a sweeping lane takes four slots)
+    if (split) coop_g = (int)((n + FQ_NT / split_lpr - 1) / (FQ_NT / split_lpr));
     if (coop_g) {
         static const int force_g = [] { const char* e = getenv("SSDR_FPS_COOP_G"); return e ? atoi(e) : 0; }();      // tests: a grid above residency must be reported, not believed
-        if (force_g > 0 && coop_g > 0) coop_g = force_g;
+        if (force_g > 0 && coop_g > 0 && !split) coop_g = force_g;
         else {
             int per_cu = 0;
-            const hipError_t oe = coop_reg ? (coop_g > 24 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_reg, FR_NT, 8 * (size_t)coop_g * FR_REC)
+            const hipError_t oe = split ? (split_lpr == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_split<2, false>, FQ_NT, 0)
+                                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_split<4, false>, FQ_NT, 0))
+                                : coop_reg ? (coop_g > 24 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_reg, FR_NT, 8 * (size_t)coop_g * FR_REC)
                                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_tag, FR_NT, 4 * 2 * (size_t)coop_g * FT_WORDS))
                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop, FC_NT, 0);
             // half of what the query admits: the query is known to answer one block per CU high at some register counts (MI355X_MICROARCH.md), and
@@ -2174,7 +2178,8 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         }
     }
     const bool coop_ok = coop_g > 0;
-    if (coop_ok) SSDR_TRY(coop_admit(s, coop_g, std::max(coop_budget, coop_g)));
+    CoopGuard coop;
+    if (coop_ok) SSDR_TRY(coop.admit(s, coop_g, std::max(coop_budget, coop_g)));
     if (coop_ok && !Q.status_init) { SSDR_TRY(Q.status.reserve(64)); SSDR_HIP(hipMemsetAsync(Q.status.p, 0, 64, s)); Q.status_init = true; }
 #else
     const bool coop_ok = false;
@@ -2193,15 +2198,11 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         SSDR_HIP(hipMemsetAsync(sync, 0, 16, s));
         static std::once_flag once;
         std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * FR_REC * 128); });
-        if (8 * (size_t)G * FR_REC > 8 * (size_t)FR_REC * 128) { set_error("fps: %d cooperative workgroups exceed the record table of the kernel (128)", G); return SSDR_ERR_INVALID; }
+        if (!split && 8 * (size_t)G * FR_REC > 8 * (size_t)FR_REC * 128) { set_error("fps: %d cooperative workgroups exceed the record table of the kernel (128)", G); return SSDR_ERR_INVALID; }
         FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>(), d_n};
         // two hand-off forms, measured (tools/gpu_fps.sh, us per pick at 2368 / 4736 / 9472 / 20000 rows): self-validating granules 3.46 / 3.92 / 4.71 / 6.30,
         // drained record + counter 3.90 / 4.14 / 4.77 / 5.74 — the granule form polls 68 words per record and loses from ~24 workgroups on
         static const int form_env = [] { const char* e = getenv("SSDR_FPS_COOP_COUNTER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-        // round 6, the swept hand-off (fps_coop_sweep): SSDR_FPS_COOP_SWEEP = 1 chip-wide with write-through stores, 2 one XCD's workgroups with plain
-        // stores (records through that XCD's L2), 3 one XCD's workgroups with write-through stores (placement alone), 0 the forms of rounds 3-5
-        static const int sweep_env = [] { const char* e = getenv("SSDR_FPS_COOP_SWEEP"); return e ? atoi(e) : -1; }();
-        const int sweep = sweep_env >= 0 ? sweep_env : 0;
         if (sweep == 6 && (n + FW_ROWS - 1) / FW_ROWS <= 64 * FW_MAXP / FW_NW) {          // a record per wave, one sweeping wave per workgroup
             const int G2 = (int)((n + FW_ROWS - 1) / FW_ROWS);
             const size_t recb = (size_t)2 * G2 * FW_NW * 16;
@@ -2220,16 +2221,16 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
                     for (int g2 = 0; g2 < G2; ++g2) { const long long v = h[(size_t)g2 * 8 + k]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
                     fprintf(stderr, "fps_coop_wave G=%d %-24s per pick: mean %.1f min %.1f max %.1f\n", G2, nm[k], (double)sum / G2 / count, (double)mn / count, (double)mx / count);
                 }
-                return coop_launched(s, G2);
+                return coop.launched(s, G2);
             }
             hipLaunchKernelGGL(fps_coop_wave<false>, dim3(G2), dim3(FW_NT), 0, s, a, (long long*)nullptr);
             SSDR_HIP(hipGetLastError());
-            return coop_launched(s, G2);
+            return coop.launched(s, G2);
         }
-        if (sweep == 4 || sweep == 5) {          // rows split over 2 / 4 lanes, 16-byte records, the winner's row from the table
-            const int lpr = sweep == 4 ? 2 : 4, rows = FQ_NT / lpr, G2 = (int)((n + rows - 1) / rows);
+        if (split) {          // rows split over 2 / 4 lanes, 16-byte records, the winner's row from the table
+            const int lpr = split_lpr, G2 = G;
             static const int shift = [] { const char* e = getenv("SSDR_FPS_SLOT_SHIFT"); return e ? atoi(e) : 6; }();      // a record's slot: 16 bytes, or a line / several of its own
-            static const int team = [] { const char* e = getenv("SSDR_FPS_STAGGER"); return e ? atoi(e) : 0; }();      // s_sleep units between the two passes in flight (0: one pass)
+            static const int team = [] { const char* e = getenv("SSDR_FPS_DELAY"); return e ? atoi(e) : 0; }();      // s_sleep units in front of the first polling pass
             const int launch_g = G2;
             const size_t recb = ((size_t)2 * G2) << shift;
             SSDR_TRY(Q.vtmp.reserve(recb + 64));
@@ -2248,12 +2249,12 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
                     for (int g2 = 0; g2 < G2 && g2 < 512; ++g2) { const long long v = h[(size_t)g2 * 8 + k]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
                     fprintf(stderr, "fps_coop_split<%d> G=%d %-16s per pick: mean %.1f min %.1f max %.1f\n", lpr, G2, nm[k], (double)sum / std::min(G2, 512) / count, (double)mn / count, (double)mx / count);
                 }
-                return coop_launched(s, G2);
+                return coop.launched(s, G2);
             }
             if (lpr == 2) hipLaunchKernelGGL((fps_coop_split<2, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, (long long*)nullptr);
             else hipLaunchKernelGGL((fps_coop_split<4, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, (long long*)nullptr);
             SSDR_HIP(hipGetLastError());
-            return coop_launched(s, G2);
+            return coop.launched(s, G2);
         }
         if (sweep > 0 && G <= 64) {
             const bool team = sweep >= 2;
@@ -2277,11 +2278,11 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
                     for (int g2 = 0; g2 < G; ++g2) { const long long v = h[(size_t)g2 * 8 + k]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
                     fprintf(stderr, "fps_coop_sweep G=%d %-16s per pick: mean %.1f min %.1f max %.1f (%s)\n", G, nm[k], (double)sum / G / count, (double)mn / count, (double)mx / count, k == 7 ? "passes" : "s_memtime ticks");
                 }
-                return coop_launched(s, G);
+                return coop.launched(s, G);
             }
             hipLaunchKernelGGL(fps_coop_sweep<false>, dim3(team ? 8 * (G + 2) : G), dim3(FR_NT), 4 * 2 * (size_t)G * FT_WORDS, s, a, team ? 1 : 0, sweep == 2 ? 1 : 0, (long long*)nullptr);
             SSDR_HIP(hipGetLastError());
-            return coop_launched(s, G);
+            return coop.launched(s, G);
         }
         const bool counter_form = form_env >= 0 ? form_env == 1 : G > 24;
         if (!counter_form) {
@@ -2290,11 +2291,11 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
             std::call_once(once2, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_coop_tag), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * FT_WORDS * 128); });
             hipLaunchKernelGGL(fps_coop_tag, dim3(G), dim3(FR_NT), 4 * 2 * (size_t)G * FT_WORDS, s, a);
             SSDR_HIP(hipGetLastError());
-            return coop_launched(s, G);
+            return coop.launched(s, G);
         }
         hipLaunchKernelGGL(fps_coop_reg, dim3(G), dim3(FR_NT), 8 * (size_t)G * FR_REC, s, a);
         SSDR_HIP(hipGetLastError());
-        return coop_launched(s, G);
+        return coop.launched(s, G);
     }
     if (coop_ok) {          // one launch: co-resident workgroups meeting at a counter per pick
         const int G = coop_g;
@@ -2304,7 +2305,7 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         FpsCoopArgs a{d_feat, (int)n, D, seeded ? 1 : 0, start, use_sqrt, p1, nb, Q.mind.as<double>(), (int)count, d_out, part, sync, G, Q.status.as<int>(), d_n};
         hipLaunchKernelGGL(fps_coop, dim3(G), dim3(FC_NT), 0, s, a);
         SSDR_HIP(hipGetLastError());
-        return coop_launched(s, G);
+        return coop.launched(s, G);
     }
 #endif
     for (size_t it = 0; it < count; ++it) {

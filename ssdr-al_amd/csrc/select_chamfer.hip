@@ -155,7 +155,8 @@ __device__ __forceinline__ void chamfer_min(const double (&ax)[NV], const double
         for (int v = 0; v < NV; ++v) {
             const int idx = (int)((unsigned)__double_as_longlong(min_f64(m[v][0], m[v][1])) & 1023u);
             const double dx = ax[v] - tb[TS_F64 * idx], dy = ay[v] - tb[TS_F64 * idx + 1], dz = az[v] - tb[TS_F64 * idx + 2];
-            out[v] = fma(dz, dz, fma(dy, dy, dx * dx));      // fused: the chamfer terms are compared at 1e-12, not bit for bit
+            // (an empty target leaves the 1e300 sentinel, whose low bits name no staged point: the streamed form's and the screening's answer, sqrt -> 1e150)
+            out[v] = nj > 0 ? fma(dz, dz, fma(dy, dy, dx * dx)) : 1.0e300;      // fused: the chamfer terms are compared at 1e-12, not bit for bit
         }
         return;
     }

@@ -128,7 +128,7 @@ class HotPath:
         return self
 
     @classmethod
-    def from_clouds(cls, clouds, labeled, selected_class_list, config=ConfigS3DIS, **kw):
+    def from_clouds(cls, clouds, labeled, selected_class_list, config=ConfigS3DIS, room_ids=None, **kw):
         """The scoring + selection half alone, over clouds given with their network outputs (no front end, no network): clouds[b] = dict(xyz [n,3],
         gt [n], probs [n,C], feat [n,32], offsets [S_b+1], points) — what prediction() / compute_features see per cloud (sampler2.py:580-642,
         :313-342); labeled[b] = the regions of cloud b (ids inside the cloud) that total_obj["unlabeled"] no longer lists.  Clouds may differ in
@@ -144,10 +144,10 @@ class HotPath:
                                DevArray.from_host(np.concatenate([np.asarray(c["probs"], np.float32) for c in clouds])),
                                DevArray.from_host(np.concatenate([np.asarray(c["feat"], np.float32) for c in clouds])),
                                DevArray.from_host(np.concatenate([np.asarray(c["gt"]).astype(np.int32) for c in clouds])),
-                               np.concatenate(offs), np.concatenate(pts), np.concatenate(cloud), lab, selected_class_list, config, **kw)
+                               np.concatenate(offs), np.concatenate(pts), np.concatenate(cloud), lab, selected_class_list, config, room_ids=room_ids, **kw)
 
     @classmethod
-    def from_device(cls, xyz, probs, f32, labels, sp_off, sp_pts, sp_cloud, labeled, selected_class_list, config=ConfigS3DIS, **kw):
+    def from_device(cls, xyz, probs, f32, labels, sp_off, sp_pts, sp_cloud, labeled, selected_class_list, config=ConfigS3DIS, room_ids=None, **kw):
         """from_clouds over arrays that are already resident (xyz [n,3] f32, probs [n,C] f32, f32 [n,32] f32, labels [n] i32: DevArray or anything
         with .ptr): the superpoints as one CSR over the n points (host arrays), sp_cloud [S] = the cloud of every superpoint (ascending),
         labeled[b] = GLOBAL ids of cloud b's labelled regions.  This is how one AL round ends at the reference's scale (ALRound): the network
@@ -155,17 +155,17 @@ class HotPath:
         hp = cls(None, config, **kw)
         sp_cloud = np.asarray(sp_cloud, np.int32)
         hp.B = int(sp_cloud.max()) + 1 if len(sp_cloud) else 0
-        hp._dist = None; hp.room_ids = list(range(hp.B)); hp.rooms = []
+        hp._dist = None; hp.room_ids = list(range(hp.B)) if room_ids is None else list(room_ids); hp.rooms = []      # room_ids: the clouds' global ids (sharded runs)
         hp.n_pts = int(xyz.shape[0])
         hp.xyz, hp.probs, hp.f32, hp.tile_l = xyz, probs, f32, labels
         hp.unc = DevArray((hp.n_pts,), np.float32); hp.cls = DevArray((hp.n_pts,), np.int32)
         hp._set_regions(sp_off, sp_pts, sp_cloud, labeled, selected_class_list)
         return hp
 
-    def step_selection(self):
-        """scoring + selection over the resident network outputs (from_clouds)"""
-        self._score_async(None)
-        return self._select(None)
+    def step_selection(self, comm=None):
+        """scoring + selection over the resident network outputs (from_clouds); comm: the sharded run's exchanges"""
+        self._score_async(comm)
+        return self._select(comm)
 
     def _set_regions(self, sp_off, sp_pts, sp_cloud, labeled, selected_class_list):
         """superpoints (one CSR over the batch's points), which of them are already labelled, the already-selected class list; then everything
@@ -187,6 +187,7 @@ class HotPath:
     def set_labeled(self, labeled):
         """labeled[b] = the (global) ids of cloud b's regions that are already labelled (what total_obj["unlabeled"] no longer lists)"""
         cfg = self.cfg
+        self._dist = None; self.global_order = None      # a sharded run's static tables (labelled mask, populations, the global draw) belong to the labelling
         self.labeled = labeled
         self.labeled_mask = np.zeros(self.S, bool)
         for b in self.labeled:
@@ -717,11 +718,13 @@ class ALRound:
             if 0 <= k - 2 < self.nb:
                 _lib.check(L.ssdr_stream_wait(s_i, s_k))          # (the pyramid stream holds batch k - 2's pyramid and nothing later)
                 self._bind(k - 2)._infer()
-                _lib.check(L.ssdr_stream_wait(s_f, s_i))          # the next front end reuses a buffer set whose inference must have finished
             if 0 <= k - 1 < self.nb:
-                _lib.check(L.ssdr_stream_wait(s_k, s_f))
+                _lib.check(L.ssdr_stream_wait(s_k, s_f))          # (the front stream holds batch k - 1's tiles and nothing later: the wait below comes after this one)
                 self._bind(k - 1)._pyramid()
             if k < self.nb:
+                # batch k reuses the buffer set of batch k - 3: its inference has finished once batch k - 2's has (one stream).  Waiting for k - 2 rather than
+                # k - 3 costs nothing: batch k - 1's inference runs beside this front end and pyramid either way
+                _lib.check(L.ssdr_stream_wait(s_f, s_i))
                 self._bind(k)._front_end()
 
     def run(self):

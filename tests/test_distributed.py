@@ -30,6 +30,26 @@ def test_two_rank_sharded_selection_equals_single_process(tmp_path, emu_lib):
     assert all(x["pipelined_equal"] and x["pipelined_selected"] == x["selected"] for x in r)    # batches in flight: same result
 
 
+@pytest.mark.parametrize("shards,nolab,port", [("3,2,1", 2, 29551), ("1,1,1,1,1,1,1,1", -1, 29553)])
+def test_unequal_shards_and_eight_ranks_equal_single_process(tmp_path, emu_lib, shards, nolab, port):
+    """world 3 with 3 + 2 + 1 clouds (the Bmax / Smax / nl_max paddings, one rank without a labelled region) and world 8 with one cloud each:
+    the sharded selection (device-side rule, both selectors, labels re-set between two steps) == ONE process over the union of the clouds,
+    index for index.  Clouds with fabricated network outputs: the stages in front of the scoring have no collective."""
+    world = len(shards.split(","))
+    env = dict(os.environ, SSDR_TEST_OUT=str(tmp_path), OMP_NUM_THREADS="2" if world <= 3 else "1", SSDR_TEST_SHARDS=shards, SSDR_TEST_NOLAB_RANK=str(nolab))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker2.py")]
+    subprocess.run(cmd, check=True, env=env, timeout=2400, cwd=ROOT)
+    r = [json.load(open(tmp_path / ("rank%d.json" % i))) for i in range(world)]
+    rooms = sum(int(x) for x in shards.split(","))
+    for sel in ("fps", "kcenter"):
+        assert all(x[sel] == r[0][sel] == x[sel + "_again"] for x in r)
+        assert r[0][sel] == r[0][sel + "_single"] and len(r[0][sel]) == 7 * rooms
+        assert all(x[sel + "_path"] == "sharded-device" for x in r)
+    if nolab >= 0:
+        assert r[nolab]["n_lab_mine"] == 0 and all(x["n_lab_mine"] > 0 for i, x in enumerate(r) if i != nolab)
+
+
 @pytest.mark.gpu
 def test_rccl_exchange_path_on_one_gpu_equals_plain_path(tmp_path):
     """bench.py's N > 1 code path (device-resident exchanges through RCCL, ordered on the library's streams) on one GPU."""
