@@ -39,6 +39,28 @@ TILES_PER_GPU = 16
 RAW_DENSITY = 5000.0              # points / m^2 -> 0.4-1.2 M raw points per room
 
 
+def count_gpus():
+    """GPU agents the kernel driver lists (KFD topology nodes with SIMDs), without touching HIP: the parent of an N-rank launch must not
+    initialise a GPU, and a launch onto fewer devices than ranks must fail before any rank does."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for d in os.listdir(base):
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(base, d, "properties")) if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n):
     """One process per GPU on this node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a
     child process (never an exec: this process may not have touched the GPU, and it must stay that way until the child is started)."""
@@ -80,6 +102,10 @@ def main():
                          "N > 1 control flow on a box without GPUs, measures nothing")
     args = ap.parse_args()
 
+    if args.gpus > 1 and not args.emu and not os.environ.get("SSDR_BENCH_SKIP_DEVICE_COUNT"):
+        have = count_gpus()
+        if have < args.gpus:       # before any rank touches a GPU (every rank of a launcher's job checks for itself: same answer, same exit)
+            raise SystemExit("bench.py: --gpus %d but this node lists %d GPU(s) (KFD topology / *_VISIBLE_DEVICES)" % (args.gpus, have))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as CHILDREN, through
         # torch.distributed.run, before this process has made any GPU call; rank 0's JSON line comes through on the
@@ -189,6 +215,40 @@ def main():
 
     npts = world * tiles_per_gpu * Cfg.num_points * args.steps
     value = npts / dt / 1e6
+
+    # N > 1: the second reading.  `value` keeps the bench's default, 37 regions per tile of the WHOLE job (the picks grow with N, so the replicated
+    # global farthest-point chain is N x the picks over N x the rows: N^2); the reference's own reading is ONE batch_size per round whatever the
+    # number of clouds (ssdr_main_S3DIS2.py:134) — the chain then stays what one rank runs.  Same path, same timed region, the other batch size.
+    fixed_batch = None
+    if use_dist and args.global_batch == 0 and (world > 1 or os.environ.get("SSDR_BENCH_FORCE_DIST")):
+        K_fixed = hp.select_per_tile * tiles_per_gpu
+        hps = [hp] + (list(pipe.hp) if pipe is not None else [])
+
+        def set_batch(k):
+            for h in hps:
+                h.batch_size = k; h._dist = None; h._select_static()
+        set_batch(K_fixed)
+        if pipe is not None:
+            pipe.run(max(args.warmup, 1), gather)
+        else:
+            hp.step(gather)
+        barrier()
+        t1 = time.perf_counter()
+        if pipe is not None:
+            pipe.run(args.steps, gather)
+        else:
+            for _ in range(args.steps):
+                hp.step(gather)
+        barrier()
+        dt2 = time.perf_counter() - t1
+        if use_dist:
+            import torch
+            t = torch.tensor([dt2], device="cpu" if args.emu else "cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        fixed_batch = {"value": round(npts / dt2 / 1e6, 3), "unit": "Mpoints/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3), "selected_per_step": int(K_fixed),
+                       "note": "the reference's reading: sampling()'s batch_size is ONE number for the round (here what one rank's 16 tiles select), the replicated chain does not grow with N"}
+        set_batch(None)
 
     # ---- roofline leg (untimed): per-launch HIP-event timing of the instrumented kernels ------------------
     L = _lib.lib()
@@ -395,12 +455,15 @@ def main():
                                       "ranking -> FPS-GCN select (gcn_number=1, gcn_top=0, %s)" % (tiles_per_gpu, args.precision, "FPS start fixed to candidate 0" if args.selector == "fps" else "global k-center over candidates + labelled regions"),
                           "tiles_per_gpu": tiles_per_gpu, "tile_points": Cfg.num_points, "raw_points_per_step_per_gpu": int(sum(len(r[0]) for r in rooms)),
                           "superpoints_per_gpu": int(hp.S), "selected_per_step": int(args.global_batch if args.global_batch > 0 else hp.select_per_tile * tiles_per_gpu * world), "sharding": "tiles",
+                          "selection_batch": ("--global-batch %d: ONE batch_size for the job (the reference's reading)" % args.global_batch) if args.global_batch > 0 else
+                                             ("%d regions per tile x the tiles of ALL ranks: the picks grow with N and the replicated global chain with N^2 (the harsher reading; "
+                                              "`fixed_batch` is the same run with the reference's one batch_size per round)" % hp.select_per_tile),
                           "selection_rule": (getattr(pipe.hp[0], "rule_path", None) if pipe is not None else None) or getattr(hp, "rule_path", None),
                           **({"emulated_world": int(os.environ["SSDR_EMULATE_WORLD"])} if os.environ.get("SSDR_EMULATE_WORLD") else {}),
                           "batches_in_flight": args.pipeline_depth if pipe is not None else 1,
                           "timed_region": "GPU idle at both ends (every stream drained): K launch sequences of every stage and K completed selections, fill and "
                                           "drain of the %d-deep pipe included" % args.pipeline_depth if pipe is not None else "strictly sequential steps"},
-               "stage_ms": stage_ms, "stage_roofline": stage_roofline, "whole_step": whole_step, "al_round": al_round, "roofline": roofline, "cpu_baseline": cpu}
+               "stage_ms": stage_ms, "stage_roofline": stage_roofline, "whole_step": whole_step, "al_round": al_round, "fixed_batch": fixed_batch, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -24,6 +24,17 @@ def test_bench_gpus2_launches_two_ranks(emu_lib):
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["ms_per_step"] > 0
     assert j["config"]["selected_per_step"] == 2 * 2 * 5          # both ranks' tiles take part in the global selection
+    # the second reading of an N-rank job: the reference's ONE batch_size per round (what one rank's tiles select), named beside the default
+    assert j["fixed_batch"]["selected_per_step"] == 2 * 5 and j["fixed_batch"]["ms_per_step"] > 0 and "N^2" in j["config"]["selection_batch"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` on a node with fewer than N GPUs exits non-zero with one line, before any rank is started or any GPU touched
+    (the KFD topology is read, not HIP).  This box lists fewer than 64 GPUs whatever it is."""
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("SSDR_BENCH_SKIP_DEVICE_COUNT", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 64 but this node lists" in (r.stderr + r.stdout)
+    assert '{"metric"' not in r.stdout
 
 
 def test_bench_rejects_world_size_mismatch(emu_lib):
