@@ -31,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA pe
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 PEAK_F64_VECTOR_TFLOPS = 78.6     # AMD's public MI355X figure for vector float64 (the guide lists none; measured issue rate: one v_fma_f64 per 5.4 cycles and SIMD = 58 TF)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_ROUND = "r05"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
+PROFILE_ROUND = "r06"             # profiles/<round>_pmc_summary.json supplies roofline.traffic (with its commit)
 DTYPE = {"f32": "f32 (exact f32-input MFMA)",
          "bf16x3": "bf16x3: split-bf16 MFMA operands (hi*hi + lo*hi + hi*lo), fp32 accumulate, fp32 activations and non-matrix arithmetic",
          "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 activations and non-matrix arithmetic"}
@@ -265,7 +265,8 @@ def main():
         return sorted(rows, key=lambda r: -r[2])
 
     NPROF = 3
-    mfma_kernels = ("dense_kernel", "lfa_att_kernel")
+    def is_mfma(n_):          # the matrix-core kernel templates (per template since round 6; the 16 x 16 formulation keeps its two family names)
+        return n_.startswith(("lfa32_", "lfa_att_kernel", "dense_bf16_kernel", "dense_chain_kernel", "dense_kernel"))
     mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
     mfma_insn = "v_mfma_f32_16x16x4_f32" if args.precision == "f32" else ("v_mfma_f32_16x16x32_bf16 (LocSE K = 10 and the d = 16 level on v_mfma_f32_16x16x4_f32)" if args.tiles16 else "v_mfma_f32_32x32x16_bf16 (every level; softmax over the neighbours inside the lane)")
     # (a) the way the timed region ran (every rank takes part because of the exchanges) ...
@@ -290,14 +291,21 @@ def main():
         ref_sp = np.concatenate([res[8 + T["picks"]: 8 + T["picks"] + n_unl], np.array([s_ for b_ in range(hp.B) for s_ in hp.lab_rows.get(b_, [])], np.int64)]).astype(np.int64)
         sz = hp.sp_size_h[ref_sp].astype(np.float64); cl = hp.sp_cloud_h[ref_sp]
         pairs = float(sum(sz[cl == b_].sum() ** 2 - (sz[cl == b_] ** 2).sum() for b_ in range(hp.B)))      # ordered (source, target) pairs of points, i != j
-        extra_work = {"fe_reduce": 28.0 * sub_rows * NPROF, "sel_chamfer": 8.0 * pairs * NPROF}
+        raw_pts = int(sum(len(r_[0]) for r_ in rooms))
+        # fe_reduce is charged the operation's algorithmic bytes for the units its launch processes (28 B per input point, which it reads as
+        # records, + 28 B per voxel, which it writes); the scatter the 28 B per point it reads
+        extra_work = {"fe_reduce": 28.0 * (raw_pts + sub_rows) * NPROF, "sel_chamfer": 8.0 * pairs * NPROF}
         rows = [(r[0], r[1], r[2], r[3] + extra_work.get(r[0], 0.0), r[4]) for r in rows]
         # one-workgroup dependent chains occupy one CU of 256 and cost the pipelined step nothing (profiles/rNN_marginal.txt): they are listed with the
         # others, the roofline line is the longest CHIP-WIDE kernel
         one_cu = ("fps_chain",)
+        # profiler sites that cover SEVERAL different kernels (latency chains of small launches): listed with the others, never the roofline line, which is
+        # the single kernel TEMPLATE with the largest time per step (all launches of that template)
+        multi_kernel_sites = ("knn_tree_handover", "fe_bbox_count_scan", "fe_rows_move", "tile_select", "knn_grid_build", "sel_candidate_rule", "sel_features_pack",
+                              "sel_adjacency_propagate", "sel_clsbal", "sel_rank")
         f64_kernels = ("sel_chamfer",)
-        name, calls, ms, work, work2 = [r for r in rows if r[0] not in one_cu][0]
-        mfma = name in mfma_kernels
+        name, calls, ms, work, work2 = [r for r in rows if r[0] not in one_cu and r[0] not in multi_kernel_sites][0]
+        mfma = is_mfma(name)
         unit_div = 1e12 if mfma else 1e9
         achieved = work / (ms * 1e-3) / unit_div
         peak = mfma_peak if mfma else PEAK_HBM_GBS
@@ -329,8 +337,8 @@ def main():
         def family(r):
             d = {"ms_per_step": round(r[2] / NPROF, 3), "launches_per_step": r[1] // NPROF}
             rate = r[3] / (r[2] * 1e-3) if r[2] > 0 else 0.0
-            if r[0] in mfma_kernels:
-                d.update({"algorithmic_TFLOPs": round(rate / 1e12, 2), "executed_mfma_TFLOPs": round(r[4] / (r[2] * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(rate / 1e12 / mfma_peak, 4)})
+            if is_mfma(r[0]):
+                d.update({"algorithmic_GFLOP_per_tile": round(r[3] / NPROF / TILES_PER_GPU / 1e9, 4), "algorithmic_TFLOPs": round(rate / 1e12, 2), "executed_mfma_TFLOPs": round(r[4] / (r[2] * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(rate / 1e12 / mfma_peak, 4)})
             elif r[0] in f64_kernels:
                 d.update({"algorithmic_f64_TFLOPs": round(rate / 1e12, 2), "frac_of_f64_vector_peak": round(rate / 1e12 / PEAK_F64_VECTOR_TFLOPS, 4),
                           "note": "8 float64 FLOP per point pair of the reference's formulation; since round 5 the pairs are screened by v_mfma_f32_32x32x16_f16 "
@@ -343,6 +351,19 @@ def main():
                 d["one_workgroup_chain"] = True
             return d
         roofline["others"] = {r[0]: family(r) for r in rows}
+        for r in rows:
+            if r[0] in multi_kernel_sites:
+                roofline["others"][r[0]]["several_kernels"] = True
+        # the two matrix-core families of rounds 1-5 as sums over their templates (continuity with the earlier rounds' roofline line)
+        fam = {}
+        for fname, pref in (("attention (lfa32_* templates)", ("lfa32_", "lfa_att_kernel")), ("per-point layers (dense_* templates)", ("dense_bf16_kernel", "dense_chain_kernel", "dense_kernel"))):
+            rr = [r for r in rows if r[0].startswith(pref)]
+            if rr:
+                tms, w1, w2 = sum(r[2] for r in rr), sum(r[3] for r in rr), sum(r[4] for r in rr)
+                fam[fname] = {"ms_per_step": round(tms / NPROF, 3), "launches_per_step": sum(r[1] for r in rr) // NPROF, "algorithmic_GFLOP_per_tile": round(w1 / NPROF / TILES_PER_GPU / 1e9, 3),
+                              "algorithmic_TFLOPs": round(w1 / (tms * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(w1 / (tms * 1e-3) / 1e12 / mfma_peak, 4),
+                              "executed_mfma_TFLOPs": round(w2 / (tms * 1e-3) / 1e12, 2)}
+        roofline["families"] = fam
         for r in timed_rows:
             if r[0] == name and pipe is not None:
                 roofline["as_timed"] = {"conditions": "%d batches in flight on %d streams" % (args.pipeline_depth, args.pipeline_depth),

@@ -289,6 +289,10 @@ int ssdr_cloud_graph_dev(const float* d_xyz, const int32_t* d_sp_off, const int3
 int ssdr_cloud_graph_batch_dev(const float* d_xyz, const int32_t* d_sp_off, const int32_t* d_sp_pts, const int32_t* d_sel,
                                const int32_t* d_coff, const int64_t* d_boff, size_t num_clouds, size_t n_total, size_t n_max,
                                int gcn_top, double* d_centres, double* d_cd_dir, double* d_adj, void* stream);
+/* Arithmetic of the chamfer term in every selection-graph entry point: 0 = float64 (S3DIS: fps_gcn_cpu.py:12-38, the default), 1 = the Semantic3D code's
+ * float32 CUDA-kernel values (SSRD_AL_semantic3d/fps_gcn_cuda.py:13-30: centred coordinates rounded to float32, chamfer3D.cu's squared distances,
+ * sqrt and the two means in float32, widened).  Process-wide, read at every call. */
+int ssdr_select_set_chamfer_mode(int mode);
 int ssdr_propagate_batch_dev(const double* d_adj, const int32_t* d_coff, const int64_t* d_boff, size_t num_clouds, size_t n_max,
                              const int32_t* d_rows, const double* d_vin, int feat_dim, double* d_vout, double* d_comb, void* stream);
 /* One hop of sum_i A^i V on a block (fps_gcn_cpu.py:162-167): vout[rows] = adj * vin[rows]; comb[rows] += vout[rows] */

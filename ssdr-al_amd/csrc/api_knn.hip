@@ -57,16 +57,14 @@ int grid_knn(KnnState& S, const std::vector<GridDesc>& sets, const std::vector<G
     {
         double bytes = 0;      // algorithmic bytes: support + query coordinates read once, indices written once
         for (auto& j : jobs16) bytes += 24.0 * j.nq + (i64 ? 8.0 : 4.0) * 16 * j.nq;
-        ProfScope prof("knn_grid_search<16>", s, bytes);
-        SSDR_TRY(grid_search(S.grid, 0, (int)jobs16.size(), mq16, 16, i64, s));
+        SSDR_TRY(grid_search(S.grid, 0, (int)jobs16.size(), mq16, 16, i64, s, bytes));
     }
     {
         double bytes = 0;
         for (auto& j : jobs1) bytes += 24.0 * j.nq + (i64 ? 8.0 : 4.0) * j.nq;
-        ProfScope prof("knn_grid_search<1>", s, bytes);
         bool fused = !jobs16.empty() && !jobs1.empty();       // every K = 1 job rides on a K = 16 scan: only the second pass runs for them
         for (auto& j : jobs16) fused = fused && j.job1 >= 0;
-        SSDR_TRY(grid_search(S.grid, (int)jobs16.size(), (int)jobs1.size(), fused ? 0 : mq1, 1, i64, s));
+        SSDR_TRY(grid_search(S.grid, (int)jobs16.size(), (int)jobs1.size(), fused ? 0 : mq1, 1, i64, s, bytes));
     }
     // exact nanoflann trees only for the support sets that own handed-over rows (flags set by the searches above)
     std::vector<KdTreeDesc> trees(sets.size());

@@ -580,7 +580,7 @@ int grid_build(GridForest& g, const std::vector<GridDesc>& sets_in, int target_p
 }
 
 // jobs [job0, job0 + njobs) of the table uploaded by grid_set_jobs, all with the same K; rows that need the tree go to the K's work list
-int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, bool out_i64, hipStream_t s) {
+int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, bool out_i64, hipStream_t s, double prof_bytes) {
     if (njobs <= 0) return SSDR_OK;
     if (K != 16 && K != 1) { set_error("grid search: K=%d has no instantiation (1, 16)", K); return SSDR_ERR_UNSUPPORTED; }
     const int wl = K == 16 ? 0 : 1;
@@ -591,13 +591,22 @@ int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, boo
     const dim3 grid((unsigned)((max_nq + 255) / 256), (unsigned)njobs);
     const dim3 rgrid((unsigned)std::max(1, std::min(g.work_cap / 64 + 1, ctx().num_cu * 16)));
     const bool first = max_nq > 0;      // max_nq == 0: the jobs were answered inside another scan, only their left-over rows remain
-    if (K == 16) {
-        static const bool lds_form = [] { const char* e = getenv("SSDR_KNN_LDS"); return e && e[0] == '1'; }();      // the LDS-staged first pass (measured beside the default, profiles/)
-        if (out_i64) { if (first) { if (lds_form) hipLaunchKernelGGL((grid_search_lds_kernel<16, int64_t>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((grid_search_kernel<16, int64_t>), grid, dim3(256), 0, s, a); } hipLaunchKernelGGL((grid_retry_kernel<16, int64_t>), rgrid, dim3(64), 0, s, a); }
-        else { if (first) { if (lds_form) hipLaunchKernelGGL((grid_search_lds_kernel<16, int32_t>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((grid_search_kernel<16, int32_t>), grid, dim3(256), 0, s, a); } hipLaunchKernelGGL((grid_retry_kernel<16, int32_t>), rgrid, dim3(64), 0, s, a); }
-    } else {
-        if (out_i64) { if (first) hipLaunchKernelGGL((grid_search_kernel<1, int64_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<1, int64_t>), rgrid, dim3(64), 0, s, a); }
-        else { if (first) hipLaunchKernelGGL((grid_search_kernel<1, int32_t>), grid, dim3(256), 0, s, a); hipLaunchKernelGGL((grid_retry_kernel<1, int32_t>), rgrid, dim3(64), 0, s, a); }
+    // profiler sites: one per kernel template (the first pass carries the stage's algorithmic bytes; the retry answers what it left over)
+    static const bool lds_form = [] { const char* e = getenv("SSDR_KNN_LDS"); return e && e[0] == '1'; }();      // the LDS-staged first pass (measured beside the default, profiles/)
+    if (first) {
+        ProfScope prof(K == 16 ? "grid_search_kernel<16>" : "grid_search_kernel<1>", s, prof_bytes);
+        if (K == 16) {
+            if (out_i64) { if (lds_form) hipLaunchKernelGGL((grid_search_lds_kernel<16, int64_t>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((grid_search_kernel<16, int64_t>), grid, dim3(256), 0, s, a); }
+            else { if (lds_form) hipLaunchKernelGGL((grid_search_lds_kernel<16, int32_t>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((grid_search_kernel<16, int32_t>), grid, dim3(256), 0, s, a); }
+        } else {
+            if (out_i64) hipLaunchKernelGGL((grid_search_kernel<1, int64_t>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((grid_search_kernel<1, int32_t>), grid, dim3(256), 0, s, a);
+        }
+    }
+    {
+        ProfScope prof(K == 16 ? "grid_retry_kernel<16>" : "grid_retry_kernel<1>", s, first ? 0.0 : prof_bytes);
+        if (K == 16) { if (out_i64) hipLaunchKernelGGL((grid_retry_kernel<16, int64_t>), rgrid, dim3(64), 0, s, a); else hipLaunchKernelGGL((grid_retry_kernel<16, int32_t>), rgrid, dim3(64), 0, s, a); }
+        else { if (out_i64) hipLaunchKernelGGL((grid_retry_kernel<1, int64_t>), rgrid, dim3(64), 0, s, a); else hipLaunchKernelGGL((grid_retry_kernel<1, int32_t>), rgrid, dim3(64), 0, s, a); }
     }
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;

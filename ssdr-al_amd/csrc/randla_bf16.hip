@@ -766,7 +766,7 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     const bool small = a.M <= 16384;
     const double tm = small ? 32.0 : 128.0, kc = small ? 64.0 : 32.0;
     const double exec = 2.0 * std::ceil(a.M / tm) * tm * std::ceil((a.k1 + a.k2) / kc) * kc * std::ceil(a.N / 64.0) * 64.0 * (prec == PREC_BF16X3 ? 3.0 : 1.0);
-    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N, exec);
+    ProfScope prof(small ? "dense_bf16_kernel<32,64>" : "dense_bf16_kernel<128,32>", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N, exec);
     const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0;
     // (a split-K form for these layers — every wave a quarter of the k steps, both operands straight from global memory in the MFMA layout, no LDS or
     // barrier in the K loop, partial tiles summed in LDS — was built and measured: 32 us per launch against 18.7: a 32-row tile re-reads its whole
@@ -791,7 +791,7 @@ int launch_dense_chain(const DenseArgs& l1, const DenseArgs& l2, int prec, hipSt
     if (d == 16 && d + l2.k2 <= 32) k2p = 32; else if (d == 64 && d + l2.k2 <= 96) k2p = 96; else return SSDR_ERR_UNSUPPORTED;
     ChainArgs a{l1.x1, l2.x2, l2.k2, l1.wt_hi, l1.wt_lo, l1.kp, l1.b, l2.wt_hi, l2.wt_lo, l2.kp, l2.b, l2.y, l1.M};
     const double np = prec == PREC_BF16X3 ? 3.0 : 1.0, m128 = std::ceil(l1.M / 128.0) * 128.0;
-    ProfScope prof("dense_kernel", s, 2.0 * (double)l1.M * ((double)d * d + (double)(d + l2.k2) * 2.0 * d),
+    ProfScope prof(d == 16 ? "dense_chain_kernel<16>" : "dense_chain_kernel<64>", s, 2.0 * (double)l1.M * ((double)d * d + (double)(d + l2.k2) * 2.0 * d),
                    2.0 * m128 * ((d == 16 ? 32.0 * 16 : 64.0 * 64) + (double)k2p * (d == 16 ? 64.0 : 128.0)) * np);
     const bool t64 = d == 64;          // measured: d = 64 48.6 us on 64-row tiles (three workgroups per CU) against 60.1 on 128-row tiles; d = 16 35.7 against 33.0
     const dim3 grid((unsigned)((l1.M + (t64 ? 63 : 127)) / (t64 ? 64 : 128)));

@@ -744,10 +744,14 @@ int launch_xyz_fill(const DenseArgs& a, hipStream_t s) {
 int launch_dense(const DenseArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SSDR_OK;
     dim3 grid((unsigned)((a.M + DTM - 1) / DTM), (unsigned)((a.N + DTN - 1) / DTN));
-    ProfScope prof("dense_kernel", s, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N, 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
     const bool vec = a.k1 % 4 == 0 && a.k2 % 4 == 0 && a.N % 4 == 0 && ((uintptr_t)a.x1 & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && ((uintptr_t)a.W & 15) == 0;
     // thin layers over many rows: one row per lane (x2 / y rows must be 16-byte aligned, x1 too unless k1 % 4 != 0)
-    if (a.M >= 1024 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && (a.k1 % 4 != 0 || ((uintptr_t)a.x1 & 15) == 0)) {
+    const bool rows_form = a.M >= 1024 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x2 & 15) == 0 && (a.k1 % 4 != 0 || ((uintptr_t)a.x1 & 15) == 0) && a.k2 == 0 && a.N == 8 &&
+                           (a.k1 == 6 || a.k1 == 8 || a.k1 == 16);
+    // (the thin one-row-per-lane layers stream their rows on fp32 FMAs: charged by the bytes they move, 4 (k + N) per row)
+    ProfScope prof(rows_form ? "dense_rows_kernel" : "dense_kernel", s, rows_form ? 4.0 * (double)a.M * (double)(a.k1 + a.N) : 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N,
+                   rows_form ? 0.0 : 2.0 * (double)a.M * (double)(a.k1 + a.k2) * (double)a.N);
+    if (rows_form) {
         const dim3 g((unsigned)((a.M + 255) / 256));
 #define SSDR_ROWS(K1_, K2_, N_) if (a.k1 == K1_ && a.k2 == K2_ && a.N == N_) { hipLaunchKernelGGL((dense_rows_kernel<K1_, K2_, N_>), g, dim3(256), 0, s, a); SSDR_HIP(hipGetLastError()); return SSDR_OK; }
         SSDR_ROWS(6, 0, 8) SSDR_ROWS(8, 0, 8) SSDR_ROWS(16, 0, 8)      // wider outputs: register allocation degrades, the MFMA tile wins
@@ -768,8 +772,7 @@ int launch_dense_rows2(const DenseArgs& a, const DenseArgs& b, hipStream_t s) {
     const bool ok = a.k1 == 6 && a.k2 == 0 && a.N == 8 && b.k1 == 8 && b.k2 == 0 && b.N == 8 && b.x1 == a.y && a.M == b.M && a.M >= 1024 && !a.ldy && !a.xyz && !a.idx2 && !b.idx2 &&
                     (((uintptr_t)a.y | (uintptr_t)b.y) & 15) == 0 && (!b.ldy || b.ldy % 4 == 0);
     if (!ok) return SSDR_ERR_UNSUPPORTED;
-    const double fl = 2.0 * (double)a.M * (6.0 * 8 + 8.0 * 8);
-    ProfScope prof("dense_kernel", s, fl, fl);
+    ProfScope prof("dense_rows_kernel", s, 4.0 * (double)a.M * (6.0 + 8.0 + 8.0), 0.0);      // bytes: 6 inputs, 8 + 8 outputs per row
     hipLaunchKernelGGL((dense_rows2_kernel<6, 8, 8>), dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a, b);
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;

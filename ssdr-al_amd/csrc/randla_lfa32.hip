@@ -617,7 +617,7 @@ static int launch_lfa32_l0(const Lfa32Args& a, bool second, int B, int prec, hip
     const double rows = (double)B * (double)a.n * 16.0, np = terms == 2 ? 3.0 : 1.0;
     // executed: every product is a 32 x 32 x 16 tile for 4 points (LocSE in both orientations, LFAmlp2 in both + its bias product, the two halves of the scores)
     const double exec = (double)B * std::ceil(a.n / 4.0) * 2.0 * 32 * 32 * 16 * (np * (second ? 5.0 : 4.0) + (second ? 1.0 : 0.0));
-    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * 8 + (second ? 2.0 * 8 * 8 : 0.0) + 2.0 * 16 * 16 + 2.0 * 16), exec);
+    ProfScope prof("lfa32_l0_kernel", s, rows * (2.0 * 10 * 8 + (second ? 2.0 * 8 * 8 : 0.0) + 2.0 * 16 * 16 + 2.0 * 16), exec);
     if (terms == 2) {
         if (second) hipLaunchKernelGGL((lfa32_l0_kernel<true, 2>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((lfa32_l0_kernel<false, 2>), grid, dim3(256), 0, s, a);
@@ -639,7 +639,7 @@ template <int D> static int launch_lfa32_d(const Lfa32Args& a, bool second, int 
     // LFAmlp2 in both orientations and the position half of the attention product (one or three bf16 products)
     const double np = terms == 2 ? 3.0 : 1.0;
     const double exec = rows * (2.0 * 2.0 * 16 * C::H * terms + (second ? 2.0 * 2.0 * C::H * C::H * np : 0.0) + 2.0 * C::H * D * np);
-    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
+    ProfScope prof(D == 128 ? "lfa32_kernel<128>" : D == 256 ? "lfa32_kernel<256>" : "lfa32_kernel<512>", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
     if (terms == 2) {
         if (second) hipLaunchKernelGGL((lfa32_kernel<D, true, 2>), grid, dim3(nw * 64), 0, s, a);
         else hipLaunchKernelGGL((lfa32_kernel<D, false, 2>), grid, dim3(nw * 64), 0, s, a);
@@ -668,7 +668,7 @@ template <int D> static int launch_lfa32_res(const Lfa32Args& a, bool second, in
     const double rows = (double)B * (double)a.n * 16.0, np = terms == 2 ? 3.0 : 1.0;
     // executed: LocSE (K padded to 16, both orientations, two instructions for the four products), LFAmlp2 in both orientations, the whole d x d attention product
     const double exec = rows * (2.0 * 2.0 * 16 * C::H * terms + (second ? 2.0 * 2.0 * C::H * C::H * np : 0.0) + 2.0 * D * D * np);
-    ProfScope prof("lfa_att_kernel", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
+    ProfScope prof("lfa32_res_kernel<64>", s, rows * (2.0 * 10 * C::H + (second ? 2.0 * C::H * C::H : 0.0) + 2.0 * D * D + 2.0 * D), exec);
     const dim3 blk(C::NW * 64);
     if (terms == 2) {
         if (second) hipLaunchKernelGGL((lfa32_res_kernel<D, true, 2>), grid, blk, lds, s, a);

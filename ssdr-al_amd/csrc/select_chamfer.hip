@@ -30,6 +30,7 @@
 // SSDR_CHAMFER_F64=1, and for targets too large to stage) writes that distance for the target its float64 key names: the same bits wherever the
 // nearest target is unique, and within the last ulp where two targets are equally near (a lattice); `tests/test_select.py` compares the two on
 // random, duplicated and lattice clouds.
+#include <atomic>
 #include "select_chamfer.hpp"
 #include "block_prims.hpp"
 #include <cfloat>
@@ -411,6 +412,61 @@ __global__ __launch_bounds__(256) SSDR_WAVES_PER_EU(MF ? 4 : 5) void sel_chamfer
     chamfer_dir_body<MF>(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, ta0, ta1, s_val);
 }
 
+// ---- the Semantic3D flavour: float32 CUDA-kernel chamfer values (SSRD_AL_semantic3d/fps_gcn_cuda.py:13-30) --------------------------------------------
+// create_cd_cuda centres a superpoint in NumPy (float32 coordinates minus a float64 bounding-box centre -> float64), rounds the result to float32
+// (torch.Tensor), runs chamfer3D.cu on the pair — squared float32 distances, (dx*dx + dy*dy) + dz*dz — and keeps mean(sqrt(dist1)) + mean(sqrt(dist2))
+// in float32, widened into the float64 matrix.  dir[i][j] = the float32 mean over the points of superpoint i of sqrtf(min_b d2(a, b in j)), stored widened;
+// the adjacency adds the two directions (in float64 here: 2^-24 relative from the reference's float32 addition, below what its own reduction order fixes —
+// torch.mean on CUDA is a tree whose shape is the library's).  One wave per ordered pair (i, j); the target staged in LDS in slabs.
+constexpr int C32_SLAB = 512;
+__device__ void chamfer_dir_f32_body(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts, const int* __restrict__ sel, int n,
+                                     const double* __restrict__ centres, double* __restrict__ dir, float* slab /* [4][C32_SLAB * 3] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* tb = slab + (size_t)w * C32_SLAB * 3;
+    for (long e = (long)blockIdx.x * 4 + w; e < (long)n * n; e += (long)gridDim.x * 4) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        if (i == j) { if (lane == 0) dir[e] = 0.0; continue; }
+        const int loi = sp_off[sel[i]], ni = sp_off[sel[i] + 1] - loi, loj = sp_off[sel[j]], nj = sp_off[sel[j] + 1] - loj;
+        const double cix = centres[3 * (size_t)i], ciy = centres[3 * (size_t)i + 1], ciz = centres[3 * (size_t)i + 2];
+        const double cjx = centres[3 * (size_t)j], cjy = centres[3 * (size_t)j + 1], cjz = centres[3 * (size_t)j + 2];
+        float sum = 0.f;
+        for (int a0 = 0; a0 < ni; a0 += 64) {
+            const int a = a0 + lane;
+            const size_t qa = sp_pts[loi + min(a, ni - 1)];
+            const float ax = (float)((double)xyz[3 * qa] - cix), ay = (float)((double)xyz[3 * qa + 1] - ciy), az = (float)((double)xyz[3 * qa + 2] - ciz);
+            float best = 3.402823466e+38f;
+            for (int s0 = 0; s0 < nj; s0 += C32_SLAB) {
+                const int cnt = min(nj - s0, C32_SLAB);
+                for (int t = lane; t < cnt; t += 64) {
+                    const size_t qb = sp_pts[loj + s0 + t];
+                    tb[3 * t] = (float)((double)xyz[3 * qb] - cjx); tb[3 * t + 1] = (float)((double)xyz[3 * qb + 1] - cjy); tb[3 * t + 2] = (float)((double)xyz[3 * qb + 2] - cjz);
+                }
+                for (int k = 0; k < cnt; ++k) {
+                    const float dx = tb[3 * k] - ax, dy = tb[3 * k + 1] - ay, dz = tb[3 * k + 2] - az;      // chamfer3D.cu: b - a, every product and sum rounded on its own
+                    const float dd = (dx * dx + dy * dy) + dz * dz;
+                    best = (dd < best || (s0 + k == 0)) ? dd : best;
+                }
+            }
+            sum += a < ni ? sqrtf(best) : 0.f;          // a lane's points in ascending order, then the lanes in a fixed tree
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) dir[e] = ni > 0 ? (double)(sum / (float)ni) : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void sel_chamfer_dir_f32(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts, const int* __restrict__ sel, int n,
+                                                           const double* __restrict__ centres, double* __restrict__ dir) {
+    __shared__ float slab[4 * C32_SLAB * 3];
+    chamfer_dir_f32_body(xyz, sp_off, sp_pts, sel, n, centres, dir, slab);
+}
+__global__ __launch_bounds__(256) void sel_chamfer_dir_f32_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts, const int* __restrict__ sel,
+                                                                 const int* __restrict__ coff, const long long* __restrict__ boff, const double* __restrict__ centres, double* __restrict__ dir) {
+    __shared__ float slab[4 * C32_SLAB * 3];
+    const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
+    chamfer_dir_f32_body(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], slab);
+}
+static std::atomic<int> g_chamfer_mode{0};
+
 bool chamfer_f64() { const char* e = getenv("SSDR_CHAMFER_F64"); return e && atoi(e) != 0; }      // read per launch: the tests run both forms in one process
 // slices of the source items per target (blockIdx.y): a workgroup stages its target once and its four waves take items slice * 4 + wave, + 4 * slices, ...
 // (measured for the float64 kernel, tools/gpu_chamfer_slices.sh, the bench's ~35 items per cloud: 16 slices 0.491-0.495 ms, 8: 0.481-0.484, 4: 0.53, 2: 0.62, 1: 0.83)
@@ -423,6 +479,11 @@ int chamfer_slices(int nm) {
 
 int chamfer_dir_launch(const float* d_xyz, const int* d_sp_off, const int* d_sp_pts, const int* d_sel, int n, const double* d_centres, double* d_dir,
                        const ChamferPack& P, hipStream_t s) {
+    if (g_chamfer_mode.load() == 1) {
+        hipLaunchKernelGGL(sel_chamfer_dir_f32, dim3((unsigned)std::min<long>(((long)n * n + 3) / 4, 65535)), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     const dim3 grid(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16)));
     if (chamfer_f64()) hipLaunchKernelGGL(sel_chamfer_dir<false>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir, P);
     else hipLaunchKernelGGL(sel_chamfer_dir<true>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir, P);
@@ -432,6 +493,12 @@ int chamfer_dir_launch(const float* d_xyz, const int* d_sp_off, const int* d_sp_
 
 int chamfer_dir_batch_launch(const float* d_xyz, const int* d_sp_off, const int* d_sp_pts, const int* d_sel, const int* d_coff, const long long* d_boff,
                              int n_max, unsigned nclouds, const double* d_centres, double* d_dir, const ChamferPack& P, hipStream_t s) {
+    if (g_chamfer_mode.load() == 1) {
+        hipLaunchKernelGGL(sel_chamfer_dir_f32_batch, dim3((unsigned)std::min<long>(((long)n_max * n_max + 3) / 4, 16384), 1, nclouds), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel,
+                           d_coff, d_boff, d_centres, d_dir);
+        SSDR_HIP(hipGetLastError());
+        return SSDR_OK;
+    }
     const dim3 grid(std::min(n_max, 1024), chamfer_slices(n_max), nclouds);
     if (chamfer_f64()) hipLaunchKernelGGL(sel_chamfer_dir_batch<false>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, d_boff, d_centres, d_dir, P);
     else hipLaunchKernelGGL(sel_chamfer_dir_batch<true>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, d_boff, d_centres, d_dir, P);
@@ -440,3 +507,13 @@ int chamfer_dir_batch_launch(const float* d_xyz, const int* d_sp_off, const int*
 }
 
 }  // namespace ssdr
+
+/* Arithmetic of the chamfer term of the selection graph (ssdr_cloud_graph[_batch]_dev, ssdr_gcn_fps_sampling_dev and the sharded twins): 0 = float64 (the
+ * S3DIS code: sklearn KDTree distances, fps_gcn_cpu.py:12-38 — the default), 1 = float32 as the Semantic3D code's CUDA kernel computes it
+ * (SSRD_AL_semantic3d/fps_gcn_cuda.py:13-30: centred coordinates rounded to float32, squared float32 distances of chamfer3D.cu, sqrt and means in float32). */
+extern "C" int ssdr_select_set_chamfer_mode(int mode) {
+    if (mode < 0 || mode > 1) { ssdr::set_error("select_set_chamfer_mode: 0 (float64) or 1 (float32, CUDA-kernel flavour)"); return SSDR_ERR_INVALID; }
+    ssdr::g_chamfer_mode.store(mode);
+    return SSDR_OK;
+}
+

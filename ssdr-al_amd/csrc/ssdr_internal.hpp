@@ -224,7 +224,7 @@ struct GridForest {
 // Bins every set (pts / n filled in by the caller).  target_pts: number of points the measured cell radius should hold.
 int grid_build(GridForest& g, const std::vector<GridDesc>& sets, int target_pts, hipStream_t s);
 int grid_set_jobs(GridForest& g, const std::vector<GridJob>& jobs, hipStream_t s);
-int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, bool out_i64, hipStream_t s);
+int grid_search(const GridForest& g, int job0, int njobs, int max_nq, int K, bool out_i64, hipStream_t s, double prof_bytes = 0.0);
 // Answers the rows of a work list (pairs job id, query) by the exact tree walk; tree ids == set ids.  d_fallback (optional): rows whose
 // walk met a closed node of a partly built tree are appended there (and their tree flagged in d_need2) instead of being written.
 int kd_search_worklist(const KdForest& f, const GridJob* d_jobs, const int* d_work, const int* d_count, int work_cap, int K, bool out_i64, hipStream_t s,

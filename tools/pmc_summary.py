@@ -10,9 +10,25 @@ D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p
 def family(name):
     n = re.sub(r"^void ", "", name).replace("ssdr::", "").replace("(anonymous namespace)::", "")
     n = n.split("(")[0]
-    for fam in ("lfa_att_kernel", "lfa_bf16_kernel", "lfa32_", "dense_rows", "dense_small_kernel", "dense_bf16_kernel", "dense_chain_kernel", "dense_kernel", "tail_bf16_kernel", "tail_kernel"):
-        if n.startswith(fam):      # bench.py's ProfScope names
-            return "dense_kernel" if fam.startswith("dense_") else ("lfa_att_kernel" if fam.startswith("lfa") else ("tail_kernel" if fam.startswith("tail") else fam))
+    # bench.py's ProfScope names: one per kernel template since round 6
+    m = re.match(r"lfa32_l0_kernel", n)
+    if m:
+        return "lfa32_l0_kernel"
+    m = re.match(r"lfa32_res_kernel<(\d+)", n)
+    if m:
+        return "lfa32_res_kernel<%s>" % m.group(1)
+    m = re.match(r"lfa32_kernel<(\d+)", n)
+    if m:
+        return "lfa32_kernel<%s>" % m.group(1)
+    m = re.match(r"dense_bf16_kernel<(\d+), ?(\d+)", n)
+    if m:
+        return "dense_bf16_kernel<%s,%s>" % (m.group(1), m.group(2))
+    m = re.match(r"dense_chain_kernel<(\d+)", n)
+    if m:
+        return "dense_chain_kernel<%s>" % m.group(1)
+    for fam in ("lfa_att_kernel", "lfa_bf16_kernel", "dense_rows", "dense_small_kernel", "dense_kernel", "tail_bf16_kernel", "tail_kernel"):
+        if n.startswith(fam):
+            return "dense_rows_kernel" if fam == "dense_rows" else ("dense_kernel" if fam.startswith("dense_") else ("lfa_att_kernel" if fam.startswith("lfa") else "tail_kernel"))
     # the profiler sites of round 5 (bench.py's roofline.others): one family per site
     for pre, fam in (("fe_scatter", "fe_scatter"), ("fe_reduce", "fe_reduce"), ("fe_row", "fe_rows_move"), ("fe_move", "fe_rows_move"), ("fe_", "fe_bbox_count_scan"),
                      ("tile_", "tile_select"), ("sel_chamfer_dir", "sel_chamfer"), ("fps_", "fps_chain"), ("kc_init", "fps_chain"), ("fill_double", "fps_chain"),
