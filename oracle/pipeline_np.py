@@ -64,7 +64,7 @@ def labelled_selection(clouds, labelled, class_num, round_num, random_state):
 
 
 def selection_round(clouds, labelled, selected_class_list, class_num, sampler_args, min_size, round_num, batch_size, gcn_number, gcn_top,
-                    start, random_state, selector="fps", max_size=None, graph_clouds=None):
+                    start, random_state, selector="fps", max_size=None, graph_clouds=None, chamfer="f64"):
     """TSampler.sampling, gcn_fps branch (sampler2.py:736-781), over in-memory clouds instead of files.  clouds[b] = dict(xyz [n,3] f32,
     gt [n] int, probs [n,C] f32, feat [n,32] f32, offsets [S+1], points [T]); labelled[b] = ids of the regions NOT in total_obj["unlabeled"].
 
@@ -139,7 +139,8 @@ def selection_round(clouds, labelled, selected_class_list, class_num, sampler_ar
         spts = np.concatenate([cl["points"][cl["offsets"][refs[i][1]]:cl["offsets"][refs[i][1] + 1]] for i in rows])
         xyz = np.asarray(cl["xyz"], np.float32)
         cen = S.bbox_centres(xyz, so, spts)
-        blocks.append(S.keep_top(S.block_adjacency(cen, S.create_cd(xyz, so, spts, cen)), gcn_top)); rows_l.append(rows)
+        cd = S.create_cd_cuda(xyz, so, spts, cen) if chamfer == "f32_cuda" else S.create_cd(xyz, so, spts, cen)      # (the Semantic3D code's float32 CUDA values, fps_gcn_cuda.py:13-30)
+        blocks.append(S.keep_top(S.block_adjacency(cen, cd), gcn_top)); rows_l.append(rows)
     comb = S.propagate(blocks, rows_l, V, gcn_number)
     if graph_clouds is not None:
         return dict(region=ref, region_class=np.asarray(rclass, np.int32), region_unc_raw=raw, region_unc=np.asarray(ru, np.float64), sorted_inds=sorted_inds,

@@ -111,6 +111,22 @@ def create_cd(xyz, offsets, points, centres):
     return dirm + dirm.T
 
 
+def create_cd_cuda(xyz, offsets, points, centres):
+    """create_cd_cuda (SSRD_AL_semantic3d/fps_gcn_cuda.py:13-30), the Semantic3D flavour: the centred superpoints are rounded to float32 (torch.Tensor),
+    chamfer3D.cu gives squared float32 nearest distances ((dx*dx + dy*dy) + dz*dz, dx = b - a), and cd[i,j] = mean(sqrt(dist1)) + mean(sqrt(dist2)) in
+    float32, widened.  PARITY UNPINNED: the CUDA op cannot run here, and torch.mean's reduction order on CUDA is the library's — compare at 1e-6 relative."""
+    S = len(offsets) - 1
+    al = [(xyz[points[offsets[s]:offsets[s + 1]]].astype(np.float64) - centres[s]).astype(np.float32) for s in range(S)]
+    dirm = np.zeros((S, S), np.float32)
+    for i in range(S):
+        for j in range(S):
+            if i != j and len(al[i]) and len(al[j]):
+                d = al[j][None, :, :] - al[i][:, None, :]
+                dist = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+                dirm[i, j] = np.mean(np.sqrt(dist.min(1)), dtype=np.float32)
+    return (dirm + dirm.T).astype(np.float64)
+
+
 def block_adjacency(centres, cd):
     """One cloud's block of fps_adj_all (fps_gcn_cpu.py:95-115): exp(-(ED+CD)), minus I, column-scaled by the
     inverse row sums, plus I.  Entries across clouds are exactly 0 (exp(-2e10)), so blocks are independent."""

@@ -437,10 +437,12 @@ __device__ void chamfer_dir_f32_body(const float* __restrict__ xyz, const int* _
             float best = 3.402823466e+38f;
             for (int s0 = 0; s0 < nj; s0 += C32_SLAB) {
                 const int cnt = min(nj - s0, C32_SLAB);
+                (void)__ballot(1);          // the wave's lanes are done with the previous slab (a wave runs its LDS operations in order: this orders the CPU logic build's fibers)
                 for (int t = lane; t < cnt; t += 64) {
                     const size_t qb = sp_pts[loj + s0 + t];
                     tb[3 * t] = (float)((double)xyz[3 * qb] - cjx); tb[3 * t + 1] = (float)((double)xyz[3 * qb + 1] - cjy); tb[3 * t + 2] = (float)((double)xyz[3 * qb + 2] - cjz);
                 }
+                (void)__ballot(1);
                 for (int k = 0; k < cnt; ++k) {
                     const float dx = tb[3 * k] - ax, dy = tb[3 * k + 1] - ay, dz = tb[3 * k + 2] - az;      // chamfer3D.cu: b - a, every product and sum rounded on its own
                     const float dd = (dx * dx + dy * dy) + dz * dz;

@@ -18,7 +18,7 @@ from .helper_tool import ConfigS3DIS
 class HotPath:
     def __init__(self, weights, config=ConfigS3DIS, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=1, gcn_top=0,
                  select_per_tile=37, labeled_per_tile=15, seed=0, precision="f32", selector="fps", tiles32=True, min_size=1, round_num=5,
-                 label_seed=None, batch_size=None, max_size=None):
+                 label_seed=None, batch_size=None, max_size=None, chamfer_mode="f64"):
         self.cfg = config
         self.net = None if weights is None else randlanet.Network(config).load(weights).set_precision(precision).set_formulation(tiles32)
         self.sampler_args = list(sampler_args)
@@ -31,6 +31,8 @@ class HotPath:
         # section 8d quotes the workload at round 5); label_seed seeds NumPy's legacy generator for that draw (the reference draws from np.random)
         # max_size: the Semantic3D flavour also drops regions of more than 1000 points from both populations (SSRD_AL_semantic3d/sampler2.py:644, :655)
         self.max_size = None if max_size is None else int(max_size)
+        # chamfer_mode: "f64" (S3DIS, fps_gcn_cpu.create_cd) or "f32_cuda" (the Semantic3D code's create_cd_cuda values, fps_gcn_cuda.py:13-30)
+        self.chamfer_mode = {"f64": 0, "f32_cuda": 1}[chamfer_mode]
         self.min_size, self.round_num = int(min_size), int(round_num)
         self.label_seed = int(seed if label_seed is None else label_seed)
         # "fps": farthest_features_sample over the candidates' propagated features (the gcn_fps branch, sampler2.py:736-781);
@@ -413,6 +415,7 @@ class HotPath:
         """everything of the selection up to the enqueued FPS chain (the host decisions and uploads happen here)"""
         L = _lib.lib()
         st = self.sel_stream          # None: the library stream; a stream of its own lets the selections of consecutive batches overlap
+        _lib.check(L.ssdr_select_set_chamfer_mode(self.chamfer_mode))
         T = self._sel_static
         kc = self.selector == "kcenter"
         if (self.global_order is None and T["picks"] > 0 and (not kc or T["n_lab"] > 0)

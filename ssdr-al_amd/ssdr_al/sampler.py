@@ -129,6 +129,12 @@ def segment_mean_features(last_second_features, pixel_class, dom, offsets, point
     return d_out.to_host()
 
 
+def set_chamfer_mode(mode):
+    """arithmetic of the graph's chamfer term, process-wide: "f64" (S3DIS: fps_gcn_cpu.create_cd, the default) or "f32_cuda" (the Semantic3D code's
+    create_cd_cuda: float32 CUDA-kernel values, SSRD_AL_semantic3d/fps_gcn_cuda.py:13-30)"""
+    _lib.check(_lib.lib().ssdr_select_set_chamfer_mode({"f64": 0, "f32_cuda": 1}[mode]))
+
+
 def cloud_graph(xyz, offsets, points, sel, gcn_top=0):
     """One cloud's block of fps_adj_all (fps_gcn_cpu.py:40-117): returns (centres [n,3], cd [n,n], adj [n,n])."""
     xyz = np.ascontiguousarray(xyz, np.float32); sel = np.ascontiguousarray(sel, np.int32)

@@ -182,6 +182,31 @@ def test_semantic3d_population_filter(golden, backend):
     assert np.array_equal(sel, r["seq"])
 
 
+def test_semantic3d_chamfer_flavour_in_the_round(golden, backend):
+    """the Semantic3D code builds the graph from float32 CUDA-kernel chamfer values (SSRD_AL_semantic3d/fps_gcn_cuda.py:13-30): HotPath(chamfer_mode="f32_cuda")
+    through the one-call device chain == the oracle round with the float32 restatement (parity unpinned for the CUDA op), candidates and picks alike"""
+    from oracle import pipeline_np as P
+    from ssdr_al import pipeline, sampler
+    from ssdr_al.helper_tool import ConfigS3DIS
+    g = golden("composition_golden.npz")
+    clouds, labelled, p = _case_a(g)
+    r = P.selection_round(clouds, labelled, g["a/selected_class_list"], p["C"], ["sb", "WetSU", "clsbal", "gcn_fps"], p["min_size"], p["round_num"],
+                          p["batch_size"], p["gcn_number"], p["gcn_top"], 0, np.random.RandomState(7), chamfer="f32_cuda")
+
+    class Cfg(ConfigS3DIS):
+        num_classes = p["C"]
+    hp = pipeline.HotPath.from_clouds(clouds, labelled, g["a/selected_class_list"], Cfg, sampler_args=("sb", "WetSU", "clsbal", "gcn_fps"), gcn_number=p["gcn_number"],
+                                      gcn_top=p["gcn_top"], min_size=p["min_size"], round_num=p["round_num"], label_seed=7, batch_size=p["batch_size"], chamfer_mode="f32_cuda")
+    try:
+        sel, unl = hp.step_selection()
+    finally:
+        sampler.set_chamfer_mode("f64")
+    base = np.asarray(hp.sp_base)
+    assert hp.rule_path == "device"
+    assert [(b, s - int(base[b])) for b, s in unl] == r["unl"]
+    assert np.array_equal(sel, r["seq"])
+
+
 def test_round_without_labelled_regions(golden, backend):
     """round 1 of the loop's shape: nothing labelled yet in the clouds at hand (no labelled rows, no draw): product == oracle, FPS and k-center refused
     (kCenterGreedy needs its seeds: the reference's gcn branch is not run before labelled regions exist)"""

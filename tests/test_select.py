@@ -172,6 +172,34 @@ def test_chamfer_matrix_screening_at_other_scales(backend, scale, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_chamfer_f32_cuda_flavour(backend):
+    """Semantic3D's create_cd_cuda (SSRD_AL_semantic3d/fps_gcn_cuda.py:13-30): float32 CUDA-kernel chamfer values in the graph — ssdr_select_set_chamfer_mode(1)
+    against the NumPy float32 restatement (parity unpinned: the CUDA op cannot run here; 1e-6 relative = the freedom of a float32 mean's order), and the
+    adjacency built from them; the float64 default is a different matrix (1e-7 .. 1e-6 apart) and comes back with mode 0"""
+    from oracle import select_np as S
+    from ssdr_al import sampler
+    rng = np.random.default_rng(23)
+    sizes = np.array([1, 3, 17, 64, 65, 130, 300, 700, 40, 2, 90, 513])      # below / above a wave, above the staging slab
+    n = int(sizes.sum())
+    cen = rng.random((len(sizes), 3)) * 5.0
+    xyz = (np.repeat(cen, sizes, axis=0) + rng.normal(0, 0.2, (n, 3))).astype(np.float32)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32); points = rng.permutation(n).astype(np.int32)
+    xyz_s = np.empty_like(xyz); xyz_s[points] = xyz            # region s holds the points points[offsets[s]:offsets[s+1]]
+    sel = np.arange(len(sizes), dtype=np.int32)
+    c64, cd64, _ = sampler.cloud_graph(xyz_s, offsets, points, sel)
+    sampler.set_chamfer_mode("f32_cuda")
+    try:
+        c, cd, adj = sampler.cloud_graph(xyz_s, offsets, points, sel)
+    finally:
+        sampler.set_chamfer_mode("f64")
+    exp = S.create_cd_cuda(xyz_s, offsets, points, S.bbox_centres(xyz_s, offsets, points))
+    assert np.array_equal(c, c64)
+    assert np.allclose(cd, exp, rtol=2e-6, atol=0) and np.array_equal(np.diag(cd), np.zeros(len(sizes)))
+    assert np.allclose(adj, S.block_adjacency(c, exp), rtol=1e-5, atol=1e-12)
+    assert not np.array_equal(cd, cd64) and np.allclose(cd, cd64, rtol=1e-5)
+    assert np.array_equal(sampler.cloud_graph(xyz_s, offsets, points, sel)[1], cd64)
+
+
 def test_chamfer_more_superpoints_than_the_packer_lays_out():
     """4300 superpoints in one cloud (> PACK_MAX = 4096): the packer hands every superpoint to the pair-by-pair path.  The summation
     rule depends on a superpoint's size alone, so any sub-block must equal the packed computation over just those superpoints, bit for bit."""
