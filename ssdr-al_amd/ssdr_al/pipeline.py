@@ -662,14 +662,18 @@ class ALRound:
         self.cfg, self.nb, self.B, self.rooms = config, int(n_batches), len(rooms), rooms
         N = config.num_points
         self.tiles = self.nb * self.B
+        # five streams: front end and pyramid alternate between two streams each by the parity of the batch, so that a cross-stream wait ("everything
+        # the producer holds so far", ssdr_stream_wait) names exactly the batch it is meant for — with one stream per stage one of the three waits of a
+        # step always caught the neighbouring batch as well, and the stages overlapped two deep instead of three
         self.streams = []
-        for _ in range(3):
+        for _ in range(5):
             st = C.c_void_p(); _lib.check(L.ssdr_stream_create(C.byref(st))); self.streams.append(st.value)
-        s_f, s_k, s_i = self.streams
+        self.s_front, self.s_knn, self.s_inf = self.streams[0:2], self.streams[2:4], self.streams[4]
+        s_i = self.s_inf
         self.work = []
         for w in range(self.SLOTS):
             h = HotPath(weights, config, precision=precision, tiles32=tiles32, seed=seed, select_per_tile=1, labeled_per_tile=1)
-            h.front_stream, h.knn_stream, h.stream, h.pipelined = s_f, s_k, s_i, True
+            h.front_stream, h.knn_stream, h.stream, h.pipelined = self.s_front[0], self.s_knn[0], s_i, True
             h.load_rooms(rooms, list(range(self.B)))
             self.work.append(h)
         P = self.tiles * N
@@ -687,8 +691,9 @@ class ALRound:
         # setup (untimed): every batch's tiles once, their superpoints (stand-in for the partition, as HotPath.load_rooms), the labelled stand-in
         for b in range(self.nb):
             self._bind(b)._front_end()
-        _lib.sync(s_f)
-        _lib.check(L.ssdr_grid_subsample_status(s_f, None))
+        for st in self.s_front:
+            _lib.sync(st)
+            _lib.check(L.ssdr_grid_subsample_status(st, None))
         from .synthetic import superpoints_from_tile
         tiles = self.xyz.to_host().reshape(self.tiles, N, 3)
         offs, pts, cloud, labeled = [np.zeros(1, np.int64)], [], [], {}
@@ -707,28 +712,28 @@ class ALRound:
         self.tile_points = P
 
     def _bind(self, b):
-        """worker of batch b with the batch's randomness and output slices"""
+        """worker of batch b with the batch's randomness, output slices and streams"""
         h, d = self.work[b % self.SLOTS], self.batches[b]
         h.centers, h.perm, h.dup = d["centers"], d["perm"], d["dup"]
         h.xyz, h.tile_l, h.probs, h.f32 = d["xyz"], d["tile_l"], d["probs"], d["f32"]
+        h.front_stream, h.knn_stream = self.s_front[b & 1], self.s_knn[b & 1]
         return h
 
     def infer_all(self):
-        """front end | KNN pyramid | inference of every batch, enqueued: batch k's inference runs beside batch k + 1's front end and pyramid"""
+        """front end | KNN pyramid | inference of every batch, enqueued: batch k's front end runs beside batch k - 1's pyramid and batch k - 2's inference"""
         L = _lib.lib()
-        s_f, s_k, s_i = self.streams
+        s_i = self.s_inf
         for k in range(self.nb + 2):
+            if k < self.nb:
+                # batch k reuses the buffer set of batch k - 3, whose inference is the newest the inference stream holds at this point
+                _lib.check(L.ssdr_stream_wait(self.s_front[k & 1], s_i))
+                self._bind(k)._front_end()
             if 0 <= k - 2 < self.nb:
-                _lib.check(L.ssdr_stream_wait(s_i, s_k))          # (the pyramid stream holds batch k - 2's pyramid and nothing later)
+                _lib.check(L.ssdr_stream_wait(s_i, self.s_knn[k & 1]))            # (that pyramid stream's newest work is batch k - 2's)
                 self._bind(k - 2)._infer()
             if 0 <= k - 1 < self.nb:
-                _lib.check(L.ssdr_stream_wait(s_k, s_f))          # (the front stream holds batch k - 1's tiles and nothing later: the wait below comes after this one)
+                _lib.check(L.ssdr_stream_wait(self.s_knn[(k - 1) & 1], self.s_front[(k - 1) & 1]))      # (batch k - 1's tiles: batch k's went to the other front stream)
                 self._bind(k - 1)._pyramid()
-            if k < self.nb:
-                # batch k reuses the buffer set of batch k - 3: its inference has finished once batch k - 2's has (one stream).  Waiting for k - 2 rather than
-                # k - 3 costs nothing: batch k - 1's inference runs beside this front end and pyramid either way
-                _lib.check(L.ssdr_stream_wait(s_f, s_i))
-                self._bind(k)._front_end()
 
     def run(self):
         """the whole round; returns (picked candidate indices, candidate list) as HotPath.step does"""
@@ -737,8 +742,10 @@ class ALRound:
         self.sel._select_issue(None)
         out = self.sel._select_collect()
         from . import knn as _knn
-        _knn.knn_status(self.streams[1])
-        _lib.check(_lib.lib().ssdr_grid_subsample_status(self.streams[0], None))
+        for st in self.s_knn:
+            _knn.knn_status(st)
+        for st in self.s_front:
+            _lib.check(_lib.lib().ssdr_grid_subsample_status(st, None))
         return out
 
 

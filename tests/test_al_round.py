@@ -98,3 +98,46 @@ def test_fps_20000_rows_10000_picks(backend):
     f = np.random.default_rng(1).normal(size=(20000, 32))
     got = sampler.farthest_features_sample(f, 10000, 0)
     assert np.array_equal(got, S.farthest_features_sample(f, 10000, 0))
+
+
+def test_al_round_plumbing_equals_per_batch_runs(backend):
+    """pipeline.ALRound (batches overlapped on streams, tiles / labels / network outputs written into slices of the round's arrays, ONE selection over all
+    clouds): every batch's tiles and network outputs == a HotPath of its own over the same rooms and room ids, and the round's selection == the
+    selection half run over host copies of the round's arrays (HotPath.from_clouds)"""
+    from oracle import randla_np as R
+    from ssdr_al import pipeline, synthetic
+    from ssdr_al.helper_tool import ConfigS3DIS
+    emu = backend == "emu"
+
+    class Cfg(ConfigS3DIS):
+        num_points = 1024 if emu else 40960
+    W = R.init_weights(0)
+    rooms = [synthetic.make_room(8100 + i, density=70.0 if emu else 2500.0) for i in range(2)]
+    nb = 4
+    ar = pipeline.ALRound(W, rooms, nb, Cfg, batch_size=24, round_num=2, labeled_per_tile=3, precision="f32")
+    sel, unl = ar.run()
+    sel2, unl2 = ar.run()
+    assert np.array_equal(sel, sel2) and unl == unl2 and len(sel) == 24
+    N, B = Cfg.num_points, len(rooms)
+    xyz, probs, f32, lab = ar.xyz.to_host(), ar.probs.to_host(), ar.f32.to_host(), ar.tile_l.to_host()
+    for b in (0, nb - 1):
+        hp = pipeline.HotPath(W, Cfg, precision="f32").load_rooms(rooms, [b * B + i for i in range(B)])
+        hp._front_end(); hp._pyramid(); hp._infer()
+        from ssdr_al import _lib
+        _lib.sync()
+        lo, hi = b * B * N, (b + 1) * B * N
+        assert np.array_equal(hp.xyz.to_host().reshape(-1, 3), xyz[lo:hi]) and np.array_equal(hp.tile_l.to_host(), lab[lo:hi])
+        assert np.array_equal(hp.probs.to_host(), probs[lo:hi]) and np.array_equal(hp.f32.to_host(), f32[lo:hi])
+    # the selection half over host copies of the same arrays
+    S = ar.sel
+    T = nb * B
+    clouds, labelled = [], []
+    for t in range(T):
+        s0, s1 = S.sp_base[t], (S.sp_base[t + 1] if t + 1 < T else S.S)
+        off = S.sp_off_h[s0:s1 + 1].astype(np.int64)
+        clouds.append(dict(xyz=xyz[t * N:(t + 1) * N], gt=lab[t * N:(t + 1) * N], probs=probs[t * N:(t + 1) * N], feat=f32[t * N:(t + 1) * N],
+                           offsets=off - off[0], points=S.sp_pts_h[off[0]:off[-1]].astype(np.int64) - t * N))
+        labelled.append(set(int(x) - s0 for x in S.labeled[t]))
+    ref = pipeline.HotPath.from_clouds(clouds, labelled, S.selected_class_list.to_host(), Cfg, batch_size=24, round_num=2)
+    rsel, runl = ref.step_selection()
+    assert runl == unl and np.array_equal(rsel, sel)
