@@ -411,7 +411,7 @@ def main():
         t_al = []
         for _ in range(2):
             ta = time.perf_counter(); ar.infer_all()
-            for st_ in ar.streams:
+            for st_ in ar.streams + ar.bstreams:
                 _lib.sync(st_)
             tb = time.perf_counter(); ar.sel._score_async(None); ar.sel._select_issue(None); sel_al, unl_al = ar.sel._select_collect(); tc = time.perf_counter()
             t_al.append((tc - ta, tb - ta, tc - tb))

@@ -51,6 +51,11 @@ int  ssdr_stream_create_priority(void** out_stream, int priority);
 int  ssdr_stream_destroy(void* stream);
 int  ssdr_main_stream(void** out_stream);            /* the library's own stream (what stream == NULL means) */
 int  ssdr_stream_wait(void* waiter, void* waited);   /* waiter continues after what is enqueued on waited so far */
+/* events: ssdr_event_record marks a point in a stream's work; ssdr_stream_wait_event makes a stream wait for that point (issued any time later) */
+int  ssdr_event_create(void** ev);
+int  ssdr_event_record(void* ev, void* stream);
+int  ssdr_stream_wait_event(void* stream, void* ev);
+int  ssdr_event_destroy(void* ev);
 /* Optional per-launch timing (HIP events on the launch stream) of the instrumented kernels; used by bench.py for
  * the roofline line.  ssdr_prof_report() synchronises and returns "name calls total_ms total_work total_work2\n" lines, where
  * total_work is the summed algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels) of those launches and total_work2 the FLOPs

@@ -182,6 +182,33 @@ int ssdr_stream_wait(void* waiter, void* waited) {
     SSDR_HIP(hipEventDestroy(e));
     return SSDR_OK;
 }
+/* Events: a point in a stream's work that other streams can wait for later (ssdr_stream_wait names "everything so far" at the moment of the call;
+ * an event names it at the moment of its record, and the wait may be issued any time afterwards — what a caller with several batches in flight needs to
+ * express "this buffer set's last reader", pipeline.ALRound). */
+int ssdr_event_create(void** ev) {
+    if (!ev) { ssdr::set_error("event_create: NULL"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ssdr::ensure_init());
+    hipEvent_t e = nullptr;
+    SSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = e;
+    return SSDR_OK;
+}
+int ssdr_event_record(void* ev, void* stream) {
+    if (!ev) { ssdr::set_error("event_record: NULL"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ssdr::ensure_init());
+    SSDR_HIP(hipEventRecord(static_cast<hipEvent_t>(ev), ssdr::pick_stream(stream)));
+    return SSDR_OK;
+}
+int ssdr_stream_wait_event(void* stream, void* ev) {
+    if (!ev) { ssdr::set_error("stream_wait_event: NULL"); return SSDR_ERR_INVALID; }
+    SSDR_TRY(ssdr::ensure_init());
+    SSDR_HIP(hipStreamWaitEvent(ssdr::pick_stream(stream), static_cast<hipEvent_t>(ev), 0));
+    return SSDR_OK;
+}
+int ssdr_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
+    return SSDR_OK;
+}
 int ssdr_dev_alloc(size_t bytes, void** d_ptr) {
     if (!d_ptr) { ssdr::set_error("dev_alloc: NULL"); return SSDR_ERR_INVALID; }
     SSDR_TRY(ssdr::ensure_init());

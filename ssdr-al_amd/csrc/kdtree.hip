@@ -842,16 +842,15 @@ int kd_build(KdForest& f, const std::vector<KdTreeDesc>& trees_in, hipStream_t s
     SSDR_TRY(f.queue.reserve(16 * (size_t)f.queue_cap));
     SSDR_TRY(f.counters.reserve(4 * CTR_TOTAL));
     if (f.ntrees == 0) return SSDR_OK;
-    // descriptors travel through a pinned staging buffer; the event guards its reuse by the next build
-    if (f.staging_cap < trees.size()) {
-        if (f.staging) (void)hipHostFree(f.staging);
-        f.staging_cap = trees.size() * 2;
-        SSDR_HIP(hipHostMalloc(&f.staging, sizeof(KdTreeDesc) * f.staging_cap));
+    // descriptors travel through a ring of pinned staging buffers (ssdr_internal.hpp: StagingRing)
+    {
+        KdTreeDesc* st = nullptr;
+        const int slot = f.staging.acquire(trees.size(), &st);
+        if (slot < 0) { set_error("kd_build: pinned staging buffer"); return SSDR_ERR_HIP; }
+        memcpy(st, trees.data(), sizeof(KdTreeDesc) * trees.size());
+        SSDR_HIP(hipMemcpyAsync(f.desc.p, st, sizeof(KdTreeDesc) * trees.size(), hipMemcpyHostToDevice, s));
+        if (f.staging.release(slot, s)) { set_error("kd_build: staging event"); return SSDR_ERR_HIP; }
     }
-    if (!f.staging_ev) SSDR_HIP(hipEventCreate(&f.staging_ev)); else SSDR_HIP(hipEventSynchronize(f.staging_ev));
-    memcpy(f.staging, trees.data(), sizeof(KdTreeDesc) * trees.size());
-    SSDR_HIP(hipMemcpyAsync(f.desc.p, f.staging, sizeof(KdTreeDesc) * trees.size(), hipMemcpyHostToDevice, s));
-    SSDR_HIP(hipEventRecord(f.staging_ev, s));
     SSDR_HIP(hipMemsetAsync(f.counters.p, 0, 4 * CTR_TOTAL, s));
     ForestPtrs p = ptrs(f); p.need = d_need;
     if (balls) p.balls = *balls;

@@ -556,16 +556,15 @@ int grid_build(GridForest& g, const std::vector<GridDesc>& sets_in, int target_p
     SSDR_TRY(g.bsum.reserve(4 * (size_t)g.nsets * g.max_blk));
     SSDR_TRY(g.need.reserve(4 * (2 * (size_t)g.nsets + 16)));
     SSDR_TRY(g.balls.reserve((size_t)GRID_BALL_CAP * 20));
-    // descriptors travel through a pinned staging buffer; the event guards its reuse by the next build
-    if (g.staging_cap < sets.size()) {
-        if (g.staging) (void)hipHostFree(g.staging);
-        g.staging_cap = sets.size() * 2;
-        SSDR_HIP(hipHostMalloc(&g.staging, sizeof(GridDesc) * g.staging_cap));
+    // descriptors travel through a ring of pinned staging buffers (ssdr_internal.hpp: StagingRing)
+    {
+        GridDesc* st = nullptr;
+        const int slot = g.staging.acquire(sets.size(), &st);
+        if (slot < 0) { set_error("grid_build: pinned staging buffer"); return SSDR_ERR_HIP; }
+        memcpy(st, sets.data(), sizeof(GridDesc) * sets.size());
+        SSDR_HIP(hipMemcpyAsync(g.desc.p, st, sizeof(GridDesc) * sets.size(), hipMemcpyHostToDevice, s));
+        if (g.staging.release(slot, s)) { set_error("grid_build: staging event"); return SSDR_ERR_HIP; }
     }
-    if (!g.staging_ev) SSDR_HIP(hipEventCreate(&g.staging_ev)); else SSDR_HIP(hipEventSynchronize(g.staging_ev));
-    memcpy(g.staging, sets.data(), sizeof(GridDesc) * sets.size());
-    SSDR_HIP(hipMemcpyAsync(g.desc.p, g.staging, sizeof(GridDesc) * sets.size(), hipMemcpyHostToDevice, s));
-    SSDR_HIP(hipEventRecord(g.staging_ev, s));
     SSDR_HIP(hipMemsetAsync(g.need.p, 0, 4 * (2 * (size_t)g.nsets + 16), s));      // need[nsets], counters()[16], need2[nsets]
     GridDesc* dd = g.desc.as<GridDesc>();
     const dim3 gp((unsigned)((maxn + 255) / 256), (unsigned)g.nsets), gb((unsigned)g.max_blk, (unsigned)g.nsets);
@@ -618,15 +617,14 @@ int grid_set_jobs(GridForest& g, const std::vector<GridJob>& jobs, hipStream_t s
     g.work_cap = (int)std::min(std::max(tq, 1024L), 0x3fffffffL);      // per list: every query of every job can go to the tree
     SSDR_TRY(g.work.reserve(4 * 8 * (size_t)g.work_cap));      // hand-over lists (K = 16, K = 1) and retry lists
     SSDR_TRY(g.jobs.reserve(sizeof(GridJob) * jobs.size()));
-    if (g.jstaging_cap < jobs.size()) {
-        if (g.jstaging) (void)hipHostFree(g.jstaging);
-        g.jstaging_cap = jobs.size() * 2;
-        SSDR_HIP(hipHostMalloc(&g.jstaging, sizeof(GridJob) * g.jstaging_cap));
+    {
+        GridJob* st = nullptr;
+        const int slot = g.jstaging.acquire(jobs.size(), &st);
+        if (slot < 0) { set_error("grid_set_jobs: pinned staging buffer"); return SSDR_ERR_HIP; }
+        memcpy(st, jobs.data(), sizeof(GridJob) * jobs.size());
+        SSDR_HIP(hipMemcpyAsync(g.jobs.p, st, sizeof(GridJob) * jobs.size(), hipMemcpyHostToDevice, s));
+        if (g.jstaging.release(slot, s)) { set_error("grid_set_jobs: staging event"); return SSDR_ERR_HIP; }
     }
-    if (!g.jstaging_ev) SSDR_HIP(hipEventCreate(&g.jstaging_ev)); else SSDR_HIP(hipEventSynchronize(g.jstaging_ev));
-    memcpy(g.jstaging, jobs.data(), sizeof(GridJob) * jobs.size());
-    SSDR_HIP(hipMemcpyAsync(g.jobs.p, g.jstaging, sizeof(GridJob) * jobs.size(), hipMemcpyHostToDevice, s));
-    SSDR_HIP(hipEventRecord(g.jstaging_ev, s));
     return SSDR_OK;
 }
 

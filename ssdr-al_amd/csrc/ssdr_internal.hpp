@@ -125,6 +125,30 @@ struct RadixSorter {
 };
 
 // ---- kd-tree forest (kdtree.hip) ----------------------------------------------------------------
+// Descriptor tables travel to the device through pinned staging buffers.  A RING of them (an event per slot guards its reuse): with ONE buffer the host
+// waited, at every call, for the previous call's copy to have executed on the stream — i.e. for the stream to have come that far — and a caller that keeps
+// several stages in flight (pipeline.ALRound: 43 of 48 ms of host time inside the pyramid's enqueue) was throttled to the GPU's progress on that stream.
+template <class T> struct StagingRing {
+    static constexpr int SLOTS = 4;
+    T* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr}; size_t cap[SLOTS] = {0, 0, 0, 0}; hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr}; int next = 0;
+    // the slot to fill for `n` entries (waits only if the copy of SLOTS calls ago has not executed yet)
+    int acquire(size_t n, T** out) {
+        const int i = next; next = (next + 1) % SLOTS;
+        if (cap[i] < n) {
+            if (ev[i]) { if (hipEventSynchronize(ev[i]) != hipSuccess) return -1; }
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            cap[i] = n * 2;
+            if (hipHostMalloc(reinterpret_cast<void**>(&buf[i]), sizeof(T) * cap[i]) != hipSuccess) { buf[i] = nullptr; cap[i] = 0; return -1; }
+        }
+        if (!ev[i]) { if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return -1; }
+        else if (hipEventSynchronize(ev[i]) != hipSuccess) return -1;
+        *out = buf[i];
+        return i;
+    }
+    int release(int i, hipStream_t s) { return hipEventRecord(ev[i], s) == hipSuccess ? 0 : -1; }
+    ~StagingRing() { for (int i = 0; i < SLOTS; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); } }
+};
+
 struct KdTreeDesc {      // one independent support set
     const float* pts;    // device pointer, n x 3 row-major
     int n;
@@ -135,7 +159,7 @@ struct KdTreeDesc {      // one independent support set
 
 struct KdForest {
     DevBuf desc, sorted, node_a, node_box, node_tree, queue, counters, tmp;     // node_a: 32-byte records {int4 range+children; float4 divlow, divhigh, dim, -}
-    KdTreeDesc* staging = nullptr; size_t staging_cap = 0; hipEvent_t staging_ev = nullptr;
+    StagingRing<KdTreeDesc> staging;
     int ntrees = 0;
     int total_pts = 0;
     int node_cap = 0;
@@ -144,7 +168,7 @@ struct KdForest {
     KdForest() = default;
     KdForest(const KdForest&) = delete;
     KdForest& operator=(const KdForest&) = delete;
-    ~KdForest() { if (staging) (void)hipHostFree(staging); if (staging_ev) (void)hipEventDestroy(staging_ev); }
+
 };
 
 // Queries that will walk the forest, known before it is built: (x, y, z, r^2) and the tree each belongs to.  A build that is given
@@ -199,8 +223,7 @@ struct GridJob {         // one search: queries of one batch element against one
 constexpr int GRID_BALL_CAP = 2048;
 struct GridForest {
     DevBuf desc, cell, rank, sorted, bsum, work, need, jobs, balls;
-    GridDesc* staging = nullptr; size_t staging_cap = 0; hipEvent_t staging_ev = nullptr;
-    GridJob* jstaging = nullptr; size_t jstaging_cap = 0; hipEvent_t jstaging_ev = nullptr;
+    StagingRing<GridDesc> staging; StagingRing<GridJob> jstaging;
     int nsets = 0, total_pts = 0, max_n = 0, max_blk = 0, work_cap = 0;
     // device ints behind the per-set `need` flags: [0], [1] hand-over list lengths (K = 16, K = 1), [2] status, [3] unsettled rows,
     // [4], [5] retry list lengths, [6] balls, [8], [9] rows the partly built trees could not answer (fall-back lists);
@@ -215,10 +238,6 @@ struct GridForest {
     GridForest(const GridForest&) = delete;
     GridForest& operator=(const GridForest&) = delete;
     ~GridForest() {
-        if (staging) (void)hipHostFree(staging);
-        if (staging_ev) (void)hipEventDestroy(staging_ev);
-        if (jstaging) (void)hipHostFree(jstaging);
-        if (jstaging_ev) (void)hipEventDestroy(jstaging_ev);
     }
 };
 // Bins every set (pts / n filled in by the caller).  target_pts: number of points the measured cell radius should hold.

@@ -98,6 +98,7 @@ def lib():
         L.ssdr_gcn_fps_sampling_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, sz, vp, vp, sz, sz, i32, i32, i32, i32, sz, sz, sz, sz, sz, vp, vp]
         L.ssdr_fps_superpoint_dev.argtypes = [vp, vp, sz, i32, sz, vp, vp]
         L.ssdr_gcn_fps_sharded_local_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp, sz, vp, vp, i32, i32, sz, sz, sz, i32, i32, sz, sz, sz, sz, sz, vp, vp, vp]
+        L.ssdr_event_create.argtypes = [C.POINTER(vp)]; L.ssdr_event_record.argtypes = [vp, vp]; L.ssdr_stream_wait_event.argtypes = [vp, vp]; L.ssdr_event_destroy.argtypes = [vp]
         L.ssdr_select_set_chamfer_mode.argtypes = [i32]
         L.ssdr_gcn_fps_sampling_rows.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
         L.ssdr_kcenter_gathered_dev.argtypes = [vp, vp, i32, sz, sz, vp, sz, sz, sz, vp, vp, vp, vp]

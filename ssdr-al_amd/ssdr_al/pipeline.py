@@ -654,7 +654,7 @@ class ALRound:
     buffer sets, batches overlapped), their tiles / labels / probabilities / features land in the round's arrays, then scoring over all points and
     the one-call device chain (ssdr_gcn_fps_sampling_dev) over all clouds' regions.  Tiles of batch b are cut from the same raw rooms with the
     randomness of room id b * len(rooms) + i (another pick point, shuffle and padding draw: another tile)."""
-    SLOTS = 3
+    SLOTS = 4          # batches in flight = HIP streams = the runtime's hardware queues (2: 54.9 ms for 17 batches, 3: 52.2, 4: 49.1, 5: 56.9, 6: 49.4, 8: 49.6; a stream per STAGE: 60-64)
 
     def __init__(self, weights, rooms, n_batches, config=ConfigS3DIS, batch_size=10000, round_num=5, labeled_per_tile=15, precision="f32",
                  selector="fps", tiles32=True, seed=0, gcn_number=1, gcn_top=0, min_size=1):
@@ -665,15 +665,26 @@ class ALRound:
         # five streams: front end and pyramid alternate between two streams each by the parity of the batch, so that a cross-stream wait ("everything
         # the producer holds so far", ssdr_stream_wait) names exactly the batch it is meant for — with one stream per stage one of the three waits of a
         # step always caught the neighbouring batch as well, and the stages overlapped two deep instead of three
+        # One stream per stage.  A consumer stage waits for "everything its producer stream holds so far" (ssdr_stream_wait), which names exactly its own
+        # batch because a step enqueues consumer first (inference k - 2, pyramid k - 1, front end k); the front end's wait for the LAST READER of the buffer
+        # set it reuses (inference k - SLOTS) is an event recorded behind that inference (ssdr_event_*): with three buffer sets and a stream-wide wait the
+        # front end ran at most two batches ahead and the 17 batches took 60 ms; five sets and the event: the stages run as far ahead as their inputs allow.
         self.streams = []
-        for _ in range(5):
+        for _ in range(3):
             st = C.c_void_p(); _lib.check(L.ssdr_stream_create(C.byref(st))); self.streams.append(st.value)
-        self.s_front, self.s_knn, self.s_inf = self.streams[0:2], self.streams[2:4], self.streams[4]
+        self.s_front, self.s_knn, self.s_inf = self.streams
+        self.SLOTS = int(os.environ.get("SSDR_AL_SLOTS", self.SLOTS))
+        self.bstreams = []
+        for _ in range(self.SLOTS):
+            st = C.c_void_p(); _lib.check(L.ssdr_stream_create(C.byref(st))); self.bstreams.append(st.value)
+        self.ev_inf = []
+        for _ in range(self.nb):
+            e = C.c_void_p(); _lib.check(L.ssdr_event_create(C.byref(e))); self.ev_inf.append(e.value)
         s_i = self.s_inf
         self.work = []
         for w in range(self.SLOTS):
             h = HotPath(weights, config, precision=precision, tiles32=tiles32, seed=seed, select_per_tile=1, labeled_per_tile=1)
-            h.front_stream, h.knn_stream, h.stream, h.pipelined = self.s_front[0], self.s_knn[0], s_i, True
+            h.front_stream, h.knn_stream, h.stream, h.pipelined = self.s_front, self.s_knn, s_i, True
             h.load_rooms(rooms, list(range(self.B)))
             self.work.append(h)
         P = self.tiles * N
@@ -691,9 +702,8 @@ class ALRound:
         # setup (untimed): every batch's tiles once, their superpoints (stand-in for the partition, as HotPath.load_rooms), the labelled stand-in
         for b in range(self.nb):
             self._bind(b)._front_end()
-        for st in self.s_front:
-            _lib.sync(st)
-            _lib.check(L.ssdr_grid_subsample_status(st, None))
+        _lib.sync(self.s_front)
+        _lib.check(L.ssdr_grid_subsample_status(self.s_front, None))
         from .synthetic import superpoints_from_tile
         tiles = self.xyz.to_host().reshape(self.tiles, N, 3)
         offs, pts, cloud, labeled = [np.zeros(1, np.int64)], [], [], {}
@@ -712,28 +722,47 @@ class ALRound:
         self.tile_points = P
 
     def _bind(self, b):
-        """worker of batch b with the batch's randomness, output slices and streams"""
+        """worker of batch b with the batch's randomness and output slices"""
         h, d = self.work[b % self.SLOTS], self.batches[b]
         h.centers, h.perm, h.dup = d["centers"], d["perm"], d["dup"]
         h.xyz, h.tile_l, h.probs, h.f32 = d["xyz"], d["tile_l"], d["probs"], d["f32"]
-        h.front_stream, h.knn_stream = self.s_front[b & 1], self.s_knn[b & 1]
         return h
 
     def infer_all(self):
-        """front end | KNN pyramid | inference of every batch, enqueued: batch k's front end runs beside batch k - 1's pyramid and batch k - 2's inference"""
+        """front end -> KNN pyramid -> inference of every batch, enqueued.  A BATCH PER STREAM (default): batch b runs its three stages in order on stream
+        b mod SLOTS, whose previous batch used the same buffer set — no cross-stream wait at all, and what overlaps is whatever the SLOTS batches in flight
+        have to offer each other (a pyramid's latency-bound tree hand-over beside the next batch's grid search as well as beside another stage).
+        SSDR_AL_SCHED=stage: a stream per stage with producer waits and an event for the buffer set's last reader (measured slower, tools/al_probe.py)."""
         L = _lib.lib()
-        s_i = self.s_inf
+        if os.environ.get("SSDR_AL_SCHED", "batch") == "batch":
+            for b in range(self.nb):
+                h = self._bind(b)
+                st = self.bstreams[b % self.SLOTS]
+                h.front_stream = h.knn_stream = h.stream = st
+                if b < self.SLOTS:
+                    _lib.check(L.ssdr_stream_wait(st, self.s_inf))      # (the previous round's selection, which read these arrays, has finished)
+                h._front_end(); h._pyramid(); h._infer()
+            for st in self.bstreams[: min(self.SLOTS, self.nb)]:
+                _lib.check(L.ssdr_stream_wait(self.s_inf, st))          # the selection (on the inference stream) starts after every batch
+            return
+        s_f, s_k, s_i = self.s_front, self.s_knn, self.s_inf
+        nowait = bool(os.environ.get("SSDR_AL_NOSLOTWAIT"))       # (development, timing only: a front end may then overwrite buffers an inference still reads)
+        _lib.check(L.ssdr_stream_wait(s_f, s_i))                  # (a previous round's inferences, and the selection that read their outputs, have finished)
         for k in range(self.nb + 2):
-            if k < self.nb:
-                # batch k reuses the buffer set of batch k - 3, whose inference is the newest the inference stream holds at this point
-                _lib.check(L.ssdr_stream_wait(self.s_front[k & 1], s_i))
-                self._bind(k)._front_end()
             if 0 <= k - 2 < self.nb:
-                _lib.check(L.ssdr_stream_wait(s_i, self.s_knn[k & 1]))            # (that pyramid stream's newest work is batch k - 2's)
-                self._bind(k - 2)._infer()
+                h = self._bind(k - 2); h.stream = s_i
+                _lib.check(L.ssdr_stream_wait(s_i, s_k))          # (the pyramid stream's newest work is batch k - 2's)
+                h._infer()
+                _lib.check(L.ssdr_event_record(self.ev_inf[k - 2], s_i))
             if 0 <= k - 1 < self.nb:
-                _lib.check(L.ssdr_stream_wait(self.s_knn[(k - 1) & 1], self.s_front[(k - 1) & 1]))      # (batch k - 1's tiles: batch k's went to the other front stream)
-                self._bind(k - 1)._pyramid()
+                h = self._bind(k - 1); h.knn_stream = s_k
+                _lib.check(L.ssdr_stream_wait(s_k, s_f))          # (the front stream's newest work is batch k - 1's)
+                h._pyramid()
+            if k < self.nb:
+                h = self._bind(k); h.front_stream = s_f
+                if k >= self.SLOTS and not nowait:                # the buffer set's last reader: the inference of batch k - SLOTS
+                    _lib.check(L.ssdr_stream_wait_event(s_f, self.ev_inf[k - self.SLOTS]))
+                h._front_end()
 
     def run(self):
         """the whole round; returns (picked candidate indices, candidate list) as HotPath.step does"""
@@ -742,10 +771,10 @@ class ALRound:
         self.sel._select_issue(None)
         out = self.sel._select_collect()
         from . import knn as _knn
-        for st in self.s_knn:
+        for st in [self.s_knn] + self.bstreams:
             _knn.knn_status(st)
-        for st in self.s_front:
             _lib.check(_lib.lib().ssdr_grid_subsample_status(st, None))
+        _lib.check(_lib.lib().ssdr_grid_subsample_status(self.s_front, None))
         return out
 
 
