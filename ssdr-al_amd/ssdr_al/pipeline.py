@@ -591,7 +591,7 @@ class HotPath:
             sel = res[8:8 + picks].copy()
             cand = res[8 + T["picks"]: 8 + T["picks"] + n_unl].astype(np.int64)
             ccloud = self.sp_cloud_h[cand]
-            unl = [(int(b), int(s)) for b, s in zip(ccloud, cand)]
+            unl = list(zip(ccloud.tolist(), cand.tolist()))          # (20 000 candidates in one AL round: no per-element Python conversions)
             self.unl_cloud_ids = np.asarray(self.room_ids, np.int64)[ccloud]; self.unl_sp = cand - np.asarray(self.sp_base, np.int64)[ccloud]
         else:
             sel = d_out.to_host(self.sel_stream)             # waits for the selection stream alone
@@ -608,7 +608,8 @@ class HotPath:
             raise RuntimeError("selection: the FPS / k-center chain left unset picks (an aborted cooperative launch)")
         if getattr(self, "_emu_mod", 0):                    # (SSDR_EMULATE_WORLD: the picks index the repeated rows)
             sel = sel % self._emu_mod
-        self.selected = [(int(self.unl_cloud_ids[i]), int(self.unl_sp[i])) for i in sel]      # (room id, superpoint in room)
+        si = np.asarray(sel, np.int64)
+        self.selected = list(zip(np.asarray(self.unl_cloud_ids)[si].tolist(), np.asarray(self.unl_sp)[si].tolist()))      # (room id, superpoint in room)
         return sel, unl
 
     def step(self, comm=None, timed_stages=False):
