@@ -49,6 +49,10 @@ constexpr int FE_VMAX = 1024;        // voxels per bucket (sx <= 4)
 #endif
 constexpr int FE_RNT = FE_RNT_OPT;   // workgroup size of the reduction: 128 threads with eight records each (two waves per barrier; 256 threads: front end 1.154-1.161 against
                                      // 1.106-1.110 ms on one box, tools/gpu_fe_ab2.sh; 512 threads were 13 % slower in round 4; 64 threads leave two waves per SIMD by LDS)
+#ifndef FE_WALK_OPT
+#define FE_WALK_OPT 4
+#endif
+constexpr int FE_WALK = FE_WALK_OPT; // members of a voxel whose gathers the ordered walk keeps in flight
 constexpr int FE_CAP = 1024;         // records of a bucket (or of a slice of it) the reduction holds in LDS
 constexpr int FE_RPT = FE_CAP / FE_RNT;
 constexpr int FE_SLICES = 62;        // slices of a bucket with more than FE_CAP records
@@ -335,14 +339,14 @@ __device__ __forceinline__ void fe_reduce_voxels(FeRedLds<IMG>& L, const FeRedAr
         float f[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned long long pk0[4] = {0ull, 0ull, 0ull, 0ull}, pk1[4] = {0ull, 0ull, 0ull, 0ull}, fp0[4] = {0ull, 0ull, 0ull, 0ull}, fp1[4] = {0ull, 0ull, 0ull, 0ull};
         bool big = false;
-        for (int j = s; j < e; j += 4) {                     // four members' positions, then their halves, in flight together
-            int p[4]; uint4 w[4];
+        for (int j = s; j < e; j += FE_WALK) {               // FE_WALK members' positions, then their halves, in flight together
+            int p[FE_WALK]; uint4 w[FE_WALK];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) p[h] = L.perm[min(j + h, e - 1)];
+            for (int h = 0; h < FE_WALK; ++h) p[h] = L.perm[min(j + h, e - 1)];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) w[h] = IMG ? L.rec[2 * p[h] + half] : Rg[2 * (size_t)p[h] + half];
+            for (int h = 0; h < FE_WALK; ++h) w[h] = IMG ? L.rec[2 * p[h] + half] : Rg[2 * (size_t)p[h] + half];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
+            for (int h = 0; h < FE_WALK; ++h) {
                 if (j + h < e) {
                     const uint32_t ww[4] = {w[h].x, w[h].y, w[h].z, w[h].w};
 #pragma unroll
