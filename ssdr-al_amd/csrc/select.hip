@@ -2230,7 +2230,7 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         if (split) {          // rows split over 2 / 4 lanes, 16-byte records, the winner's row from the table
             const int lpr = split_lpr, G2 = G;
             static const int shift = [] { const char* e = getenv("SSDR_FPS_SLOT_SHIFT"); return e ? atoi(e) : 6; }();      // a record's slot: 16 bytes, or a line / several of its own
-            static const int team = [] { const char* e = getenv("SSDR_FPS_DELAY"); return e ? atoi(e) : 0; }();      // s_sleep units in front of the first polling pass
+            static const int delay = [] { const char* e = getenv("SSDR_FPS_DELAY"); return e ? atoi(e) : 0; }();      // (development) s_sleep units in front of the first polling pass
             const int launch_g = G2;
             const size_t recb = ((size_t)2 * G2) << shift;
             SSDR_TRY(Q.vtmp.reserve(recb + 64));
@@ -2239,8 +2239,8 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
             static const bool dbg_env = getenv("SSDR_FPS_DBG") != nullptr;
             if (dbg_env) {
                 static DevBuf dbgbuf; SSDR_TRY(dbgbuf.reserve(8 * 8 * 512)); SSDR_HIP(hipMemsetAsync(dbgbuf.p, 0, 8 * 8 * 512, s));
-                if (lpr == 2) hipLaunchKernelGGL((fps_coop_split<2, true>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, dbgbuf.as<long long>());
-                else hipLaunchKernelGGL((fps_coop_split<4, true>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, dbgbuf.as<long long>());
+                if (lpr == 2) hipLaunchKernelGGL((fps_coop_split<2, true>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, delay, dbgbuf.as<long long>());
+                else hipLaunchKernelGGL((fps_coop_split<4, true>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, delay, dbgbuf.as<long long>());
                 SSDR_HIP(hipStreamSynchronize(s));
                 std::vector<long long> h(8 * 512); SSDR_HIP(hipMemcpy(h.data(), dbgbuf.p, 8 * 8 * 512, hipMemcpyDeviceToHost));
                 const char* nm[8] = {"row fetch", "dist", "wave_argmax", "barrier1", "combine+store", "sweep", "argmax+barrier2", "passes"};
@@ -2251,12 +2251,12 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
                 }
                 return coop.launched(s, G2);
             }
-            if (lpr == 2) hipLaunchKernelGGL((fps_coop_split<2, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, (long long*)nullptr);
-            else hipLaunchKernelGGL((fps_coop_split<4, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, team, (long long*)nullptr);
+            if (lpr == 2) hipLaunchKernelGGL((fps_coop_split<2, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, delay, (long long*)nullptr);
+            else hipLaunchKernelGGL((fps_coop_split<4, false>), dim3(launch_g), dim3(FQ_NT), 0, s, a, shift, delay, (long long*)nullptr);
             SSDR_HIP(hipGetLastError());
             return coop.launched(s, G2);
         }
-        if (sweep > 0 && G <= 64) {
+        if (sweep >= 1 && sweep <= 3 && G <= 64) {          // the swept 544-byte records (A/B runs)
             const bool team = sweep >= 2;
             SSDR_TRY(Q.vtmp.reserve(16 * 2 * (size_t)G * FS_SLOTS + 64));
             int* sync2 = reinterpret_cast<int*>(Q.vtmp.as<char>() + 16 * 2 * (size_t)G * FS_SLOTS);
