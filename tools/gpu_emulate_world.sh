@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29561 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 SSDR_BENCH_FORCE_DIST=1
 rm -f $OUT/lines.jsonl
 for N in 1 2 4 8; do
-  SSDR_EMULATE_WORLD=$N python3 bench.py --steps ${STEPS:-100} --no-cpu-baseline 2>/dev/null | grep '^{"metric"' >> $OUT/lines.jsonl
+  SSDR_EMULATE_WORLD=$N python3 bench.py --steps ${STEPS:-100} --no-cpu-baseline --no-al-round 2>/dev/null | grep '^{"metric"' >> $OUT/lines.jsonl
 done
 python3 - <<PY
 import json
