@@ -143,3 +143,29 @@ def test_al_round_plumbing_equals_per_batch_runs(backend):
     ref = pipeline.HotPath.from_clouds(clouds, labelled, S.selected_class_list.to_host(), Cfg, batch_size=24, round_num=2)
     rsel, runl = ref.step_selection()
     assert runl == unl and np.array_equal(rsel, sel)
+
+
+@pytest.mark.gpu
+def test_al_round_stage_schedule_and_events(backend, monkeypatch):
+    """the other schedule of ALRound.infer_all (a stream per stage, producer waits, an ssdr_event_* for the buffer set's last reader; measured slower and kept for
+    A/B runs) selects what the default schedule selects; the event entry points refuse NULL"""
+    if backend != "gpu":
+        pytest.skip("timing variant: GPU only")
+    import ctypes as C
+    from oracle import randla_np as R
+    from ssdr_al import _lib, pipeline, synthetic
+    from ssdr_al.helper_tool import ConfigS3DIS
+    L = _lib.lib()
+    assert L.ssdr_event_record(None, None) != 0 and L.ssdr_stream_wait_event(None, None) != 0 and L.ssdr_event_create(None) != 0
+    ev = C.c_void_p()
+    _lib.check(L.ssdr_event_create(C.byref(ev))); _lib.check(L.ssdr_event_record(ev, None)); _lib.check(L.ssdr_stream_wait_event(None, ev)); _lib.check(L.ssdr_event_destroy(ev))
+
+    class Cfg(ConfigS3DIS):
+        num_points = 8192
+    W = R.init_weights(0)
+    rooms = [synthetic.make_room(8200 + i, density=800.0) for i in range(2)]
+    ar = pipeline.ALRound(W, rooms, 7, Cfg, batch_size=40, round_num=2, labeled_per_tile=3, precision="f32")
+    sel, unl = ar.run()
+    monkeypatch.setenv("SSDR_AL_SCHED", "stage")
+    sel2, unl2 = ar.run()
+    assert unl2 == unl and np.array_equal(sel2, sel) and len(sel) == 40
