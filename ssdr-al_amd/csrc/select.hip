@@ -1600,6 +1600,54 @@ __global__ __launch_bounds__(256) void kc_init(const double* __restrict__ f, int
     }
 }
 
+// The same for the reference's own round (kcenterGreedy over 20 000 candidates + 4 000 labelled rows seeded with the 4 000: 96 M pairs): kc_init above reads the
+// seed's row from L2 for every (row, seed) pair — 24.6 GB through the vector-memory path, ~10 ms.  Here a thread keeps ITS row in registers, the seeds of a slice
+// pass through LDS in tiles of 32 (every lane reads the same address: a broadcast), and the slices of the seeds are spread over blockIdx.y and meet in an atomic
+// minimum on the bit pattern (non-negative doubles order like their bits).  min over the seeds of sqrt(d) == sqrt(min d), bit for bit (sqrt is monotone and
+// correctly rounded), so one root per row is taken afterwards (kc_finish, which also leaves the partial maxima the chain starts from).
+constexpr int KT_SEEDS = 32;
+__global__ __launch_bounds__(256) void kc_init_tiled(const double* __restrict__ f, int n, const int* __restrict__ already, int na, unsigned long long* mind2, const int* __restrict__ dn) {
+    __shared__ double s_seed[KT_SEEDS][32];
+    if (dn) n = min(n, *dn);
+    const int tid = threadIdx.x, row = blockIdx.x * 256 + tid;
+    const int per = (na + (int)gridDim.y - 1) / (int)gridDim.y, a0 = blockIdx.y * per, a1 = min(na, a0 + per);
+    double reg[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) reg[k] = row < n ? f[(size_t)row * 32 + k] : 0.0;
+    double m = 1.0e300;
+    for (int t0 = a0; t0 < a1; t0 += KT_SEEDS) {
+        const int cnt = min(KT_SEEDS, a1 - t0);
+        __syncthreads();
+        for (int e = tid; e < cnt * 32; e += 256) s_seed[e >> 5][e & 31] = f[(size_t)already[t0 + (e >> 5)] * 32 + (e & 31)];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const double dist = np_pairwise_fixed<32>([&](int k) { const double d = reg[k] - s_seed[j][k]; return d * d; });
+            m = fmin(m, dist);
+        }
+    }
+    if (row < n && a1 > a0) atomicMin(&mind2[row], (unsigned long long)__double_as_longlong(m));
+}
+__global__ __launch_bounds__(256) void kc_finish(unsigned long long* mind2, int n, Part* pout, const int* __restrict__ dn) {
+    __shared__ Part s_p[4];
+    if (dn) n = min(n, *dn);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double* mind = reinterpret_cast<double*>(mind2);
+    double v = -1.0; int i = 0x7fffffff;
+    for (int r = blockIdx.x * 256 + tid; r < n; r += gridDim.x * 256) {
+        const double mm = sqrt(__longlong_as_double((long long)mind2[r]));
+        mind[r] = mm;
+        if (better(mm, r, v, i)) { v = mm; i = r; }
+    }
+    wave_argmax(v, i);
+    if (lane == 0) { s_p[wid].v = v; s_p[wid].i = i; }
+    __syncthreads();
+    if (tid == 0) {
+        Part b = s_p[0];
+        for (int w = 1; w < 4; ++w) if (better(s_p[w].v, s_p[w].i, b.v, b.i)) b = s_p[w];
+        pout[blockIdx.x] = b;
+    }
+}
+
 // ---- gcn.create_adj (gcn.py:116-191): the adjacency of the trained-GCN branch, torch float32 in the reference ---------------------------
 // rows of V: features / max(|features|_2, 1e-12) (torch.nn.functional.normalize)
 __global__ __launch_bounds__(256) void ca_normalize(const float* __restrict__ f, int n, int F, float* V) {
@@ -2133,7 +2181,14 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
     if (d_already && na && n <= 16384) nb = std::max(nb, (int)std::min<size_t>((n + 15) / 16, 2048));
     SSDR_TRY(Q.part.reserve(sizeof(Part) * 2 * (size_t)nb)); SSDR_TRY(Q.mind.reserve(8 * n));
     Part* p0 = Q.part.as<Part>(); Part* p1 = p0 + nb;
-    if (d_already && na) hipLaunchKernelGGL(kc_init, dim3(nb), dim3(256), 0, s, d_feat, (int)n, D, d_already, (int)na, Q.mind.as<double>(), p1, d_n);
+    static const bool kc_tiled = [] { const char* e = getenv("SSDR_KC_TILED"); return !e || e[0] != '0'; }();      // (A/B: 0 keeps kc_init at every size)
+    if (kc_tiled && d_already && na && D == 32 && (double)n * (double)na > 4.0e6) {       // the reference's own round: rows in registers, seeds through LDS, seed slices over blockIdx.y
+        const int rb = (int)((n + 255) / 256), ys = (int)std::max<size_t>(1, std::min<size_t>((na + KT_SEEDS - 1) / KT_SEEDS, (size_t)std::max(1, 2 * ctx().num_cu / rb)));
+        SSDR_HIP(hipMemsetAsync(Q.mind.p, 0x7f, 8 * n, s));                    // 0x7f7f...: a positive double above every squared distance
+        hipLaunchKernelGGL(kc_init_tiled, dim3(rb, ys), dim3(256), 0, s, d_feat, (int)n, d_already, (int)na, Q.mind.as<unsigned long long>(), d_n);
+        hipLaunchKernelGGL(kc_finish, dim3(nb), dim3(256), 0, s, Q.mind.as<unsigned long long>(), (int)n, p1, d_n);
+        SSDR_HIP(hipGetLastError());
+    } else if (d_already && na) hipLaunchKernelGGL(kc_init, dim3(nb), dim3(256), 0, s, d_feat, (int)n, D, d_already, (int)na, Q.mind.as<double>(), p1, d_n);
     else hipLaunchKernelGGL(fill_double, dim3(grid_for((long)n)), dim3(256), 0, s, Q.mind.as<double>(), (int)n, 1.0e10);   // fps_gcn_cpu.py:135
     const bool seeded = d_already && na;
     if (D == 32 && n <= 1536) {   // register-resident single workgroup

@@ -288,6 +288,22 @@ def test_kcenter_larger_golden_and_at_scale(backend, golden):
         assert len(set(got)) == 300 and not set(got) & set(already.tolist())
 
 
+def test_kcenter_seeding_at_the_rounds_scale(backend):
+    """the seeding of kCenterGreedy (min distance to every already-selected row, kcenterGreedy.py:72-82) for many rows x many seeds on 32-d features — the
+    shape of the reference's own round (24 000 rows, 4 000 seeds) takes the tiled kernel (rows in registers, seeds through LDS, seed slices met by an atomic
+    minimum): the picks are the oracle's, index for index, duplicates among the seeds and a seed that is also the farthest row's twin included"""
+    from ssdr_al import sampler
+    n, na, count = (3000, 1400, 30) if backend == "emu" else (24000, 4000, 400)
+    rng = np.random.default_rng(12)
+    f = rng.normal(0, 1, (n, 32)).astype(np.float32)
+    already = rng.choice(n, na, replace=False)
+    f[already[3]] = f[already[5]]                      # two equal seeds
+    f[(already[7] + 1) % n] = f[already[7]]            # a row at distance 0 from a seed
+    got = sampler.kCenterGreedy(f).select_batch_(already, count)
+    assert got == list(O.kcenter_greedy(f.astype(np.float64), already, count))
+    assert len(set(got)) == count and not set(got) & set(already.tolist())
+
+
 def test_edcd_farthest_superpoint_sample_golden(backend, golden):
     from ssdr_al import sampler
     g = golden("select_golden.npz")
