@@ -408,32 +408,36 @@ def main():
     # over 2 x 10 000 candidates + the labelled rows (ssdr_main_S3DIS2.py:134, sampler2.py:736-781).  pipeline.ALRound is that round.
     al_round = None
     if rank == 0 and world == 1 and not args.emu and not args.no_al_round:
-        ar = pipeline.ALRound(weights, rooms, args.al_batches, Cfg, batch_size=args.al_batch_size, precision=args.precision, selector=args.selector, tiles32=not args.tiles16)
-        ar.run()                                   # untimed: grows the scratch buffers
-        _lib.sync()
-        t_al = []
-        for _ in range(2):
-            ta = time.perf_counter(); ar.infer_all()
-            for st_ in ar.streams + ar.bstreams:
-                _lib.sync(st_)
-            tb = time.perf_counter(); ar.sel._score_async(None); ar.sel._select_issue(None); sel_al, unl_al = ar.sel._select_collect(); tc = time.perf_counter()
-            t_al.append((tc - ta, tb - ta, tc - tb))
-        ta = time.perf_counter(); sel_al, unl_al = ar.run(); t_run = time.perf_counter() - ta          # the round as one enqueue sequence
-        L.ssdr_prof_enable(1); ar.sel._score_async(None); ar.sel._select_issue(None); ar.sel._select_collect()
-        rep = {ln.rsplit(" ", 4)[0]: float(ln.rsplit(" ", 4)[2]) for ln in L.ssdr_prof_report().decode().strip().splitlines()}
-        L.ssdr_prof_enable(0)
-        best = min(t_al)
-        Tal = ar.sel._sel_static
-        al_round = {"rooms": ar.tiles, "tile_points": int(ar.tile_points), "regions": int(ar.sel.S), "picks": int(len(sel_al)), "candidates": int(len(unl_al)), "labelled_rows": int(Tal["n_lab"]),
-                    "ms": round(t_run * 1e3, 2), "Mpoints_per_s": round(ar.tile_points / t_run / 1e6, 2),
-                    "inference_ms": round(best[1] * 1e3, 2), "selection_ms": round(best[2] * 1e3, 2), "fps_ms": round(rep.get("fps_chain", 0.0), 2),
-                    "fps_us_per_pick": round(rep.get("fps_chain", 0.0) * 1e3 / max(len(sel_al), 1), 3), "chamfer_ms": round(rep.get("sel_chamfer", 0.0), 2),
-                    "selection_families_ms": {k_: round(v_, 3) for k_, v_ in sorted(rep.items(), key=lambda kv: -kv[1])},
-                    "selection_rule": ar.sel.rule_path,
-                    "note": "front end -> KNN pyramid -> inference of %d batches of %d tiles (three streams, batches overlapped), then scoring over all points and ONE "
-                            "ssdr_gcn_fps_sampling_dev over all clouds' regions; ms = the whole round, GPU idle at both ends; inference_ms + selection_ms = the same with a "
-                            "sync between the two halves; fps_ms = the farthest-point chain alone (hipEvent pair)" % (ar.nb, ar.B)}
-        del ar
+        try:
+            ar = pipeline.ALRound(weights, rooms, args.al_batches, Cfg, batch_size=args.al_batch_size, precision=args.precision, selector=args.selector, tiles32=not args.tiles16)
+            ar.run()                                   # untimed: grows the scratch buffers
+            _lib.sync()
+            t_al = []
+            for _ in range(2):
+                ta = time.perf_counter(); ar.infer_all()
+                for st_ in ar.streams + ar.bstreams:
+                    _lib.sync(st_)
+                tb = time.perf_counter(); ar.sel._score_async(None); ar.sel._select_issue(None); sel_al, unl_al = ar.sel._select_collect(); tc = time.perf_counter()
+                t_al.append((tc - ta, tb - ta, tc - tb))
+            ta = time.perf_counter(); sel_al, unl_al = ar.run(); t_run = time.perf_counter() - ta          # the round as one enqueue sequence
+            L.ssdr_prof_enable(1); ar.sel._score_async(None); ar.sel._select_issue(None); ar.sel._select_collect()
+            rep = {ln.rsplit(" ", 4)[0]: float(ln.rsplit(" ", 4)[2]) for ln in L.ssdr_prof_report().decode().strip().splitlines()}
+            L.ssdr_prof_enable(0)
+            best = min(t_al)
+            Tal = ar.sel._sel_static
+            al_round = {"rooms": ar.tiles, "tile_points": int(ar.tile_points), "regions": int(ar.sel.S), "picks": int(len(sel_al)), "candidates": int(len(unl_al)), "labelled_rows": int(Tal["n_lab"]),
+                        "ms": round(t_run * 1e3, 2), "Mpoints_per_s": round(ar.tile_points / t_run / 1e6, 2),
+                        "inference_ms": round(best[1] * 1e3, 2), "selection_ms": round(best[2] * 1e3, 2), "fps_ms": round(rep.get("fps_chain", 0.0), 2),
+                        "fps_us_per_pick": round(rep.get("fps_chain", 0.0) * 1e3 / max(len(sel_al), 1), 3), "chamfer_ms": round(rep.get("sel_chamfer", 0.0), 2),
+                        "selection_families_ms": {k_: round(v_, 3) for k_, v_ in sorted(rep.items(), key=lambda kv: -kv[1])},
+                        "selection_rule": ar.sel.rule_path,
+                        "note": "front end -> KNN pyramid -> inference of %d batches of %d tiles (a batch per stream, four batches in flight), then scoring over all points and ONE "
+                                "ssdr_gcn_fps_sampling_dev over all clouds' regions; ms = the whole round, GPU idle at both ends; inference_ms + selection_ms = the same with a "
+                                "sync between the two halves; fps_ms = the farthest-point chain alone (hipEvent pair)" % (ar.nb, ar.B)}
+            del ar
+        except Exception as e:            # this leg is beside the headline: its failure must not cost the JSON line
+            al_round = {"error": "%s: %s" % (type(e).__name__, e)}
+            L.ssdr_prof_enable(0)
 
     # ---- CPU baseline leg (rank 0, N = 1 only): the oracle pipeline on ONE room/tile of the same workload ----
     cpu = None
