@@ -147,6 +147,29 @@ def test_chamfer_matrix_screening_equals_float64(backend, kind, monkeypatch):
     assert np.allclose(got, O.create_cd(xyz, off, pts, cent), rtol=1e-12, atol=1e-14)
 
 
+def test_chamfer_empty_superpoint_both_forms_agree(backend, monkeypatch):
+    """an EMPTY superpoint among the targets (the reference's partition never makes one; the header documents it as supported): the screening on the matrix
+    cores, the float64 kernel behind SSDR_CHAMFER_F64 and the streamed form for targets beyond the staging limit give the same matrix — the 1e300 sentinel's
+    root where nothing can be nearest, never a stale LDS value (the advisor's round-5 finding)"""
+    from ssdr_al import sampler
+    rng = np.random.default_rng(77)
+    sizes = [5, 0, 40, 130, 0, 700, 12]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(off[-1])
+    xyz = (rng.random((n, 3)) * 3.0 + 10.0).astype(np.float32)
+    pts = rng.permutation(n).astype(np.int32)
+    sel = np.arange(len(sizes))
+    got = sampler.create_cd(xyz, off, pts, sel)
+    monkeypatch.setenv("SSDR_CHAMFER_F64", "1")
+    ref = sampler.create_cd(xyz, off, pts, sel)
+    monkeypatch.delenv("SSDR_CHAMFER_F64")
+    assert np.array_equal(got, ref, equal_nan=True)
+    live = np.array([s > 0 for s in sizes])
+    assert np.isfinite(got[np.ix_(live, live)]).all()
+    # a non-empty source against an empty target: every point's "nearest" distance is the sentinel's root
+    assert np.all(got[np.ix_(live, ~live)] >= 1e149)
+
+
 @pytest.mark.parametrize("scale", [1e-3, 1.0, 50.0, 80.0, 250.0])
 def test_chamfer_matrix_screening_at_other_scales(backend, scale, monkeypatch):
     """The screening's error bound has absolute terms (half-precision subnormals) and a range limit (|p|^2 <= 1000 m^2 after centring): superpoints a
