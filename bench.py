@@ -86,6 +86,10 @@ def main():
                     help="batches in flight (stages on separate HIP streams); 0 = 5 on one GPU, 4 with the exchanges of N > 1")
     ap.add_argument("--global-batch", type=int, default=0, help="sampling()'s batch_size as ONE number for the job (the reference's 10 000 / 3 000 regions per round, "
                     "ssdr_main_S3DIS2.py:134) instead of 37 regions per tile: with N ranks the replicated global chain then stays the size of one rank's")
+    ap.add_argument("--schedule", choices=("stage", "batch"), default=os.environ.get("SSDR_BENCH_SCHEDULE", "stage"),
+                    help="batches in flight as a stream per STAGE (pipeline.Pipelined) or a stream per BATCH (pipeline.BatchStreams)")
+    ap.add_argument("--slots", type=int, default=4, help="--schedule batch: batches (= streams) in flight")
+    ap.add_argument("--sel-streams", type=int, default=0, help="--schedule batch: streams the selections take in turn (0: the batch's own stream)")
     ap.add_argument("--select-lag", type=int, default=1, help="selections in flight behind the newest one the host waits for (pipeline.Pipelined sel_lag; 1 = the previous batch's)")
     ap.add_argument("--spare-set", action="store_true", help="one more buffer set than batches in flight: no stage is deferred behind the wait for the previous selection (A/B timing)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing line to stderr")
@@ -178,7 +182,11 @@ def main():
     # ordered on the same streams, in the same order on every rank.
     pipe = None
     if not args.no_pipeline:
-        pipe = pipeline.Pipelined(mk, args.pipeline_depth, sel_lag=args.select_lag, spare_set=args.spare_set)
+        if args.schedule == "batch":
+            pipe = pipeline.BatchStreams(mk, args.slots, args.sel_streams)
+            args.pipeline_depth = args.slots
+        else:
+            pipe = pipeline.Pipelined(mk, args.pipeline_depth, sel_lag=args.select_lag, spare_set=args.spare_set)
 
     def barrier():
         # EVERYTHING issued so far has finished on this rank (all stage and selection streams, not only the library stream), then all ranks meet

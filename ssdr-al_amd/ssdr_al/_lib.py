@@ -18,6 +18,8 @@ ORDER_REFERENCE, ORDER_KEY = 0, 1
 
 _lib = None
 _forced_path = None
+_libs = {}          # path -> its CDLL, kept for the life of the process: DevArray's pool of freed buffers is keyed by the object, and a collected CDLL's id() can
+                    # come back as another library's (the tests switch between the CPU logic build and the gfx950 build: a host pointer handed to hipMemcpy)
 
 
 class SsdrError(RuntimeError):
@@ -42,6 +44,9 @@ def lib():
     global _lib
     if _lib is None:
         path = lib_path()
+        if path in _libs:
+            _lib = _libs[path]
+            return _lib
         if not os.path.exists(path):
             raise SsdrError(-1, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
@@ -128,7 +133,7 @@ def lib():
         L.ssdr_knn_status_poll.argtypes = [vp, vp]
         L.ssdr_grid_subsample_status.argtypes = [vp, vp]
         L.ssdr_grid_subsample_set_method.argtypes = [i32]
-        _lib = L
+        _lib = _libs[path] = L
     return _lib
 
 

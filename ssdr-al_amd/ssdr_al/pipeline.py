@@ -779,9 +779,64 @@ class ALRound:
         return out
 
 
+class BatchStreams:
+    """`slots` batches in flight, A BATCH PER STREAM: batch k runs front end -> KNN pyramid -> network -> scoring -> selection in order on stream
+    k mod slots, on the buffer set that stream's previous batch used.  No cross-stream wait exists; what overlaps is whatever the batches in flight
+    have to offer each other (a selection's one-workgroup chain beside another batch's network, a pyramid's tree hand-over beside a front end).
+    Against Pipelined (a stream per STAGE) there is no fill — every stream is busy from the first launch on — and the drain is the last batches'
+    selections; the host waits for the selection of batch k - slots before it reuses its buffers.  Same interface as Pipelined for bench.py."""
+
+    def __init__(self, make_hot_path, slots=4, sel_streams=0):
+        """sel_streams > 0: the selections run on that many streams of their own, taken in turn (a selection waits for its batch's stream; the batch's
+        stream goes on to its next batch only after the host has read that selection: the buffer set is the same)"""
+        L = _lib.lib()
+        self.depth = self.slots = int(slots)
+
+        def mkstream():
+            st = C.c_void_p(); _lib.check(L.ssdr_stream_create(C.byref(st))); return st.value
+        self.streams = [mkstream() for _ in range(self.slots)]
+        self.sel_streams = [mkstream() for _ in range(int(sel_streams))]
+        self.hp = [make_hot_path() for _ in range(self.slots)]
+        for h, st in zip(self.hp, self.streams):
+            h.pipelined = True
+            h.front_stream = h.knn_stream = h.stream = h.score_stream = h.sel_stream = st
+        self._issued = []
+        self._k = 0
+        self.finish()
+
+    def run(self, steps, comm=None, steady=False):
+        """finishes `steps` selections (every batch issued is completed before the call returns)"""
+        out = None
+        for k in range(steps):
+            h = self.hp[k % self.slots]
+            if len(self._issued) >= self.slots:              # the buffer set's previous batch: its result is read before the set is reused
+                out = self._issued.pop(0)._select_collect()
+            h._front_end(); h._pyramid(); h._infer(); h._score_async(comm)
+            if self.sel_streams:
+                h.sel_stream = self.sel_streams[self._k % len(self.sel_streams)]
+                _lib.check(_lib.lib().ssdr_stream_wait(h.sel_stream, h.stream))
+            h._select_issue(comm)
+            self._issued.append(h); self._k += 1
+        while self._issued:
+            out = self._issued.pop(0)._select_collect()
+        return out
+
+    def finish(self):
+        while self._issued:
+            self._issued.pop(0)._select_collect()
+        _lib.sync()
+        for st in self.streams + self.sel_streams:
+            _lib.sync(st)
+        from . import knn as _knn
+        for st in self.streams:
+            _knn.knn_status(st)
+            _lib.check(_lib.lib().ssdr_grid_subsample_status(st, None))
+
+
 class _Prefix:
     """the first `count` elements of a DevArray as a flat array of its own (exchange buffers)"""
     def __init__(self, arr, count):
+        self.base = arr          # (the buffer stays the array's: a prefix that outlived it would point into the pool of freed buffers)
         self.ptr, self.dtype, self.shape, self.nbytes = arr.ptr, arr.dtype, (int(count),), int(count) * arr.dtype.itemsize
         self.__cuda_array_interface__ = {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr), False), "version": 2, "strides": None}
 

@@ -124,6 +124,13 @@ def test_overlapped_batches_give_the_same_selection(backend, depth):
             assert np.array_equal(sel, one)
         pipe2.run(4, steady=True); sel, _ = pipe2.run(3, steady=True); pipe2.finish()
         assert np.array_equal(sel, one)
+        # the other schedule bench.py offers (--schedule batch, measured slower: profiles/r06_bench_schedules.txt): a batch per stream
+        for ss in (0, 2):
+            pipe3 = pipeline.BatchStreams(make, 3, ss)
+            for k in (1, 7):
+                sel, _ = pipe3.run(k)
+                assert np.array_equal(sel, one)
+            pipe3.finish()
 
 
 def test_semantic3d_configuration_matches_oracle(backend):
