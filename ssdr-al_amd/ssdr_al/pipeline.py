@@ -875,12 +875,27 @@ class Pipelined:
             st = C.c_void_p()
             _lib.check(L.ssdr_stream_create(C.byref(st)))
             return st.value
-        self._spare = mkstream()
-        self.streams = [mkstream() for _ in range(depth - 1)]
+        qmap = os.environ.get("SSDR_PIPE_QMAP")              # development: "f,k,i,s,a,b" = the hardware queue (0..3) wanted for the front / knn / infer / score
+        if qmap and depth == 5 and overlap_select:           # streams and the two selection streams ("-" for a: the library stream); spares are created to get there
+            want = qmap.split(",")
+            self._made = 2                                   # streams in existence: NULL, the library's
+            self._spares = []
+
+            def on_queue(q):
+                while self._made % 4 != int(q):
+                    self._spares.append(mkstream()); self._made += 1
+                self._made += 1
+                return mkstream()
+            self.streams = [on_queue(q) for q in want[:4]]
+            self.sel_streams = [None if want[4] == "-" else on_queue(want[4]), on_queue(want[5])]
+            self._spare = None
+        else:
+            self._spare = mkstream()
+            self.streams = [mkstream() for _ in range(depth - 1)]
+            self.sel_streams = [None]                        # selections alternate between the library stream and one of their own
+            if overlap_select:
+                self.sel_streams.append(mkstream())
         self.overlap_select = overlap_select
-        self.sel_streams = [None]                            # selections alternate between the library stream and one of their own
-        if overlap_select:
-            self.sel_streams.append(mkstream())
         # sel_lag: how many selections behind the newest the host waits for (1: the previous batch's).  The sharded run's replicated global FPS
         # grows with the square of the rank count: from 4 ranks on a chain is longer than two steps, and sel_lag = 2 keeps
         # three chains in flight on three streams, with one more buffer set so that no stage overwrites what a running selection reads
