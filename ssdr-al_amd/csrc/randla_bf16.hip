@@ -776,6 +776,8 @@ int launch_dense_bf16(const DenseArgs& a, int prec, hipStream_t s) {
     // K loop waits a global-load latency per 32-k chunk with nothing else resident to cover it; 128 x 128 tiles at M = 41-164 k ran level with the kernel below,
     // which is bound by what a CU fetches from L2 per clock, not by the matrix or LDS pipes.  Two more forms of THIS kernel for the small-M layers, same conclusion: 64-row
     // tiles (waves 2 x 2, half the weight re-reads) for K x N >= 512 x 512: 37.1 -> 35.0 and 37.5 -> 36.6 us; two K chunks in flight in registers: 470 -> 486 us over the 25 launches)
+    // (round 6: 64-deep K chunks for the 128-row tiles — half the barriers and global-load round trips of the short K loops, 55 KB of LDS, two workgroups per CU:
+    // 0.27 against 0.214 ms for the ten launches)
     if (small) return launch_dense_bf16_t<32, 64>(a, prec, vec, s);      // too few 128-row tiles to fill the chip
     return launch_dense_bf16_t<128, 32>(a, prec, vec, s);
 }
