@@ -875,19 +875,37 @@ class Pipelined:
             st = C.c_void_p()
             _lib.check(L.ssdr_stream_create(C.byref(st)))
             return st.value
-        qmap = os.environ.get("SSDR_PIPE_QMAP")              # development: "f,k,i,s,a,b" = the hardware queue (0..3) wanted for the front / knn / infer / score
-        if qmap and depth == 5 and overlap_select:           # streams and the two selection streams ("-" for a: the library stream); spares are created to get there
+        qmap = os.environ.get("SSDR_PIPE_QMAP")              # development: "f,k,i,s,a,b" = the hardware queue (1..GPU_MAX_HW_QUEUES) wanted for the front / knn / infer /
+        if qmap and depth == 5 and overlap_select:           # score streams and the two selection streams ("-" for a: the library stream, queue 1)
+            # ROCm 7.2's runtime (read off rocprofv3's queue ids, tools/gpu_qdiscover.sh): the library's stream holds queue 1, the NULL stream queue 2, every new stream
+            # opens a new queue until GPU_MAX_HW_QUEUES (4) exist and then joins the queue with the fewest streams, the HIGHEST id among equals; unused streams count
             want = qmap.split(",")
-            self._made = 2                                   # streams in existence: NULL, the library's
+            maxq = int(os.environ.get("GPU_MAX_HW_QUEUES") or 4)
+            refs = {1: 1, 2: 1}
             self._spares = []
 
+            def next_queue():
+                if len(refs) < maxq:
+                    return len(refs) + 1
+                low = min(refs.values())
+                return max(q for q, r in refs.items() if r == low)
+
             def on_queue(q):
-                while self._made % 4 != int(q):
-                    self._spares.append(mkstream()); self._made += 1
-                self._made += 1
-                return mkstream()
-            self.streams = [on_queue(q) for q in want[:4]]
-            self.sel_streams = [None if want[4] == "-" else on_queue(want[4]), on_queue(want[5])]
+                q = int(q)
+                for _ in range(64):
+                    nq = next_queue()
+                    refs[nq] = refs.get(nq, 0) + 1
+                    st = mkstream()
+                    if nq == q:
+                        return st
+                    self._spares.append(st)
+                raise RuntimeError("SSDR_PIPE_QMAP: queue %d not reachable" % q)
+            order = sorted(range(6), key=lambda i: 0)      # creation in the order given: front, knn, infer, score, selA, selB
+            made = {}
+            for i in order:
+                made[i] = None if want[i] == "-" else on_queue(want[i])
+            self.streams = [made[0], made[1], made[2], made[3]]
+            self.sel_streams = [made[4], made[5]]
             self._spare = None
         else:
             self._spare = mkstream()

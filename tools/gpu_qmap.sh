@@ -1,15 +1,16 @@
 #!/bin/bash
-# which hardware queue each stage / selection stream lands on (SSDR_PIPE_QMAP = front,knn,infer,score,selA,selB; "-" = the library stream), same box
+# deliberate groupings of the six streams over the hardware queues (SSDR_PIPE_QMAP = front,knn,infer,score,selA,selB -> queue id; "-" = the library stream on queue 1;
+# the NULL stream idles on queue 2), same box; HWQ = GPU_MAX_HW_QUEUES
 mkdir -p gpurun_out/sched
-o=gpurun_out/sched/qmap2.txt; : > $o
-run() { python bench.py --no-al-round --no-cpu-baseline "$@" 2>gpurun_out/sched/err.txt | python -c "import sys,json,os; d=json.loads(sys.stdin.readlines()[-1]); print('QMAP=%-14s %-22s value %.1f ms/step %.3f' % (os.environ.get('SSDR_PIPE_QMAP','default'), ' '.join(sys.argv[1:3]), d['value'], d['ms_per_step']))" "$@" >> $o || tail -3 gpurun_out/sched/err.txt >> $o; }
-run --steps 100 --warmup 5
-for p in $(python -c "
-import itertools
-print(' '.join(','.join(map(str,p)) for p in itertools.permutations(range(4))))"); do
-SSDR_PIPE_QMAP=$p,-,3 run --steps 100 --warmup 5
+o=gpurun_out/sched/qmap3.txt; : > $o
+run() { python bench.py --no-al-round --no-cpu-baseline "$@" 2>gpurun_out/sched/err.txt | python -c "import sys,json,os; d=json.loads(sys.stdin.readlines()[-1]); print('QMAP=%-14s HWQ=%s %-10s value %.1f ms/step %.3f' % (os.environ.get('SSDR_PIPE_QMAP','default'), os.environ.get('GPU_MAX_HW_QUEUES','4'), ' '.join(sys.argv[1:3]), d['value'], d['ms_per_step']))" "$@" >> $o || tail -3 gpurun_out/sched/err.txt >> $o; }
+for st in 20 100; do
+run --steps $st --warmup 5
+for m in 4,4,3,2,-,1 4,4,3,3,-,2 4,4,3,1,-,2 4,4,3,2,-,2 4,4,3,3,-,1 4,3,2,4,-,1 4,3,2,2,-,1 4,3,2,1,-,1 3,3,4,4,-,2 4,4,2,2,-,3; do
+SSDR_PIPE_QMAP=$m run --steps $st --warmup 5
 done
-run --steps 100 --warmup 5
-for b in 0 1 2; do SSDR_PIPE_QMAP=3,0,1,2,-,$b run --steps 100 --warmup 5; done
-for a in 0 1 2 3; do SSDR_PIPE_QMAP=3,0,1,2,$a,3 run --steps 100 --warmup 5; done
+for m in 4,5,3,3,-,2 4,4,3,5,-,2 4,4,3,3,-,5 4,5,3,2,-,1; do
+GPU_MAX_HW_QUEUES=5 SSDR_PIPE_QMAP=$m run --steps $st --warmup 5
+done
+done
 cat $o
