@@ -1328,6 +1328,12 @@ __global__ __launch_bounds__(FQ_NT) void fps_coop_split(FpsCoopArgs a, int slot_
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, (2 * G) << slot_shift, 0x00020000);
+    // The first polling pass WAITS `delay` units of 64 cycles: a pass that finds a record missing costs another round trip through the fabric (~2300 cycles), and right
+    // behind the workgroup's own store the other workgroups' records are still on their way (1.6 passes per pick at 20 000 rows, 1.1 with 16 units).  Fixed delays
+    // measured at seven row counts (tools/gpu_fps_delay.sh, profiles/r06_fps_poll_delay.txt): the best is 16 units up to ~70 workgroups and 20 above (20 000 rows 2.78
+    // -> 2.60 us per pick, 9 472 rows 2.65 -> 2.37, 65 000 rows 3.29 -> 2.92); 24 is already slower everywhere.  A per-workgroup controller on the miss rate (two units
+    // more after a missed pass, one less after sixteen clean picks) was built and drifts upwards — a few per cent of the picks have a straggler whatever the delay.
+    const int dly = delay;
     for (int it = 0; it < a.count; ++it) {
         if (g == 0 && tid == 0) a.out[it] = c;
         if (it + 1 == a.count) break;
@@ -1385,7 +1391,7 @@ __global__ __launch_bounds__(FQ_NT) void fps_coop_split(FpsCoopArgs a, int slot_
 #pragma unroll
                 for (int j = 0; j < P; ++j) if (k0 + j * 64 < G) pend |= 1u << j;
                 long spins = 0;
-                for (int z = 0; z < delay; ++z) __builtin_amdgcn_s_sleep(1);      // (development: the first pass a little later, when more records have landed)
+                for (int z = 0; z < dly; ++z) __builtin_amdgcn_s_sleep(1);
                 while (pend) {
                     fs_u4 u[P];
                     if (TIMED) ++passes;
@@ -2285,7 +2291,8 @@ static int fps_like(const double* d_feat, size_t n, int D, const int32_t* d_alre
         if (split) {          // rows split over 2 / 4 lanes, 16-byte records, the winner's row from the table
             const int lpr = split_lpr, G2 = G;
             static const int shift = [] { const char* e = getenv("SSDR_FPS_SLOT_SHIFT"); return e ? atoi(e) : 6; }();      // a record's slot: 16 bytes, or a line / several of its own
-            static const int delay = [] { const char* e = getenv("SSDR_FPS_DELAY"); return e ? atoi(e) : 0; }();      // (development) s_sleep units in front of the first polling pass
+            static const int delay_env = [] { const char* e = getenv("SSDR_FPS_DELAY"); return e ? atoi(e) : -1; }();      // (development) s_sleep units in front of the first polling pass
+            const int delay = delay_env >= 0 ? delay_env : (G2 >= 72 ? 20 : 16);
             const int launch_g = G2;
             const size_t recb = ((size_t)2 * G2) << shift;
             SSDR_TRY(Q.vtmp.reserve(recb + 64));
