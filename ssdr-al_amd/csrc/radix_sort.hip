@@ -351,14 +351,18 @@ int RadixSorter::sort_segments(uint64_t* keys, uint32_t* vals, int nseg, const i
         hipLaunchKernelGGL(rs_andor, dim3(gao, nseg), dim3(RS_BS), 0, st, s);
         hipLaunchKernelGGL(rs_andor_fold, dim3(nseg), dim3(64), 0, st, s, gao);
     }
-    const int npass = std::min(4, (std::max(key_bits, 1) + 7) / 8);      // wide passes for the low 32 bits ...
+    // wide passes for the low 32 bits; the high ones in one single-workgroup kernel (voxel and distance keys never vary up there) — unless the set is large:
+    // the ranking of an AL round's 123 k regions (float bits above the index) spent 1.14 ms in that kernel, 4 x 22 us as wide passes
+    const int all = (std::max(key_bits, 1) + 7) / 8;
+    const bool wide_high = this->wide_high && key_bits > 32 && maxn >= 16384;
+    const int npass = wide_high ? all : std::min(4, all);      // (maxn >= 16384: below, the one kernel is as fast as twelve launches)
     for (int p = 0; p < npass; ++p) {
         hipLaunchKernelGGL(rs_hist, dim3(g), dim3(RS_BS), 0, st, s, p);
         hipLaunchKernelGGL(rs_scan, dim3(256, nseg), dim3(RS_BS), 0, st, s, p);
         if (s.kv) hipLaunchKernelGGL(rs_scatter<true>, dim3(g), dim3(RS_BS), 0, st, s, p);
         else hipLaunchKernelGGL(rs_scatter<false>, dim3(g), dim3(RS_BS), 0, st, s, p);
     }
-    if (key_bits > 32) hipLaunchKernelGGL(rs_high_passes, dim3(1), dim3(1024), 0, st, s);   // ... one kernel for the rest
+    if (key_bits > 32 && !wide_high) hipLaunchKernelGGL(rs_high_passes, dim3(1), dim3(1024), 0, st, s);   // ... one kernel for the rest
     hipLaunchKernelGGL(rs_finish, dim3(std::min(gseg, std::max(1, 2048 / nseg)), nseg), dim3(RS_BS), 0, st, s);     // usually nothing to copy: keep the (empty) launch small
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;

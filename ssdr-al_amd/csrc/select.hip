@@ -2015,6 +2015,7 @@ int ssdr_rank_regions_dev(const double* d_region_unc, size_t S, int32_t* d_sorte
     }
     SSDR_TRY(Q.keys.reserve(8 * S)); SSDR_TRY(Q.vals.reserve(4 * S));
     hipLaunchKernelGGL(sel_rank_keys, dim3(grid_for((long)S)), dim3(256), 0, s, d_region_unc, (int)S, Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>());
+    Q.sorter.wide_high = true;       // the keys' high words are the uncertainties' float bits: every pass up there runs
     SSDR_TRY(Q.sorter.sort(Q.keys.as<uint64_t>(), Q.vals.as<uint32_t>(), (int)S, nullptr, s));
     SSDR_HIP(hipMemcpyAsync(d_sorted_inds, Q.vals.p, 4 * S, hipMemcpyDeviceToDevice, s));
     return SSDR_OK;

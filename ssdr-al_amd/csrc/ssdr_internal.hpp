@@ -107,6 +107,7 @@ constexpr int RADIX_MAX_SEG = 64;
 struct RadixSorter {
     DevBuf k1, v1, hist, andor;
     int nblocks_max = 0;
+    bool wide_high = false;      // keys whose bits above 32 vary (a ranking by float value): wide passes up there too when the set is large, not the one-workgroup kernel
     int reserve(size_t slots);
     // key_bits: upper bound on the significant key bits when the caller knows one (skips launching higher passes)
     // input_in_alt: the caller wrote the unsorted pairs into alt_keys() / alt_vals() (valid after reserve()) instead of keys / vals;

@@ -58,7 +58,8 @@ def test_grid_subsample_invariants_at_room_size(backend):
 def test_ranking_and_fps_invariants(backend):
     from ssdr_al import sampler
     rng = np.random.default_rng(47)
-    for S in ((12000, 8192, 3001, 2) if backend == "emu" else (800000, 8192, 7149)):      # above 8192: segmented radix sort; up to 8192: one workgroup, in LDS
+    # above 8192: radix sort (from 16384 keys on every pass a wide one, below the float bits' passes in one workgroup); up to 8192: one workgroup, in LDS
+    for S in ((40000, 12000, 8192, 3001, 2) if backend == "emu" else (800000, 123252, 12000, 8192, 7149)):
         u = rng.normal(0, 1, S); u[rng.integers(0, S, S // 10 + 1)] = 0.25  # plenty of exact ties
         order = sampler.rank_regions(u)
         assert np.array_equal(np.sort(order), np.arange(S))                  # a permutation
