@@ -117,6 +117,13 @@ def main():
         # inherited stdout and the exit code is non-zero if any rank failed.
         sys.exit(launch_ranks(args.gpus))
 
+    # ONE JSON line on stdout and nothing else: native libraries in the process write there too (RCCL prints a five-line version banner through C stdio, which
+    # a pipe holds back until exit — BEHIND the JSON line).  Everything that is not the line goes to stderr: descriptor 1 is pointed at stderr for the life of the
+    # process and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -500,7 +507,8 @@ def main():
                           "timed_region": "GPU idle at both ends (every stream drained): K launch sequences of every stage and K completed selections, fill and "
                                           "drain of the %d-deep pipe included" % args.pipeline_depth if pipe is not None else "strictly sequential steps"},
                "stage_ms": stage_ms, "stage_roofline": stage_roofline, "whole_step": whole_step, "al_round": al_round, "fixed_batch": fixed_batch, "roofline": roofline, "cpu_baseline": cpu}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

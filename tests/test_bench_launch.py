@@ -22,6 +22,7 @@ def test_bench_gpus2_launches_two_ranks(emu_lib):
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-4000:]
     j = _line(r.stdout)
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-2000:]      # ONE line on stdout: whatever else the ranks (or a library in them) print goes to stderr
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["ms_per_step"] > 0
     assert j["config"]["selected_per_step"] == 2 * 2 * 5          # both ranks' tiles take part in the global selection
     # the second reading of an N-rank job: the reference's ONE batch_size per round (what one rank's tiles select), named beside the default
