@@ -123,6 +123,7 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's driver shares device memory between processes through dmabuf only: RCCL needs it; set before HIP starts)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
