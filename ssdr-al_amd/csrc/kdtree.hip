@@ -259,13 +259,14 @@ __global__ __launch_bounds__(NT) void kd_split_kernel(ForestPtrs f, int level) {
 // handed-over rows opens one to three nodes per level: the level-wide launches above spent 2 x 26 launches (0.6 ms of stream time) on what is a
 // few tens of microseconds of work per tree.  Trees are independent, so no grid-wide step is needed.
 constexpr int TREE_NT = 512, TREE_Q = 4096;
-__global__ __launch_bounds__(TREE_NT) void kd_tree_kernel(ForestPtrs f) {
+__global__ __launch_bounds__(TREE_NT) void kd_tree_kernel(ForestPtrs f, int max_one_wg) {
     __shared__ SplitLds<TREE_NT> L;
     __shared__ int s_q[TREE_Q];            // open nodes above SMALL_MAX points (a ring) and their levels
     __shared__ unsigned char s_lv[TREE_Q];
     __shared__ int s_head, s_tail;
     const int t = blockIdx.x, tid = threadIdx.x;
     if (f.need && !f.need[t]) return;
+    if (max_one_wg > 0 && f.desc[t].n > max_one_wg) return;      // a large tree: kd_levels_kernel's
     const int nballs = f.balls.q ? *f.balls.count : 0;
     const bool cut_to_balls = f.balls.q && nballs <= f.balls.cap;
     // root (kd_init_kernel)
@@ -309,6 +310,84 @@ __global__ __launch_bounds__(TREE_NT) void kd_tree_kernel(ForestPtrs f) {
         if (maxlevel + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
     }
 }
+
+#ifndef HIPEMU
+// A COMPLETE build of the LARGE flagged trees in one launch.  kd_tree_kernel's one workgroup per tree is right for the usual case of the re-build behind the
+// hand-over (no tree flagged: one launch that finds nothing to do) and for small trees, but a flagged 40 960-point tree took its single workgroup 6.6 ms — once
+// per ~17 batches of an AL round, on the critical path of that batch's stream (round 6, tools/gpu_al_kdtree.sh).  Here W co-operating workgroups split the open
+// nodes of a level between them (as kd_split_kernel's grid does) and meet at a counter between levels; a grid in which no large tree is flagged leaves at once.
+// Cross-workgroup visibility (the workgroups sit on all eight XCDs): agent-scope fences on both sides of the meeting point.  Not co-residency-critical: a
+// workgroup that starts late finds the others waiting, and nothing it waits for depends on it.
+constexpr int LV_NT = 512, LV_BAR = CTR_TOTAL - 2;
+__device__ __forceinline__ void kd_levels_meet(int* ctr, int nwg, int& phase) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++phase;
+        atomicAdd(&ctr[LV_BAR], 1);
+        while (__hip_atomic_load(&ctr[LV_BAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * nwg) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    __threadfence();
+}
+__global__ __launch_bounds__(LV_NT) void kd_levels_kernel(ForestPtrs f, int min_n) {
+    __shared__ SplitLds<LV_NT> L;
+    __shared__ int s_any;
+    const int tid = threadIdx.x, W = (int)gridDim.x;
+    auto mine = [&](int t) { return (!f.need || f.need[t]) && f.desc[t].n > min_n; };
+    {
+        int any = 0;
+        for (int t = tid; t < f.ntrees; t += LV_NT) any |= mine(t) ? 1 : 0;
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        if (any) s_any = 1;
+        __syncthreads();
+    }
+    if (!s_any) return;                                    // (uniform over the grid: every workgroup reads the same flags)
+    for (int t = blockIdx.x; t < f.ntrees; t += W) {       // the roots (kd_init_kernel's work)
+        if (!mine(t)) continue;
+        const float* P = f.desc[t].pts; const int n = f.desc[t].n, voff = f.desc[t].voff;
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = tid; i < n; i += LV_NT) {
+            const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+            f.sorted[voff + i] = make_float4(x, y, z, __int_as_float(i));
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x); mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y); mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        }
+        block_minmax3<LV_NT>(mn, mx, L.mm);
+        if (tid == 0) {
+            for (int d = 0; d < 3; ++d) { f.desc[t].lo[d] = mn[d]; f.desc[t].hi[d] = mx[d]; f.node_box[6 * t + d] = mn[d]; f.node_box[6 * t + 3 + d] = mx[d]; }
+            f.desc[t].root = t;
+            f.node_a[2 * (size_t)(t)] = make_int4(voff, voff + n, -1, -1);
+            f.node_b[2 * (size_t)(t)] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f.node_tree[t] = t;
+            const int q = atomicAdd(&f.ctr[CTR_QUEUE0], 1);      // (n > min_n > SMALL_MAX)
+            if (q < f.queue_cap) f.queue[q] = t; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+        }
+        __syncthreads();
+    }
+    int phase = 0;
+    kd_levels_meet(f.ctr, W, phase);
+    const int nballs = f.balls.q ? *f.balls.count : 0;
+    const bool cut_to_balls = f.balls.q && nballs <= f.balls.cap;
+    for (int level = 0; level < BIG_LEVELS; ++level) {
+        const int nq = min(__hip_atomic_load(&f.ctr[CTR_QUEUE0 + level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), f.queue_cap);
+        if (nq == 0) break;                                // (uniform: the counter is final behind the meeting point)
+        const int* qin = f.queue + (level & 1) * f.queue_cap;
+        int* qout = f.queue + ((level + 1) & 1) * f.queue_cap;
+        if (blockIdx.x == 0 && tid == 0) {
+            atomicMax(&f.ctr[CTR_DEPTH], level + 1);
+            if (level + 1 >= MAX_LEVELS) atomicOr(&f.ctr[CTR_STATUS], ST_DEPTH_OVF);
+        }
+        for (int qi = blockIdx.x; qi < nq; qi += W) {
+            kd_split_node<LV_NT>(f, L, qin[qi], level, cut_to_balls, nballs, [&](int c) {
+                const int q = atomicAdd(&f.ctr[CTR_QUEUE0 + level + 1], 1);
+                if (q < f.queue_cap) qout[q] = c; else atomicOr(&f.ctr[CTR_STATUS], ST_QUEUE_OVF);
+            });
+        }
+        kd_levels_meet(f.ctr, W, phase);
+    }
+}
+#endif
 
 // The levels a balanced tree does not reach: ONE launch instead of one per level.  The level-wide launches below go on for BIG_LEVELS levels because a
 // degenerate cloud needs them; a cloud of n points has big nodes (above 64 points) down to level log2(n / 64) or a few more (nanoflann splits boxes in
@@ -801,7 +880,16 @@ static int launch_build(const KdForest& f, const ForestPtrs& p, hipStream_t s, b
         // always all clear (26 launches that find nothing to do cost 0.13 ms of stream time; this one costs a launch).  A flagged tree is built
         // by its one workgroup node after node — measured 2x slower than the level-wide launches for the first, ball-cut build (its one to
         // three open nodes per level run side by side there), which therefore keeps them.
-        hipLaunchKernelGGL(kd_tree_kernel, dim3(f.ntrees), dim3(TREE_NT), 0, s, p);
+#ifndef HIPEMU
+        // ... up to ONE_WG_MAX points; a larger flagged tree (rare: a handed-over row the ball-cut tree could not settle) is split by W workgroups level by level
+        constexpr int ONE_WG_MAX = 4096;
+        static const bool levels_off = [] { const char* e = getenv("SSDR_KD_LEVELS"); return e && e[0] == '0'; }();      // (A/B: 0 = the one workgroup at every size)
+        const bool big = f.max_n > ONE_WG_MAX && !levels_off;
+        hipLaunchKernelGGL(kd_tree_kernel, dim3(f.ntrees), dim3(TREE_NT), 0, s, p, big ? ONE_WG_MAX : 0);
+        if (big) hipLaunchKernelGGL(kd_levels_kernel, dim3(std::min(64, ctx().num_cu)), dim3(LV_NT), 0, s, p, ONE_WG_MAX);
+#else
+        hipLaunchKernelGGL(kd_tree_kernel, dim3(f.ntrees), dim3(TREE_NT), 0, s, p, 0);
+#endif
         hipLaunchKernelGGL(kd_small_subtree_kernel, dim3(std::max(1, std::min(f.queue_cap / 2 + 1, ctx().num_cu * 16))), dim3(BS), 0, s, p);
         SSDR_HIP(hipGetLastError());
         return SSDR_OK;

@@ -181,6 +181,40 @@ def test_tree_hand_over_cut_to_balls(backend, orc, scale, monkeypatch, capfd):
     assert_bits_equal(got1, orc.knn_batch(p[:, : n // 4], p, 1, threads=4), "K=1 scale " + scale)
 
 
+@pytest.mark.gpu
+def test_complete_rebuild_of_several_large_trees_in_one_launch(monkeypatch, capfd):
+    """The re-build behind the hand-over (complete trees for rows the ball-cut trees could not settle) takes one workgroup per flagged tree up to 4096 points
+    and kd_levels_kernel — W co-operating workgroups, a meeting point per level — above: a 40 960-point tree took its one workgroup 6.6 ms.  Balls far too
+    small (SSDR_KNN_BALL_SCALE=1e-9) send every handed-over row of a four-tile pyramid there: several large trees at once, levels 0 and 1 through the new
+    kernel, the deeper ones through the old one; the pyramid must be the default path's, bit for bit, and SSDR_KD_LEVELS=0 (the old kernel alone) as well."""
+    from conftest import GPU_LIB, _have_gpu
+    if not _have_gpu():
+        pytest.skip("no GPU")
+    from ssdr_al import _lib, knn
+    _lib.use(GPU_LIB)
+    try:
+        rng = np.random.default_rng(77)
+        B, N = 4, 40960
+        xyz = (rng.random((B, N, 3), dtype=np.float32) * np.array([9, 7, 3], np.float32)).astype(np.float32)
+        for b in range(B):                                 # a few duplicated points per tile: tie rows around them, fewer than the ball list holds
+            xyz[b, -6 - 2 * b:] = xyz[b, : 6 + 2 * b]
+            xyz[b] = xyz[b][rng.permutation(N)]
+        ref = knn.knn_pyramid(xyz, [4, 4, 4, 4, 2], 16)
+        monkeypatch.setenv("SSDR_KNN_BALL_SCALE", "1e-9")
+        monkeypatch.setenv("SSDR_KNN_DEBUG", "1")
+        capfd.readouterr()
+        got = knn.knn_pyramid(xyz, [4, 4, 4, 4, 2], 16)
+        assert knn.knn_status()[0] > 0                     # rows were handed over (the status call prints the debug line)
+        err = capfd.readouterr().err
+        line = [ln for ln in err.splitlines() if "again on complete trees" in ln][-1]
+        assert int(line.split(";")[-1].split()[0]) > 20, line      # the K = 16 rows that went through the complete trees
+        for a, b in zip(ref, got):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+    finally:
+        _lib.use(None)
+
+
 @pytest.mark.parametrize("margin", ["-20", "0", "99"])
 def test_tree_lower_levels_in_one_launch(backend, orc, margin, monkeypatch):
     """The kd forest's big nodes are split by level-wide launches down to the depth a balanced tree needs + SSDR_KD_REST_MARGIN levels, the rest by one
