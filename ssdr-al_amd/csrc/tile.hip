@@ -28,13 +28,38 @@ __device__ __forceinline__ void tile_keys_body(const float* __restrict__ pts, co
     }
 }
 
+// A cloud smaller than num_points (avail = m < num_points): the entries of perm below avail, in order, shuffle its points; `padmap` holds them compacted
+// (padmap[k] = the k-th such entry) so that a row finds its source with one load.  One workgroup of 256 threads per cloud: every thread counts its
+// stretch of perm, an exclusive scan of the 256 counts, every thread writes its stretch.  (Until round 6 every ROW scanned perm for its entry: num_points^2
+// steps — 13.6 ms of a 22 ms step in the Semantic3D flavour with 65 536-point tiles over rooms of ~50 k points, tools/sem3d_probe.py; S3DIS rooms below
+// 40 960 subsampled points take the same path.)
+__device__ __forceinline__ void tile_padmap_body(int m, int num_points, const int* __restrict__ perm, int* __restrict__ padmap, unsigned* s_part) {
+    const int avail = min(m, num_points), tid = threadIdx.x;
+    if (avail == num_points) return;                       // (uniform)
+    const int per = (num_points + 255) / 256, q0 = min(tid * per, num_points), q1 = min(q0 + per, num_points);
+    unsigned cnt = 0;
+    for (int q = q0; q < q1; ++q) cnt += perm[q] < avail ? 1u : 0u;
+    __syncthreads();
+    s_part[tid] = cnt;
+    __syncthreads();
+    unsigned incl = cnt;
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned y = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        incl += y; s_part[tid] = incl;
+        __syncthreads();
+    }
+    unsigned at = incl - cnt;
+    for (int q = q0; q < q1; ++q) { const int v = perm[q]; if (v < avail) padmap[at++] = v; }
+}
+
 // out row r takes sorted position perm[r] when that position exists (< min(m, num_points)); a cloud smaller than
 // num_points is padded: rows >= m duplicate point floor(dup_u[r] * m) of the *shuffled* list (data_aug).
 __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, const float* __restrict__ colors, int cdim,
                                                    const uint32_t* __restrict__ sorted, const int* __restrict__ d_count,
                                                    const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
                                                    float cx, float cy, float cz, float color_scale,
-                                                   float* out_xyz, float* out_feat, int* out_idx, int stride = 1, int bx = -1,
+                                                   float* out_xyz, float* out_feat, int* out_idx, const int* __restrict__ padmap, int stride = 1, int bx = -1,
                                                    const int* __restrict__ labels = nullptr, int* out_lab = nullptr) {
     const int m = *d_count;
     const int avail = min(m, num_points);
@@ -42,16 +67,11 @@ __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, 
         int pos;
         if (avail == num_points) pos = perm[r];
         else {
-            // perm is a permutation of [0,num_points); its entries < avail, in order, shuffle the avail points
-            // (computed by the caller into the first `avail` slots is not possible without m, so: rank on the fly)
-            pos = -1;
-        }
-        if (pos < 0) {
-            // small cloud: row r < avail takes the r-th entry of perm that is < avail; row r >= avail duplicates
+            // small cloud: perm is a permutation of [0,num_points); its entries < avail, in order, shuffle the avail points (padmap, above):
+            // row r < avail takes the r-th of them; row r >= avail duplicates one
             int want = r < avail ? r : (int)(dup_u[r] * (float)avail);
             if (want >= avail) want = avail - 1;
-            int seen = 0; pos = 0;
-            for (int q = 0; q < num_points; ++q) { const int v = perm[q]; if (v < avail) { if (seen == want) { pos = v; break; } ++seen; } }
+            pos = want >= 0 ? padmap[want] : 0;
         }
         const uint32_t id = sorted[(size_t)pos * stride];        // stride 2: the low words of 64-bit sort words
         const float x = pts[3 * (size_t)id] - cx, y = pts[3 * (size_t)id + 1] - cy, z = pts[3 * (size_t)id + 2] - cz;
@@ -69,7 +89,8 @@ __device__ __forceinline__ void tile_gather_body(const float* __restrict__ pts, 
 
 // kernel entry points: one cloud, or all clouds of a batch (blockIdx.y = cloud)
 __global__ __launch_bounds__(256) void tile_keys(const float* __restrict__ pts, const long long* __restrict__ d_m, int n_host, float cx, float cy, float cz, uint64_t* keys, uint32_t* vals, int* d_count) { tile_keys_body(pts, d_m, n_host, cx, cy, cz, keys, vals, d_count); }
-__global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted, const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points, float cx, float cy, float cz, float color_scale, float* out_xyz, float* out_feat, int* out_idx) { tile_gather_body(pts, colors, cdim, sorted, d_count, perm, dup_u, num_points, cx, cy, cz, color_scale, out_xyz, out_feat, out_idx); }
+__global__ __launch_bounds__(256) void tile_padmap(const int* __restrict__ d_count, int num_points, const int* __restrict__ perm, int* padmap) { __shared__ unsigned s_part[256]; tile_padmap_body(*d_count, num_points, perm, padmap, s_part); }
+__global__ __launch_bounds__(256) void tile_gather(const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted, const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points, float cx, float cy, float cz, float color_scale, float* out_xyz, float* out_feat, int* out_idx, const int* __restrict__ padmap) { tile_gather_body(pts, colors, cdim, sorted, d_count, perm, dup_u, num_points, cx, cy, cz, color_scale, out_xyz, out_feat, out_idx, padmap); }
 
 struct TileTab { int nr; int off[RADIX_MAX_SEG + 1]; int toff[RADIX_MAX_SEG + 1]; float cx[RADIX_MAX_SEG], cy[RADIX_MAX_SEG], cz[RADIX_MAX_SEG]; };
 
@@ -80,11 +101,11 @@ __global__ __launch_bounds__(256) void tile_keys_b(TileTab t, const float* __res
 __global__ __launch_bounds__(256) void tile_gather_b(TileTab t, const float* __restrict__ pts, const float* __restrict__ colors, int cdim, const uint32_t* __restrict__ sorted,
                                                      const int* __restrict__ d_count, const int* __restrict__ perm, const float* __restrict__ dup_u, int num_points,
                                                      float color_scale, float* out_xyz, float* out_feat, int* out_idx, int stride,
-                                                     const int* __restrict__ labels, int* out_lab) {
+                                                     const int* __restrict__ labels, int* out_lab, const int* __restrict__ padmap) {
     int bx, r; xcd_tile_map(bx, r);            // the rows of a room are gathered at random: one room per XCD's L2
     const size_t o = (size_t)t.off[r], q = (size_t)r * num_points;
     tile_gather_body(pts + 3 * o, colors ? colors + o * cdim : nullptr, cdim, sorted + (size_t)t.toff[r] * stride, d_count + r, perm + q, dup_u + q, num_points, t.cx[r], t.cy[r], t.cz[r],
-                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, stride, bx,
+                     color_scale, out_xyz + 3 * q, out_feat ? out_feat + q * (3 + cdim) : nullptr, out_idx ? out_idx + q : nullptr, padmap + q, stride, bx,
                      labels ? labels + o : nullptr, out_lab ? out_lab + q : nullptr);
 }
 
@@ -120,7 +141,8 @@ __global__ __launch_bounds__(256) void tile_hist_b(TileTab t, const float* __res
 // of every bin <= T among the room's candidates (the histogram becomes the bins' write cursors; bins beyond T are cleared); the ranges the
 // sort works on: range k = the bins that START in [k TS_RSTEP, (k + 1) TS_RSTEP)
 constexpr int TS_RCAP = 4096, TS_RSTEP = 1024;
-__global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand, unsigned* rstart, unsigned* rcur, int rstride) {
+__global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, const int* __restrict__ d_count, int num_points, unsigned* thr, int* d_cand, unsigned* rstart, unsigned* rcur, int rstride,
+                                                     const int* __restrict__ perm, int* padmap) {
     __shared__ unsigned s_h[TS_BINS + TS_BINS / 32];          // the room's histogram (coalesced in, coalesced out); one pad word per 32 bins: a thread's stretch starts in its own bank pair
     __shared__ unsigned s_part[256];
     __shared__ unsigned s_T;
@@ -167,6 +189,7 @@ __global__ __launch_bounds__(256) void tile_thresh_b(TileTab t, unsigned* hist, 
     if ((unsigned)(tid * PER) <= T && (unsigned)(tid * PER + PER - 1) >= T) { thr[r] = T; d_cand[r] = (int)ncand; }
     __syncthreads();
     for (int b = tid; b < TS_BINS; b += 256) h[b] = s_h[at(b)];
+    tile_padmap_body(d_count[r], num_points, perm + (size_t)r * num_points, padmap + (size_t)r * num_points, s_part);      // (a room smaller than a tile only)
 }
 // candidates (bin <= T) to their RANGE's slots (the sort orders a range completely, so the order inside it is free): a workgroup counts its
 // candidates per range in LDS (the range of bin b is (start of b) / TS_RSTEP: the histogram now holds the starts), reserves each range's share
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(1024) void possibility_min(const double* __restrict
     if (tid == 0) { *out_min = s_v[0]; *out_arg = s_i[0]; }
 }
 
-struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand, rstart, rcur; bool hist_clear = false; };
+struct TileState { RadixSorter sorter; DevBuf keys, vals, count, hist, thr, cand, rstart, rcur, padmap; bool hist_clear = false; };
 TileState& tst(hipStream_t st) { return per_stream<TileState>(st); }
 
 }  // namespace
@@ -374,8 +397,10 @@ extern "C" int ssdr_tile_select_possibility_dev(const float* d_points, const flo
                        T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), T.count.as<int>());
     SSDR_TRY(T.sorter.sort(T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), (int)n_max, T.count.as<int>(), s, 32));   // float bit patterns
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 1024));
+    SSDR_TRY(T.padmap.reserve(4 * num_points));
+    hipLaunchKernelGGL(tile_padmap, dim3(1), dim3(256), 0, s, T.count.as<int>(), (int)num_points, d_perm, T.padmap.as<int>());
     hipLaunchKernelGGL(tile_gather, dim3(g2), dim3(256), 0, s, d_points, d_colors, d_colors ? color_dim : 0, T.vals.as<uint32_t>(), T.count.as<int>(),
-                       d_perm, d_dup_u, (int)num_points, center[0], center[1], center[2], color_scale, d_out_xyz, d_out_feat, d_out_idx);
+                       d_perm, d_dup_u, (int)num_points, center[0], center[1], center[2], color_scale, d_out_xyz, d_out_feat, d_out_idx, T.padmap.as<int>());
     if (d_possibility) {
         hipLaunchKernelGGL(tile_possibility, dim3(g2), dim3(256), 0, s, T.keys.as<uint64_t>(), T.vals.as<uint32_t>(), T.count.as<int>(), (int)num_points, d_possibility);
         if (d_out_min_possibility && d_out_argmin)
@@ -407,12 +432,14 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
     const int rstride = (maxn + TS_RSTEP - 1) / TS_RSTEP + 1;
     SSDR_TRY(T.hist.reserve(4 * (size_t)TS_BINS * RADIX_MAX_SEG)); SSDR_TRY(T.thr.reserve(4 * RADIX_MAX_SEG)); SSDR_TRY(T.cand.reserve(4 * RADIX_MAX_SEG));
     SSDR_TRY(T.rstart.reserve(4 * (size_t)rstride * num_clouds)); SSDR_TRY(T.rcur.reserve(4 * (size_t)rstride * num_clouds));
+    SSDR_TRY(T.padmap.reserve(4 * num_clouds * num_points));
     if (!T.hist_clear) { SSDR_HIP(hipMemsetAsync(T.hist.p, 0, 4 * (size_t)TS_BINS * RADIX_MAX_SEG, s)); T.hist_clear = true; }      // tile_clear_b leaves it clear
     const unsigned R = (unsigned)num_clouds;
     const int g = std::max(1, std::min((maxn + 255) / 256, 64));
     ProfScope prof("tile_select", s, (12.0 + 4.0 * (12 + 4 * (d_out_feat ? color_dim + 3 : 0))) * 0.0 + 40.0 * (double)num_clouds * (double)num_points);      // 40 B per tile point
     hipLaunchKernelGGL(tile_hist_b, dim3(g, R), dim3(256), 0, s, t, d_points, (const long long*)d_m, T.hist.as<unsigned>(), T.count.as<int>());
-    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, t, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>(), T.rstart.as<unsigned>(), T.rcur.as<unsigned>(), rstride);
+    hipLaunchKernelGGL(tile_thresh_b, dim3(R), dim3(256), 0, s, t, T.hist.as<unsigned>(), T.count.as<int>(), (int)num_points, T.thr.as<unsigned>(), T.cand.as<int>(), T.rstart.as<unsigned>(), T.rcur.as<unsigned>(), rstride,
+                       d_perm, T.padmap.as<int>());
     if (rstride <= TS_RMAX)
         hipLaunchKernelGGL(tile_compact_b, dim3(std::max(1, std::min((maxn + 256 * TS_CPT - 1) / (256 * TS_CPT), 256)), R), dim3(256), 0, s, t, d_points, T.count.as<int>(), T.thr.as<unsigned>(),
                            T.hist.as<unsigned>(), T.rstart.as<unsigned>(), T.rcur.as<unsigned>(), rstride, T.keys.as<uint64_t>());
@@ -421,7 +448,7 @@ extern "C" int ssdr_tile_select_batch_dev(const float* d_points, const float* d_
     hipLaunchKernelGGL(tile_binsort_b, dim3(std::min(rstride, 64), R), dim3(256), 0, s, t, T.rstart.as<unsigned>(), rstride, T.cand.as<int>(), T.keys.as<uint64_t>());
     const int g2 = (int)std::max<size_t>(1, std::min<size_t>((num_points + 255) / 256, 256));
     hipLaunchKernelGGL(tile_gather_b, dim3(g2, R), dim3(256), 0, s, t, d_points, d_colors, d_colors ? color_dim : 0, reinterpret_cast<const uint32_t*>(T.keys.as<uint64_t>()), T.count.as<int>(),
-                       d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2, d_labels, d_out_labels);
+                       d_perm, d_dup_u, (int)num_points, color_scale, d_out_xyz, d_out_feat, d_out_idx, 2, d_labels, d_out_labels, T.padmap.as<int>());
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }

@@ -92,3 +92,9 @@ def test_tile_select_batch_ties_and_crowded_distance_bins(backend):
     # the small room: its rows, shuffled, then duplicates of them (data_aug)
     m = len(clouds[2])
     assert set(got[2].tolist()) == set(range(m))
+    # ... index for index: the entries of the permutation below m, in order, shuffle the m rows (nearest first); row r >= m repeats entry floor(u_r * m) of that list
+    dd = clouds[2] - cen[2][None]
+    order = np.argsort((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2], kind="stable")
+    shuffled = order[perm[2][perm[2] < m]]
+    pick = np.minimum((dup[2, m:] * np.float32(m)).astype(np.int64), m - 1)
+    assert np.array_equal(got[2], np.concatenate([shuffled, shuffled[pick]]))
