@@ -118,6 +118,32 @@ __device__ T np_pairwise_wave(Get get, int n, int lane) {
     return ret;
 }
 
+// The same recursion for MORE terms than a wave can stage at once: the call tree is walked down to nodes of at most `cap` terms; such a node's terms are staged
+// by all lanes (stage(lo, n): terms lo .. lo + n - 1 into slots 0 .. n - 1) and summed by np_pairwise_wave over the staged values — exactly the sub-call
+// sum(a[lo:lo+n]) of the reference's recursion.  Two sums over the same members (WetSU's) share the walk and the staging.  Results on lane 0.
+template <class T, class Stage, class GetA, class GetB>
+__device__ void np_pairwise_wave_chunked2(Stage stage, GetA get_a, GetB get_b, bool two, int n, int lane, int cap, T& out_a, T& out_b) {
+    struct Fr { int lo, n; int state; T left_a, left_b; };
+    Fr st[24]; int sp = 0; T ra = T(0), rb = T(0);
+    st[0] = Fr{0, n, 0, T(0), T(0)};
+    while (sp >= 0) {
+        Fr& f = st[sp];
+        if (f.n <= cap) {
+            stage(f.lo, f.n);
+            if (f.n >= 8) { ra = np_pairwise_wave<T>(get_a, f.n, lane); if (two) rb = np_pairwise_wave<T>(get_b, f.n, lane); }
+            else { ra = np_pairwise<T>(get_a, f.n); if (two) rb = np_pairwise<T>(get_b, f.n); }
+            --sp;
+        } else if (f.state == 0) {
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            f.state = 1; st[sp + 1] = Fr{f.lo, n2, 0, T(0), T(0)}; ++sp;
+        } else if (f.state == 1) {
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            f.left_a = ra; f.left_b = rb; f.state = 2; st[sp + 1] = Fr{f.lo + n2, f.n - n2, 0, T(0), T(0)}; ++sp;
+        } else { ra = f.left_a + ra; rb = f.left_b + rb; --sp; }
+    }
+    out_a = ra; out_b = rb;
+}
+
 // ---- U1: compute_point_uncertainty (sampler2.py:28-47) + argmax class (:602) ------------------------------
 // (round 4: a workgroup's 256 rows of C <= 32 probabilities are one contiguous run: loaded coalesced into LDS, read back one row per lane — a lane reading its
 // own 52-byte row straight from memory made every load instruction touch 64 lines)
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(256) void sel_region_stats(const float* __restrict_
 // on the whole chip (0.37 ms at 1 % of the HBM rate).  Here the 64 lanes of a wave fetch the members' classes and uncertainties together
 // into LDS (RS_CAP members per wave; a larger superpoint takes the one-lane routine), count the class histogram there, and lane 0 then runs
 // the SAME summation routines (NumPy's pairwise order) over the staged values: same operations in the same order, same result.
-constexpr int RS_CAP = 1024;
+constexpr int RS_CAP = 1024, NP_BUFSIZE = 8192;
 __global__ __launch_bounds__(256) void sel_region_stats_w(const float* __restrict__ unc, const int* __restrict__ cls,
                                                           const int* __restrict__ sp_off, const int* __restrict__ sp_pts, int S, int C, int mode,
                                                           double* region_unc, int* dom, int* dom_cnt) {
@@ -214,7 +240,40 @@ __global__ __launch_bounds__(256) void sel_region_stats_w(const float* __restric
         auto K = [&](int j) { return staged ? s_c[w][j] : cls[sp_pts[lo + j]]; };
         const bool w8 = staged && n >= 8;                             // the blocks of NumPy's pairwise sum with their eight accumulators on eight lanes
         double r = 0.0;
-        if (mode == 0) {
+        if (!staged) {
+            // more members than the wave stages at once (a floor or a wall of a real partition: thousands of points; until round 6 lane 0 chased them one
+            // dependent load at a time — 1.8 ms for a 3 600-point region, tools/sp_probe.py): the recursion's nodes of at most RS_CAP terms are staged one
+            // after the other by all lanes and summed as above
+            // ... and NumPy's reduction hands its inner loop at most NP_BUFSIZE = 8192 elements at a time (the ufunc buffer, whatever the dtype): a sum over more
+            // terms is pairwise(first 8192) + pairwise(next 8192) + ..., accumulated left to right — not one recursion over everything (measured against np.sum
+            // for 4 099 .. 40 000 terms: the chunked order 20 / 20, the single recursion 11-17 / 20; found when this path met a 8 193-point region)
+            int base = 0;
+            auto stage = [&](int l0, int cnt) {
+                wave_sync();                                      // the previous node's reads are done
+                for (int j = lane; j < cnt; j += 64) { const int p = sp_pts[lo + base + l0 + j]; s_c[w][j] = cls[p]; s_u[w][j] = unc[p]; }
+                wave_sync();
+            };
+            float fa = 0.f; double da = 0.0, db = 0.0;
+            for (; base < n; base += NP_BUFSIZE) {
+                const int cn = min(NP_BUFSIZE, n - base);
+                if (mode == 0) {
+                    float sa = 0.f, sb = 0.f;
+                    np_pairwise_wave_chunked2<float>(stage, [&](int j) { return s_u[w][j]; }, [&](int j) { return s_u[w][j]; }, false, cn, lane, RS_CAP, sa, sb);
+                    fa = base == 0 ? sa : fa + sa;
+                } else if (mode == 1) {
+                    double sa = 0.0, sb = 0.0;
+                    auto term = [&](int j) { return ((double)h[s_c[w][j]] / (double)n) * (double)s_u[w][j]; };
+                    np_pairwise_wave_chunked2<double>(stage, term, term, false, cn, lane, RS_CAP, sa, sb);
+                    da = base == 0 ? sa : da + sa;
+                } else {
+                    double sa = 0.0, sb = 0.0;
+                    np_pairwise_wave_chunked2<double>(stage, [&](int j) { return (double)s_u[w][j] * (s_c[w][j] == d ? 1.0 : 0.0); },
+                                                      [&](int j) { return (double)s_u[w][j] * (1.0 - (s_c[w][j] == d ? 1.0 : 0.0)); }, true, cn, lane, RS_CAP, sa, sb);
+                    da = base == 0 ? sa : da + sa; db = base == 0 ? sb : db + sb;
+                }
+            }
+            r = mode == 0 ? (double)(float)((double)fa / (double)n) : mode == 1 ? da : da - db;
+        } else if (mode == 0) {
             float sum = 0.f;
             if (w8) sum = np_pairwise_wave<float>([&](int j) { return U(j); }, n, lane);
             else if (lane == 0) sum = np_pairwise<float>([&](int j) { return U(j); }, n);

@@ -341,10 +341,14 @@ def test_edcd_farthest_superpoint_sample_golden(backend, golden):
 def test_selection_fresh_inputs_against_oracle(backend):
     from ssdr_al import sampler
     rng = np.random.default_rng(21)
-    n, C = (8000, 13) if backend == "emu" else (200000, 13)
+    n, C = (18000, 13) if backend == "emu" else (300000, 13)
     prob = rng.dirichlet(np.ones(C) * 0.5, n).astype(np.float32)
     feat = rng.normal(0, 1, (n, 32)).astype(np.float32)
-    sizes = [1300, 1025, 1024, 700, 129, 128]               # above / at the wave routine's staging capacity, several blocks of the pairwise sum, one block
+    # above / at the wave routine's staging capacity (larger ones are staged node by node of the recursion), several blocks of the pairwise sum, one block; and
+    # above 8192 members — NumPy's reduction works through its 8192-element buffer: pairwise(first 8192) + pairwise(next 8192) + ..., not one recursion
+    sizes = [8193, 2500, 1300, 1025, 1024, 700, 129, 128]
+    if backend != "emu":
+        sizes = [40003, 20011, 16385, 16384, 12000, 8200, 8192, 4099] + sizes          # floors and walls of a real partition
     while sum(sizes) < n:
         sizes.append(int(rng.integers(5, 400)))
     sizes[-1] -= sum(sizes) - n
