@@ -319,6 +319,101 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
             __syncthreads();
         }
         const TargetTiles ta{ta0, ta1};
+        // the item's means from the roots in s_val[wid] (slot order): a superpoint's sum depends on its size alone
+        auto emit_item = [&](int k) {
+            (void)__ballot(1);                               // the wave's LDS writes are visible to its lanes
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cnt = P.cnt[k + 64 * v], seg = P.seg[k + 64 * v];
+                if (cnt > 0 && cnt <= SEQ_MAX) dir[(size_t)seg * nsel + j] = seg == j ? 0.0 : sum_short(&s_val[wid][lane + 64 * v], cnt) / (double)cnt;
+                unsigned long long todo = __ballot(cnt > SEQ_MAX);          // the larger ones, one after the other, all lanes on each
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int c = __shfl(cnt, src), sg = __shfl(seg, src);
+                    const double sum = sum_wave(&s_val[wid][src + 64 * v], c, lane);
+                    if (lane == 0) dir[(size_t)sg * nsel + j] = sg == j ? 0.0 : sum / (double)c;
+                }
+            }
+            (void)__ballot(1);
+        };
+        if (nj > CH_TILE) {
+            // A LARGE target (a floor or a wall of a real partition: thousands of points; the synthetic stand-in's regions never get here).  Until round 6 every
+            // wave streamed such a target from global memory for every item (~30 x the staged cost per pair: 14 ms of a step with 117 such regions,
+            // tools/sp_probe.py).  Now the workgroup walks its items in lockstep — four at a time, one per wave — and for each group stages the target CHUNK
+            // points at a time; a wave keeps its sources' running minima in registers across the chunks (float64 screening per chunk: the exact distance to
+            // the chunk's nearest point, so the minimum over the chunks is the exact distance to the target).
+            constexpr int CHUNK = MF ? (CH_TILE * TS_MF) / TS_F64 : CH_TILE;      // points in the float64 layout (x, y, z, |b|^2) the staging buffer holds
+            auto stage_chunk = [&](int c0, int cn) {
+                __syncthreads();
+                for (int b = threadIdx.x; b < cn; b += 256) {
+                    const size_t q = sp_pts[loj + c0 + b];
+                    const double x = (double)xyz[3 * q] - cjx, y = (double)xyz[3 * q + 1] - cjy, z = (double)xyz[3 * q + 2] - cjz;
+                    tb[TS_F64 * b] = x; tb[TS_F64 * b + 1] = y; tb[TS_F64 * b + 2] = z; tb[TS_F64 * b + 3] = fma(z, z, fma(y, y, x * x));
+                }
+                __syncthreads();
+            };
+            auto min_over_target = [&](bool on, const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&m)[NV]) {      // (uniform over the workgroup)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) m[v] = 1.0e300;
+                for (int c0 = 0; c0 < nj; c0 += CHUNK) {
+                    const int cn = min(CHUNK, nj - c0);
+                    stage_chunk(c0, cn);
+                    if (on) {
+                        double mc[NV];
+                        chamfer_min(ax, ay, az, mc, tb, cn, true, xyz, sp_pts, loj, cjx, cjy, cjz);
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) m[v] = min_f64(m[v], mc[v]);
+                    }
+                }
+            };
+            for (int itb = blockIdx.y * 4; itb < nitems; itb += 4 * gridDim.y) {
+                const int it = itb + wid; const bool on = it < nitems;
+                const int k0 = on ? P.item_slot[it] : 0, k = k0 + lane;
+                double ax[NV], ay[NV], az[NV], m[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { ax[v] = on ? P.x[k + 64 * v] : 0.0; ay[v] = on ? P.y[k + 64 * v] : 0.0; az[v] = on ? P.z[k + 64 * v] : 0.0; }
+                min_over_target(on, ax, ay, az, m);
+                if (on) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+                    emit_item(k);
+                }
+            }
+            __shared__ int s_ni[4];
+            for (int bib = blockIdx.y * 4; bib < nbig; bib += 4 * gridDim.y) {           // the large SOURCES, a wave each, their passes of ITEM points in lockstep
+                const int bi = bib + wid; const bool act = bi < nbig;
+                const int i = act ? P.big[bi] : j;
+                const int si = sel[i], loi = sp_off[si], ni = (act && i != j) ? sp_off[si + 1] - loi : 0;
+                const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
+                __syncthreads();
+                if (lane == 0) s_ni[wid] = ni;
+                __syncthreads();
+                const int ni_max = max(max(s_ni[0], s_ni[1]), max(s_ni[2], s_ni[3]));
+                double acc = 0.0;
+                for (int a0 = 0; a0 < ni_max; a0 += ITEM) {
+                    const bool on = a0 < ni;
+                    double ax[NV], ay[NV], az[NV], m[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const int a = max(min(a0 + lane + 64 * v, ni - 1), 0);     // beyond the end: the last point again, not summed
+                        const size_t p = on ? sp_pts[loi + a] : 0;
+                        ax[v] = on ? (double)xyz[3 * p] - cix : 0.0; ay[v] = on ? (double)xyz[3 * p + 1] - ciy : 0.0; az[v] = on ? (double)xyz[3 * p + 2] - ciz : 0.0;
+                    }
+                    min_over_target(on, ax, ay, az, m);
+                    if (on) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+                        (void)__ballot(1);
+                        if (ni <= SEQ_MAX) { if (lane == 0) acc = sum_short(&s_val[wid][0], ni); }
+                        else acc += sum_wave(&s_val[wid][0], min(ITEM, ni - a0), lane);
+                        (void)__ballot(1);
+                    }
+                }
+                if (act && lane == 0) dir[(size_t)i * nsel + j] = (i != j && ni > 0) ? acc / (double)ni : 0.0;
+            }
+            continue;
+        }
         // 2 eps in the scaled units (file header), from the largest |a|^2 of the item and |b|^2 of the target
         auto thr_of = [&](float r2a) { return 2.0f * (0x1p-17f * (MF_SCALE * MF_SCALE) * (r2a + r2j) + 0x1p-22f * MF_SCALE * (sqrtf(r2a) + sqrtf(r2j)) + 0x1p-12f); };
         for (int it = blockIdx.y * 4 + wid; it < nitems; it += 4 * gridDim.y) {          // whole superpoints per wave
@@ -337,21 +432,7 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
 #pragma unroll
                 for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
             }
-            (void)__ballot(1);                               // the wave's LDS writes are visible to its lanes
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int cnt = P.cnt[k + 64 * v], seg = P.seg[k + 64 * v];
-                if (cnt > 0 && cnt <= SEQ_MAX) dir[(size_t)seg * nsel + j] = seg == j ? 0.0 : sum_short(&s_val[wid][lane + 64 * v], cnt) / (double)cnt;
-                unsigned long long todo = __ballot(cnt > SEQ_MAX);          // the larger ones, one after the other, all lanes on each
-                while (todo) {
-                    const int src = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    const int c = __shfl(cnt, src), sg = __shfl(seg, src);
-                    const double sum = sum_wave(&s_val[wid][src + 64 * v], c, lane);
-                    if (lane == 0) dir[(size_t)sg * nsel + j] = sg == j ? 0.0 : sum / (double)c;
-                }
-            }
-            (void)__ballot(1);
+            emit_item(k);
         }
         for (int bi = blockIdx.y * 4 + wid; bi < nbig; bi += 4 * gridDim.y) {            // pair by pair: more than ITEM points (or none)
             const int i = P.big[bi];

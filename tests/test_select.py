@@ -125,6 +125,9 @@ def test_chamfer_matrix_screening_equals_float64(backend, kind, monkeypatch):
     from ssdr_al import sampler
     rng = np.random.default_rng({"blobs": 51, "duplicates": 52, "lattice": 53}[kind])
     sizes = [1, 2, 5, 31, 32, 33, 64, 90, 100, 127, 128, 160, 200, 255, 256, 257, 300, 420, 511, 640, 641, 700, 9, 17, 40, 75]
+    # targets beyond the staging limit are walked chunk by chunk, the workgroup's waves in lockstep (480 points per chunk in the screening build, 640 in the
+    # float64 one): one, two and several chunks, as target and as source
+    sizes += [1000] if backend == "emu" else [961, 1300, 2049, 3001]
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     n = int(off[-1])
     xyz = np.empty((n, 3), np.float32)
