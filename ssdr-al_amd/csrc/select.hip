@@ -1805,13 +1805,16 @@ __global__ __launch_bounds__(256) void cand_cloud(const int* __restrict__ rankpo
     __shared__ int s_red[8];
     const int tid = threadIdx.x, c = blockIdx.x, lo = sp_base[c], n = sp_base[c + 1] - lo;
     const int lim = min(batch_size, S);
+    // blockIdx.y: a slice of the cloud's regions (every 256 * gridDim.y-th block of 256).  A region's place inside its cloud is found by counting, n^2 per cloud:
+    // nothing at the ~450 regions of the stand-in's tiles, 5 ms on one workgroup at 8 300 (a partition of many small regions, tools/variety_probe.py)
+    if ((int)blockIdx.y * 256 >= n && blockIdx.y > 0) return;
     int nv = 0, nt = 0;
     for (int j = tid; j < n; j += 256)
         if (!labelled[lo + j]) { ++nv; const int r = rankpos[lo + j]; nt += (chunkoff[r / CR_NT] + cploc[lo + j]) < lim; }
     block_sum2<256>(nv, nt, s_red);
     const int take = min(2 * nt, nv);
-    if (tid == 0) { ncand[c] = take; ntop[c] = nt; }
-    for (int j0 = 0; j0 < n; j0 += 256) {
+    if (tid == 0 && blockIdx.y == 0) { ncand[c] = take; ntop[c] = nt; }
+    for (int j0 = (int)blockIdx.y * 256; j0 < n; j0 += 256 * (int)gridDim.y) {
         const int j = j0 + tid;
         const bool live = j < n && !labelled[lo + j];
         const int rj = live ? rankpos[lo + j] : 0x7fffffff;
@@ -1829,6 +1832,8 @@ __global__ __launch_bounds__(256) void cand_cloud(const int* __restrict__ rankpo
         if (live && pos < take) stage[lo + pos] = lo + j;
     }
 }
+// slices of a cloud's regions for cand_cloud: one below ~1000 regions per cloud on average, up to 32 above (the host knows the totals, not a cloud's own count)
+static unsigned cand_slices(size_t S, size_t B) { const size_t avg = S / std::max<size_t>(B, 1); return (unsigned)std::min<size_t>(32, std::max<size_t>(1, avg / 512)); }
 __global__ __launch_bounds__(256) void cand_layout(const int* __restrict__ ncand, const int* __restrict__ ntop, const int* __restrict__ lab_off, int B,
                                                    long long cap_rows, long long cap_sq, int* uoff, int* coff, long long* boff, int* counts) {
     __shared__ long long s_p[3][257];
@@ -2493,7 +2498,7 @@ int ssdr_gcn_fps_sampling_dev(const float* d_feat, int feat_dim, const int32_t* 
     std::optional<ProfScope> prof; prof.emplace("sel_candidate_rule", s, 0.0);
     hipLaunchKernelGGL(cand_rank, dim3(nchunks), dim3(CR_NT), 0, s, d_order, (int)S, d_labelled, rankpos, cploc, chunk);
     hipLaunchKernelGGL(cand_chunkscan, dim3(1), dim3(256), 0, s, chunk, nchunks);
-    hipLaunchKernelGGL(cand_cloud, dim3(B), dim3(256), 0, s, rankpos, cploc, chunk, d_labelled, d_sp_base, (int)S, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
+    hipLaunchKernelGGL(cand_cloud, dim3(B, cand_slices((size_t)S, (size_t)B)), dim3(256), 0, s, rankpos, cploc, chunk, d_labelled, d_sp_base, (int)S, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
     hipLaunchKernelGGL(cand_layout, dim3(1), dim3(256), 0, s, ncand, ntop, d_lab_off, B, (long long)cap_rows, (long long)cap_sq, uoff, coff, boff, counts);
     hipLaunchKernelGGL(cand_fill, dim3(B), dim3(256), 0, s, stage, d_sp_base, ncand, uoff, coff, d_lab_off, d_lab_sp, counts, sel, gsel, rows, already);
     const int nt = (int)cap_rows, nm = (int)cap_nmax; const unsigned nc = (unsigned)B;
@@ -2582,7 +2587,7 @@ int ssdr_gcn_fps_sharded_local_dev(const float* d_feat, int feat_dim, const int3
     std::optional<ProfScope> prof; prof.emplace("sel_candidate_rule", s, 0.0);
     hipLaunchKernelGGL(cand_rank, dim3(nchunks), dim3(CR_NT), 0, s, d_gorder, (int)Sg, d_glabelled, rankpos, cploc, chunk);
     hipLaunchKernelGGL(cand_chunkscan, dim3(1), dim3(256), 0, s, chunk, nchunks);
-    hipLaunchKernelGGL(cand_cloud, dim3(Bg), dim3(256), 0, s, rankpos, cploc, chunk, d_glabelled, d_gbase, (int)Sg, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
+    hipLaunchKernelGGL(cand_cloud, dim3(Bg, cand_slices((size_t)Sg, (size_t)Bg)), dim3(256), 0, s, rankpos, cploc, chunk, d_glabelled, d_gbase, (int)Sg, (int)std::min<size_t>(batch_size, 0x7fffffff), stage, ncand, ntop);
     // this rank's clouds: the layout every kernel below reads (counts in plan[0..7]); then what the other ranks contribute
     hipLaunchKernelGGL(cand_layout, dim3(1), dim3(256), 0, s, ncand + (size_t)rank * Bmax, ntop + (size_t)rank * Bmax, d_lab_off, B, (long long)cap_rows, (long long)cap_sq, uoff, coff, boff, plan);
     hipLaunchKernelGGL(cand_global, dim3(1), dim3(256), 0, s, ncand, ntop, W, (int)Bmax, (int)nu_max, guoff, plan);

@@ -159,15 +159,21 @@ def test_semantic3d_configuration_matches_oracle(backend):
     assert _ranking_matches(hp, ref2) and unl == ref2["unl"] and np.array_equal(sel, ref2["selected"])
 
 
-@pytest.mark.parametrize("case", ["cloud_all_labelled", "batch_exceeds_regions", "kcenter"])
+@pytest.mark.parametrize("case", ["cloud_all_labelled", "batch_exceeds_regions", "kcenter", "many_small_regions"])
 def test_candidate_rule_on_device_equals_host_rule(backend, case, monkeypatch):
     """sampler2.py:533-552, :745-753 as device kernels (ssdr_gcn_fps_sampling_dev: counts stay on the device) against the vectorised host rule +
     the separate entry points: same candidates, same picks — also when a cloud has no region left to offer and when the batch asks for
     more regions than are unlabelled."""
+    if case == "many_small_regions":       # a partition of thousands of regions per cloud: the rule's place-inside-the-cloud counting runs in slices over several workgroups
+        from ssdr_al import synthetic
+        orig = synthetic.superpoints_from_tile
+        monkeypatch.setattr(synthetic, "superpoints_from_tile", lambda xyz, cell=0.3: orig(xyz, 0.05 if backend == "emu" else 0.07))
     if backend == "emu":
         hp, rooms, W = _setup(2048, 2, 150.0, 6, 3)
     else:
         hp, rooms, W = _setup(40960, 3, 2500.0, 37, 15)
+    if case == "many_small_regions":
+        assert hp.S / hp.B > 1024, hp.S
     if case == "cloud_all_labelled":
         hp.labeled[1] = set(np.flatnonzero(hp.sp_cloud_h == 1).tolist())
     if case == "batch_exceeds_regions":
