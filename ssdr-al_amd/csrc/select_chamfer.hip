@@ -337,83 +337,7 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
             }
             (void)__ballot(1);
         };
-        if (nj > CH_TILE) {
-            // A LARGE target (a floor or a wall of a real partition: thousands of points; the synthetic stand-in's regions never get here).  Until round 6 every
-            // wave streamed such a target from global memory for every item (~30 x the staged cost per pair: 14 ms of a step with 117 such regions,
-            // tools/sp_probe.py).  Now the workgroup walks its items in lockstep — four at a time, one per wave — and for each group stages the target CHUNK
-            // points at a time; a wave keeps its sources' running minima in registers across the chunks (float64 screening per chunk: the exact distance to
-            // the chunk's nearest point, so the minimum over the chunks is the exact distance to the target).
-            constexpr int CHUNK = MF ? (CH_TILE * TS_MF) / TS_F64 : CH_TILE;      // points in the float64 layout (x, y, z, |b|^2) the staging buffer holds
-            auto stage_chunk = [&](int c0, int cn) {
-                __syncthreads();
-                for (int b = threadIdx.x; b < cn; b += 256) {
-                    const size_t q = sp_pts[loj + c0 + b];
-                    const double x = (double)xyz[3 * q] - cjx, y = (double)xyz[3 * q + 1] - cjy, z = (double)xyz[3 * q + 2] - cjz;
-                    tb[TS_F64 * b] = x; tb[TS_F64 * b + 1] = y; tb[TS_F64 * b + 2] = z; tb[TS_F64 * b + 3] = fma(z, z, fma(y, y, x * x));
-                }
-                __syncthreads();
-            };
-            auto min_over_target = [&](bool on, const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&m)[NV]) {      // (uniform over the workgroup)
-#pragma unroll
-                for (int v = 0; v < NV; ++v) m[v] = 1.0e300;
-                for (int c0 = 0; c0 < nj; c0 += CHUNK) {
-                    const int cn = min(CHUNK, nj - c0);
-                    stage_chunk(c0, cn);
-                    if (on) {
-                        double mc[NV];
-                        chamfer_min(ax, ay, az, mc, tb, cn, true, xyz, sp_pts, loj, cjx, cjy, cjz);
-#pragma unroll
-                        for (int v = 0; v < NV; ++v) m[v] = min_f64(m[v], mc[v]);
-                    }
-                }
-            };
-            for (int itb = blockIdx.y * 4; itb < nitems; itb += 4 * gridDim.y) {
-                const int it = itb + wid; const bool on = it < nitems;
-                const int k0 = on ? P.item_slot[it] : 0, k = k0 + lane;
-                double ax[NV], ay[NV], az[NV], m[NV];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) { ax[v] = on ? P.x[k + 64 * v] : 0.0; ay[v] = on ? P.y[k + 64 * v] : 0.0; az[v] = on ? P.z[k + 64 * v] : 0.0; }
-                min_over_target(on, ax, ay, az, m);
-                if (on) {
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
-                    emit_item(k);
-                }
-            }
-            __shared__ int s_ni[4];
-            for (int bib = blockIdx.y * 4; bib < nbig; bib += 4 * gridDim.y) {           // the large SOURCES, a wave each, their passes of ITEM points in lockstep
-                const int bi = bib + wid; const bool act = bi < nbig;
-                const int i = act ? P.big[bi] : j;
-                const int si = sel[i], loi = sp_off[si], ni = (act && i != j) ? sp_off[si + 1] - loi : 0;
-                const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
-                __syncthreads();
-                if (lane == 0) s_ni[wid] = ni;
-                __syncthreads();
-                const int ni_max = max(max(s_ni[0], s_ni[1]), max(s_ni[2], s_ni[3]));
-                double acc = 0.0;
-                for (int a0 = 0; a0 < ni_max; a0 += ITEM) {
-                    const bool on = a0 < ni;
-                    double ax[NV], ay[NV], az[NV], m[NV];
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        const int a = max(min(a0 + lane + 64 * v, ni - 1), 0);     // beyond the end: the last point again, not summed
-                        const size_t p = on ? sp_pts[loi + a] : 0;
-                        ax[v] = on ? (double)xyz[3 * p] - cix : 0.0; ay[v] = on ? (double)xyz[3 * p + 1] - ciy : 0.0; az[v] = on ? (double)xyz[3 * p + 2] - ciz : 0.0;
-                    }
-                    min_over_target(on, ax, ay, az, m);
-                    if (on) {
-#pragma unroll
-                        for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
-                        (void)__ballot(1);
-                        if (ni <= SEQ_MAX) { if (lane == 0) acc = sum_short(&s_val[wid][0], ni); }
-                        else acc += sum_wave(&s_val[wid][0], min(ITEM, ni - a0), lane);
-                        (void)__ballot(1);
-                    }
-                }
-                if (act && lane == 0) dir[(size_t)i * nsel + j] = (i != j && ni > 0) ? acc / (double)ni : 0.0;
-            }
-            continue;
-        }
+        if (nj > CH_TILE) continue;          // a large target: sel_chamfer_big (its own kernel: inlined here, that path's registers made this one spill)
         // 2 eps in the scaled units (file header), from the largest |a|^2 of the item and |b|^2 of the target
         auto thr_of = [&](float r2a) { return 2.0f * (0x1p-17f * (MF_SCALE * MF_SCALE) * (r2a + r2j) + 0x1p-22f * MF_SCALE * (sqrtf(r2a) + sqrtf(r2j)) + 0x1p-12f); };
         for (int it = blockIdx.y * 4 + wid; it < nitems; it += 4 * gridDim.y) {          // whole superpoints per wave
@@ -469,6 +393,129 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
             if (lane == 0) dir[(size_t)i * nsel + j] = ni > 0 ? acc / (double)ni : 0.0;
         }
     }
+}
+
+
+// ---- targets beyond the staging limit ---------------------------------------------------------------------------------------------------------------
+// A LARGE target (a floor or a wall of a real partition: thousands of points; the synthetic stand-in's regions never get here).  Until round 6 every wave
+// streamed such a target from global memory for every item (~30 x the staged cost per pair: 14 ms of a step with 117 such regions, tools/sp_probe.py).
+// Here the workgroup walks its items in lockstep — four at a time, one per wave — and for each group stages the target CHUNK points at a time; a wave
+// keeps its sources' running minima in registers across the chunks (float64 screening per chunk: the exact distance to the chunk's nearest point, so the
+// minimum over the chunks is the exact distance to the target).  A kernel of its own behind the main one (a workgroup without a large target leaves at
+// once): inlined into chamfer_dir_body the path's registers made the COMMON path spill (scratch 16 -> 52 bytes per lane, 320 -> 335 us); as a noinline
+// call the frame cost more still (0.31 -> 0.47 ms).  Its grid takes more slices of the items than the main kernel's: the few large targets carry the work.
+__device__ void chamfer_big_targets(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                    const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P, const int* counts,
+                                    double* tb, double (*s_val)[ITEM], int* s_ni) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nitems = counts[0], nbig = counts[1];
+    constexpr int CHUNK = CH_TILE;
+    for (int bj = blockIdx.x; bj < nbig; bj += gridDim.x) {          // the large targets are among the packer's pair-by-pair superpoints (above ITEM points): usually none
+        const int j = P.big[bj];
+        const int sj = sel[j], loj = sp_off[sj], nj = sp_off[sj + 1] - loj;
+        if (nj <= CH_TILE) continue;
+        const double cjx = centres[3 * j], cjy = centres[3 * j + 1], cjz = centres[3 * j + 2];
+        auto emit_item = [&](int k) {
+            (void)__ballot(1);                               // the wave's LDS writes are visible to its lanes
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cnt = P.cnt[k + 64 * v], seg = P.seg[k + 64 * v];
+                if (cnt > 0 && cnt <= SEQ_MAX) dir[(size_t)seg * nsel + j] = seg == j ? 0.0 : sum_short(&s_val[wid][lane + 64 * v], cnt) / (double)cnt;
+                unsigned long long todo = __ballot(cnt > SEQ_MAX);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int c = __shfl(cnt, src), sg = __shfl(seg, src);
+                    const double sum = sum_wave(&s_val[wid][src + 64 * v], c, lane);
+                    if (lane == 0) dir[(size_t)sg * nsel + j] = sg == j ? 0.0 : sum / (double)c;
+                }
+            }
+            (void)__ballot(1);
+        };
+        auto stage_chunk = [&](int c0, int cn) {
+            __syncthreads();
+            for (int b = threadIdx.x; b < cn; b += 256) {
+                const size_t q = sp_pts[loj + c0 + b];
+                const double x = (double)xyz[3 * q] - cjx, y = (double)xyz[3 * q + 1] - cjy, z = (double)xyz[3 * q + 2] - cjz;
+                tb[TS_F64 * b] = x; tb[TS_F64 * b + 1] = y; tb[TS_F64 * b + 2] = z; tb[TS_F64 * b + 3] = fma(z, z, fma(y, y, x * x));
+            }
+            __syncthreads();
+        };
+        auto min_over_target = [&](bool on, const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&m)[NV]) {      // (uniform over the workgroup)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) m[v] = 1.0e300;
+            for (int c0 = 0; c0 < nj; c0 += CHUNK) {
+                const int cn = min(CHUNK, nj - c0);
+                stage_chunk(c0, cn);
+                if (on) {
+                    double mc[NV];
+                    chamfer_min(ax, ay, az, mc, tb, cn, true, xyz, sp_pts, loj, cjx, cjy, cjz);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) m[v] = min_f64(m[v], mc[v]);
+                }
+            }
+        };
+        for (int itb = blockIdx.y * 4; itb < nitems; itb += 4 * gridDim.y) {
+            const int it = itb + wid; const bool on = it < nitems;
+            const int k0 = on ? P.item_slot[it] : 0, k = k0 + lane;
+            double ax[NV], ay[NV], az[NV], m[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { ax[v] = on ? P.x[k + 64 * v] : 0.0; ay[v] = on ? P.y[k + 64 * v] : 0.0; az[v] = on ? P.z[k + 64 * v] : 0.0; }
+            min_over_target(on, ax, ay, az, m);
+            if (on) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+                emit_item(k);
+            }
+        }
+        for (int bib = blockIdx.y * 4; bib < nbig; bib += 4 * gridDim.y) {           // the large SOURCES, a wave each, their passes of ITEM points in lockstep
+            const int bi = bib + wid; const bool act = bi < nbig;
+            const int i = act ? P.big[bi] : j;
+            const int si = sel[i], loi = sp_off[si], ni = (act && i != j) ? sp_off[si + 1] - loi : 0;
+            const double cix = centres[3 * i], ciy = centres[3 * i + 1], ciz = centres[3 * i + 2];
+            __syncthreads();
+            if (lane == 0) s_ni[wid] = ni;
+            __syncthreads();
+            const int ni_max = max(max(s_ni[0], s_ni[1]), max(s_ni[2], s_ni[3]));
+            double acc = 0.0;
+            for (int a0 = 0; a0 < ni_max; a0 += ITEM) {
+                const bool on = a0 < ni;
+                double ax[NV], ay[NV], az[NV], m[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int a = max(min(a0 + lane + 64 * v, ni - 1), 0);     // beyond the end: the last point again, not summed
+                    const size_t p = on ? sp_pts[loi + a] : 0;
+                    ax[v] = on ? (double)xyz[3 * p] - cix : 0.0; ay[v] = on ? (double)xyz[3 * p + 1] - ciy : 0.0; az[v] = on ? (double)xyz[3 * p + 2] - ciz : 0.0;
+                }
+                min_over_target(on, ax, ay, az, m);
+                if (on) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) s_val[wid][lane + 64 * v] = sqrt(m[v]);
+                    (void)__ballot(1);
+                    if (ni <= SEQ_MAX) { if (lane == 0) acc = sum_short(&s_val[wid][0], ni); }
+                    else acc += sum_wave(&s_val[wid][0], min(ITEM, ni - a0), lane);
+                    (void)__ballot(1);
+                }
+            }
+            if (act && lane == 0) dir[(size_t)i * nsel + j] = (i != j && ni > 0) ? acc / (double)ni : 0.0;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void sel_chamfer_big(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                      const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P) {
+    __shared__ double tb[CH_TILE * TS_F64];
+    __shared__ double s_val[4][ITEM];
+    __shared__ int s_ni[4];
+    chamfer_big_targets(xyz, sp_off, sp_pts, sel, nsel, centres, dir, P, P.counts, tb, s_val, s_ni);
+}
+__global__ __launch_bounds__(256) void sel_chamfer_big_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
+                                                            const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
+                                                            const double* __restrict__ centres, double* dir, ChamferPack P) {
+    __shared__ double tb[CH_TILE * TS_F64];
+    __shared__ double s_val[4][ITEM];
+    __shared__ int s_ni[4];
+    const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
+    chamfer_big_targets(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, s_val, s_ni);
 }
 
 template <bool MF>
@@ -570,6 +617,7 @@ int chamfer_dir_launch(const float* d_xyz, const int* d_sp_off, const int* d_sp_
     const dim3 grid(std::min(n, 4096), std::max(1, std::min((n + 3) / 4, 16)));
     if (chamfer_f64()) hipLaunchKernelGGL(sel_chamfer_dir<false>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir, P);
     else hipLaunchKernelGGL(sel_chamfer_dir<true>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir, P);
+    hipLaunchKernelGGL(sel_chamfer_big, dim3(16, std::min(8 * grid.y, 32u)), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, n, d_centres, d_dir, P);      // the targets beyond the staging limit (usually none)
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
@@ -585,6 +633,7 @@ int chamfer_dir_batch_launch(const float* d_xyz, const int* d_sp_off, const int*
     const dim3 grid(std::min(n_max, 1024), chamfer_slices(n_max), nclouds);
     if (chamfer_f64()) hipLaunchKernelGGL(sel_chamfer_dir_batch<false>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, d_boff, d_centres, d_dir, P);
     else hipLaunchKernelGGL(sel_chamfer_dir_batch<true>, grid, dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, d_boff, d_centres, d_dir, P);
+    hipLaunchKernelGGL(sel_chamfer_big_batch, dim3(16, std::min(8 * grid.y, 32u), grid.z), dim3(256), 0, s, d_xyz, d_sp_off, d_sp_pts, d_sel, d_coff, d_boff, d_centres, d_dir, P);      // the targets beyond the staging limit (usually none)
     SSDR_HIP(hipGetLastError());
     return SSDR_OK;
 }
