@@ -406,7 +406,7 @@ __device__ void chamfer_dir_body(const float* __restrict__ xyz, const int* __res
 // call the frame cost more still (0.31 -> 0.47 ms).  Its grid takes more slices of the items than the main kernel's: the few large targets carry the work.
 __device__ void chamfer_big_targets(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                     const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P, const int* counts,
-                                    double* tb, double (*s_val)[ITEM], int* s_ni) {
+                                    double* tb, double (*s_val)[ITEM], int* s_ni, int* s_aux, double* s_r) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nitems = counts[0], nbig = counts[1];
     constexpr int CHUNK = CH_TILE;
@@ -432,26 +432,66 @@ __device__ void chamfer_big_targets(const float* __restrict__ xyz, const int* __
             }
             (void)__ballot(1);
         };
-        auto stage_chunk = [&](int c0, int cn) {
+        // Both superpoints are centred on their own boxes, so the sources sit around the ORIGIN of the target's frame (a small region within ~0.3 m of it): the
+        // target's points beyond R1 = (the workgroup's largest |a|) + 0.25 m cannot be nearest to a source whose best distance so far is below R1 - |a|.  Two passes
+        // over the target: the points inside R1 (a quarter of a 1.5 m slab), then — only if some wave's sources are not settled by that bound — the ones outside.
+        // A block's points of the pass are compacted into the staging buffer in their own order (ballots: the same layout on every run).
+        auto wave_max = [&](double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, xor_f64(v, o)); return v; };
+        auto stage_part = [&](int c0, int cn, double r1sq, bool inner) -> int {
             __syncthreads();
-            for (int b = threadIdx.x; b < cn; b += 256) {
-                const size_t q = sp_pts[loj + c0 + b];
-                const double x = (double)xyz[3 * q] - cjx, y = (double)xyz[3 * q + 1] - cjy, z = (double)xyz[3 * q + 2] - cjz;
-                tb[TS_F64 * b] = x; tb[TS_F64 * b + 1] = y; tb[TS_F64 * b + 2] = z; tb[TS_F64 * b + 3] = fma(z, z, fma(y, y, x * x));
+            int base = 0;
+            for (int b0 = 0; b0 < cn; b0 += 256) {
+                const int b = b0 + (int)threadIdx.x;
+                double x = 0.0, y = 0.0, z = 0.0, w = 0.0; bool take = false;
+                if (b < cn) {
+                    const size_t q = sp_pts[loj + c0 + b];
+                    x = (double)xyz[3 * q] - cjx; y = (double)xyz[3 * q + 1] - cjy; z = (double)xyz[3 * q + 2] - cjz;
+                    w = fma(z, z, fma(y, y, x * x));
+                    take = (w <= r1sq) == inner;
+                }
+                const unsigned long long bal = __ballot(take);
+                if (lane == 0) s_aux[wid] = __popcll(bal);
+                __syncthreads();
+                int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                for (int w2 = 0; w2 < wid; ++w2) pos += s_aux[w2];
+                if (take) { tb[TS_F64 * pos] = x; tb[TS_F64 * pos + 1] = y; tb[TS_F64 * pos + 2] = z; tb[TS_F64 * pos + 3] = w; }
+                base += s_aux[0] + s_aux[1] + s_aux[2] + s_aux[3];
+                __syncthreads();
             }
-            __syncthreads();
+            return base;
         };
         auto min_over_target = [&](bool on, const double (&ax)[NV], const double (&ay)[NV], const double (&az)[NV], double (&m)[NV]) {      // (uniform over the workgroup)
+            double ra2 = 0.0;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) m[v] = 1.0e300;
-            for (int c0 = 0; c0 < nj; c0 += CHUNK) {
-                const int cn = min(CHUNK, nj - c0);
-                stage_chunk(c0, cn);
-                if (on) {
-                    double mc[NV];
-                    chamfer_min(ax, ay, az, mc, tb, cn, true, xyz, sp_pts, loj, cjx, cjy, cjz);
+            for (int v = 0; v < NV; ++v) { m[v] = 1.0e300; if (on) ra2 = fmax(ra2, fma(az[v], az[v], fma(ay[v], ay[v], ax[v] * ax[v]))); }
+            ra2 = wave_max(ra2);
+            __syncthreads();
+            if (lane == 0) s_r[wid] = ra2;
+            __syncthreads();
+            const double ra = sqrt(ra2), r1 = sqrt(fmax(fmax(s_r[0], s_r[1]), fmax(s_r[2], s_r[3]))) + 0.25, r1sq = r1 * r1;
+            bool need = on;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) {          // settled: every point outside R1 is at least R1 - |a| from each of the wave's sources
+                    double mx = 0.0;
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) m[v] = min_f64(m[v], mc[v]);
+                    for (int v = 0; v < NV; ++v) mx = fmax(mx, m[v]);
+                    mx = wave_max(on ? mx : 0.0);
+                    need = on && !(sqrt(mx) * (1.0 + 1.0e-9) + 1.0e-12 <= r1 - ra);
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_aux[4] = 0;
+                    __syncthreads();
+                    if (need && lane == 0) s_aux[4] = 1;
+                    __syncthreads();
+                    if (!s_aux[4]) break;
+                }
+                for (int c0 = 0; c0 < nj; c0 += CHUNK) {
+                    const int cn = stage_part(c0, min(CHUNK, nj - c0), r1sq, pass == 0);
+                    if (need && cn > 0) {
+                        double mc[NV];
+                        chamfer_min(ax, ay, az, mc, tb, cn, true, xyz, sp_pts, loj, cjx, cjy, cjz);
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) m[v] = min_f64(m[v], mc[v]);
+                    }
                 }
             }
         };
@@ -505,17 +545,19 @@ __global__ __launch_bounds__(256) void sel_chamfer_big(const float* __restrict__
                                                       const int* __restrict__ sel, int nsel, const double* __restrict__ centres, double* dir, ChamferPack P) {
     __shared__ double tb[CH_TILE * TS_F64];
     __shared__ double s_val[4][ITEM];
-    __shared__ int s_ni[4];
-    chamfer_big_targets(xyz, sp_off, sp_pts, sel, nsel, centres, dir, P, P.counts, tb, s_val, s_ni);
+    __shared__ int s_ni[4], s_aux[8];
+    __shared__ double s_r[4];
+    chamfer_big_targets(xyz, sp_off, sp_pts, sel, nsel, centres, dir, P, P.counts, tb, s_val, s_ni, s_aux, s_r);
 }
 __global__ __launch_bounds__(256) void sel_chamfer_big_batch(const float* __restrict__ xyz, const int* __restrict__ sp_off, const int* __restrict__ sp_pts,
                                                             const int* __restrict__ sel, const int* __restrict__ coff, const long long* __restrict__ boff,
                                                             const double* __restrict__ centres, double* dir, ChamferPack P) {
     __shared__ double tb[CH_TILE * TS_F64];
     __shared__ double s_val[4][ITEM];
-    __shared__ int s_ni[4];
+    __shared__ int s_ni[4], s_aux[8];
+    __shared__ double s_r[4];
     const int c = blockIdx.z, lo = coff[c], n = coff[c + 1] - lo;
-    chamfer_big_targets(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, s_val, s_ni);
+    chamfer_big_targets(xyz, sp_off, sp_pts, sel + lo, n, centres + 3 * (size_t)lo, dir + boff[c], pack_at(P, lo), P.counts + 2 * c, tb, s_val, s_ni, s_aux, s_r);
 }
 
 template <bool MF>
