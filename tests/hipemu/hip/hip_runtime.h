@@ -56,18 +56,62 @@ static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hip
 
 namespace hipemu {
 enum { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
-struct Fiber { ucontext_t ctx; char* stack = nullptr; int state = READY; uint3e tid; int lane, wave, op; };
+// Context switches: glibc's swapcontext saves and restores the signal mask — two system calls per switch, and a work-item yields at every wave operation and
+// barrier: ~45 % of the CPU suite's time was spent in the kernel.  On x86-64 (outside the sanitizer build, whose runtime follows swapcontext only) a switch is
+// the six callee-saved registers and the stack pointer.
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(HIPEMU_UCONTEXT)
+#define HIPEMU_FAST_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(".text\n.weak hipemu_switch\n.type hipemu_switch,@function\nhipemu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  subq $8, %rsp\n  stmxcsr (%rsp)\n  fnstcw 4(%rsp)\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  ldmxcsr (%rsp)\n  fldcw 4(%rsp)\n  addq $8, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size hipemu_switch,.-hipemu_switch\n");
+#endif
+struct Fiber {
+#ifdef HIPEMU_FAST_SWITCH
+    void* sp = nullptr;
+#else
+    ucontext_t ctx;
+#endif
+    char* stack = nullptr; int state = READY; uint3e tid; int lane, wave, op;
+};
 struct WaveX { uint64_t val[64], snap[64]; uint64_t snap_mask; };
 struct BlockState {
-    std::vector<Fiber> fibers; std::vector<WaveX> waves; ucontext_t sched; Fiber* cur = nullptr;
+    std::vector<Fiber> fibers; std::vector<WaveX> waves;
+#ifdef HIPEMU_FAST_SWITCH
+    void* sched = nullptr;
+#else
+    ucontext_t sched;
+#endif
+    Fiber* cur = nullptr;
     const std::function<void()>* body = nullptr;
 };
 inline thread_local BlockState* g_bs = nullptr;
 inline thread_local char* g_dynshared = nullptr;
 constexpr size_t STACK = 256 * 1024;
 
+#ifdef HIPEMU_FAST_SWITCH
+inline void yield_to_sched() { BlockState* b = g_bs; hipemu_switch(&b->cur->sp, b->sched); }
+inline void fiber_entry() { BlockState* b = g_bs; (*b->body)(); b->cur->state = DONE; hipemu_switch(&b->cur->sp, b->sched); __builtin_trap(); }
+// a new fiber's stack as hipemu_switch expects to find it: control words, six zeroed registers, the entry point as the return address (the stack pointer
+// is 8 modulo 16 when fiber_entry starts, as behind a call)
+inline void* fiber_boot(char* stack, size_t size) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 8);                     // [top - 8]: a slot the entry point may take for its return address' place (never returns)
+    *--sp = (void*)fiber_entry;                         // ret -> fiber_entry, rsp = top - 8 afterwards
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;        // rbp, rbx, r12-r15
+    unsigned csr = 0, cw = 0;
+    asm volatile("stmxcsr %0" : "=m"(csr)); asm volatile("fnstcw %0" : "=m"(*(unsigned short*)&cw));
+    --sp; ((unsigned*)sp)[0] = csr; ((unsigned*)sp)[1] = cw;
+    return sp;
+}
+#else
 inline void yield_to_sched() { BlockState* b = g_bs; swapcontext(&b->cur->ctx, &b->sched); }
 inline void fiber_entry() { BlockState* b = g_bs; (*b->body)(); b->cur->state = DONE; swapcontext(&b->cur->ctx, &b->sched); }
+#endif
 }  // namespace hipemu
 
 inline thread_local uint3e threadIdx, blockIdx;
@@ -83,14 +127,22 @@ inline void run_block(BlockState& bs, unsigned nthreads, const std::function<voi
         if (!f.stack) f.stack = (char*)malloc(STACK);
         f.state = READY; f.lane = t & 63; f.wave = t >> 6;
         f.tid.x = t % blockDim.x; f.tid.y = (t / blockDim.x) % blockDim.y; f.tid.z = t / (blockDim.x * blockDim.y);
+#ifdef HIPEMU_FAST_SWITCH
+        f.sp = fiber_boot(f.stack, STACK);
+#else
         getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &bs.sched;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
     }
     for (;;) {
         bool any = false; unsigned done = 0;
         for (unsigned t = 0; t < nthreads; ++t) {
             Fiber& f = bs.fibers[t];
+#ifdef HIPEMU_FAST_SWITCH
+            if (f.state == READY) { bs.cur = &f; threadIdx = f.tid; hipemu_switch(&bs.sched, f.sp); any = true; }
+#else
             if (f.state == READY) { bs.cur = &f; threadIdx = f.tid; swapcontext(&bs.sched, &f.ctx); any = true; }
+#endif
             if (f.state == DONE) ++done;
         }
         if (done == nthreads) break;
@@ -121,14 +173,15 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
     const long nblocks = (long)grid.x * grid.y * grid.z; const unsigned nthreads = block.x * block.y * block.z;
 #pragma omp parallel
     {
-        BlockState bs; std::vector<char> dyn(shmem + 64);
+        // the fibers' stacks stay with the OpenMP thread from launch to launch (a launch used to malloc and free nthreads x 256 KB per thread: a third of the
+        // CPU suite's time was the kernel mapping and unmapping them)
+        static thread_local BlockState bs; std::vector<char> dyn(shmem + 64);
         g_dynshared = dyn.data(); blockDim = block; gridDim = grid;
 #pragma omp for schedule(dynamic, 1)
         for (long b = 0; b < nblocks; ++b) {
             blockIdx.x = (unsigned)(b % grid.x); blockIdx.y = (unsigned)((b / grid.x) % grid.y); blockIdx.z = (unsigned)(b / ((long)grid.x * grid.y));
             run_block(bs, nthreads, body);
         }
-        for (auto& f : bs.fibers) free(f.stack);
     }
 }
 
